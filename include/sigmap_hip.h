@@ -1,0 +1,202 @@
+/*
+ * sigmap_hip.h -- C ABI of the MI355X (gfx950) device side of the Sigmap hot path.
+ *
+ * The reference (haowenz/sigmap) has no FFI / plugin layer: the seam is the C++ class API
+ * its driver calls.  Each entry point below names the reference interface it replaces
+ * (file:line relative to /root/reference/src).  Callers are the host-side mirrors of the
+ * reference classes in sigmap_amd/host/ (SpatialIndex, Sigmap), the `sigmap` CLI, and the
+ * ctypes binding in sigmap_amd/_abi.py -- never end-user code.
+ *
+ * Conventions: plain C, POD structs, plain pointers + sizes.  Return 0 on success,
+ * negative SMHIP_E* on failure (never exit()/abort(); the reference's assert/exit(-1),
+ * utils.h:67, become error codes + smhip_last_error()).  One context per GPU, one host
+ * thread per context at a time; different contexts are independent.  All device memory
+ * is context-owned unless attached with smhip_index_attach().
+ */
+#ifndef SIGMAP_HIP_H_
+#define SIGMAP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMHIP_OK 0
+#define SMHIP_EINVAL (-1)   /* bad argument */
+#define SMHIP_EHIP (-2)     /* HIP runtime error (message in smhip_last_error) */
+#define SMHIP_ENOMEM (-3)   /* device allocation failed */
+#define SMHIP_ESTATE (-4)   /* call order violated (no index, no batch ...) */
+#define SMHIP_ECAP (-5)     /* a device-side capacity was exceeded (see status bits) */
+
+typedef struct smhip_ctx smhip_ctx;
+
+/* Flattened nanoflann node (replaces the 32-byte pointer node, nanoflann.hpp:755-768, as
+ * dumped pre-order by save_tree, nanoflann.hpp:1025-1033).  child1 is always self+1.
+ *   inner: feat = split dimension (>=0), a = divlow bits, b = divhigh bits, child2 = index
+ *   leaf : feat = -1, a = left, b = right (range into the tree-ordered point list) */
+typedef struct {
+  int32_t feat;
+  uint32_t a;
+  uint32_t b;
+  uint32_t child2;
+} smhip_node;
+
+/* Every constant the reference hard-codes on this path, surfaced once. */
+typedef struct {
+  /* event detector, event.h:31-37 */
+  uint32_t window_length1, window_length2;
+  float threshold1, threshold2, peak_height;
+  double compress_delta;      /* sigmap.cc:1075 (0.1) */
+  uint32_t min_num_events;    /* sigmap.cc:660: chains only if features > 50 */
+  /* seeding, sigmap.cc:1381-1388 */
+  float search_radius;        /* 0.08, compared against SQUARED L2 */
+  int32_t step_size;          /* 2 */
+  /* chaining, spatial_index.cc:284-291 */
+  int32_t max_gap_length;         /* 2000 */
+  int32_t max_target_gap_length;  /* 5000 */
+  int32_t chaining_band_length;   /* 5000 */
+  int32_t max_num_skips;          /* 25 */
+  int32_t min_num_anchors;        /* 2 */
+  int32_t num_best_chains;        /* 3 */
+  int32_t num_nearest_points;     /* 5000 */
+  float min_chaining_score;       /* 10 */
+  /* device-side capacities (not reference semantics; exceeding one is reported, never
+   * silently truncated) */
+  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (128) */
+  uint32_t lanes_per_query;       /* 8/16/32/64: wave sub-group width of the tree walk */
+  uint32_t reserved;
+} smhip_params;
+
+void smhip_default_params(smhip_params *p);
+
+/* ---- lifecycle ---- */
+int smhip_init(int device_ordinal, smhip_ctx **out);
+void smhip_destroy(smhip_ctx *ctx);
+const char *smhip_last_error(smhip_ctx *ctx);
+/* HIP stream all kernels of this context are launched on (hipStream_t as void*). */
+void *smhip_stream(smhip_ctx *ctx);
+
+/* ---- index: replaces SpatialIndex::Load, spatial_index.cc:132-163 ----
+ * values/positions: the `.pt` point cloud (Point{position,value}, sigmap_adaptor.h:7-17)
+ * split into two arrays; vind + nodes + bbox: the `.si` tree (nanoflann.hpp:1051-1058).
+ * root_bbox = {low0, high0, low1, high1, ...}. */
+int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
+                       uint64_t n_points, const uint32_t *vind, uint64_t m_size,
+                       const smhip_node *nodes, uint64_t n_nodes, const float *root_bbox);
+
+/* Device-resident index arrays, for replication to peer GPUs by one RCCL broadcast per
+ * array.  The caller owns the transport (torch.distributed / RCCL). */
+typedef struct {
+  int32_t dim;
+  uint32_t pad;
+  uint64_t n_nodes, m_size;
+  void *nodes;      uint64_t nodes_bytes;      /* smhip_node[n_nodes] */
+  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* float[m_size][dim], tree (leaf-major) order */
+  void *leaf_pos;   uint64_t leaf_pos_bytes;   /* uint64[m_size], Point.position in tree order */
+  void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */
+  void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
+} smhip_index_dev;
+int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
+/* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */
+int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in);
+
+/* ---- one batch of signal chunks: replaces the body of the taskloop in
+ * Sigmap::StreamingMap (sigmap.cc:647-666): GenerateEvents + GenerateChains per chunk ---- */
+
+#define SMHIP_TOPK 4
+typedef struct {
+  float score;
+  uint32_t ref, start, end, n_anchors;
+  uint32_t mapq;       /* only chains[0] carries a MAPQ (spatial_index.cc:255-274) */
+  uint32_t direction;  /* 1 = Positive (+), 0 = Negative (-), spatial_index.h:13-16 */
+  uint32_t pad;
+} smhip_chain; /* SignalAnchorChain, spatial_index.h:28-45, without the anchor vector */
+
+#define SMHIP_ST_FEW_PEAKS 1u      /* < 2 peaks: reference is out of bounds (event.h:213-223); chunk yields nothing */
+#define SMHIP_ST_HIT_POOL_FULL 2u  /* overflow hit pool exhausted */
+#define SMHIP_ST_STACK_FULL 4u     /* tree-walk stack deeper than the device stack */
+#define SMHIP_ST_CHAIN_CAP 8u      /* more candidate chains than the per-chunk scratch */
+#define SMHIP_ST_SORT_CAP 16u      /* more anchors than the sort key can index */
+
+typedef struct {
+  uint32_t status;       /* SMHIP_ST_* bits */
+  uint32_t n_events;     /* raw events (event.h:226) */
+  uint32_t n_features;   /* after z-score + compression (sigmap.cc:1073-1079) */
+  uint32_t n_queries;    /* radius searches issued (spatial_index.cc:351) */
+  uint32_t n_anchors;    /* sum over queries of min(hits, num_nearest_points) + carried */
+  uint32_t n_chains;     /* primary chains (spatial_index.cc:571-576) */
+  float sum_score;       /* chain scores added in order, float (sigmap.cc:702-705) */
+  uint32_t pad0;
+  uint64_t nodes_visited;  /* tree nodes touched by this chunk's queries */
+  uint64_t points_tested;  /* leaf points distance-tested */
+  uint64_t hits_total;     /* hits before the 5000 cap */
+  smhip_chain chains[SMHIP_TOPK];
+  /* chain[0] anchor statistics in the reference's accumulation order (sigmap.cc:714-729) */
+  float c0_sum_dist, c0_sum_tgap, c0_sum_qgap;
+  uint32_t c0_first_qpos; /* anchors[0].query_position (chain end) */
+  uint32_t c0_last_qpos;  /* anchors.back().query_position (chain start) */
+  uint32_t pad1;
+} smhip_chunk_result;
+
+typedef struct {
+  uint32_t ref_strand;  /* (ref << 1) | strand, strand 0 = + */
+  uint32_t target_position, query_position;
+  float distance;
+} smhip_carried_anchor; /* SignalAnchor + its bucket, spatial_index.cc:303-322 */
+
+/* Stage inputs into HBM.  samples_pa: pA values (after SignalBatch::AddSignal's conversion
+ * and (30,200) filter, signal_batch.cc:139-151); chunk c = samples[offsets[c]..offsets[c+1]).
+ * query_start_offsets (nullable = zeros): events consumed by earlier chunks of the same read
+ * (sigmap.cc:663).  carried (nullable): anchors of the previous chunk's chains. */
+int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets,
+                       uint32_t n_chunks, const uint32_t *query_start_offsets,
+                       const smhip_carried_anchor *carried, const uint32_t *carried_offsets);
+/* Launch events -> seeds -> radius search -> sort -> chain on the context stream (async). */
+int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs);
+int smhip_map_sync(smhip_ctx *ctx);
+/* results: n_chunks records. chain_anchors (nullable): anchors of ALL primary chains,
+ * chain-major, end->start order, chunk c at [chain_anchor_offsets[c], ..[c+1]). */
+int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results,
+                       smhip_carried_anchor *chain_anchors, uint64_t chain_anchor_cap,
+                       uint64_t *chain_anchor_offsets /* n_chunks+1 */);
+/* upload + run + sync + download */
+int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
+                     const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                     const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                     const uint32_t *carried_offsets, smhip_chunk_result *results);
+/* Mean device time (ms) of the named kernel over the launches since the last
+ * smhip_timing_reset(), measured with HIP events on the context stream.
+ * names: "events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw". */
+int smhip_timing_enable(smhip_ctx *ctx, int on);
+int smhip_timing_reset(smhip_ctx *ctx);
+int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64_t *launches);
+
+/* ---- per-stage entry points (parity tests address each kernel in isolation) ---- */
+
+/* Sigmap::GenerateEvents, sigmap.cc:1048-1083 (DetectEvents event.h:226 + z-score
+ * sigmap.cc:1131 + compression).  feat/stdv: n_chunks x feat_stride floats. */
+int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,
+                 const uint32_t *sample_offsets, uint32_t n_chunks, uint32_t feat_stride,
+                 float *feat, float *stdv, uint32_t *n_features, uint32_t *n_events,
+                 uint32_t *status);
+/* nanoflann radiusSearch, nanoflann.hpp:1278-1301, for n_queries windows of `dim` floats.
+ * Hits of query i in traversal order at point_idx/dist[i*cap ..], counts[i] = total hits
+ * (may exceed cap).  point_idx = original point-cloud index (the pair.first nanoflann
+ * returns). */
+int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *queries,
+                      uint32_t n_queries, uint32_t cap, uint32_t *counts, uint64_t *point_idx,
+                      float *dist, uint64_t *nodes_visited, uint64_t *points_tested);
+/* Banded subsequence DTW refinement (recurrence of Sigmap::sDTW, sigmap.cc:1259-1291,
+ * restricted to per-row column windows).  Problem i: target[t_off[i]..t_off[i+1]),
+ * query[q_off[i]..q_off[i+1]); row r of problem i may use query columns
+ * [lo[r], hi[r]] (1-based, inclusive; rows indexed globally like target). */
+int smhip_sdtw_banded(smhip_ctx *ctx, const float *target, const uint64_t *t_off,
+                      const float *query, const uint64_t *q_off, const uint32_t *lo,
+                      const uint32_t *hi, uint32_t n_problems, float *dist, int64_t *end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGMAP_HIP_H_ */

@@ -1,0 +1,82 @@
+/*
+ * sigmap_host.h -- C ABI over the host-side (CPU, no HIP) plumbing around the hot path:
+ * index construction and the reference's `.pt` / `.si` files, ADC->pA conversion, and the
+ * per-read PAF decision.  Implemented in C++ in sigmap_amd/host/ (the mirrors of the
+ * reference's SpatialIndex / PoreModel / SequenceBatch / SignalBatch / Sigmap classes);
+ * this header exists so that tests, bench.py and other-language hosts can drive them.
+ * Citations: file:line under /root/reference/src.
+ */
+#ifndef SIGMAP_HOST_H_
+#define SIGMAP_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sigmap_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smhost_index smhost_index;
+
+/* Sigmap::ConstructIndex, sigmap.cc:999-1046: reverse complements, high-frequency
+ * (dim+k-1)-mer mask (freq > 2e-4), pore-model expected signal, per-contig per-strand
+ * z-score, point cloud (+ strands of all contigs, then - strands), k-d tree.
+ * level_means: 4^k table indexed by 2-bit k-mer hash.  seqs need not be NUL terminated. */
+smhost_index *smhost_index_build(const float *level_means, int kmer_size, const char *const *seqs,
+                                 const uint32_t *seq_lens, uint32_t n_seqs, int dim, int max_leaf,
+                                 int num_threads);
+/* SpatialIndex::Construct tail only (spatial_index.cc:95-97): tree over a given point cloud */
+smhost_index *smhost_index_from_points(const uint64_t *positions, const float *values,
+                                       uint64_t n_points, int dim, int max_leaf, int num_threads);
+/* SpatialIndex::Load / Save, spatial_index.cc:103-163 (PREFIX.pt + PREFIX.si) */
+smhost_index *smhost_index_load(const char *prefix);
+int smhost_index_save(const smhost_index *ix, const char *prefix);
+void smhost_index_free(smhost_index *ix);
+
+typedef struct {
+  int32_t dim, max_leaf, depth, pad;
+  uint64_t n_points, m_size, n_nodes;
+  const float *values;        /* n_points */
+  const uint64_t *positions;  /* n_points */
+  const uint32_t *vind;       /* m_size */
+  const smhip_node *nodes;    /* n_nodes, pre-order */
+  const float *bbox;          /* 2*dim: low0, high0, ... */
+} smhost_index_view;
+int smhost_index_get(const smhost_index *ix, smhost_index_view *out);
+
+/* Z-scored expected reference signal of one contig strand as the index build computes it
+ * (sigmap.cc:1019-1036); used as the sDTW target.  Returns length written (len-k+1). */
+uint64_t smhost_reference_signal(const float *level_means, int kmer_size, const char *seq,
+                                 uint32_t seq_len, int negative_strand, float *out);
+/* PoreModel::GetLevelMeansAt, pore_model.cc:57-81 */
+uint64_t smhost_level_means(const float *level_means, int kmer_size, const char *seq,
+                            uint32_t seq_len, float *out);
+
+/* SignalBatch::AddSignal, signal_batch.cc:139-151 / :195-207: pA = (raw+offset)*(range/
+ * digitisation), keep iff 30 < pA < 200.  Returns number kept. */
+uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation, float range,
+                          float offset, float *out);
+
+typedef struct {
+  float search_radius;
+  int32_t step_size, max_num_chunks, stop_min_anchors, output_min_anchors;
+  float stop_ratio, output_ratio, stop_mean_ratio, output_mean_ratio;
+} smhost_map_params; /* CLI defaults, sigmap.cc:1380-1419 */
+void smhost_default_map_params(smhost_map_params *p);
+
+/* sigmap.cc:667-687: 1 = stop feeding chunks of this read */
+int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p);
+/* sigmap.cc:690-865 + output_tools.h:200-210,336-354: PAF line (without the wall-clock
+ * mt:f: tag) for a read whose last processed chunk produced *r.  ref_bucket receives the
+ * reference index the row is filed under.  Returns bytes written (excluding NUL). */
+int smhost_format_paf(const smhip_chunk_result *r, const char *read_name, uint32_t read_length,
+                      uint32_t chunk_index, uint32_t num_events, const char *const *ref_names,
+                      const uint32_t *ref_lengths, uint32_t n_refs, const smhost_map_params *p,
+                      char *buf, size_t cap, uint32_t *ref_bucket);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

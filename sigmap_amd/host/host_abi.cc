@@ -1,0 +1,188 @@
+// host_abi.cc -- extern "C" surface of the host library (include/sigmap_host.h).
+#include <omp.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sigmap_host.h"
+#include "mapping_logic.h"
+#include "pore_model.h"
+#include "sequence_batch.h"
+#include "signal_batch.h"
+#include "spatial_index.h"
+
+using namespace sigmap;
+
+struct smhost_index {
+  SpatialIndex *si;
+};
+
+namespace sigmap {
+// The ConstructIndex pipeline shared by the CLI (-i) and the C ABI.
+void BuildIndex(SequenceBatch &ref, const PoreModel &pore_model, SpatialIndex &index) {
+  const uint32_t n = ref.GetNumSequences();
+  for (uint32_t i = 0; i < n; ++i) ref.PrepareNegativeSequenceAt(i);
+  std::vector<std::vector<bool>> pos_masked, neg_masked;
+  GenerateMaskedPositions(index.dimension() + pore_model.GetKmerSize() - 1, 0.0002f, ref, pos_masked,
+                          neg_masked);
+  SignalBatch ref_signals;
+  ref_signals.ConvertSequencesToSignals(ref, pore_model, n);
+  std::vector<std::vector<float>> pos(n), neg(n);
+#pragma omp parallel for schedule(dynamic)
+  for (uint32_t i = 0; i < n; ++i) {
+    const Signal &s = ref_signals.GetSignalAt(i);
+    ZscoreNormalize(s.signal_values.data(), s.signal_values.size(), pos[i]);
+    ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), neg[i]);
+  }
+  index.Construct(n, pos_masked, neg_masked, pos, neg);
+}
+}  // namespace sigmap
+
+extern "C" {
+
+smhost_index *smhost_index_build(const float *level_means, int kmer_size, const char *const *seqs,
+                                 const uint32_t *seq_lens, uint32_t n_seqs, int dim, int max_leaf,
+                                 int num_threads) {
+  if (num_threads < 1) num_threads = omp_get_max_threads();
+  PoreModel pm;
+  pm.SetTable(kmer_size, level_means);
+  SequenceBatch sb;
+  for (uint32_t i = 0; i < n_seqs; ++i)
+    sb.AddSequence("ref" + std::to_string(i), std::string(seqs[i], seq_lens[i]));
+  smhost_index *ix = new smhost_index;
+  ix->si = new SpatialIndex(dim, max_leaf, num_threads, "");
+  omp_set_num_threads(num_threads);
+  BuildIndex(sb, pm, *ix->si);
+  return ix;
+}
+
+smhost_index *smhost_index_from_points(const uint64_t *positions, const float *values,
+                                       uint64_t n_points, int dim, int max_leaf, int num_threads) {
+  if (num_threads < 1) num_threads = omp_get_max_threads();
+  if (n_points < (uint64_t)dim) return nullptr;
+  smhost_index *ix = new smhost_index;
+  ix->si = new SpatialIndex(dim, max_leaf, num_threads, "");
+  ix->si->SetPointCloud(std::vector<uint64_t>(positions, positions + n_points),
+                        std::vector<float>(values, values + n_points));
+  ix->si->BuildTree();
+  return ix;
+}
+
+smhost_index *smhost_index_load(const char *prefix) {
+  smhost_index *ix = new smhost_index;
+  ix->si = new SpatialIndex(1000, std::vector<int>(), prefix);
+  ix->si->Load();
+  return ix;
+}
+
+int smhost_index_save(const smhost_index *ix, const char *prefix) {
+  ix->si->set_index_file_path_prefix(prefix);
+  ix->si->Save();
+  return 0;
+}
+
+void smhost_index_free(smhost_index *ix) {
+  if (!ix) return;
+  delete ix->si;
+  delete ix;
+}
+
+int smhost_index_get(const smhost_index *ix, smhost_index_view *out) {
+  if (!ix || !out) return -1;
+  const SpatialIndex &si = *ix->si;
+  out->dim = si.dimension();
+  out->max_leaf = si.max_leaf();
+  out->depth = si.tree().depth;
+  out->pad = 0;
+  out->n_points = si.values().size();
+  out->m_size = si.tree().m_size;
+  out->n_nodes = si.tree().nodes.size();
+  out->values = si.values().data();
+  out->positions = si.positions().data();
+  out->vind = si.tree().vind.data();
+  out->nodes = si.tree().nodes.data();
+  out->bbox = si.tree().bbox.data();
+  return 0;
+}
+
+uint64_t smhost_level_means(const float *level_means, int kmer_size, const char *seq,
+                            uint32_t seq_len, float *out) {
+  PoreModel pm;
+  pm.SetTable(kmer_size, level_means);
+  const std::string s(seq, seq_len);  // guarantees the NUL the rolling hash reads
+  const std::vector<float> v = pm.GetLevelMeansAt(s.c_str(), 0, seq_len);
+  memcpy(out, v.data(), v.size() * sizeof(float));
+  return v.size();
+}
+
+uint64_t smhost_reference_signal(const float *level_means, int kmer_size, const char *seq,
+                                 uint32_t seq_len, int negative_strand, float *out) {
+  PoreModel pm;
+  pm.SetTable(kmer_size, level_means);
+  SequenceBatch sb;
+  sb.AddSequence("r", std::string(seq, seq_len));
+  sb.PrepareNegativeSequenceAt(0);
+  const char *s = negative_strand ? sb.GetNegativeSequenceAt(0).c_str() : sb.GetSequenceAt(0);
+  const std::vector<float> lv = pm.GetLevelMeansAt(s, 0, seq_len);
+  std::vector<float> z;
+  ZscoreNormalize(lv.data(), lv.size(), z);
+  memcpy(out, z.data(), z.size() * sizeof(float));
+  return z.size();
+}
+
+uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation, float range,
+                          float offset, float *out) {
+  SignalBatch b;
+  b.AddSignal("", digitisation, range, offset, raw, n_raw);
+  const std::vector<float> &v = b.GetSignalAt(0).signal_values;
+  memcpy(out, v.data(), v.size() * sizeof(float));
+  return (uint32_t)v.size();
+}
+
+void smhost_default_map_params(smhost_map_params *p) {
+  const MappingParams d;
+  p->search_radius = d.search_radius;
+  p->step_size = d.read_seeding_step_size;
+  p->max_num_chunks = d.max_num_chunks;
+  p->stop_min_anchors = d.stop_mapping_min_num_anchors;
+  p->output_min_anchors = d.output_mapping_min_num_anchors;
+  p->stop_ratio = d.stop_mapping_ratio;
+  p->output_ratio = d.output_mapping_ratio;
+  p->stop_mean_ratio = d.stop_mapping_mean_ratio;
+  p->output_mean_ratio = d.output_mapping_mean_ratio;
+}
+
+static MappingParams ToParams(const smhost_map_params *p) {
+  MappingParams m;
+  m.search_radius = p->search_radius;
+  m.read_seeding_step_size = p->step_size;
+  m.max_num_chunks = p->max_num_chunks;
+  m.stop_mapping_min_num_anchors = p->stop_min_anchors;
+  m.output_mapping_min_num_anchors = p->output_min_anchors;
+  m.stop_mapping_ratio = p->stop_ratio;
+  m.output_mapping_ratio = p->output_ratio;
+  m.stop_mapping_mean_ratio = p->stop_mean_ratio;
+  m.output_mapping_mean_ratio = p->output_mean_ratio;
+  return m;
+}
+
+int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p) {
+  return ShouldStopMapping(*r, ToParams(p)) ? 1 : 0;
+}
+
+int smhost_format_paf(const smhip_chunk_result *r, const char *read_name, uint32_t read_length,
+                      uint32_t chunk_index, uint32_t num_events, const char *const *ref_names,
+                      const uint32_t *ref_lengths, uint32_t n_refs, const smhost_map_params *p,
+                      char *buf, size_t cap, uint32_t *ref_bucket) {
+  std::vector<uint32_t> lens(ref_lengths, ref_lengths + n_refs);
+  uint32_t bucket = 0;
+  const PAFMapping m = MakeMapping(*r, 0, read_name, read_length, chunk_index, num_events, lens,
+                                   ToParams(p), false, 0.0, &bucket);
+  const std::string line = FormatPAF(m, ref_names[bucket], ref_lengths[bucket]);
+  if (ref_bucket) *ref_bucket = bucket;
+  if (line.size() + 1 > cap) return -1;
+  memcpy(buf, line.c_str(), line.size() + 1);
+  return (int)line.size();
+}
+}

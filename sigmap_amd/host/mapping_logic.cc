@@ -1,0 +1,66 @@
+#include "mapping_logic.h"
+
+namespace sigmap {
+bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p) {
+  if (r.n_chains >= 2) {
+    if (r.chains[0].score / r.chains[1].score >= p.stop_mapping_ratio) return true;
+    float mean_chain_score = r.sum_score;
+    mean_chain_score /= r.n_chains;
+    if (r.chains[0].score >= p.stop_mapping_mean_ratio * mean_chain_score) return true;
+  } else if (r.n_chains == 1 && r.chains[0].n_anchors >= (uint32_t)p.stop_mapping_min_num_anchors) {
+    return true;
+  }
+  return false;
+}
+
+PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std::string &read_name,
+                       uint32_t read_length, uint32_t chunk_index, uint32_t num_events,
+                       const std::vector<uint32_t> &ref_lengths, const MappingParams &p,
+                       bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket) {
+  const uint32_t bp_per_sec = 450, sample_rate = 4000, chunk_size = 4000;
+  const float read_position_scale =
+      ((float)(chunk_index + 1) * chunk_size / num_events) / ((float)sample_rate / bp_per_sec);
+  float mean_chain_score = r.sum_score;  // 0 when there are no chains -> 0/0 = NaN below
+  mean_chain_score /= r.n_chains;
+  std::string tags;
+  if (include_time_tag) tags.append("mt:f:" + std::to_string(mapping_time_ms) + "\t");
+  tags.append("ci:i:" + std::to_string(chunk_index + 1));
+  tags.append("\tsl:i:" + std::to_string(read_length));
+  if (r.n_chains >= 1) {
+    const smhip_chain &c0 = r.chains[0];
+    float ad = r.c0_sum_dist, at = r.c0_sum_tgap, aq = r.c0_sum_qgap;
+    ad /= c0.n_anchors;
+    at /= c0.n_anchors;
+    aq /= c0.n_anchors;
+    tags.append("\tcm:i:" + std::to_string(c0.n_anchors));
+    tags.append("\tnc:i:" + std::to_string(r.n_chains));
+    tags.append("\ts1:f:" + std::to_string(c0.score));
+    tags.append("\ts2:f:" + std::to_string(r.n_chains > 1 ? r.chains[1].score : 0.0f));
+    tags.append("\tsm:f:" + std::to_string(mean_chain_score));
+    tags.append("\tad:f:" + std::to_string(ad));
+    tags.append("\tat:f:" + std::to_string(at));
+    tags.append("\taq:f:" + std::to_string(aq));
+  }
+  const bool output =
+      (r.n_chains >= 2 && (r.chains[0].score / r.chains[1].score >= p.output_mapping_ratio ||
+                           r.chains[0].score >= p.output_mapping_mean_ratio * mean_chain_score)) ||
+      (r.n_chains == 1 && r.chains[0].n_anchors >= (uint32_t)p.output_mapping_min_num_anchors);
+  if (output) {
+    const smhip_chain &c0 = r.chains[0];
+    *out_ref_bucket = c0.ref;
+    return PAFMapping{read_id,
+                      read_name,
+                      read_length,
+                      (uint32_t)(read_position_scale * r.c0_last_qpos),
+                      (uint32_t)(read_position_scale * r.c0_first_qpos),
+                      c0.direction == 1 ? c0.start : (uint32_t)(ref_lengths[c0.ref] + 1 - c0.end),
+                      (uint32_t)(c0.end - c0.start + 1),
+                      (uint8_t)c0.mapq,
+                      (uint8_t)(c0.direction == 1 ? 1 : 0),
+                      1,
+                      tags};
+  }
+  *out_ref_bucket = 0;
+  return PAFMapping{read_id, read_name, read_length, 0, 0, 0, 0, 61, 0, 1, tags};
+}
+}  // namespace sigmap

@@ -1,0 +1,39 @@
+// mapping_logic.h -- the per-read control logic of Sigmap::StreamingMap that stays on the
+// host (sigmap.cc:631-866): early-stop test after each chunk, output test, coordinates,
+// tag string.  Inputs are the device results of include/sigmap_hip.h.
+#ifndef SIGMAP_AMD_MAPPINGLOGIC_H_
+#define SIGMAP_AMD_MAPPINGLOGIC_H_
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sigmap_hip.h"
+#include "output_tools.h"
+
+namespace sigmap {
+struct MappingParams {  // CLI defaults, sigmap.cc:1380-1419
+  float search_radius = 0.08f;
+  int read_seeding_step_size = 2;
+  int max_num_chunks = 30;
+  int stop_mapping_min_num_anchors = 10;
+  int output_mapping_min_num_anchors = 10;
+  float stop_mapping_ratio = 1.4f;
+  float output_mapping_ratio = 1.2f;
+  float stop_mapping_mean_ratio = 5;
+  float output_mapping_mean_ratio = 5;
+};
+
+// true = stop feeding chunks of this read (sigmap.cc:667-687).  Only meaningful when the
+// chunk produced more than 50 features (the caller checks n_features like sigmap.cc:660).
+bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p);
+
+// Build the PAF record after the last processed chunk (sigmap.cc:690-865).
+// chunk_index = index of the last chunk counted the way the reference counts it
+// (sigmap.cc:690-693), num_events = features consumed over all chunks with > 50 features.
+// include_time_tag: prepend "mt:f:<ms>" like the reference (wall clock; excluded from parity).
+PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std::string &read_name,
+                       uint32_t read_length, uint32_t chunk_index, uint32_t num_events,
+                       const std::vector<uint32_t> &ref_lengths, const MappingParams &p,
+                       bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket);
+}  // namespace sigmap
+#endif

@@ -1,0 +1,125 @@
+#include "signal_batch.h"
+
+#include <dirent.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "utils.h"
+
+namespace sigmap {
+void SignalBatch::AddSignal(const std::string &id, float digitisation, float range, float offset,
+                            const int16_t *raw, size_t n_raw) {
+  Signal s;
+  s.id = id;
+  s.digitisation = digitisation;
+  s.range = range;
+  s.offset = offset;
+  s.signal_values.reserve(n_raw);
+  const float scale = range / digitisation;
+  for (size_t i = 0; i < n_raw; ++i) {
+    const float pa = ((float)raw[i] + offset) * scale;
+    if (pa > 30 && pa < 200) s.signal_values.push_back(pa);
+  }
+  signals_.push_back(std::move(s));
+}
+
+void SignalBatch::AddSignalsFromSGR(const std::string &path) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) ExitWithMessage("Cannot open signal file " + path);
+  char magic[4];
+  uint32_t n = 0;
+  if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "SGR1", 4) != 0 || fread(&n, 4, 1, f) != 1)
+    ExitWithMessage("Not an SGR1 signal file: " + path);
+  std::vector<int16_t> raw;
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t id_len = 0, n_raw = 0;
+    float dig = 0, range = 0, offset = 0;
+    if (fread(&id_len, 4, 1, f) != 1) ExitWithMessage("Truncated signal file " + path);
+    std::string id(id_len, '\0');
+    if (fread(&id[0], 1, id_len, f) != id_len || fread(&dig, 4, 1, f) != 1 ||
+        fread(&range, 4, 1, f) != 1 || fread(&offset, 4, 1, f) != 1 || fread(&n_raw, 4, 1, f) != 1)
+      ExitWithMessage("Truncated signal file " + path);
+    raw.resize(n_raw);
+    if (fread(raw.data(), 2, n_raw, f) != n_raw) ExitWithMessage("Truncated signal file " + path);
+    AddSignal(id, dig, range, offset, raw.data(), n_raw);
+  }
+  fclose(f);
+}
+
+bool SignalBatch::WriteSGR(const std::string &path, const std::vector<std::string> &ids,
+                           float digitisation, float range, float offset,
+                           const std::vector<std::vector<int16_t>> &raws) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const uint32_t n = (uint32_t)ids.size();
+  fwrite("SGR1", 1, 4, f);
+  fwrite(&n, 4, 1, f);
+  for (uint32_t r = 0; r < n; ++r) {
+    const uint32_t id_len = (uint32_t)ids[r].size(), n_raw = (uint32_t)raws[r].size();
+    fwrite(&id_len, 4, 1, f);
+    fwrite(ids[r].data(), 1, id_len, f);
+    fwrite(&digitisation, 4, 1, f);
+    fwrite(&range, 4, 1, f);
+    fwrite(&offset, 4, 1, f);
+    fwrite(&n_raw, 4, 1, f);
+    fwrite(raws[r].data(), 2, n_raw, f);
+  }
+  return fclose(f) == 0;
+}
+
+size_t SignalBatch::LoadAllReadSignals() {
+  const double t0 = GetRealTime();
+  std::vector<std::string> files;
+  DIR *dir = opendir(signal_directory_.c_str());
+  if (dir) {
+    struct dirent *ent;
+    while ((ent = readdir(dir)) != nullptr) {
+      const std::string name = ent->d_name;
+      if (name.size() > 4 && name.compare(name.size() - 4, 4, ".sgr") == 0)
+        files.push_back(signal_directory_ + "/" + name);
+      else if (name.find(".fast5") != std::string::npos || name.find(".blow5") != std::string::npos ||
+               name.find(".slow5") != std::string::npos)
+        std::cerr << "Skipping " << name << ": FAST5/BLOW5 ingestion is not built (use .sgr).\n";
+    }
+    closedir(dir);
+    std::sort(files.begin(), files.end());
+  } else {
+    files.push_back(signal_directory_);  // a single file
+  }
+  for (const auto &p : files) AddSignalsFromSGR(p);
+  std::cerr << "Loaded " << signals_.size() << " reads in " << GetRealTime() - t0 << "s.\n";
+  return signals_.size();
+}
+
+void SignalBatch::ConvertSequencesToSignals(const SequenceBatch &sequence_batch,
+                                            const PoreModel &pore_model, size_t num_sequences) {
+  const double t0 = GetRealTime();
+  for (size_t i = 0; i < num_sequences; ++i) {
+    const size_t len = sequence_batch.GetSequenceLengthAt(i);
+    Signal s;
+    s.id = sequence_batch.GetSequenceNameAt(i);
+    s.signal_values = pore_model.GetLevelMeansAt(sequence_batch.GetSequenceAt(i), 0, (uint32_t)len);
+    s.negative_signal_values =
+        pore_model.GetLevelMeansAt(sequence_batch.GetNegativeSequenceAt(i).c_str(), 0, (uint32_t)len);
+    signals_.push_back(std::move(s));
+  }
+  std::cerr << "Convert " << num_sequences << " sequences to signals in " << GetRealTime() - t0
+            << "s.\n";
+}
+
+float ZscoreNormalize(const float *x, size_t n, std::vector<float> &out) {
+  double mean = 0;
+  for (size_t i = 0; i < n; ++i) mean += x[i];
+  mean /= n;
+  double SD = 0;
+  for (size_t i = 0; i < n; ++i) SD += (x[i] - mean) * (x[i] - mean);
+  SD /= (n - 1);
+  SD = sqrt(SD);
+  out.reserve(out.size() + n);
+  for (size_t i = 0; i < n; ++i) out.push_back((float)((x[i] - mean) / SD));
+  return (float)SD;
+}
+}  // namespace sigmap

@@ -1,0 +1,58 @@
+// signal_batch.h -- raw-signal container (API of the reference's SignalBatch/Signal,
+// signal_batch.h:14-57: InitializeLoading, LoadAllReadSignals, GetSignalAt,
+// GetSignalNameAt, GetSignalLengthAt, FinalizeLoading, ConvertSequencesToSignals).
+//
+// On-disk read container: this build's own flat format (".sgr", below).  FAST5 / BLOW5
+// ingestion is the reference's third-party I/O layer (hdf5_tools.hpp, slow5lib) and is a
+// "next" row of the scope table; the pA conversion and (30,200) pA
+// filter that define what the hot path sees are implemented here.
+//
+//   .sgr : "SGR1" | u32 n_reads | n_reads x { u32 id_len | id bytes | f32 digitisation |
+//          f32 range | f32 offset | u32 n_raw | i16 raw[n_raw] }       (little endian)
+#ifndef SIGMAP_AMD_SIGNALBATCH_H_
+#define SIGMAP_AMD_SIGNALBATCH_H_
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pore_model.h"
+#include "sequence_batch.h"
+
+namespace sigmap {
+struct Signal {
+  std::string id;
+  float digitisation = 0, range = 0, offset = 0;
+  std::vector<float> signal_values;           // pA, filtered
+  std::vector<float> negative_signal_values;  // reference minus strand only
+  size_t GetSignalLength() const { return signal_values.size(); }
+};
+
+class SignalBatch {
+ public:
+  void InitializeLoading(const std::string &signal_directory) { signal_directory_ = signal_directory; }
+  void FinalizeLoading() {}
+  size_t LoadAllReadSignals();  // every *.sgr under the directory (or the file itself)
+  // pA = (raw + offset) * (range / digitisation); kept iff 30 < pA < 200
+  void AddSignal(const std::string &id, float digitisation, float range, float offset,
+                 const int16_t *raw, size_t n_raw);
+  void AddSignalsFromSGR(const std::string &path);
+  static bool WriteSGR(const std::string &path, const std::vector<std::string> &ids,
+                       float digitisation, float range, float offset,
+                       const std::vector<std::vector<int16_t>> &raws);
+  void ConvertSequencesToSignals(const SequenceBatch &sequence_batch, const PoreModel &pore_model,
+                                 size_t num_sequences);
+  size_t GetNumSignals() const { return signals_.size(); }
+  const Signal &GetSignalAt(size_t i) const { return signals_[i]; }
+  const char *GetSignalNameAt(size_t i) const { return signals_[i].id.data(); }
+  size_t GetSignalLengthAt(size_t i) const { return signals_[i].signal_values.size(); }
+
+ protected:
+  std::string signal_directory_;
+  std::vector<Signal> signals_;
+};
+
+// (x - mean) / SD with mean and SD = sqrt(sum((x-mean)^2)/(n-1)) accumulated in double in
+// index order, narrowed to float (Sigmap::GenerateZscoreNormalizedSignal, sigmap.cc:1131-1155).
+float ZscoreNormalize(const float *x, size_t n, std::vector<float> &out);
+}  // namespace sigmap
+#endif

@@ -1,0 +1,209 @@
+"""Host-side driver objects over the C ABI: HostIndex (CPU index build / files) and
+DeviceMapper (one GPU context: index upload, batch map).  Plumbing only."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import ptr
+
+
+class HostIndex:
+    """smhost_index wrapper (Sigmap::ConstructIndex / SpatialIndex::{Load,Save})."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("host index construction failed")
+        self._h = C.c_void_p(handle)
+        v = _abi.IndexView()
+        if _abi.host_lib().smhost_index_get(self._h, C.byref(v)) != 0:
+            raise RuntimeError("smhost_index_get failed")
+        self.dim, self.max_leaf, self.depth = v.dim, v.max_leaf, v.depth
+        self.n_points, self.m_size, self.n_nodes = v.n_points, v.m_size, v.n_nodes
+        as_np = np.ctypeslib.as_array
+        self.values = as_np(v.values, shape=(self.n_points,))
+        self.positions = as_np(v.positions, shape=(self.n_points,))
+        self.vind = as_np(v.vind, shape=(self.m_size,))
+        self.nodes = np.frombuffer(
+            (C.c_char * (16 * self.n_nodes)).from_address(C.addressof(v.nodes.contents)),
+            dtype=_abi.NODE_DTYPE)
+        self.bbox = as_np(v.bbox, shape=(2 * self.dim,))
+
+    @classmethod
+    def build(cls, genome, level_means, k=6, dim=6, max_leaf=20, threads=0):
+        L = _abi.host_lib()
+        arr = (C.c_char_p * len(genome))(*genome)
+        lens = np.array([len(g) for g in genome], dtype=np.uint32)
+        lm = np.ascontiguousarray(level_means, dtype=np.float32)
+        return cls(L.smhost_index_build(ptr(lm), k, arr, ptr(lens), len(genome), dim, max_leaf, threads))
+
+    @classmethod
+    def from_points(cls, positions, values, dim=6, max_leaf=20, threads=0):
+        p = np.ascontiguousarray(positions, dtype=np.uint64)
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        return cls(_abi.host_lib().smhost_index_from_points(ptr(p), ptr(v), len(v), dim, max_leaf, threads))
+
+    @classmethod
+    def load(cls, prefix):
+        return cls(_abi.host_lib().smhost_index_load(prefix.encode()))
+
+    def save(self, prefix):
+        if _abi.host_lib().smhost_index_save(self._h, prefix.encode()) != 0:
+            raise RuntimeError("smhost_index_save failed")
+
+    def close(self):
+        if self._h:
+            _abi.host_lib().smhost_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def raw_to_pa(raw, digitisation, rng, offset):
+    """SignalBatch::AddSignal conversion + (30,200) pA filter for one read."""
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    out = np.empty(len(raw), dtype=np.float32)
+    n = _abi.host_lib().smhost_raw_to_pa(ptr(raw), len(raw), digitisation, rng, offset, ptr(out))
+    return out[:n]
+
+
+def default_params():
+    p = _abi.Params()
+    _abi.hip_lib().smhip_default_params(C.byref(p))
+    return p
+
+
+class DeviceMapper:
+    """One GPU context (smhip_ctx).  Raises if the HIP library or a GPU is missing."""
+
+    def __init__(self, device=0):
+        self.L = _abi.hip_lib()
+        h = C.c_void_p()
+        rc = self.L.smhip_init(device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"smhip_init(device={device}) failed with {rc}: no usable MI355X GPU")
+        self._h = h
+        self.params = default_params()
+        self.n_chunks = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.L.smhip_last_error(self._h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def upload_index(self, ix: HostIndex):
+        self._check(self.L.smhip_index_upload(self._h, ix.dim, ptr(ix.values), ptr(ix.positions),
+                                              ix.n_points, ptr(ix.vind), ix.m_size, ptr(ix.nodes),
+                                              ix.n_nodes, ptr(ix.bbox)), "smhip_index_upload")
+
+    def export_index(self):
+        d = _abi.IndexDev()
+        self._check(self.L.smhip_index_export(self._h, C.byref(d)), "smhip_index_export")
+        return d
+
+    def attach_index(self, d):
+        self._check(self.L.smhip_index_attach(self._h, C.byref(d)), "smhip_index_attach")
+
+    def upload_batch(self, samples, offsets, query_start_offsets=None, carried=None, carried_offsets=None):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        self.n_chunks = len(offsets) - 1
+        qs = None if query_start_offsets is None else np.ascontiguousarray(query_start_offsets, dtype=np.uint32)
+        ca = None if carried is None else np.ascontiguousarray(carried, dtype=_abi.CARRIED_DTYPE)
+        co = None if carried_offsets is None else np.ascontiguousarray(carried_offsets, dtype=np.uint32)
+        self._check(self.L.smhip_batch_upload(self._h, ptr(samples), ptr(offsets), self.n_chunks,
+                                              ptr(qs), ptr(ca), ptr(co)), "smhip_batch_upload")
+
+    def run(self, n_refs):
+        self._check(self.L.smhip_map_run(self._h, C.byref(self.params), n_refs), "smhip_map_run")
+
+    def sync(self):
+        self._check(self.L.smhip_map_sync(self._h), "smhip_map_sync")
+
+    def download(self, with_anchors=False):
+        res = np.zeros(self.n_chunks, dtype=_abi.RESULT_DTYPE)
+        if not with_anchors:
+            self._check(self.L.smhip_map_download(self._h, ptr(res), None, 0, None), "smhip_map_download")
+            return res
+        cap = int(1 << 22)
+        while True:
+            anchors = np.zeros(cap, dtype=_abi.CARRIED_DTYPE)
+            offs = np.zeros(self.n_chunks + 1, dtype=np.uint64)
+            rc = self.L.smhip_map_download(self._h, ptr(res), ptr(anchors), cap, ptr(offs))
+            if rc == -5 and cap < (1 << 30):
+                cap *= 4
+                continue
+            self._check(rc, "smhip_map_download")
+            return res, anchors[:int(offs[-1])], offs
+
+    def map_chunks(self, samples, offsets, n_refs, **kw):
+        self.upload_batch(samples, offsets, **kw)
+        self.run(n_refs)
+        self.sync()
+        return self.download()
+
+    def timing(self, enable=True):
+        self._check(self.L.smhip_timing_enable(self._h, 1 if enable else 0), "smhip_timing_enable")
+
+    def timing_reset(self):
+        self._check(self.L.smhip_timing_reset(self._h), "smhip_timing_reset")
+
+    def timing_get(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.smhip_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)), "smhip_timing_get")
+        return ms.value, n.value
+
+    def events(self, samples, offsets, feat_stride=2672):
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        n = len(offsets) - 1
+        feat = np.zeros((n, feat_stride), dtype=np.float32)
+        stdv = np.zeros((n, feat_stride), dtype=np.float32)
+        nf = np.zeros(n, dtype=np.uint32)
+        ne = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint32)
+        self._check(self.L.smhip_events(self._h, C.byref(self.params), ptr(samples), ptr(offsets), n,
+                                        feat_stride, ptr(feat), ptr(stdv), ptr(nf), ptr(ne), ptr(st)),
+                    "smhip_events")
+        return feat, stdv, nf, ne, st
+
+    def seed_lookup(self, queries, cap=512):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        n = q.shape[0]
+        counts = np.zeros(n, dtype=np.uint32)
+        idx = np.zeros((n, cap), dtype=np.uint64)
+        dist = np.zeros((n, cap), dtype=np.float32)
+        nodes = np.zeros(n, dtype=np.uint64)
+        pts = np.zeros(n, dtype=np.uint64)
+        self._check(self.L.smhip_seed_lookup(self._h, C.byref(self.params), ptr(q), n, cap, ptr(counts),
+                                             ptr(idx), ptr(dist), ptr(nodes), ptr(pts)), "smhip_seed_lookup")
+        return counts, idx, dist, nodes, pts
+
+    def sdtw_banded(self, target, t_off, query, q_off, lo, hi):
+        target = np.ascontiguousarray(target, dtype=np.float32)
+        query = np.ascontiguousarray(query, dtype=np.float32)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        lo = np.ascontiguousarray(lo, dtype=np.uint32)
+        hi = np.ascontiguousarray(hi, dtype=np.uint32)
+        n = len(t_off) - 1
+        dist = np.zeros(n, dtype=np.float32)
+        end = np.zeros(n, dtype=np.int64)
+        self._check(self.L.smhip_sdtw_banded(self._h, ptr(target), ptr(t_off), ptr(query), ptr(q_off),
+                                             ptr(lo), ptr(hi), n, ptr(dist), ptr(end)), "smhip_sdtw_banded")
+        return dist, end
+
+    def close(self):
+        if self._h:
+            self.L.smhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
