@@ -1,0 +1,42 @@
+# Top-level build: host library (g++), HIP library (hipcc, gfx950 only), CLI, oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+HOSTFLAGS = -std=c++17 -O2 -ffp-contract=off -fopenmp -fPIC -Wall
+
+LIBDIR = sigmap_amd/lib
+CSRC = sigmap_amd/csrc
+HOST = sigmap_amd/host
+HIP_SRCS = $(CSRC)/api.hip $(CSRC)/events.hip $(CSRC)/seed_lookup.hip $(CSRC)/sort.hip $(CSRC)/chain.hip $(CSRC)/sdtw.hip
+HIP_OBJS = $(HIP_SRCS:$(CSRC)/%.hip=build/%.o)
+HOST_SRCS = $(HOST)/kdtree.cc $(HOST)/pore_model.cc $(HOST)/sequence_batch.cc $(HOST)/signal_batch.cc \
+            $(HOST)/spatial_index.cc $(HOST)/mapping_logic.cc $(HOST)/host_abi.cc
+
+all: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so oracle
+
+$(LIBDIR)/libsigmap_host.so: $(HOST_SRCS) $(wildcard $(HOST)/*.h) include/sigmap_host.h include/sigmap_hip.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -lz
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sigmap_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libsigmap_hip.so: $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+
+cli: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so
+	@mkdir -p sigmap_amd/bin
+	$(HIPCC) -std=c++17 -O2 -ffp-contract=off -fopenmp -o sigmap_amd/bin/sigmap $(HOST)/sigmap.cc \
+	   -L$(LIBDIR) -lsigmap_host -lsigmap_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIBDIR)/*.so sigmap_amd/bin
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean cli

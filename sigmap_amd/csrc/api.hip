@@ -1,0 +1,669 @@
+// api.hip -- the C ABI of include/sigmap_hip.h: context, index residency, batch staging,
+// kernel sequencing, timing.  Host code only (compiled by hipcc for the runtime API).
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+using namespace smhip;
+
+namespace {
+const char *kTimerNames[] = {"events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw"};
+enum { T_EVENTS = 0, T_SEED, T_OVF, T_SORT, T_CHAIN, T_SDTW, T_COUNT };
+
+int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
+  return Fail(ctx, e == hipErrorOutOfMemory ? SMHIP_ENOMEM : SMHIP_EHIP,
+              std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(expr)                                   \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return HipFail(ctx, _e, #expr); \
+  } while (0)
+
+struct ScopedTimer {  // brackets one kernel with HIP events on the context stream
+  smhip_ctx *ctx;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(smhip_ctx *c, int i) : ctx(c), id(i) {
+    if (!ctx->timing) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!ctx->event_pool.empty()) {
+        e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ScopedTimer() {
+    if (!ctx->timing) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({id, a, b});
+  }
+};
+
+void ResolveTimers(smhip_ctx *ctx) {
+  for (auto &p : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->timers[p.timer].total_ms += ms;
+      ctx->timers[p.timer].launches += 1;
+    }
+    ctx->event_pool.push_back(p.a);
+    ctx->event_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+
+__global__ void HitsToArraysKernel(const Hit *__restrict__ region, const uint32_t *__restrict__ counts,
+                                   uint32_t n, uint32_t cap, const uint32_t *__restrict__ leaf_vind,
+                                   uint64_t *__restrict__ idx, float *__restrict__ dist) {
+  const uint64_t total = (uint64_t)n * cap;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t q = (uint32_t)(i / cap), k = (uint32_t)(i % cap);
+    if (k < counts[q]) {
+      const Hit h = region[i];
+      idx[i] = leaf_vind[h.slot];
+      dist[i] = h.dist;
+    }
+  }
+}
+
+__global__ void CompactAnchorsKernel(const smhip_carried_anchor *__restrict__ src,
+                                     const uint64_t *__restrict__ anchor_off,
+                                     const uint64_t *__restrict__ out_off, smhip_carried_anchor *__restrict__ dst) {
+  const uint32_t c = blockIdx.x;
+  const uint64_t b = anchor_off[c], o = out_off[c];
+  const uint32_t n = (uint32_t)(out_off[c + 1] - o);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[o + i] = src[b + i];
+}
+
+__global__ void OrStatusKernel(smhip_chunk_result *results, uint32_t n, const uint32_t *counters) {
+  uint32_t bits = 0;
+  if (counters[0]) bits |= SMHIP_ST_STACK_FULL;
+  if (counters[3]) bits |= SMHIP_ST_HIT_POOL_FULL;
+  if (!bits) return;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    results[i].status |= bits;
+}
+}  // namespace
+
+extern "C" {
+
+void smhip_default_params(smhip_params *p) {
+  memset(p, 0, sizeof *p);
+  p->window_length1 = 3;  // event.h:31-37
+  p->window_length2 = 6;
+  p->threshold1 = 4.30265f;
+  p->threshold2 = 2.57058f;
+  p->peak_height = 1.0f;
+  p->compress_delta = 0.1;   // sigmap.cc:1075
+  p->min_num_events = 50;    // sigmap.cc:660
+  p->search_radius = 0.08f;  // sigmap.cc:1380
+  p->step_size = 2;          // sigmap.cc:1384
+  p->max_gap_length = 2000;  // spatial_index.cc:284-291
+  p->max_target_gap_length = 5000;
+  p->chaining_band_length = 5000;
+  p->max_num_skips = 25;
+  p->min_num_anchors = 2;
+  p->num_best_chains = 3;
+  p->num_nearest_points = 5000;
+  p->min_chaining_score = 10;
+  p->hits_per_query_fast = 128;
+  p->lanes_per_query = 16;
+}
+
+int smhip_init(int device_ordinal, smhip_ctx **out) {
+  if (!out) return SMHIP_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SMHIP_EHIP;
+  if (device_ordinal < 0 || device_ordinal >= n) return SMHIP_EINVAL;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return SMHIP_EHIP;
+  smhip_ctx *ctx = new smhip_ctx;
+  ctx->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return SMHIP_EHIP;
+  }
+  ctx->timers.resize(T_COUNT);
+  for (int i = 0; i < T_COUNT; ++i) ctx->timers[i].name = kTimerNames[i];
+  *out = ctx;
+  return SMHIP_OK;
+}
+
+void smhip_destroy(smhip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->ix_pos, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+                    &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
+                    &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
+                    &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
+                    &ctx->ovf_pool, &ctx->counters, &ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp,
+                    &ctx->keys, &ctx->s_tpos, &ctx->s_qpos, &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred,
+                    &ctx->used, &ctx->group_start, &ctx->chain_tmp, &ctx->chain_cnt, &ctx->out_anchors,
+                    &ctx->out_anchor_cnt};
+  for (DevBuf *b : bufs) b->Free();
+  for (auto &p : ctx->pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *smhip_last_error(smhip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+void *smhip_stream(smhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
+                       uint64_t n_points, const uint32_t *vind, uint64_t m_size, const smhip_node *nodes,
+                       uint64_t n_nodes, const float *root_bbox) {
+  if (!ctx || !values || !positions || !vind || !nodes || !root_bbox) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
+  if (n_points < (uint64_t)dim || m_size != n_points - dim + 1 || n_nodes == 0 || n_nodes > 0xFFFFFFFFull)
+    return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->ix_nodes.Reserve(n_nodes * sizeof(smhip_node)));
+  HIPCHK(ctx->ix_pts.Reserve(m_size * dim * sizeof(float)));
+  HIPCHK(ctx->ix_pos.Reserve(m_size * sizeof(uint64_t)));
+  HIPCHK(ctx->ix_vind.Reserve(m_size * sizeof(uint32_t)));
+  HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
+  // staging copies of the original-order point cloud, freed after the leaf-major gather
+  DevBuf d_values, d_positions;
+  HIPCHK(d_values.Reserve(n_points * sizeof(float)));
+  hipError_t e = d_positions.Reserve(n_points * sizeof(uint64_t));
+  if (e != hipSuccess) {
+    d_values.Free();
+    return HipFail(ctx, e, "staging allocation");
+  }
+  auto cleanup = [&]() {
+    d_values.Free();
+    d_positions.Free();
+  };
+#define HIPCHK2(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) {                            \
+      cleanup();                                       \
+      return HipFail(ctx, _e, #expr);                  \
+    }                                                  \
+  } while (0)
+  HIPCHK2(hipMemcpyAsync(d_values.p, values, n_points * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(d_positions.p, positions, n_points * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_vind.p, vind, m_size * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, nodes, n_nodes * sizeof(smhip_node), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_bbox.p, root_bbox, 2 * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), ctx->ix_vind.as<uint32_t>(),
+                           m_size, ctx->ix_pts.as<float>(), ctx->ix_pos.as<uint64_t>()));
+  HIPCHK2(hipStreamSynchronize(ctx->stream));
+#undef HIPCHK2
+  cleanup();
+  ctx->dim = dim;
+  ctx->index = IndexView{ctx->ix_nodes.as<smhip_node>(), ctx->ix_pts.as<float>(), ctx->ix_pos.as<uint64_t>(),
+                         ctx->ix_vind.as<uint32_t>(), ctx->ix_bbox.as<float>(), n_nodes, m_size};
+  ctx->have_index = true;
+  ctx->index_owned = true;
+  return SMHIP_OK;
+}
+
+int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
+  if (!ctx || !out) return SMHIP_EINVAL;
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "no index resident");
+  memset(out, 0, sizeof *out);
+  out->dim = ctx->dim;
+  out->n_nodes = ctx->index.n_nodes;
+  out->m_size = ctx->index.m_size;
+  out->nodes = (void *)ctx->index.nodes;
+  out->nodes_bytes = ctx->index.n_nodes * sizeof(smhip_node);
+  out->leaf_pts = (void *)ctx->index.leaf_pts;
+  out->leaf_pts_bytes = ctx->index.m_size * ctx->dim * sizeof(float);
+  out->leaf_pos = (void *)ctx->index.leaf_pos;
+  out->leaf_pos_bytes = ctx->index.m_size * sizeof(uint64_t);
+  out->leaf_vind = (void *)ctx->index.leaf_vind;
+  out->leaf_vind_bytes = ctx->index.m_size * sizeof(uint32_t);
+  out->bbox = (void *)ctx->index.bbox;
+  out->bbox_bytes = 2 * ctx->dim * sizeof(float);
+  return SMHIP_OK;
+}
+
+int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
+  if (!ctx || !in) return SMHIP_EINVAL;
+  if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
+  if (!in->nodes || !in->leaf_pts || !in->leaf_pos || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
+    return Fail(ctx, SMHIP_EINVAL, "null index array");
+  if (in->nodes_bytes < in->n_nodes * sizeof(smhip_node) || in->leaf_pts_bytes < in->m_size * 6 * sizeof(float) ||
+      in->leaf_pos_bytes < in->m_size * 8 || in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
+    return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");
+  ctx->dim = in->dim;
+  ctx->index = IndexView{(const smhip_node *)in->nodes, (const float *)in->leaf_pts, (const uint64_t *)in->leaf_pos,
+                         (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->m_size};
+  ctx->have_index = true;
+  ctx->index_owned = false;
+  return SMHIP_OK;
+}
+
+int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                       const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                       const uint32_t *carried_offsets) {
+  if (!ctx || !samples_pa || !sample_offsets) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if ((carried == nullptr) != (carried_offsets == nullptr))
+    return Fail(ctx, SMHIP_EINVAL, "carried and carried_offsets must be given together");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    if (sample_offsets[c + 1] < sample_offsets[c]) return Fail(ctx, SMHIP_EINVAL, "sample offsets must be non-decreasing");
+    if (sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kMaxSamples)
+      return Fail(ctx, SMHIP_EINVAL, "a chunk exceeds 4096 samples (reference chunk size is 4000, sigmap.cc:639)");
+  }
+  const uint64_t n_samples = n_chunks ? sample_offsets[n_chunks] : 0;
+  const uint64_t n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
+  HIPCHK(ctx->samples.Reserve(std::max<uint64_t>(n_samples, 1) * sizeof(float)));
+  HIPCHK(ctx->sample_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->qstart.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->carried_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->carried.Reserve(std::max<uint64_t>(n_carried, 1) * sizeof(smhip_carried_anchor)));
+  HIPCHK(hipMemcpyAsync(ctx->samples.p, samples_pa, n_samples * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->sample_off.p, sample_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
+                        hipMemcpyHostToDevice, ctx->stream));
+  if (query_start_offsets)
+    HIPCHK(hipMemcpyAsync(ctx->qstart.p, query_start_offsets, (uint64_t)n_chunks * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, ctx->stream));
+  else
+    HIPCHK(hipMemsetAsync(ctx->qstart.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  if (carried) {
+    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, carried_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->carried.p, carried, n_carried * sizeof(smhip_carried_anchor), hipMemcpyHostToDevice,
+                          ctx->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->carried_off.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are caller-owned: safe to reuse on return
+  ctx->n_chunks = n_chunks;
+  ctx->n_samples = n_samples;
+  ctx->n_carried = n_carried;
+  ctx->batch_ready = true;
+  ctx->run_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
+  if (!ctx || !p) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before an index is resident");
+  if (!ctx->batch_ready) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before smhip_batch_upload");
+  if (n_refs == 0 || p->step_size < 1 || p->hits_per_query_fast == 0 || p->num_nearest_points < 1 ||
+      p->num_best_chains > 3)
+    return Fail(ctx, SMHIP_EINVAL, "bad parameter");
+  if (p->lanes_per_query != 8 && p->lanes_per_query != 16 && p->lanes_per_query != 32 && p->lanes_per_query != 64)
+    return Fail(ctx, SMHIP_EINVAL, "lanes_per_query must be 8, 16, 32 or 64");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  ctx->run_done = false;
+  if (R == 0) {
+    ctx->run_done = true;
+    return SMHIP_OK;
+  }
+  HIPCHK(ctx->feat.Reserve((uint64_t)R * kFeatStride * sizeof(float)));
+  HIPCHK(ctx->results.Reserve((uint64_t)R * sizeof(smhip_chunk_result)));
+  HIPCHK(ctx->nq.Reserve((uint64_t)R * sizeof(uint32_t)));
+  HIPCHK(ctx->q_off.Reserve(((uint64_t)R + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->chunk_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
+  HIPCHK(ctx->anchor_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t)));
+  HIPCHK(ctx->n_groups.Reserve((uint64_t)R * sizeof(uint32_t)));
+  HIPCHK(ctx->chain_tmp.Reserve((uint64_t)R * kChainCap * sizeof(ChainTmp)));
+  HIPCHK(ctx->out_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
+  HIPCHK(ctx->counters.Reserve(16 * sizeof(uint32_t)));
+  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+  {
+    ScopedTimer t(ctx, T_EVENTS);
+    HIPCHK(LaunchEvents(ctx, *p, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), R, kFeatStride,
+                        ctx->feat.as<float>(), nullptr, results, ctx->nq.as<uint32_t>()));
+  }
+  HIPCHK(LaunchScanU32(ctx, ctx->nq.as<uint32_t>(), R, ctx->q_off.as<uint32_t>()));
+  uint32_t NQ = 0;
+  HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
+  HIPCHK(ctx->q_count.Reserve(nq_cap * sizeof(uint32_t)));
+  HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * sizeof(uint32_t)));
+  HIPCHK(ctx->ovf_list.Reserve(nq_cap * sizeof(uint32_t)));
+  HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
+  const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 32 + (1u << 20), 0xFFFF0000ull);
+  HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
+  HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+  {
+    ScopedTimer t(ctx, T_SEED);
+    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R,
+                            ctx->region.as<Hit>(), ctx->q_count.as<uint32_t>(), results,
+                            ctx->counters.as<uint32_t>()));
+  }
+  {
+    ScopedTimer t(ctx, T_OVF);
+    HIPCHK(LaunchSeedOverflow(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R,
+                              ctx->q_count.as<uint32_t>(), ctx->q_ovf_off.as<uint32_t>(),
+                              ctx->ovf_list.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), pool_cap, results,
+                              ctx->counters.as<uint32_t>(), nq_cap));
+  }
+  HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
+                           ctx->carried_off.as<uint32_t>(), R, ctx->chunk_anchor_cnt.as<uint32_t>()));
+  HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
+  uint64_t NA = 0;
+  HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t na = std::max<uint64_t>(NA, 1);
+  DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
+                  &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};
+  for (DevBuf *b : b4) HIPCHK(b->Reserve(na * 4));
+  HIPCHK(ctx->keys.Reserve(na * 2 * sizeof(uint64_t)));
+  HIPCHK(ctx->used.Reserve(na));
+  HIPCHK(ctx->out_anchors.Reserve(na * sizeof(smhip_carried_anchor)));
+  SortArgs sa;
+  sa.q_off = ctx->q_off.as<uint32_t>();
+  sa.q_count = ctx->q_count.as<uint32_t>();
+  sa.q_ovf_off = ctx->q_ovf_off.as<uint32_t>();
+  sa.qstart = ctx->qstart.as<uint32_t>();
+  sa.carried_off = ctx->carried_off.as<uint32_t>();
+  sa.carried = ctx->carried.as<smhip_carried_anchor>();
+  sa.region = ctx->region.as<Hit>();
+  sa.ovf_pool = ctx->ovf_pool.as<Hit>();
+  sa.anchor_off = ctx->anchor_off.as<uint64_t>();
+  sa.fast_cap = p->hits_per_query_fast;
+  sa.nnp = (uint32_t)p->num_nearest_points;
+  sa.step = (uint32_t)p->step_size;
+  sa.n_refs = n_refs;
+  sa.a_tpos = ctx->a_tpos.as<uint32_t>();
+  sa.a_qpos = ctx->a_qpos.as<uint32_t>();
+  sa.a_grp = ctx->a_grp.as<uint32_t>();
+  sa.a_dist = ctx->a_dist.as<float>();
+  sa.keys = ctx->keys.as<uint64_t>();
+  sa.s_tpos = ctx->s_tpos.as<uint32_t>();
+  sa.s_qpos = ctx->s_qpos.as<uint32_t>();
+  sa.s_grp = ctx->s_grp.as<uint32_t>();
+  sa.s_dist = ctx->s_dist.as<float>();
+  sa.group_start = ctx->group_start.as<uint32_t>();
+  sa.n_groups = ctx->n_groups.as<uint32_t>();
+  sa.results = results;
+  {
+    ScopedTimer t(ctx, T_SORT);
+    HIPCHK(LaunchSort(ctx, sa, R));
+  }
+  ChainArgs ca;
+  ca.anchor_off = sa.anchor_off;
+  ca.s_tpos = sa.s_tpos;
+  ca.s_qpos = sa.s_qpos;
+  ca.s_grp = sa.s_grp;
+  ca.s_dist = sa.s_dist;
+  ca.group_start = sa.group_start;
+  ca.n_groups = sa.n_groups;
+  ca.score = ctx->score.as<float>();
+  ca.pred = ctx->pred.as<uint32_t>();
+  ca.used = ctx->used.as<uint8_t>();
+  ca.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
+  ca.scratch = ctx->keys.as<uint64_t>();
+  ca.results = results;
+  ca.out_anchors = ctx->out_anchors.as<smhip_carried_anchor>();
+  ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();
+  {
+    ScopedTimer t(ctx, T_CHAIN);
+    HIPCHK(LaunchChain(ctx, *p, ca, R));
+  }
+  hipLaunchKernelGGL(OrStatusKernel, dim3(64), dim3(256), 0, ctx->stream, results, R, ctx->counters.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  ctx->run_done = true;
+  return SMHIP_OK;
+}
+
+int smhip_map_sync(smhip_ctx *ctx) {
+  if (!ctx) return SMHIP_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ResolveTimers(ctx);
+  return SMHIP_OK;
+}
+
+int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carried_anchor *chain_anchors,
+                       uint64_t chain_anchor_cap, uint64_t *chain_anchor_offsets) {
+  if (!ctx || !results) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download before smhip_map_run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  if (R == 0) {
+    if (chain_anchor_offsets) chain_anchor_offsets[0] = 0;
+    return SMHIP_OK;
+  }
+  HIPCHK(hipMemcpyAsync(results, ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ResolveTimers(ctx);
+  if (chain_anchors && chain_anchor_offsets) {
+    DevBuf out_off, compact;
+    HIPCHK(out_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t)));
+    hipError_t e = LaunchScanU32ToU64(ctx, ctx->out_anchor_cnt.as<uint32_t>(), R, out_off.as<uint64_t>());
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(chain_anchor_offsets, out_off.p, ((uint64_t)R + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                         ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      out_off.Free();
+      return HipFail(ctx, e, "chain anchor offsets");
+    }
+    const uint64_t total = chain_anchor_offsets[R];
+    if (total > chain_anchor_cap) {
+      out_off.Free();
+      return Fail(ctx, SMHIP_ECAP, "chain_anchor_cap too small");
+    }
+    if (total > 0) {
+      e = compact.Reserve(total * sizeof(smhip_carried_anchor));
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(CompactAnchorsKernel, dim3(R), dim3(64), 0, ctx->stream,
+                           ctx->out_anchors.as<smhip_carried_anchor>(), ctx->anchor_off.as<uint64_t>(),
+                           out_off.as<uint64_t>(), compact.as<smhip_carried_anchor>());
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(chain_anchors, compact.p, total * sizeof(smhip_carried_anchor), hipMemcpyDeviceToHost,
+                           ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    out_off.Free();
+    compact.Free();
+    if (e != hipSuccess) return HipFail(ctx, e, "chain anchor download");
+  }
+  return SMHIP_OK;
+}
+
+int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, const float *samples_pa,
+                     const uint32_t *sample_offsets, uint32_t n_chunks, const uint32_t *query_start_offsets,
+                     const smhip_carried_anchor *carried, const uint32_t *carried_offsets,
+                     smhip_chunk_result *results) {
+  int rc = smhip_batch_upload(ctx, samples_pa, sample_offsets, n_chunks, query_start_offsets, carried, carried_offsets);
+  if (rc) return rc;
+  rc = smhip_map_run(ctx, p, n_refs);
+  if (rc) return rc;
+  rc = smhip_map_sync(ctx);
+  if (rc) return rc;
+  return smhip_map_download(ctx, results, nullptr, 0, nullptr);
+}
+
+int smhip_timing_enable(smhip_ctx *ctx, int on) {
+  if (!ctx) return SMHIP_EINVAL;
+  ctx->timing = on != 0;
+  return SMHIP_OK;
+}
+
+int smhip_timing_reset(smhip_ctx *ctx) {
+  if (!ctx) return SMHIP_EINVAL;
+  for (auto &t : ctx->timers) {
+    t.total_ms = 0;
+    t.launches = 0;
+  }
+  return SMHIP_OK;
+}
+
+int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64_t *launches) {
+  if (!ctx || !kernel || !mean_ms || !launches) return SMHIP_EINVAL;
+  for (auto &t : ctx->timers) {
+    if (t.name == kernel) {
+      *launches = t.launches;
+      *mean_ms = t.launches ? t.total_ms / (double)t.launches : 0.0;
+      return SMHIP_OK;
+    }
+  }
+  return Fail(ctx, SMHIP_EINVAL, "unknown kernel name");
+}
+
+int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa, const uint32_t *sample_offsets,
+                 uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv, uint32_t *n_features,
+                 uint32_t *n_events, uint32_t *status) {
+  if (!ctx || !p || !feat || !n_features) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (feat_stride < (uint32_t)kFeatStride) return Fail(ctx, SMHIP_EINVAL, "feat_stride must be >= 2736");
+  int rc = smhip_batch_upload(ctx, samples_pa, sample_offsets, n_chunks, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (n_chunks == 0) return SMHIP_OK;
+  const uint64_t nf = (uint64_t)n_chunks * feat_stride;
+  HIPCHK(ctx->feat.Reserve(nf * sizeof(float)));
+  HIPCHK(ctx->stdv.Reserve(nf * sizeof(float)));
+  HIPCHK(ctx->results.Reserve((uint64_t)n_chunks * sizeof(smhip_chunk_result)));
+  HIPCHK(ctx->nq.Reserve((uint64_t)n_chunks * sizeof(uint32_t)));
+  {
+    ScopedTimer t(ctx, T_EVENTS);
+    HIPCHK(LaunchEvents(ctx, *p, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), n_chunks, feat_stride,
+                        ctx->feat.as<float>(), ctx->stdv.as<float>(), ctx->results.as<smhip_chunk_result>(),
+                        ctx->nq.as<uint32_t>()));
+  }
+  std::vector<smhip_chunk_result> res(n_chunks);
+  HIPCHK(hipMemcpyAsync(feat, ctx->feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (stdv) HIPCHK(hipMemcpyAsync(stdv, ctx->stdv.p, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(res.data(), ctx->results.p, (uint64_t)n_chunks * sizeof(smhip_chunk_result),
+                        hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ResolveTimers(ctx);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    n_features[c] = res[c].n_features;
+    if (n_events) n_events[c] = res[c].n_events;
+    if (status) status[c] = res[c].status;
+  }
+  ctx->run_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *queries, uint32_t n_queries, uint32_t cap,
+                      uint32_t *counts, uint64_t *point_idx, float *dist, uint64_t *nodes_visited,
+                      uint64_t *points_tested) {
+  if (!ctx || !p || !queries || !counts || !point_idx || !dist || cap == 0)
+    return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_seed_lookup before an index is resident");
+  if (n_queries == 0) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist;
+  const uint64_t total = (uint64_t)n_queries * cap;
+  auto free_all = [&]() {
+    for (DevBuf *b : {&d_q, &d_region, &d_cnt, &d_nodes, &d_pts, &d_idx, &d_dist}) b->Free();
+  };
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  step(d_q.Reserve((uint64_t)n_queries * 6 * sizeof(float)));
+  step(d_region.Reserve(total * sizeof(Hit)));
+  step(d_cnt.Reserve((uint64_t)n_queries * 4));
+  step(d_nodes.Reserve((uint64_t)n_queries * 4));
+  step(d_pts.Reserve((uint64_t)n_queries * 4));
+  step(d_idx.Reserve(total * 8));
+  step(d_dist.Reserve(total * 4));
+  step(ctx->counters.Reserve(16 * sizeof(uint32_t)));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+  if (e == hipSuccess) {
+    ScopedTimer t(ctx, T_SEED);
+    step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, d_region.as<Hit>(), d_cnt.as<uint32_t>(),
+                             d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>()));
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(HitsToArraysKernel, dim3(1024), dim3(256), 0, ctx->stream, d_region.as<Hit>(),
+                       d_cnt.as<uint32_t>(), n_queries, cap, ctx->index.leaf_vind, d_idx.as<uint64_t>(),
+                       d_dist.as<float>());
+    step(hipGetLastError());
+  }
+  std::vector<uint32_t> hn(n_queries), hp(n_queries);
+  uint32_t hc[16] = {0};
+  if (e == hipSuccess) step(hipMemcpyAsync(counts, d_cnt.p, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(point_idx, d_idx.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(dist, d_dist.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(hn.data(), d_nodes.p, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(hp.data(), d_pts.p, (uint64_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipStreamSynchronize(ctx->stream));
+  free_all();
+  if (e != hipSuccess) return HipFail(ctx, e, "smhip_seed_lookup");
+  ResolveTimers(ctx);
+  for (uint32_t i = 0; i < n_queries; ++i) {
+    if (nodes_visited) nodes_visited[i] = hn[i];
+    if (points_tested) points_tested[i] = hp[i];
+  }
+  if (hc[0]) return Fail(ctx, SMHIP_ECAP, "tree walk stack overflow (tree deeper than 64 pending visits)");
+  return SMHIP_OK;
+}
+
+int smhip_sdtw_banded(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
+                      const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n_problems, float *dist,
+                      int64_t *end) {
+  if (!ctx || !target || !t_off || !query || !q_off || !lo || !hi || !dist || !end)
+    return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (n_problems == 0) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t nt = t_off[n_problems], nqv = q_off[n_problems];
+  uint32_t max_t = 0;
+  for (uint32_t i = 0; i < n_problems; ++i) {
+    if (t_off[i + 1] < t_off[i] || q_off[i + 1] < q_off[i]) return Fail(ctx, SMHIP_EINVAL, "offsets must be non-decreasing");
+    max_t = std::max<uint32_t>(max_t, (uint32_t)std::min<uint64_t>(t_off[i + 1] - t_off[i], 0xFFFFFFFFull));
+  }
+  DevBuf d_t, d_q, d_to, d_qo, d_lo, d_hi, d_d, d_e;
+  auto free_all = [&]() {
+    for (DevBuf *b : {&d_t, &d_q, &d_to, &d_qo, &d_lo, &d_hi, &d_d, &d_e}) b->Free();
+  };
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  step(d_t.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_q.Reserve(std::max<uint64_t>(nqv, 1) * 4));
+  step(d_to.Reserve(((uint64_t)n_problems + 1) * 8));
+  step(d_qo.Reserve(((uint64_t)n_problems + 1) * 8));
+  step(d_lo.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_hi.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_d.Reserve((uint64_t)n_problems * 4));
+  step(d_e.Reserve((uint64_t)n_problems * 8));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_t.p, target, nt * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, query, nqv * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_to.p, t_off, ((uint64_t)n_problems + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_qo.p, q_off, ((uint64_t)n_problems + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_lo.p, lo, nt * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_hi.p, hi, nt * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) {
+    ScopedTimer t(ctx, T_SDTW);
+    step(LaunchSdtw(ctx, d_t.as<float>(), d_to.as<uint64_t>(), d_q.as<float>(), d_qo.as<uint64_t>(),
+                    d_lo.as<uint32_t>(), d_hi.as<uint32_t>(), n_problems, d_d.as<float>(), d_e.as<int64_t>(), max_t));
+  }
+  if (e == hipSuccess) step(hipMemcpyAsync(dist, d_d.p, (uint64_t)n_problems * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(end, d_e.p, (uint64_t)n_problems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipStreamSynchronize(ctx->stream));
+  free_all();
+  if (e != hipSuccess) return HipFail(ctx, e, "smhip_sdtw_banded");
+  ResolveTimers(ctx);
+  return SMHIP_OK;
+}
+}  // extern "C"

@@ -1,0 +1,167 @@
+// common.h -- shared declarations of the gfx950 device side (libsigmap_hip.so).
+// Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the FP pin of
+// SURVEY.md section 0.4 applies to device code as well: no FMA contraction).
+#ifndef SIGMAP_AMD_CSRC_COMMON_H_
+#define SIGMAP_AMD_CSRC_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sigmap_hip.h"
+
+namespace smhip {
+
+constexpr int kMaxDim = 6;           // device kernels are specialised for the index dimension 6
+constexpr int kMaxSamples = 4096;    // samples per chunk held in LDS (reference chunk = 4000)
+constexpr int kFeatStride = 2736;    // >= 2/3 * kMaxSamples + 2: upper bound on events per chunk
+constexpr int kStackDepth = 64;      // pending "other child" entries per tree walk
+constexpr int kChainCap = 128;       // candidate chains per chunk before the primary filter
+
+struct Hit {  // 16 B: one radius-search result
+  uint64_t position;  // Point.position of the matched reference window
+  float dist;         // squared L2
+  uint32_t slot;      // index in tree (leaf-major) order
+};
+
+struct ChainTmp {
+  float score;
+  uint32_t ref, start, end, n_anchors, direction;
+  uint32_t end_anchor;  // chunk-local index of the chain's last (highest target) anchor
+};
+
+// Device view of the index (all pointers device memory).
+struct IndexView {
+  const smhip_node *nodes;
+  const float *leaf_pts;      // [m_size][6]
+  const uint64_t *leaf_pos;   // [m_size]
+  const uint32_t *leaf_vind;  // [m_size]
+  const float *bbox;          // [12] low0, high0, ...
+  uint64_t n_nodes, m_size;
+};
+
+// Grow-only device buffer.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t Reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void Free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelTimer {
+  std::string name;
+  double total_ms = 0;
+  uint64_t launches = 0;
+};
+
+}  // namespace smhip
+
+struct smhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // index
+  bool have_index = false, index_owned = false;
+  int dim = 0;
+  smhip::IndexView index{};
+  smhip::DevBuf ix_nodes, ix_pts, ix_pos, ix_vind, ix_bbox;
+  // batch inputs
+  uint32_t n_chunks = 0;
+  uint64_t n_samples = 0, n_carried = 0;
+  bool batch_ready = false, run_done = false;
+  smhip::DevBuf samples, sample_off, qstart, carried, carried_off;
+  // per-chunk intermediates
+  smhip::DevBuf feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
+  // per-query
+  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters;
+  // per-anchor
+  smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
+      group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
+  uint64_t cap_queries = 0, cap_anchors = 0;
+  // host staging
+  std::vector<uint64_t> h_anchor_off;
+  // timing
+  bool timing = false;
+  std::vector<smhip::KernelTimer> timers;
+  struct Pending { int timer; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace smhip {
+// Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
+// launch status.
+hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
+                            const uint32_t *vind, uint64_t m_size, float *leaf_pts, uint64_t *leaf_pos);
+hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
+                        uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
+                        smhip_chunk_result *results, uint32_t *nq);
+hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
+hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
+                            const uint32_t *q_off, uint32_t n_chunks, Hit *region, uint32_t *q_count,
+                            smhip_chunk_result *results, uint32_t *counters);
+// explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
+hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
+                               uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
+                               uint32_t *q_points, uint32_t *counters);
+hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
+                              const uint32_t *q_off, uint32_t n_chunks, uint32_t *q_count,
+                              uint32_t *q_ovf_off, uint32_t *ovf_list, Hit *ovf_pool, uint64_t pool_cap,
+                              smhip_chunk_result *results, uint32_t *counters, uint64_t max_queries);
+hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
+                             const uint32_t *q_count, const uint32_t *carried_off, uint32_t n_chunks,
+                             uint32_t *chunk_cnt);
+hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *out_excl);
+struct SortArgs {
+  const uint32_t *q_off, *q_count, *q_ovf_off, *qstart, *carried_off;
+  const smhip_carried_anchor *carried;
+  const Hit *region, *ovf_pool;
+  const uint64_t *anchor_off;
+  uint32_t fast_cap, nnp, step, n_refs;
+  uint32_t *a_tpos, *a_qpos, *a_grp;
+  float *a_dist;
+  uint64_t *keys;
+  uint32_t *s_tpos, *s_qpos, *s_grp;
+  float *s_dist;
+  uint32_t *group_start, *n_groups;
+  smhip_chunk_result *results;
+};
+hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks);
+struct ChainArgs {
+  const uint64_t *anchor_off;
+  const uint32_t *s_tpos, *s_qpos, *s_grp;
+  const float *s_dist;
+  const uint32_t *group_start, *n_groups;
+  float *score;
+  uint32_t *pred;
+  uint8_t *used;
+  ChainTmp *chain_tmp;
+  uint64_t *scratch;  // the sort's key buffer (2 keys per anchor), dead by now
+  smhip_chunk_result *results;
+  smhip_carried_anchor *out_anchors;
+  uint32_t *out_anchor_cnt;
+};
+hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks);
+hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
+                      const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n,
+                      float *dist, int64_t *end, uint32_t max_t);
+}  // namespace smhip
+
+#endif

@@ -1,0 +1,230 @@
+// sort.hip -- anchor decode + per-(reference, strand) ordering, one workgroup per chunk.
+//
+// Replaces spatial_index.cc:371-417: each of the first min(hits, 5000) results of a seed
+// becomes SignalAnchor{target_position, query_position, distance} in bucket
+// [strand][reference] (position layout: sigmap_adaptor.h:7-17 / spatial_index.cc:48-52),
+// anchors carried over from the previous chunk's chains come first (spatial_index.cc:303-322),
+// and every bucket is std::sort'ed by (target_position, query_position, distance).
+// The chaining loop then visits buckets in the order ref0+, ref0-, ref1+, ...
+// (spatial_index.cc:421-423), so the device produces ONE array per chunk ordered by
+// (group = ref*2 + strand, target, query, distance) plus the list of group boundaries.
+//
+// Method: 64-bit keys [group | target_position | unsorted index] sorted by a bitonic network
+// (in LDS when the padded count fits 16384 keys, otherwise in an HBM scratch region that
+// stays L2-resident for the workgroup), then runs of equal (group, target) - short - are
+// ordered by (query, distance) in place.  Every comparison key is total, so the result is
+// the unique sorted sequence the reference's std::sort produces.
+#include "common.h"
+
+namespace smhip {
+namespace {
+constexpr int kSortThreads = 1024;
+constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
+
+template <typename KeyPtr>
+__device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t tid) {
+  for (uint32_t k = 2; k <= npad; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = tid; t < npad / 2; t += kSortThreads) {
+        // t enumerates the pairs (i, i ^ j) with i < (i ^ j)
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t l = i | j;
+        const uint64_t a = keys[i], b = keys[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) {
+          keys[i] = b;
+          keys[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t gbits, uint32_t ibits) {
+  extern __shared__ __align__(16) uint64_t lds_keys[];
+  __shared__ uint32_t part[kSortThreads];
+  __shared__ uint32_t s_total;
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = a.anchor_off[c];
+  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+  const uint32_t q0 = a.q_off[c], nq = a.q_off[c + 1] - q0;
+  const uint32_t ncar = a.carried_off ? a.carried_off[c + 1] - a.carried_off[c] : 0;
+  if (tid == 0) {
+    a.results[c].n_anchors = n;
+    a.n_groups[c] = 0;
+  }
+  if (n == 0) return;
+  if (n > (1u << ibits)) {  // the key cannot index this many anchors
+    if (tid == 0) {
+      a.results[c].status |= SMHIP_ST_SORT_CAP;
+      a.results[c].n_anchors = 0;
+    }
+    return;
+  }
+  uint32_t npad = 1;
+  while (npad < n) npad <<= 1;
+  const bool in_lds = npad <= kLdsKeys;
+  uint64_t *gkeys = a.keys + 2 * base;  // per-chunk scratch of 2n >= npad keys
+  uint32_t *u_tpos = a.a_tpos + base, *u_qpos = a.a_qpos + base, *u_grp = a.a_grp + base;
+  float *u_dist = a.a_dist + base;
+
+  // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts)
+  const uint32_t per = (nq + kSortThreads - 1) / kSortThreads;
+  const uint32_t qb = min(nq, tid * per), qe = min(nq, qb + per);
+  uint32_t s = 0;
+  for (uint32_t k = qb; k < qe; ++k) s += min(a.q_count[q0 + k], a.nnp);
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  // ---- decode: carried anchors, then each query's hits in traversal order
+  const uint64_t idx_mask = (1ull << ibits) - 1;
+  for (uint32_t i = tid; i < ncar; i += kSortThreads) {
+    const smhip_carried_anchor ca = a.carried[a.carried_off[c] + i];
+    u_tpos[i] = ca.target_position;
+    u_qpos[i] = ca.query_position;
+    u_dist[i] = ca.distance;
+    u_grp[i] = ca.ref_strand;
+    const uint64_t key = ((uint64_t)ca.ref_strand << (32 + ibits)) | ((uint64_t)ca.target_position << ibits) | i;
+    if (in_lds) lds_keys[i] = key; else gkeys[i] = key;
+  }
+  {
+    uint32_t run = ncar + (tid ? part[tid - 1] : 0);
+    const uint32_t qso = a.qstart ? a.qstart[c] : 0;
+    for (uint32_t k = qb; k < qe; ++k) {
+      const uint32_t qi = q0 + k;
+      const uint32_t cnt = a.q_count[qi];
+      const uint32_t m = min(cnt, a.nnp);
+      const Hit *src = cnt <= a.fast_cap ? a.region + (size_t)qi * a.fast_cap
+                                         : (a.q_ovf_off[qi] != 0xFFFFFFFFu ? a.ovf_pool + a.q_ovf_off[qi] : nullptr);
+      const uint32_t qpos = (k + 1) * a.step + qso;  // position + query_start_offset
+      for (uint32_t h = 0; h < m; ++h) {
+        const uint32_t i = run + h;
+        Hit hit;
+        if (src) hit = src[h]; else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
+        const uint32_t ref = (uint32_t)(hit.position >> 33);
+        const uint32_t tpos = (uint32_t)(hit.position >> 1);
+        const uint32_t grp = (ref << 1) | (uint32_t)(hit.position & 1);
+        u_tpos[i] = tpos;
+        u_qpos[i] = qpos;
+        u_dist[i] = hit.dist;
+        u_grp[i] = grp;
+        const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
+        if (in_lds) lds_keys[i] = key; else gkeys[i] = key;
+      }
+      run += m;
+    }
+  }
+  for (uint32_t i = n + tid; i < npad; i += kSortThreads) {
+    if (in_lds) lds_keys[i] = ~0ull; else gkeys[i] = ~0ull;
+  }
+  __syncthreads();
+  if (in_lds) BitonicSort(lds_keys, npad, tid); else BitonicSort(gkeys, npad, tid);
+
+  // ---- scatter into sorted order
+  uint32_t *s_tpos = a.s_tpos + base, *s_qpos = a.s_qpos + base, *s_grp = a.s_grp + base;
+  float *s_dist = a.s_dist + base;
+  for (uint32_t i = tid; i < n; i += kSortThreads) {
+    const uint64_t key = in_lds ? lds_keys[i] : gkeys[i];
+    const uint32_t u = (uint32_t)(key & idx_mask);
+    s_tpos[i] = (uint32_t)(key >> ibits);
+    s_grp[i] = (uint32_t)(key >> (32 + ibits));
+    s_qpos[i] = u_qpos[u];
+    s_dist[i] = u_dist[u];
+  }
+  __syncthreads();
+  // ---- order runs of equal (group, target) by (query, distance): insertion sort by the
+  // thread that owns the run's first element
+  for (uint32_t i = tid; i < n; i += kSortThreads) {
+    const bool run_start = i == 0 || s_tpos[i - 1] != s_tpos[i] || s_grp[i - 1] != s_grp[i];
+    if (!run_start) continue;
+    uint32_t e = i + 1;
+    while (e < n && s_tpos[e] == s_tpos[i] && s_grp[e] == s_grp[i]) ++e;
+    for (uint32_t x = i + 1; x < e; ++x) {
+      const uint32_t kq = s_qpos[x];
+      const float kd = s_dist[x];
+      uint32_t y = x;
+      while (y > i && (s_qpos[y - 1] > kq || (s_qpos[y - 1] == kq && s_dist[y - 1] > kd))) {
+        s_qpos[y] = s_qpos[y - 1];
+        s_dist[y] = s_dist[y - 1];
+        --y;
+      }
+      s_qpos[y] = kq;
+      s_dist[y] = kd;
+    }
+  }
+  // ---- group boundaries, in order
+  {
+    const uint32_t per_a = (n + kSortThreads - 1) / kSortThreads;
+    const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
+    uint32_t cnt = 0;
+    for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || s_grp[i - 1] != s_grp[i]) ? 1 : 0;
+    __syncthreads();
+    part[tid] = cnt;
+    __syncthreads();
+    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+      const uint32_t v = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    uint32_t w = tid ? part[tid - 1] : 0;
+    uint32_t *gs = a.group_start + base;
+    for (uint32_t i = ab; i < ae; ++i)
+      if (i == 0 || s_grp[i - 1] != s_grp[i]) gs[w++] = i;
+    if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
+  }
+  (void)s_total;
+}
+
+// anchors per chunk = carried + sum over its queries of min(hits, num_nearest_points)
+__global__ __launch_bounds__(256) void AnchorCountKernel(const uint32_t *__restrict__ q_off,
+                                                         const uint32_t *__restrict__ q_count,
+                                                         const uint32_t *__restrict__ carried_off,
+                                                         uint32_t nnp, uint32_t *__restrict__ chunk_cnt) {
+  __shared__ uint32_t red[256];
+  const uint32_t c = blockIdx.x, tid = threadIdx.x;
+  const uint32_t q0 = q_off[c], q1 = q_off[c + 1];
+  uint32_t s = 0;
+  for (uint32_t q = q0 + tid; q < q1; q += 256) s += min(q_count[q], nnp);
+  red[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 128; d > 0; d >>= 1) {
+    if (tid < d) red[tid] += red[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) chunk_cnt[c] = red[0] + (carried_off ? carried_off[c + 1] - carried_off[c] : 0);
+}
+}  // namespace
+
+hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
+                             const uint32_t *q_count, const uint32_t *carried_off, uint32_t n_chunks,
+                             uint32_t *chunk_cnt) {
+  hipLaunchKernelGGL(AnchorCountKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, q_off, q_count,
+                     carried_off, (uint32_t)p.num_nearest_points, chunk_cnt);
+  return hipGetLastError();
+}
+
+hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks) {
+  uint32_t gbits = 1;
+  while ((1ull << gbits) < 2ull * a.n_refs) ++gbits;
+  if (gbits > 24) return hipErrorInvalidValue;
+  const uint32_t ibits = 64 - 32 - gbits;
+  const size_t lds = (size_t)kLdsKeys * sizeof(uint64_t);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(SortKernel, dim3(n_chunks), dim3(kSortThreads), lds, ctx->stream, a, gbits, ibits);
+  return hipGetLastError();
+}
+}  // namespace smhip
