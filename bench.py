@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- signal chunks/sec (4k-sample reads) mapped to a yeast-sized (12 Mb) reference.
+
+One "step" = one pass of the hot path (event detection -> k-d radius seed lookup -> anchor
+sort -> chaining) over one batch of synthetic 4000-sample chunks that is already resident in
+HBM.  At N=1 the workload is BASELINE.json configs[1]: 10 000 reads x 1 chunk vs 16 x 750 kb.
+For N>1 (launched by torch.distributed.run, one rank per GPU) rank 0 builds the index, the
+device-resident index arrays are replicated by one RCCL broadcast each, every rank maps its
+own 10 000-chunk shard (weak scaling, no data-path collective), and the reported value is
+(chunks processed by all ranks) / (max over ranks of the timed region).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : algorithmic bytes of the dominant kernel (seed_lookup) / its HIP-event time
+  cpu_baseline : the CPU restatement (oracle/, "port") timed on a bounded sample, rank 0, N=1
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CHUNK = 4000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10000, help="chunks per GPU per step")
+    ap.add_argument("--contigs", type=int, default=16)
+    ap.add_argument("--contig-len", type=int, default=750000)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per query (0 = library default)")
+    ap.add_argument("--fast-cap", type=int, default=0, help="fast hit slots per query (0 = default)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 = auto, 0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(ix, pa_list, n_refs, ref_lens, n_sample):
+    """Times the oracle (CPU restatement of the reference path) on a bounded sample with one
+    thread per host core (the reference parallelises over reads the same way, sigmap.cc:618-630).
+    This is the only place bench.py touches oracle/: as the measured CPU baseline."""
+    from oracle import pyoracle as po
+    cores = min(os.cpu_count() or 1, 32)
+    n_sample = min(n_sample, len(pa_list))
+    tree = po.OracleTree(ix.values.copy())
+    positions = np.ascontiguousarray(ix.positions)
+    idx = list(range(n_sample))
+    lock = threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                if not idx:
+                    return
+                i = idx.pop()
+            po.map_read(tree, positions, pa_list[i], n_refs, ref_lens)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work) for _ in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    tree.close()
+    return {"value": round(n_sample / dt, 2), "unit": "chunks/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample} of the same synthetic 4000-sample reads, same 12 Mb index, "
+                      f"oracle/sigmap_oracle.c so_map_read on {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from sigmap_amd import pipeline, synth
+    from sigmap_amd.multigpu import replicate_index
+
+    genome_lens = [args.contig_len] * args.contigs
+    n_refs = len(genome_lens)
+    ref_lens = np.array(genome_lens, dtype=np.uint32)
+    lm = synth.make_pore_model()
+    genome = synth.make_genome(7, genome_lens)  # every rank: cheap, and reads are cut from it
+    dev = pipeline.DeviceMapper(local_rank)
+    if args.lanes:
+        dev.params.lanes_per_query = args.lanes
+    if args.fast_cap:
+        dev.params.hits_per_query_fast = args.fast_cap
+    ix = None
+    t_build = 0.0
+    if rank == 0:
+        t0 = time.perf_counter()
+        ix = pipeline.HostIndex.build(genome, lm, threads=0)
+        t_build = time.perf_counter() - t0
+    keepalive = replicate_index(dev, ix, rank, world, local_rank, dist)  # RCCL broadcast when world > 1
+
+    raw, _ = synth.simulate_reads(genome, lm, args.reads, seed=1000 + rank)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
+    samples = np.concatenate(pa)
+    dev.upload_batch(samples, offsets)  # inputs resident in HBM before the timed region
+
+    def step():
+        dev.run(n_refs)
+        dev.sync()
+        return dev.download()
+
+    for _ in range(args.warmup):
+        res = step()
+    dev.timing(True)
+    dev.timing_reset()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dev.sync()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time (HIP events on the context stream, inside the timed region)
+    kern = {}
+    for name in ["events", "seed_lookup", "seed_overflow", "sort", "chain"]:
+        ms, n = dev.timing_get(name)
+        kern[name] = {"mean_ms": round(ms, 4), "launches": int(n)}
+
+    if rank == 0:
+        R = args.reads
+        status_bad = int((res["status"] & ~np.uint32(1)).astype(bool).sum())
+        nodes = int(res["nodes_visited"].sum())
+        points = int(res["points_tested"].sum())
+        anchors = int(res["n_anchors"].sum())
+        queries = int(res["n_queries"].sum())
+        # B_chunk = 2*S + Q*(Nn*16 + Np*28) + 24*A + 64, counted on the actual inputs
+        bytes_per_launch = 2 * CHUNK * R + 16 * nodes + 28 * points + 24 * anchors + 64 * R
+        seed_ms = kern["seed_lookup"]["mean_ms"]
+        achieved = bytes_per_launch / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("seed_lookup_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        total_chunks = R * world * args.steps
+        out = {
+            "metric": "signal chunks/sec (4k-sample reads) mapped to yeast ref",
+            "value": round(total_chunks / dt, 1),
+            "unit": "chunks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{R} synthetic 4000-sample reads (1 chunk each) per GPU vs {n_refs} x "
+                            f"{args.contig_len} bp random reference (yeast-sized), event+seed+sort+chain on GPU",
+                "chunks_per_gpu_per_step": R,
+                "index_points": int(dev_index_points(ix)) if ix is not None else None,
+                "lanes_per_query": int(dev.params.lanes_per_query),
+                "mapped_fraction": round(float((res["n_chains"] > 0).mean()), 4),
+                "queries_per_chunk": round(queries / R, 2),
+                "nodes_per_query": round(nodes / max(queries, 1), 1),
+                "points_per_query": round(points / max(queries, 1), 1),
+                "anchors_per_chunk": round(anchors / R, 1),
+                "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
+                "chunks_with_capacity_flags": status_bad,
+                "index_build_s": round(t_build, 2),
+                "kernels": kern,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "seed_lookup",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+            },
+        }
+        if world == 1 and not args.no_cpu and args.cpu_sample != 0:
+            n_sample = args.cpu_sample if args.cpu_sample > 0 else 24 * min(os.cpu_count() or 1, 32)
+            out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, n_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    del keepalive
+
+
+def dev_index_points(ix):
+    return ix.n_points
+
+
+if __name__ == "__main__":
+    main()

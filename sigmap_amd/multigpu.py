@@ -1,0 +1,98 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over
+xGMI on ROCm).  The path shards by reads with a full index replica per GPU:
+the only collective is the start-up broadcast of the device-resident index arrays; there is
+no data-path collective.  The same functions run on CPU tensors with the gloo backend, which
+is how the world_size-2 tests exercise them without GPUs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+_ARRAYS = ["nodes", "leaf_pts", "leaf_pos", "leaf_vind", "bbox"]
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of reads for `rank`: read i -> rank i*world//n."""
+    lo = (n_items * rank + world - 1) // world
+    hi = (n_items * (rank + 1) + world - 1) // world
+    return lo, hi
+
+
+def merge_ranked(per_rank_rows):
+    """Merge per-rank (ref_bucket, global_read_index, line) rows into the reference's -t 1
+    output order: reference index, then read index (sigmap.cc:201-213,223-238)."""
+    rows = [r for part in per_rank_rows for r in part]
+    rows.sort(key=lambda r: (r[0], r[1]))
+    return [r[2] for r in rows]
+
+
+def broadcast_meta(meta, rank, dist, device):
+    import torch
+    t = torch.tensor(meta if rank == 0 else [0] * len(meta), dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    return [int(x) for x in t.tolist()]
+
+
+def broadcast_host_index(ix_arrays, rank, dist):
+    """gloo/CPU variant: ix_arrays = dict name -> numpy array on rank 0 (None elsewhere).
+    Returns the dict on every rank."""
+    import torch
+    names = ["values", "positions", "vind", "nodes", "bbox"]
+    dtypes = {"values": np.float32, "positions": np.uint64, "vind": np.uint32, "nodes": np.uint8, "bbox": np.float32}
+    meta = [0] * len(names)
+    if rank == 0:
+        meta = [int(np.ascontiguousarray(ix_arrays[n]).view(np.uint8).size) for n in names]
+    meta = broadcast_meta(meta, rank, dist, "cpu")
+    out = {}
+    for n, nbytes in zip(names, meta):
+        if rank == 0:
+            buf = torch.from_numpy(np.ascontiguousarray(ix_arrays[n]).view(np.uint8).reshape(-1).copy())
+        else:
+            buf = torch.empty(nbytes, dtype=torch.uint8)
+        dist.broadcast(buf, src=0)
+        out[n] = buf.numpy().view(dtypes[n])
+    return out
+
+
+def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy D2D failed: {rc}")
+
+
+def replicate_index(dev, ix, rank, world, local_rank, dist):
+    """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
+    uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
+    attach the received buffers (smhip_index_attach).  Returns objects to keep alive."""
+    if world == 1:
+        dev.upload_index(ix)
+        return None
+    import torch
+    device = torch.device("cuda", local_rank)
+    meta = [0] * (3 + len(_ARRAYS))
+    d = None
+    if rank == 0:
+        dev.upload_index(ix)
+        d = dev.export_index()
+        meta = [d.dim, d.n_nodes, d.m_size] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
+    meta = broadcast_meta(meta, rank, dist, device)
+    tensors = []
+    for a, nbytes in zip(_ARRAYS, meta[3:]):
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if rank == 0:
+            _hip_memcpy_d2d(t.data_ptr(), getattr(d, a), nbytes)
+        dist.broadcast(t, src=0)  # RCCL broadcast over xGMI
+        tensors.append(t)
+    torch.cuda.synchronize()
+    if rank != 0:
+        nd = _abi.IndexDev()
+        nd.dim, nd.n_nodes, nd.m_size = meta[0], meta[1], meta[2]
+        for a, t, nbytes in zip(_ARRAYS, tensors, meta[3:]):
+            setattr(nd, a, t.data_ptr())
+            setattr(nd, a + "_bytes", nbytes)
+        dev.attach_index(nd)
+        return tensors  # the context borrows this memory
+    return None

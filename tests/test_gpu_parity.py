@@ -1,0 +1,298 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded
+inputs, against the reference goldens, and through size-independent properties at larger
+sizes.  Bit-exact for every integer/index/f32 result.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+from oracle import pyoracle as po
+from sigmap_amd import _abi, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(pa_list):
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa_list])]).astype(np.uint32)
+    return np.concatenate(pa_list), offsets
+
+
+# ------------------------------------------------------------------ events (A2-A8)
+
+def test_events_kernel_matches_oracle(device, small_world):
+    pa = small_world["pa"]
+    samples, offsets = _batch(pa)
+    feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    for i, x in enumerate(pa):
+        f, s = po.generate_events(x)
+        ev, _ = po.detect_events(x)
+        assert st[i] == 0 and ne[i] == len(ev) and nf[i] == len(f)
+        assert np.array_equal(bits(feat[i, :nf[i]]), bits(f))
+        assert np.array_equal(bits(stdv[i, :nf[i]]), bits(s))
+
+
+def test_events_kernel_matches_reference_golden(device):
+    g = np.load(os.path.join(GOLDEN, "events.npz"))
+    pa = [g[f"x{r}"] for r in range(6)]  # includes a ragged 1777-sample chunk
+    samples, offsets = _batch(pa)
+    feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    for r in range(6):
+        assert ne[r] == len(g[f"mean{r}"])
+        # features are the z-scored, compressed event means: recompute from the golden events
+        f, s = po.generate_events(pa[r])
+        assert np.array_equal(bits(feat[r, :nf[r]]), bits(f))
+
+
+def test_events_edge_cases(device):
+    flat = np.full(4000, 90.0, np.float32)                       # no peaks at all
+    short = np.linspace(60, 120, 10).astype(np.float32)         # shorter than two windows
+    empty = np.zeros(0, np.float32)
+    rng = np.random.default_rng(1)
+    noisy = (90 + 25 * rng.standard_normal(4096)).astype(np.float32)  # maximum chunk size, many events
+    pa = [flat, short, empty, noisy]
+    samples, offsets = _batch(pa)
+    feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    assert nf[0] == 0 and st[0] & 1 and nf[1] == 0 and nf[2] == 0
+    f, s = po.generate_events(noisy)
+    assert nf[3] == len(f) and np.array_equal(bits(feat[3, :nf[3]]), bits(f))
+    with pytest.raises(RuntimeError):  # > 4096 samples in one chunk is rejected, not truncated
+        device.events(np.zeros(5000, np.float32), np.array([0, 5000], np.uint32))
+
+
+# ------------------------------------------------------------------ seed lookup (A10)
+
+@pytest.mark.parametrize("lanes", [1, 8, 16, 32, 64])
+def test_seed_lookup_matches_oracle(device, small_world, oracle_tree, lanes):
+    qs = []
+    for x in small_world["pa"][:12]:
+        f, _ = po.generate_events(x)
+        qs += [f[p:p + 6] for p in range(2, len(f) - 5, 2)]
+    qs = np.array(qs, np.float32)
+    device.params.lanes_per_query = lanes
+    try:
+        counts, idx, dist, nodes, pts = device.seed_lookup(qs, cap=1024)
+    finally:
+        device.params.lanes_per_query = pipeline.default_params().lanes_per_query
+    total = 0
+    for k in range(len(qs)):
+        n, oi, od, stt = oracle_tree.radius_search(qs[k], 0.08)
+        assert counts[k] == n
+        assert np.array_equal(idx[k, :n], oi)                      # traversal order, point ids
+        assert np.array_equal(bits(dist[k, :n]), bits(od))
+        assert nodes[k] == stt[0] and pts[k] == stt[2]             # same nodes / points visited
+        total += n
+    assert total > 1000
+
+
+def test_seed_lookup_matches_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
+    ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=2)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    counts, idx, dist, _, _ = dev.seed_lookup(g["queries"], cap=256)
+    off = g["hit_off"]
+    for k in range(len(g["queries"])):
+        n = off[k + 1] - off[k]
+        assert counts[k] == n
+        assert np.array_equal(idx[k, :n], g["hit_idx"][off[k]:off[k + 1]])
+        assert np.array_equal(bits(dist[k, :n]), bits(g["hit_dist"][off[k]:off[k + 1]]))
+    dev.close()
+
+
+# ------------------------------------------------------------------ whole path (A1-A18)
+
+def _paf_lines(res, pa_list, names, ref_lens):
+    L = _abi.host_lib()
+    mp = _abi.MapParams(); L.smhost_default_map_params(C.byref(mp))
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    out = []
+    for i in range(len(pa_list)):
+        r = res[i:i + 1].copy()
+        nev = int(r["n_features"][0]) if r["n_features"][0] > 50 else 0
+        buf = C.create_string_buffer(2048)
+        L.smhost_format_paf(_abi.ptr(r), b"read%d" % i, len(pa_list[i]), 0, nev, arr, _abi.ptr(ref_lens),
+                            len(names), C.byref(mp), buf, 2048, None)
+        out.append(buf.value.decode())
+    return out
+
+
+@pytest.mark.parametrize("lanes", [1, 16])
+def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, lanes):
+    pa, ix, ref_lens = small_world["pa"], small_world["ix"], small_world["ref_lens"]
+    samples, offsets = _batch(pa)
+    device.params.lanes_per_query = lanes
+    try:
+        res = device.map_chunks(samples, offsets, n_refs=3)
+    finally:
+        device.params.lanes_per_query = pipeline.default_params().lanes_per_query
+    names = ["contig0", "contig1", "contig2"]
+    lines = _paf_lines(res, pa, names, ref_lens)
+    mapped = 0
+    for i, x in enumerate(pa):
+        m = po.map_read(oracle_tree, ix.positions, x, 3, ref_lens)
+        assert res[i]["status"] == 0
+        assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)   # cols 1-12 + every tag
+        assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+        assert res[i]["nodes_visited"] == m.stats.search.nodes and res[i]["points_tested"] == m.stats.search.points
+        mapped += m.mapped
+    assert mapped >= len(pa) - 2
+    # mapped locus agrees with the generator's truth (sanity of the whole setup)
+    t = small_world["truth"]
+    good = 0
+    for i in range(len(pa)):
+        c0 = res[i]["chains"][0]
+        if res[i]["n_chains"] and c0["ref"] == t["contig"][i] and (c0["direction"] == 1) == (t["strand"][i] == 0):
+            good += 1
+    assert good >= len(pa) - 3
+
+
+def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
+    """Queries with more hits than the fast slots are re-walked into exact-size segments:
+    results must not depend on the capacity."""
+    pa = small_world["pa"][:16]
+    samples, offsets = _batch(pa)
+    base = device.map_chunks(samples, offsets, n_refs=3)
+    device.params.hits_per_query_fast = 2
+    try:
+        tiny = device.map_chunks(samples, offsets, n_refs=3)
+    finally:
+        device.params.hits_per_query_fast = pipeline.default_params().hits_per_query_fast
+    assert np.array_equal(base.tobytes(), tiny.tobytes())
+
+
+def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
+    """spatial_index.cc:371-372: only the first num_nearest_points hits IN TRAVERSAL ORDER become
+    anchors.  A repeat-rich reference makes queries exceed a (lowered) cap; the oracle with the
+    same cap must agree, which pins the traversal order end to end."""
+    rng = np.random.default_rng(8)
+    unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)])
+    genome = [unit * 12 + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20000)])]
+    lm = small_world["lm"]
+    raw, _ = synth.simulate_reads([unit * 3], lm, 6, 2)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    ix = pipeline.HostIndex.build(genome, lm, threads=2)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    samples, offsets = _batch(pa)
+    res_full = dev.map_chunks(samples, offsets, n_refs=1)
+    assert (res_full["hits_total"] > res_full["n_queries"] * 4).all()   # repeats: many hits per query
+    tree = po.OracleTree(ix.values.copy())
+    for i, x in enumerate(pa):
+        f, _ = po.generate_events(x)
+        chains, st = po.generate_chains(tree, ix.positions, f, 1)
+        assert res_full[i]["n_anchors"] == st.anchors and res_full[i]["n_chains"] == len(chains)
+        if chains:
+            assert res_full[i]["chains"][0]["score"] == np.float32(chains[0]["score"])
+            assert res_full[i]["chains"][0]["start"] == chains[0]["start"]
+    tree.close(); dev.close()
+
+
+def test_pipeline_empty_and_degenerate_batches(device):
+    res = device.map_chunks(np.zeros(0, np.float32), np.array([0], np.uint32), n_refs=3)
+    assert len(res) == 0
+    flat = np.full(4000, 90.0, np.float32)
+    res = device.map_chunks(flat, np.array([0, 4000], np.uint32), n_refs=3)
+    assert res[0]["n_chains"] == 0 and res[0]["n_queries"] == 0 and res[0]["status"] & 1
+
+
+def test_chain_anchor_carry_over_roundtrip(device, small_world, oracle_tree):
+    """Chain anchors returned for chunk c can be fed back as `carried` for chunk c+1
+    (spatial_index.cc:303-322): two-chunk reads must equal the oracle's streaming result."""
+    genome, lm = small_world["genome"], small_world["lm"]
+    raw, _ = synth.simulate_reads(genome, lm, 12, 77, n_chunks=2)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    ix, ref_lens = small_world["ix"], small_world["ref_lens"]
+    first = [x[:4000] for x in pa]
+    samples, offsets = _batch(first)
+    device.upload_batch(samples, offsets)
+    device.run(3); device.sync()
+    r1, anchors, aoff = device.download(with_anchors=True)
+    second = [x[4000:8000] for x in pa]
+    samples2, offsets2 = _batch(second)
+    qstart = np.array([r["n_features"] if r["n_features"] > 50 else 0 for r in r1], np.uint32)
+    device.upload_batch(samples2, offsets2, query_start_offsets=qstart, carried=anchors,
+                        carried_offsets=aoff.astype(np.uint32))
+    device.run(3); device.sync()
+    r2 = device.download()
+    p = {"stop_ratio": 1e30, "stop_mean_ratio": 1e30, "stop_min_anchors": 1 << 30}  # never stop early
+    for i, x in enumerate(pa):
+        m = po.map_read(oracle_tree, ix.positions, x[:8000], 3, ref_lens, params=p)
+        assert m.chunks_used == 2
+        assert r2[i]["n_chains"] == m.n_chains
+        if m.n_chains:
+            assert r2[i]["chains"][0]["score"] == np.float32(m.s1)
+            assert r2[i]["chains"][0]["n_anchors"] == m.cm
+            ad = np.float32(r2[i]["c0_sum_dist"]) / np.float32(m.cm)
+            assert np.float32(ad) == np.float32(m.ad)
+
+
+# ------------------------------------------------------------------ properties at BASELINE size
+
+def test_full_size_properties():
+    """10 000 x 4000-sample chunks against a 12 Mb (16 x 750 kb) index: too big for the oracle in
+    a test, so check size-independent properties: (1) determinism (two runs bit-identical),
+    (2) lane-width independence (1 vs 32 lanes per query bit-identical), (3) a 64-read sample
+    equals the oracle, (4) accuracy vs the generator's truth."""
+    genome = synth.make_genome(7, [750000] * 16)
+    lm = synth.make_pore_model()
+    n = 10000
+    raw, truth = synth.simulate_reads(genome, lm, n, 1000)
+    ix = pipeline.HostIndex.build(genome, lm, threads=0)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    samples, offsets = _batch(pa)
+    a = dev.map_chunks(samples, offsets, n_refs=16)
+    b = dev.map_chunks(samples, offsets, n_refs=16)
+    assert a.tobytes() == b.tobytes()
+    dev.params.lanes_per_query = 32
+    c = dev.map_chunks(samples, offsets, n_refs=16)
+    assert a.tobytes() == c.tobytes()
+    assert (a["status"] == 0).all()
+    c0 = a["chains"][:, 0]
+    ok = (a["n_chains"] > 0) & (c0["ref"] == truth["contig"]) & ((c0["direction"] == 1) == (truth["strand"] == 0))
+    assert ok.mean() > 0.97
+    tree = po.OracleTree(ix.values.copy())
+    ref_lens = np.full(16, 750000, np.uint32)
+    names = ["contig%d" % i for i in range(16)]
+    idx = np.arange(0, n, n // 64)[:64]
+    lines = _paf_lines(a[idx], [pa[i] for i in idx], names, ref_lens)
+    for k, i in enumerate(idx):
+        m = po.map_read(tree, ix.positions, pa[i], 16, ref_lens)
+        assert lines[k] == po.format_paf(m, "read%d" % k, names, ref_lens)
+    tree.close(); dev.close()
+
+
+# ------------------------------------------------------------------ banded sDTW (D4/D5)
+
+def test_sdtw_kernel_matches_oracle(device):
+    rng = np.random.default_rng(3)
+    targets, queries, los, his, exp = [], [], [], [], []
+    for case in range(12):
+        T = int(rng.integers(50, 700)); Q = int(rng.integers(20, 200))
+        t = rng.normal(size=T).astype(np.float32)
+        s = int(rng.integers(0, max(1, T - Q)))
+        q = (t[s:s + Q] + rng.normal(scale=0.1, size=min(Q, T - s))).astype(np.float32)
+        Q = len(q)
+        if case % 3 == 0:      # full band == unbanded Sigmap::sDTW
+            lo = np.ones(T, np.uint32); hi = np.full(T, Q, np.uint32)
+            d, e = po.sdtw(t, q)
+            d2, e2 = po.sdtw_banded(t, q, lo, hi)
+            assert d == d2 and e == e2
+        else:                  # diagonal band of half-width w around the planted start
+            w = [16, 32, 64][case % 3]
+            centre = np.arange(1, T + 1) - s
+            lo = np.clip(centre - w, 1, Q).astype(np.uint32); hi = np.clip(centre + w, 0, Q).astype(np.uint32)
+            d, e = po.sdtw_banded(t, q, lo, hi)
+        targets.append(t); queries.append(q); los.append(lo); his.append(hi); exp.append((d, e))
+    t_off = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    q_off = np.concatenate([[0], np.cumsum([len(q) for q in queries])]).astype(np.uint64)
+    dist, end = device.sdtw_banded(np.concatenate(targets), t_off, np.concatenate(queries), q_off,
+                                   np.concatenate(los), np.concatenate(his))
+    for k, (d, e) in enumerate(exp):
+        # f32 adds in the same order as the reference recurrence: bit-exact, well inside the
+        # 1e-4 relative tolerance north_star allows for DTW distance
+        assert bits(np.float32(dist[k])) == bits(np.float32(d)), (k, dist[k], d)
+        assert end[k] == e

@@ -1,0 +1,193 @@
+"""Host-side product code (sigmap_amd/host via include/sigmap_host.h) against the oracle and
+the reference goldens: index construction, `.pt`/`.si` files, pA conversion, PAF logic."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, bits
+from oracle import pyoracle as po
+from sigmap_amd import _abi, pipeline, synth
+
+
+def _flat_from_golden(g):
+    leaf = g["is_leaf"] == 1
+    return leaf, g["a"], g["b"], g["lo"], g["hi"]
+
+
+def test_host_tree_equals_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
+    ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=3)
+    leaf, a, b, lo, hi = _flat_from_golden(g)
+    n = ix.nodes
+    assert len(n) == len(leaf)
+    assert np.array_equal(n["feat"] < 0, leaf)
+    assert np.array_equal(n["a"][leaf], a[leaf]) and np.array_equal(n["b"][leaf], b[leaf])
+    assert np.array_equal(n["feat"][~leaf], a[~leaf].astype(np.int32))
+    assert np.array_equal(n["a"][~leaf], lo[~leaf].view(np.uint32))
+    assert np.array_equal(n["b"][~leaf], hi[~leaf].view(np.uint32))
+    assert np.array_equal(ix.vind, g["vind"])
+    assert np.array_equal(bits(ix.bbox), bits(g["bbox"]))
+    # child2 = first pre-order slot after child1's subtree
+    size = np.ones(len(n), np.int64)
+    for i in range(len(n) - 1, -1, -1):
+        if n["feat"][i] >= 0:
+            c2 = n["child2"][i]
+            assert c2 == i + 1 + size[i + 1]
+            size[i] = 1 + size[i + 1] + size[c2]
+    assert size[0] == len(n)
+
+
+def test_parallel_build_is_deterministic(small_world):
+    ix = small_world["ix"]
+    one = pipeline.HostIndex.from_points(ix.positions, ix.values, threads=1)
+    many = pipeline.HostIndex.from_points(ix.positions, ix.values, threads=8)
+    assert np.array_equal(one.nodes, many.nodes) and np.array_equal(one.vind, many.vind)
+    assert np.array_equal(one.nodes, ix.nodes)
+
+
+def test_index_files_roundtrip_and_cross_read(small_world, tmp_path):
+    """PREFIX.pt/.si written by the product are read back identically by the product AND by the
+    oracle's reader (reference format), and vice versa."""
+    ix = small_world["ix"]
+    prefix = str(tmp_path / "idx")
+    ix.save(prefix)
+    assert os.path.getsize(prefix + ".pt") == 16 + 16 * ix.n_points                     # T8
+    assert os.path.getsize(prefix + ".si") == 84 + 8 * ix.m_size + 32 * ix.n_nodes     # T9
+    back = pipeline.HostIndex.load(prefix)
+    assert np.array_equal(back.nodes, ix.nodes) and np.array_equal(back.vind, ix.vind)
+    assert np.array_equal(back.positions, ix.positions) and np.array_equal(bits(back.values), bits(ix.values))
+    ot = po.OracleTree.load(prefix + ".si", ix.values.copy())
+    pa = small_world["pa"][0]
+    f, _ = po.generate_events(pa)
+    full = po.OracleTree(ix.values.copy())
+    for p in range(2, len(f) - 5, 40):
+        a = ot.radius_search(f[p:p + 6], 0.08)
+        b = full.radius_search(f[p:p + 6], 0.08)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3] == b[3]
+    # oracle-written files load in the product
+    p2 = str(tmp_path / "o")
+    full.save(p2 + ".si")
+    assert po.lib().so_points_save((p2 + ".pt").encode(), 6, 20, po._p(ix.positions.copy()),
+                                   po._p(ix.values.copy()), ix.n_points) == 0
+    again = pipeline.HostIndex.load(p2)
+    assert np.array_equal(again.nodes, ix.nodes)
+    ot.close(); full.close()
+
+
+def test_index_pipeline_matches_oracle(small_world):
+    """sigmap.cc:999-1046 end to end: masks, expected signal, z-score, dedupe, strand order."""
+    genome, lm, ix = small_world["genome"], small_world["lm"], small_world["ix"]
+    L = po.lib()
+    k, dim = 6, 6
+    n = len(genome)
+    neg = []
+    for g in genome:
+        out = C.create_string_buffer(len(g) + 1)
+        L.so_reverse_complement(g, len(g), out)
+        neg.append(out.raw[:len(g)])
+    lens = np.array([len(g) for g in genome], dtype=np.uint32)
+    pm = [np.zeros(len(g) - (dim + k - 1) + 1, np.uint8) for g in genome]
+    nm = [np.zeros(len(g) - (dim + k - 1) + 1, np.uint8) for g in genome]
+    seqs = (C.c_char_p * n)(*genome); nseqs = (C.c_char_p * n)(*neg)
+    pmp = (C.c_void_p * n)(*[a.ctypes.data for a in pm]); nmp = (C.c_void_p * n)(*[a.ctypes.data for a in nm])
+    L.so_masked_positions(dim + k - 1, 0.0002, n, seqs, nseqs, po._p(lens), pmp, nmp)
+    cap = 2 * int(lens.sum())
+    positions = np.zeros(cap, np.uint64); values = np.zeros(cap, np.float32)
+    count = 0
+    lmc = np.ascontiguousarray(lm)
+    sigs = []
+    for strand_seqs in (genome, neg):
+        row = []
+        for s in strand_seqs:
+            lv = np.zeros(len(s), np.float32)
+            m = L.so_level_means(po._p(lmc), k, s, 0, len(s), po._p(lv))
+            z = np.zeros(m, np.float32)
+            L.so_zscore(po._p(lv), m, po._p(z))
+            row.append(z)
+        sigs.append(row)
+    for i in range(n):
+        count = L.so_point_cloud_one_direction(1, i, po._p(pm[i]), po._p(sigs[0][i]), len(sigs[0][i]), dim,
+                                               po._p(positions), po._p(values), count)
+    for i in range(n):
+        count = L.so_point_cloud_one_direction(0, i, po._p(nm[i]), po._p(sigs[1][i]), len(sigs[1][i]), dim,
+                                               po._p(positions), po._p(values), count)
+    assert count == ix.n_points
+    assert np.array_equal(positions[:count], ix.positions)
+    assert np.array_equal(bits(values[:count]), bits(ix.values))
+    # the reference z-scored strand signal exported for the sDTW target is the same array
+    out = np.zeros(len(genome[1]), np.float32)
+    m = _abi.host_lib().smhost_reference_signal(_abi.ptr(lmc), k, genome[1], len(genome[1]), 1, _abi.ptr(out))
+    assert np.array_equal(bits(out[:m]), bits(sigs[1][1]))
+
+
+def test_masking_with_repeats_and_ambiguous_bases():
+    """High-frequency 11-mers (> 2e-4) and windows ending at an N are masked (sigmap.cc:101-130)."""
+    rng = np.random.default_rng(5)
+    base = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 4000)])
+    rep = b"ACGTTGCAAGGCTTAACG"
+    seq = base[:1000] + rep * 40 + base[1000:2000] + b"NNNN" + base[2000:]
+    lm = synth.make_pore_model()
+    ix = pipeline.HostIndex.build([seq], lm, threads=1)
+    L = po.lib()
+    neg = C.create_string_buffer(len(seq) + 1)
+    L.so_reverse_complement(seq, len(seq), neg)
+    m = len(seq) - 11 + 1
+    pmask = np.zeros(m, np.uint8); nmask = np.zeros(m, np.uint8)
+    lens = np.array([len(seq)], np.uint32)
+    L.so_masked_positions(11, 0.0002, 1, (C.c_char_p * 1)(seq), (C.c_char_p * 1)(neg.raw[:len(seq)]), po._p(lens),
+                          (C.c_void_p * 1)(pmask.ctypes.data), (C.c_void_p * 1)(nmask.ctypes.data))
+    assert pmask.sum() > 300 and nmask.sum() > 300
+    strand_pos = ix.positions[(ix.positions & 1) == 0]
+    kept = ((strand_pos >> 1) & 0xFFFFFFFF).astype(np.int64)
+    assert not pmask[kept].any()  # no masked position made it into the + strand cloud
+
+
+def test_raw_to_pa_filter():
+    raw = np.array([0, 100, 500, 1000, 2000, -5], dtype=np.int16)
+    out = pipeline.raw_to_pa(raw, 8192.0, 1467.61, 10.0)
+    scale = np.float32(1467.61) / np.float32(8192.0)
+    exp = [(np.float32(v) + np.float32(10.0)) * scale for v in raw]
+    exp = np.array([v for v in exp if 30 < v < 200], dtype=np.float32)
+    assert np.array_equal(bits(out), bits(exp))
+
+
+def test_paf_logic_matches_oracle(small_world, oracle_tree):
+    """smhost_format_paf on records assembled from the ORACLE's chains reproduces the oracle's
+    own PAF text: pins the host-side decision/format code independently of the GPU."""
+    L = _abi.host_lib()
+    mp = _abi.MapParams(); L.smhost_default_map_params(C.byref(mp))
+    names = [b"contig0", b"contig1", b"contig2"]
+    arr = (C.c_char_p * 3)(*names)
+    ix, ref_lens = small_world["ix"], small_world["ref_lens"]
+    checked = 0
+    for i, pa in enumerate(small_world["pa"][:24]):
+        feat, _ = po.generate_events(pa)
+        chains, st = po.generate_chains(oracle_tree, ix.positions, feat, 3)
+        m = po.map_read(oracle_tree, ix.positions, pa, 3, ref_lens)
+        r = np.zeros(1, dtype=_abi.RESULT_DTYPE)
+        r["n_features"] = len(feat); r["n_chains"] = len(chains)
+        s = np.float32(0)
+        for c in chains:
+            s = np.float32(s + np.float32(c["score"]))
+        r["sum_score"] = s
+        for k, c in enumerate(chains[:4]):
+            for f in ("score", "ref", "start", "end", "n_anchors", "mapq", "direction"):
+                r["chains"][0][k][f] = c[f]
+        if chains:
+            a = chains[0]["anchors"]
+            ad = at = aq = np.float32(0)
+            for j in range(len(a)):
+                ad = np.float32(ad + a["distance"][j])
+                if j + 1 < len(a):
+                    at = np.float32(at + np.float32(np.uint32(a["target_position"][j] - a["target_position"][j + 1])))
+                    aq = np.float32(aq + np.float32(np.uint32(a["query_position"][j] - a["query_position"][j + 1])))
+            r["c0_sum_dist"], r["c0_sum_tgap"], r["c0_sum_qgap"] = ad, at, aq
+            r["c0_first_qpos"], r["c0_last_qpos"] = a["query_position"][0], a["query_position"][-1]
+        buf = C.create_string_buffer(2048)
+        L.smhost_format_paf(_abi.ptr(r), b"read%d" % i, len(pa), 0, len(feat) if len(feat) > 50 else 0, arr,
+                            _abi.ptr(ref_lens), 3, C.byref(mp), buf, 2048, None)
+        assert buf.value.decode() == po.format_paf(m, "read%d" % i, [n.decode() for n in names], ref_lens)
+        assert L.smhost_should_stop(_abi.ptr(r), C.byref(mp)) in (0, 1)
+        checked += m.mapped
+    assert checked >= 20

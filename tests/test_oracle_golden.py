@@ -1,0 +1,162 @@
+"""The oracle (CPU restatement, oracle/sigmap_oracle.c) against golden vectors captured
+from the REAL reference code (tests/golden/make_golden.py via oracle/_ref), and, when the
+prebuilt oracle/_ref/libsigmap_ref.so is present, against the reference itself on fresh
+seeded inputs.  Bit-exact everywhere (integer/index work and IEEE f32 with contraction off)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+from oracle import pyoracle as po
+
+
+@pytest.fixture(scope="module")
+def ev_gold():
+    return np.load(os.path.join(GOLDEN, "events.npz"))
+
+
+@pytest.fixture(scope="module")
+def kd_gold():
+    return np.load(os.path.join(GOLDEN, "kdtree.npz"))
+
+
+@pytest.mark.parametrize("r", range(6))
+def test_events_against_reference_golden(ev_gold, r):
+    x = ev_gold[f"x{r}"]
+    n = len(x)
+    L = po.lib()
+    ps = np.zeros(n + 1, np.float32); pss = np.zeros(n + 1, np.float32); t = np.zeros(n + 1, np.float32)
+    L.so_prefix_sums(po._p(x), n, po._p(ps), po._p(pss))
+    assert np.array_equal(bits(ps), bits(ev_gold[f"ps{r}"]))
+    assert np.array_equal(bits(pss), bits(ev_gold[f"pss{r}"]))
+    L.so_tstat(po._p(ps), po._p(pss), n, 3, po._p(t))
+    assert np.array_equal(bits(t), bits(ev_gold[f"t1_{r}"]))
+    L.so_tstat(po._p(ps), po._p(pss), n, 6, po._p(t))
+    assert np.array_equal(bits(t), bits(ev_gold[f"t2_{r}"]))
+    ev, peaks = po.detect_events(x)
+    assert np.array_equal(peaks, ev_gold[f"peaks{r}"])
+    assert np.array_equal(ev["start"], ev_gold[f"start{r}"])
+    assert np.array_equal(ev["length"], ev_gold[f"length{r}"])
+    assert np.array_equal(bits(ev["mean"]), bits(ev_gold[f"mean{r}"]))
+    assert np.array_equal(bits(ev["stdv"]), bits(ev_gold[f"stdv{r}"]))
+
+
+def test_kdtree_build_against_reference_golden(kd_gold, tmp_path):
+    values = kd_gold["values"]
+    t = po.OracleTree(values)
+    # write the reference's .si format and compare byte-for-byte with what nanoflann wrote
+    p = str(tmp_path / "o.si")
+    t.save(p)
+    si = np.fromfile(p, dtype=np.uint8)
+    hdr = len(kd_gold["si_header"])
+    assert np.array_equal(si[:hdr], kd_gold["si_header"])  # m_size, dim, bbox, leaf_max, vind
+    nodes = si[hdr:].reshape(-1, 32).copy()
+    nodes[:, 16:].view(np.uint64)[nodes[:, 16:].view(np.uint64) != 0] = 1
+    assert np.array_equal(nodes, kd_gold["si_nodes"])
+    # and the reload of that file gives identical searches
+    t2 = po.OracleTree.load(p, values)
+    q = kd_gold["queries"][3]
+    assert t.radius_search(q, 0.08)[1].tolist() == t2.radius_search(q, 0.08)[1].tolist()
+    t.close(); t2.close()
+
+
+def test_radius_search_against_reference_golden(kd_gold):
+    t = po.OracleTree(kd_gold["values"])
+    off = kd_gold["hit_off"]
+    for k, q in enumerate(kd_gold["queries"]):
+        n, idx, dist, _ = t.radius_search(q, 0.08)
+        assert n == off[k + 1] - off[k]
+        assert np.array_equal(idx, kd_gold["hit_idx"][off[k]:off[k + 1]])  # traversal order
+        assert np.array_equal(bits(dist), bits(kd_gold["hit_dist"][off[k]:off[k + 1]]))
+    assert off[-1] > 100  # the fixture really contains hits
+    t.close()
+
+
+def test_radius_search_equals_brute_force(kd_gold):
+    """Size-independent property: the hit SET is every window with squared L2 < radius."""
+    values = kd_gold["values"]
+    t = po.OracleTree(values)
+    win = np.lib.stride_tricks.sliding_window_view(values, 6)
+    for q in kd_gold["queries"][::7]:
+        n, idx, dist, _ = t.radius_search(q, 0.08)
+        d = ((win.astype(np.float32) - q) ** 2)
+        # same association as nanoflann: ((d0+d1)+d2)+d3, then +d4, +d5
+        r = ((d[:, 0] + d[:, 1]) + d[:, 2]) + d[:, 3]
+        r = (r + d[:, 4]) + d[:, 5]
+        assert set(np.nonzero(r < np.float32(0.08))[0].tolist()) == set(idx.tolist())
+    t.close()
+
+
+def test_level_means_against_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "levels.npz"))
+    lm = np.ascontiguousarray(g["level_means"])
+    for i in range(3):
+        s = g[f"seq{i}"].tobytes()
+        out = np.zeros(len(s), np.float32)
+        n = po.lib().so_level_means(po._p(lm), 6, s, 0, len(s), po._p(out))
+        assert n == len(g[f"lv{i}"])
+        assert np.array_equal(bits(out[:n]), bits(g[f"lv{i}"]))
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_vs_live_reference_fresh_inputs():
+    from sigmap_amd import pipeline, synth
+    R = po.ref()
+    genome = synth.make_genome(99, [30000])
+    lm = synth.make_pore_model(seed=4)
+    raw, _ = synth.simulate_reads(genome, lm, 4, 3)
+    ix = pipeline.HostIndex.build(genome, lm, threads=2)
+    values = ix.values.copy()
+    ot = po.OracleTree(values)
+    rt = R.ref_kdtree_build(po._p(values), None, len(values), 6, 20)
+    for r in range(4):
+        pa = pipeline.raw_to_pa(raw[r], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        em = np.zeros(len(pa) + 1, np.float32); sd = np.zeros(len(pa) + 1, np.float32)
+        ne = R.ref_detect_events_entry(po._p(pa), len(pa), po._p(em), po._p(sd))
+        ev, _ = po.detect_events(pa)
+        assert ne == len(ev) and np.array_equal(bits(em[:ne]), bits(ev["mean"]))
+        f, _ = po.generate_events(pa)
+        for p in range(2, len(f) - 5, 16):
+            q = np.ascontiguousarray(f[p:p + 6])
+            n, idx, dist, _ = ot.radius_search(q, 0.08)
+            ridx = np.zeros(4096, np.uint64); rd = np.zeros(4096, np.float32)
+            rn = R.ref_radius_search(rt, po._p(q), 0.08, po._p(ridx), po._p(rd), 4096)
+            assert rn == n and np.array_equal(ridx[:n], idx) and np.array_equal(bits(rd[:n]), bits(dist))
+    R.ref_kdtree_free(rt)
+    ot.close()
+
+
+def test_event_edge_cases():
+    # constant signal: no peaks -> reference would index out of bounds; oracle yields nothing
+    x = np.full(4000, 90.0, np.float32)
+    ev, peaks = po.detect_events(x)
+    assert len(peaks) == 0 and len(ev) == 0
+    f, s = po.generate_events(x)
+    assert len(f) == 0
+    # shorter than two long windows: t-stat is all zero (event.h:78-83)
+    x = np.linspace(60, 120, 10).astype(np.float32)
+    ev, peaks = po.detect_events(x)
+    assert len(ev) == 0
+
+
+def test_seed_positions_degenerate_sort():
+    """spatial_index.cc:326-356: positions step, 2*step, ... (0 and 1 never queried)."""
+    L = po.lib()
+    for nq, step in [(450, 2), (51, 2), (56, 3), (7, 2), (6, 2), (100, 1)]:
+        pos = np.zeros(nq + 1, np.uint32)
+        n = L.so_seed_positions(nq, 6, step, po._p(pos))
+        nwin = nq - 6 + 1
+        assert pos[:n].tolist() == [(k + 1) * step for k in range((nwin - 1) // step)]
+
+
+def test_sdtw_full_band_equals_unbanded():
+    rng = np.random.default_rng(0)
+    t = rng.normal(size=300).astype(np.float32)
+    q = (t[100:160] + rng.normal(scale=0.05, size=60)).astype(np.float32)
+    d, end = po.sdtw(t, q)
+    lo = np.ones(300, np.uint32); hi = np.full(300, 60, np.uint32)
+    d2, end2 = po.sdtw_banded(t, q, lo, hi)
+    assert d == d2 and end == end2
+    assert 155 <= end <= 165
