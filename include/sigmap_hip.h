@@ -65,7 +65,8 @@ typedef struct {
   /* device-side capacities (not reference semantics; exceeding one is reported, never
    * silently truncated) */
   uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (128) */
-  uint32_t lanes_per_query;       /* 8/16/32/64: wave sub-group width of the tree walk */
+  uint32_t lanes_per_query;       /* 1 (default: one lane walks one query) or 8/16/32/64
+                                     (a wave sub-group walks one query) */
   uint32_t reserved;
 } smhip_params;
 
@@ -93,8 +94,8 @@ typedef struct {
   uint32_t pad;
   uint64_t n_nodes, m_size;
   void *nodes;      uint64_t nodes_bytes;      /* smhip_node[n_nodes] */
-  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* float[m_size][dim], tree (leaf-major) order */
-  void *leaf_pos;   uint64_t leaf_pos_bytes;   /* uint64[m_size], Point.position in tree order */
+  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* 32-byte records in tree (leaf-major) order:
+                                                  float v[6]; uint64 Point.position */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */
   void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
 } smhip_index_dev;

@@ -87,7 +87,6 @@ class IndexDev(C.Structure):
                 ("m_size", C.c_uint64),
                 ("nodes", C.c_void_p), ("nodes_bytes", C.c_uint64),
                 ("leaf_pts", C.c_void_p), ("leaf_pts_bytes", C.c_uint64),
-                ("leaf_pos", C.c_void_p), ("leaf_pos_bytes", C.c_uint64),
                 ("leaf_vind", C.c_void_p), ("leaf_vind_bytes", C.c_uint64),
                 ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64)]
 

@@ -122,7 +122,7 @@ void smhip_default_params(smhip_params *p) {
   p->num_nearest_points = 5000;
   p->min_chaining_score = 10;
   p->hits_per_query_fast = 128;
-  p->lanes_per_query = 16;
+  p->lanes_per_query = 1;
 }
 
 int smhip_init(int device_ordinal, smhip_ctx **out) {
@@ -148,7 +148,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->ix_pos, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
@@ -178,8 +178,8 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(ctx->ix_nodes.Reserve(n_nodes * sizeof(smhip_node)));
-  HIPCHK(ctx->ix_pts.Reserve(m_size * dim * sizeof(float)));
-  HIPCHK(ctx->ix_pos.Reserve(m_size * sizeof(uint64_t)));
+  HIPCHK(ctx->ix_pts.Reserve(m_size * 32 + 64));
+  HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, m_size * 32 + 64, ctx->stream));
   HIPCHK(ctx->ix_vind.Reserve(m_size * sizeof(uint32_t)));
   HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
   // staging copies of the original-order point cloud, freed after the leaf-major gather
@@ -208,12 +208,12 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, nodes, n_nodes * sizeof(smhip_node), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_bbox.p, root_bbox, 2 * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), ctx->ix_vind.as<uint32_t>(),
-                           m_size, ctx->ix_pts.as<float>(), ctx->ix_pos.as<uint64_t>()));
+                           ctx->ix_nodes.as<smhip_node>(), n_nodes, ctx->ix_pts.as<float>()));
   HIPCHK2(hipStreamSynchronize(ctx->stream));
 #undef HIPCHK2
   cleanup();
   ctx->dim = dim;
-  ctx->index = IndexView{ctx->ix_nodes.as<smhip_node>(), ctx->ix_pts.as<float>(), ctx->ix_pos.as<uint64_t>(),
+  ctx->index = IndexView{ctx->ix_nodes.as<smhip_node>(), ctx->ix_pts.as<float>(),
                          ctx->ix_vind.as<uint32_t>(), ctx->ix_bbox.as<float>(), n_nodes, m_size};
   ctx->have_index = true;
   ctx->index_owned = true;
@@ -230,9 +230,7 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->nodes = (void *)ctx->index.nodes;
   out->nodes_bytes = ctx->index.n_nodes * sizeof(smhip_node);
   out->leaf_pts = (void *)ctx->index.leaf_pts;
-  out->leaf_pts_bytes = ctx->index.m_size * ctx->dim * sizeof(float);
-  out->leaf_pos = (void *)ctx->index.leaf_pos;
-  out->leaf_pos_bytes = ctx->index.m_size * sizeof(uint64_t);
+  out->leaf_pts_bytes = ctx->index.m_size * 32 + 64;  // + read-ahead pad of the 4-wide leaf scan
   out->leaf_vind = (void *)ctx->index.leaf_vind;
   out->leaf_vind_bytes = ctx->index.m_size * sizeof(uint32_t);
   out->bbox = (void *)ctx->index.bbox;
@@ -243,13 +241,13 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (!ctx || !in) return SMHIP_EINVAL;
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
-  if (!in->nodes || !in->leaf_pts || !in->leaf_pos || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
+  if (!in->nodes || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
     return Fail(ctx, SMHIP_EINVAL, "null index array");
-  if (in->nodes_bytes < in->n_nodes * sizeof(smhip_node) || in->leaf_pts_bytes < in->m_size * 6 * sizeof(float) ||
-      in->leaf_pos_bytes < in->m_size * 8 || in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
+  if (in->nodes_bytes < in->n_nodes * sizeof(smhip_node) || in->leaf_pts_bytes < in->m_size * 32 + 64 ||
+      in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
     return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");
   ctx->dim = in->dim;
-  ctx->index = IndexView{(const smhip_node *)in->nodes, (const float *)in->leaf_pts, (const uint64_t *)in->leaf_pos,
+  ctx->index = IndexView{(const smhip_node *)in->nodes, (const float *)in->leaf_pts,
                          (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->m_size};
   ctx->have_index = true;
   ctx->index_owned = false;
@@ -307,8 +305,9 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   if (n_refs == 0 || p->step_size < 1 || p->hits_per_query_fast == 0 || p->num_nearest_points < 1 ||
       p->num_best_chains > 3)
     return Fail(ctx, SMHIP_EINVAL, "bad parameter");
-  if (p->lanes_per_query != 8 && p->lanes_per_query != 16 && p->lanes_per_query != 32 && p->lanes_per_query != 64)
-    return Fail(ctx, SMHIP_EINVAL, "lanes_per_query must be 8, 16, 32 or 64");
+  if (p->lanes_per_query != 1 && p->lanes_per_query != 8 && p->lanes_per_query != 16 &&
+      p->lanes_per_query != 32 && p->lanes_per_query != 64)
+    return Fail(ctx, SMHIP_EINVAL, "lanes_per_query must be 1, 8, 16, 32 or 64");
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t R = ctx->n_chunks;
   ctx->run_done = false;
@@ -341,18 +340,20 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_list.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
+  HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
+  HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
   const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 32 + (1u << 20), 0xFFFF0000ull);
   HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
   HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
   {
     ScopedTimer t(ctx, T_SEED);
-    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R,
+    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap,
                             ctx->region.as<Hit>(), ctx->q_count.as<uint32_t>(), results,
                             ctx->counters.as<uint32_t>()));
   }
   {
     ScopedTimer t(ctx, T_OVF);
-    HIPCHK(LaunchSeedOverflow(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R,
+    HIPCHK(LaunchSeedOverflow(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R,
                               ctx->q_count.as<uint32_t>(), ctx->q_ovf_off.as<uint32_t>(),
                               ctx->ovf_list.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), pool_cap, results,
                               ctx->counters.as<uint32_t>(), nq_cap));
@@ -568,10 +569,13 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_seed_lookup before an index is resident");
   if (n_queries == 0) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist;
+  if (p->lanes_per_query != 1 && p->lanes_per_query != 8 && p->lanes_per_query != 16 &&
+      p->lanes_per_query != 32 && p->lanes_per_query != 64)
+    return Fail(ctx, SMHIP_EINVAL, "lanes_per_query must be 1, 8, 16, 32 or 64");
+  DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist, d_qrec;
   const uint64_t total = (uint64_t)n_queries * cap;
   auto free_all = [&]() {
-    for (DevBuf *b : {&d_q, &d_region, &d_cnt, &d_nodes, &d_pts, &d_idx, &d_dist}) b->Free();
+    for (DevBuf *b : {&d_q, &d_region, &d_cnt, &d_nodes, &d_pts, &d_idx, &d_dist, &d_qrec}) b->Free();
   };
   hipError_t e = hipSuccess;
   auto step = [&](hipError_t r) {
@@ -584,13 +588,14 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   step(d_pts.Reserve((uint64_t)n_queries * 4));
   step(d_idx.Reserve(total * 8));
   step(d_dist.Reserve(total * 4));
+  step(d_qrec.Reserve((uint64_t)n_queries * 32));
   step(ctx->counters.Reserve(16 * sizeof(uint32_t)));
   if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
   if (e == hipSuccess) {
     ScopedTimer t(ctx, T_SEED);
     step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, d_region.as<Hit>(), d_cnt.as<uint32_t>(),
-                             d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>()));
+                             d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>(), d_qrec.p));
   }
   if (e == hipSuccess) {
     hipLaunchKernelGGL(HitsToArraysKernel, dim3(1024), dim3(256), 0, ctx->stream, d_region.as<Hit>(),

@@ -35,8 +35,7 @@ struct ChainTmp {
 // Device view of the index (all pointers device memory).
 struct IndexView {
   const smhip_node *nodes;
-  const float *leaf_pts;      // [m_size][6]
-  const uint64_t *leaf_pos;   // [m_size]
+  const float *leaf_pts;      // [m_size] x 32 B: float v[6]; uint64 position (tree order)
   const uint32_t *leaf_vind;  // [m_size]
   const float *bbox;          // [12] low0, high0, ...
   uint64_t n_nodes, m_size;
@@ -81,16 +80,16 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_nodes, ix_pts, ix_pos, ix_vind, ix_bbox;
+  smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox;
   // batch inputs
   uint32_t n_chunks = 0;
   uint64_t n_samples = 0, n_carried = 0;
   bool batch_ready = false, run_done = false;
   smhip::DevBuf samples, sample_off, qstart, carried, carried_off;
   // per-chunk intermediates
-  smhip::DevBuf feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
+  smhip::DevBuf ev_scratch, feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
   // per-query
-  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters;
+  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist;
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
@@ -109,22 +108,24 @@ namespace smhip {
 // Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
 // launch status.
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, uint64_t m_size, float *leaf_pts, uint64_t *leaf_pos);
+                            const uint32_t *vind, const smhip_node *nodes, uint64_t n_nodes, float *leaf_pts);
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
-hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
-                            const uint32_t *q_off, uint32_t n_chunks, Hit *region, uint32_t *q_count,
+hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
+                             const uint32_t *q_off, uint32_t n_chunks, void *qrec);
+hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
+                            uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
                             smhip_chunk_result *results, uint32_t *counters);
 // explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
                                uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
-                               uint32_t *q_points, uint32_t *counters);
-hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
-                              const uint32_t *q_off, uint32_t n_chunks, uint32_t *q_count,
-                              uint32_t *q_ovf_off, uint32_t *ovf_list, Hit *ovf_pool, uint64_t pool_cap,
-                              smhip_chunk_result *results, uint32_t *counters, uint64_t max_queries);
+                               uint32_t *q_points, uint32_t *counters, void *qrec);
+hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
+                              uint32_t n_chunks, uint32_t *q_count, uint32_t *q_ovf_off, uint32_t *ovf_list,
+                              Hit *ovf_pool, uint64_t pool_cap, smhip_chunk_result *results, uint32_t *counters,
+                              uint64_t max_queries);
 hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
                              const uint32_t *q_count, const uint32_t *carried_off, uint32_t n_chunks,
                              uint32_t *chunk_cnt);

@@ -2,21 +2,27 @@
 //
 // Replaces Sigmap::GenerateEvents (sigmap.cc:1048-1083) = DetectEvents (event.h:226-267)
 // + GenerateZscoreNormalizedSignal (sigmap.cc:1131-1155) + the 0.1 compression
-// (sigmap.cc:1073-1079).  One 256-thread workgroup per chunk; the whole chunk lives in LDS
-// (4 float arrays of kMaxSamples + the peak list, ~74 KB => 2 workgroups per CU).
+// (sigmap.cc:1073-1079).
 //
-// Bit-exactness rules (SURVEY.md section 7 "hard parts"): the two prefix sums are
-// sequential f32 chains (event.h:58-68), so they run in index order on two lanes of one
-// wave (lane 0: sum x, lane 1: sum x*x); the t-statistic mixes f32 with f64 fabs/sqrt/div
-// (event.h:109); the z-score sums are sequential f64.  Everything else is parallel.
+// Bit-exactness rules (SURVEY.md section 7 "hard parts"): the two prefix sums are sequential
+// f32 chains (event.h:58-68), the peak picker is a sequential state machine (event.h:117-182),
+// the z-score sums are sequential f64 (sigmap.cc:1135-1146) and the compression carries the
+// last kept value; the t-statistic mixes f32 with f64 fabs/sqrt/div (event.h:109).
+//
+// Mapping: the order-dependent stages run ONE LANE PER CHUNK (64 chunks per wavefront, loads
+// issued kBlk samples ahead of the dependent chain), the order-free stages (t-statistics,
+// event means) run one thread per element.  Five small kernels over HBM-resident scratch rows:
+//   E1 PrefixKernel (lane/chunk) -> E2 TStatKernel (thread/sample, LDS-staged prefix sums)
+//   -> E3 PeakKernel (lane/chunk) -> E4 EventMeanKernel (thread/event) -> E5 FeatureKernel
+//   (lane/chunk).
 #include <float.h>
 
 #include "common.h"
 
 namespace smhip {
 namespace {
-constexpr int kLdsStride = kMaxSamples + 4;  // floats per LDS array (16-byte multiple)
-constexpr int kEvThreads = 256;
+constexpr int kRowStride = kMaxSamples + 4;  // floats per chunk row of the scratch arrays
+constexpr int kBlk = 8;                      // samples fetched ahead of the sequential chains
 
 // event.h:89-110 for one i in [w, n-w]
 __device__ __forceinline__ float TStatAt(const float *ps, const float *pss, uint32_t i, uint32_t w) {
@@ -46,190 +52,234 @@ struct Detector {  // event.h:45-56
   bool valid_peak;
 };
 
-__global__ __launch_bounds__(kEvThreads) void EventsKernel(
-    const float *__restrict__ samples, const uint32_t *__restrict__ off, uint32_t feat_stride,
-    float *__restrict__ feat, float *__restrict__ stdv, smhip_chunk_result *__restrict__ results,
-    uint32_t *__restrict__ nq, uint32_t w1, uint32_t w2, float thr1, float thr2, float peak_height,
-    double compress_delta, uint32_t min_num_events, int dim, int step) {
-  extern __shared__ __align__(16) float lds[];
-  float *ps = lds;                    // prefix sums, later z-scores
-  float *pss = ps + kLdsStride;       // prefix sums of squares, later kept features
-  float *A = pss + kLdsStride;        // x, then t-stat (w1), then event means, then kept stdv
-  float *B = A + kLdsStride;          // x*x, then t-stat (w2), then event stdv
-  uint16_t *peaks = reinterpret_cast<uint16_t *>(B + kLdsStride);
-  __shared__ uint32_t s_npeaks, s_nfeat;
-  __shared__ double s_mean, s_sd;
-
-  const uint32_t c = blockIdx.x;
-  const uint32_t tid = threadIdx.x;
+// E1 -- event.h:58-68.  ps[i+1] = ps[i] + x[i]; pss[i+1] = pss[i] + x[i]*x[i].
+__global__ __launch_bounds__(64) void PrefixKernel(const float *__restrict__ samples,
+                                                   const uint32_t *__restrict__ off, uint32_t n_chunks,
+                                                   float *__restrict__ ps_all, float *__restrict__ pss_all) {
+  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_chunks) return;
   const uint32_t begin = off[c];
   uint32_t n = off[c + 1] - begin;
-  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;  // caller validated; defensive clamp
+  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   const float *x = samples + begin;
-
-  if (tid == 0) {  // the record is zeroed here; later kernels accumulate into it
-    smhip_chunk_result z;
-    memset(&z, 0, sizeof z);
-    results[c] = z;
-  }
-  for (uint32_t i = tid; i < n; i += kEvThreads) {
-    const float v = x[i];
-    A[i] = v;
-    B[i] = v * v;
-  }
-  __syncthreads();
-
-  // event.h:58-68: ps[i+1] = ps[i] + x[i]; pss[i+1] = pss[i] + x[i]*x[i], in index order.
-  if (tid < 2) {
-    const float *src = tid == 0 ? A : B;
-    float *dst = tid == 0 ? ps : pss;
-    float acc = 0.0f;
-    dst[0] = 0.0f;
-    uint32_t i = 0;
-    for (; i + 4 <= n; i += 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(src + i);
-      const float a0 = acc + v.x;
-      const float a1 = a0 + v.y;
-      const float a2 = a1 + v.z;
-      const float a3 = a2 + v.w;
-      dst[i + 1] = a0;
-      dst[i + 2] = a1;
-      dst[i + 3] = a2;
-      dst[i + 4] = a3;
-      acc = a3;
-    }
-    for (; i < n; ++i) {
-      acc = acc + src[i];
-      dst[i + 1] = acc;
-    }
-  }
-  __syncthreads();
-
-  // event.h:70-115 for both windows; entries [0,w) and (n-w, n] are zero.
-  for (uint32_t i = tid; i <= n; i += kEvThreads) {
-    float t1 = 0.0f, t2 = 0.0f;
-    if (!(n < 2 * w1 || w1 < 2) && i >= w1 && i <= n - w1) t1 = TStatAt(ps, pss, i, w1);
-    if (!(n < 2 * w2 || w2 < 2) && i >= w2 && i <= n - w2) t2 = TStatAt(ps, pss, i, w2);
-    A[i] = t1;
-    B[i] = t2;
-  }
-  __syncthreads();
-
-  // event.h:117-182: sequential two-detector state machine (short detector first).
-  if (tid == 0) {
-    Detector d[2] = {{thr1, w1, 0, -1, FLT_MAX, false}, {thr2, w2, 0, -1, FLT_MAX, false}};
-    uint32_t np = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+  float *ps = ps_all + (size_t)c * kRowStride, *pss = pss_all + (size_t)c * kRowStride;
+  float a = 0.0f, b = 0.0f;
+  ps[0] = 0.0f;
+  pss[0] = 0.0f;
+  uint32_t i = 0;
+  for (; i + kBlk <= n; i += kBlk) {
+    float v[kBlk];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        Detector &det = d[k];
-        if (det.masked_to >= i) continue;
-        const float cur = k == 0 ? A[i] : B[i];
-        if (det.peak_pos == -1) {
-          if (cur < det.peak_value) {
-            det.peak_value = cur;
-          } else if (cur - det.peak_value > peak_height) {
-            det.peak_value = cur;
-            det.peak_pos = (int)i;
-          }
-        } else {
-          if (cur > det.peak_value) {
-            det.peak_value = cur;
-            det.peak_pos = (int)i;
-          }
-          if (k == 0) {
-            if (det.peak_value > det.threshold) {
-              d[1].masked_to = (uint64_t)det.peak_pos + det.window_length;
-              d[1].peak_pos = -1;
-              d[1].peak_value = FLT_MAX;
-              d[1].valid_peak = false;
-            }
-          }
-          if (det.peak_value - cur > peak_height && det.peak_value > det.threshold) det.valid_peak = true;
-          if (det.valid_peak && ((uint64_t)i - (uint64_t)det.peak_pos) > det.window_length / 2) {
-            peaks[np++] = (uint16_t)det.peak_pos;
-            det.peak_pos = -1;
-            det.peak_value = cur;
-            det.valid_peak = false;
-          }
-        }
+    for (int k = 0; k < kBlk; ++k) v[k] = x[i + k];
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      a = a + v[k];
+      b = b + v[k] * v[k];
+      ps[i + k + 1] = a;
+      pss[i + k + 1] = b;
+    }
+  }
+  for (; i < n; ++i) {
+    const float v = x[i];
+    a = a + v;
+    b = b + v * v;
+    ps[i + 1] = a;
+    pss[i + 1] = b;
+  }
+}
+
+// E2 -- event.h:70-115 for both windows, one thread per sample index (entries [0,w) and
+// (n-w, n] are zero).  The chunk's prefix sums are staged in LDS.
+__global__ __launch_bounds__(256) void TStatKernel(const uint32_t *__restrict__ off,
+                                                   const float *__restrict__ ps_all,
+                                                   const float *__restrict__ pss_all, float *__restrict__ t1_all,
+                                                   float *__restrict__ t2_all, uint32_t w1, uint32_t w2) {
+  __shared__ float ps[kRowStride], pss[kRowStride];
+  const uint32_t c = blockIdx.x, tid = threadIdx.x;
+  uint32_t n = off[c + 1] - off[c];
+  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
+  const float *gps = ps_all + (size_t)c * kRowStride, *gpss = pss_all + (size_t)c * kRowStride;
+  for (uint32_t i = tid; i <= n; i += 256) {
+    ps[i] = gps[i];
+    pss[i] = gpss[i];
+  }
+  __syncthreads();
+  float *t1 = t1_all + (size_t)c * kRowStride, *t2 = t2_all + (size_t)c * kRowStride;
+  for (uint32_t i = tid; i <= n; i += 256) {
+    float a = 0.0f, b = 0.0f;
+    if (!(n < 2 * w1 || w1 < 2) && i >= w1 && i <= n - w1) a = TStatAt(ps, pss, i, w1);
+    if (!(n < 2 * w2 || w2 < 2) && i >= w2 && i <= n - w2) b = TStatAt(ps, pss, i, w2);
+    t1[i] = a;
+    t2[i] = b;
+  }
+}
+
+// One step of one detector, event.h:128-180.
+__device__ __forceinline__ void DetectorStep(Detector *d, int k, float cur, uint32_t i, float peak_height,
+                                             uint16_t *peaks, uint32_t &np) {
+  Detector &det = d[k];
+  if (det.masked_to >= i) return;
+  if (det.peak_pos == -1) {
+    if (cur < det.peak_value) {
+      det.peak_value = cur;
+    } else if (cur - det.peak_value > peak_height) {
+      det.peak_value = cur;
+      det.peak_pos = (int)i;
+    }
+  } else {
+    if (cur > det.peak_value) {
+      det.peak_value = cur;
+      det.peak_pos = (int)i;
+    }
+    if (k == 0) {
+      if (det.peak_value > det.threshold) {
+        d[1].masked_to = (uint64_t)det.peak_pos + det.window_length;
+        d[1].peak_pos = -1;
+        d[1].peak_value = FLT_MAX;
+        d[1].valid_peak = false;
       }
     }
-    s_npeaks = np;
+    if (det.peak_value - cur > peak_height && det.peak_value > det.threshold) det.valid_peak = true;
+    if (det.valid_peak && ((uint64_t)i - (uint64_t)det.peak_pos) > det.window_length / 2) {
+      peaks[np++] = (uint16_t)det.peak_pos;
+      det.peak_pos = -1;
+      det.peak_value = cur;
+      det.valid_peak = false;
+    }
   }
-  __syncthreads();
+}
 
-  // event.h:200-224: num_events = 1 + #{i>=1 : 0 < peaks[i] < n}.  Every emitted peak is a
-  // sample index in [1, n-1] (index 0 is never examined: masked_to >= 0), so that count is
-  // n_peaks.  With fewer than 2 peaks the reference reads out of bounds: the chunk is
-  // flagged and yields no features.
-  const uint32_t E = s_npeaks >= 2 ? s_npeaks : 0;
-  for (uint32_t e = tid; e < E; e += kEvThreads) {
+// E3 -- event.h:117-182: sequential in i, short detector first.
+__global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ off, uint32_t n_chunks,
+                                                 const float *__restrict__ t1_all, const float *__restrict__ t2_all,
+                                                 uint16_t *__restrict__ peaks_all, uint32_t *__restrict__ n_peaks,
+                                                 uint32_t w1, uint32_t w2, float thr1, float thr2, float peak_height) {
+  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_chunks) return;
+  uint32_t n = off[c + 1] - off[c];
+  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
+  const float *t1 = t1_all + (size_t)c * kRowStride, *t2 = t2_all + (size_t)c * kRowStride;
+  uint16_t *peaks = peaks_all + (size_t)c * kRowStride;
+  Detector d[2] = {{thr1, w1, 0, -1, FLT_MAX, false}, {thr2, w2, 0, -1, FLT_MAX, false}};
+  uint32_t np = 0;
+  uint32_t i = 0;
+  for (; i + kBlk <= n; i += kBlk) {
+    float a[kBlk], b[kBlk];
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      a[k] = t1[i + k];
+      b[k] = t2[i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      DetectorStep(d, 0, a[k], i + k, peak_height, peaks, np);
+      DetectorStep(d, 1, b[k], i + k, peak_height, peaks, np);
+    }
+  }
+  for (; i < n; ++i) {
+    DetectorStep(d, 0, t1[i], i, peak_height, peaks, np);
+    DetectorStep(d, 1, t2[i], i, peak_height, peaks, np);
+  }
+  n_peaks[c] = np;
+}
+
+// E4 -- event.h:184-224: event e spans [peaks[e-1], peaks[e]) (first from 0, last to n; the
+// last peak is dropped).  num_events = 1 + #{i>=1 : 0 < peaks[i] < n}; every emitted peak is a
+// sample index in [1, n-1] (index 0 is never examined: masked_to >= 0), so that is n_peaks.
+// With fewer than 2 peaks the reference reads out of bounds: the chunk yields no events.
+__global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restrict__ off,
+                                                       const float *__restrict__ ps_all,
+                                                       const float *__restrict__ pss_all,
+                                                       const uint16_t *__restrict__ peaks_all,
+                                                       const uint32_t *__restrict__ n_peaks,
+                                                       float *__restrict__ ev_mean, float *__restrict__ ev_stdv,
+                                                       uint32_t feat_stride) {
+  const uint32_t c = blockIdx.x;
+  uint32_t n = off[c + 1] - off[c];
+  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
+  const uint32_t E = n_peaks[c] >= 2 ? n_peaks[c] : 0;
+  const float *ps = ps_all + (size_t)c * kRowStride, *pss = pss_all + (size_t)c * kRowStride;
+  const uint16_t *peaks = peaks_all + (size_t)c * kRowStride;
+  for (uint32_t e = threadIdx.x; e < E && e < feat_stride; e += 256) {
     const uint64_t start = e > 0 ? peaks[e - 1] : 0;
     const uint64_t end = e < E - 1 ? peaks[e] : n;
     const uint64_t length = end - start;  // size_t arithmetic, wraps like the reference
     const float mean = (ps[end] - ps[start]) / (float)length;
     const float deltasqr = pss[end] - pss[start];
     const float var = deltasqr / (float)length - mean * mean;
-    A[e] = mean;
-    B[e] = sqrtf(fmaxf(var, 0.0f));
+    ev_mean[(size_t)c * feat_stride + e] = mean;
+    ev_stdv[(size_t)c * feat_stride + e] = sqrtf(fmaxf(var, 0.0f));
   }
-  __syncthreads();
+}
 
-  // sigmap.cc:1135-1146: sequential double sums
-  if (tid == 0 && E > 0) {
+// E5 -- sigmap.cc:1131-1155 (z-score: sequential f64 sums) + sigmap.cc:1073-1079 (keep i iff
+// i == 0 or |z[i] - last kept| > 0.1, float abs against the double constant).  Also derives the
+// number of seeds of the chunk and initialises its result record.
+__global__ __launch_bounds__(64) void FeatureKernel(uint32_t n_chunks, const uint32_t *__restrict__ n_peaks,
+                                                    const float *__restrict__ ev_mean,
+                                                    const float *__restrict__ ev_stdv, uint32_t feat_stride,
+                                                    float *__restrict__ feat, float *__restrict__ stdv,
+                                                    smhip_chunk_result *__restrict__ results,
+                                                    uint32_t *__restrict__ nq, double compress_delta,
+                                                    uint32_t min_num_events, int dim, int step) {
+  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uint32_t npk = n_peaks[c];
+  uint32_t E = npk >= 2 ? npk : 0;
+  if (E > feat_stride) E = feat_stride;
+  const float *m = ev_mean + (size_t)c * feat_stride, *sd = ev_stdv + (size_t)c * feat_stride;
+  float *fo = feat + (size_t)c * feat_stride;
+  float *so = stdv ? stdv + (size_t)c * feat_stride : nullptr;
+  uint32_t F = 0;
+  if (E > 0) {
     double mean = 0;
-    for (uint32_t i = 0; i < E; ++i) mean += (double)A[i];
+    uint32_t i = 0;
+    for (; i + kBlk <= E; i += kBlk) {
+      float v[kBlk];
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) v[k] = m[i + k];
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) mean += (double)v[k];
+    }
+    for (; i < E; ++i) mean += (double)m[i];
     mean /= (double)E;
     double SD = 0;
-    for (uint32_t i = 0; i < E; ++i) SD += ((double)A[i] - mean) * ((double)A[i] - mean);
+    for (i = 0; i + kBlk <= E; i += kBlk) {
+      float v[kBlk];
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) v[k] = m[i + k];
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) SD += ((double)v[k] - mean) * ((double)v[k] - mean);
+    }
+    for (; i < E; ++i) SD += ((double)m[i] - mean) * ((double)m[i] - mean);
     SD /= (double)(uint64_t)(E - 1);
     SD = sqrt(SD);
-    s_mean = mean;
-    s_sd = SD;
-  }
-  __syncthreads();
-  {
-    const double mean = s_mean, SD = s_sd;
-    for (uint32_t i = tid; i < E; i += kEvThreads) ps[i] = (float)(((double)A[i] - mean) / SD);
-  }
-  __syncthreads();
-
-  // sigmap.cc:1073-1079: keep i iff i == 0 or |z[i] - last kept| > 0.1 (float abs vs double 0.1)
-  if (tid == 0) {
-    uint32_t k = 0;
     float last = 0.0f;
-    for (uint32_t i = 0; i < E; ++i) {
-      const float z = ps[i];
+    for (i = 0; i < E; ++i) {
+      const float z = (float)(((double)m[i] - mean) / SD);
       if (i == 0 || (double)fabsf(z - last) > compress_delta) {
-        pss[k] = z;
-        A[k] = B[i];  // k <= i, and A[i] (event mean) is dead once z is computed
+        fo[F] = z;
+        if (so) so[F] = sd[i];
         last = z;
-        ++k;
+        ++F;
       }
     }
-    s_nfeat = k;
   }
-  __syncthreads();
-  const uint32_t F = s_nfeat;
-  for (uint32_t i = tid; i < F && i < feat_stride; i += kEvThreads) {
-    feat[(size_t)c * feat_stride + i] = pss[i];
-    if (stdv) stdv[(size_t)c * feat_stride + i] = A[i];
+  uint32_t Q = 0;
+  // sigmap.cc:660 (> 50 features) and spatial_index.cc:326-356,403-408: seeds at
+  // step, 2*step, ... <= nwin-1 (the "reliable seed" sort is a no-op)
+  if (F > min_num_events && F >= (uint32_t)dim) {
+    const uint32_t nwin = F - (uint32_t)dim + 1;
+    Q = (nwin - 1) / (uint32_t)step;
   }
-  if (tid == 0) {
-    uint32_t Q = 0;
-    // sigmap.cc:660 (> 50 features) and spatial_index.cc:326-356,403-408: seeds at
-    // step, 2*step, ... <= nwin-1 (the "reliable seed" sort is a no-op)
-    if (F > min_num_events && F >= (uint32_t)dim) {
-      const uint32_t nwin = F - (uint32_t)dim + 1;
-      Q = (nwin - 1) / (uint32_t)step;
-    }
-    results[c].status = s_npeaks < 2 ? SMHIP_ST_FEW_PEAKS : 0;
-    results[c].n_events = E;
-    results[c].n_features = F;
-    results[c].n_queries = Q;
-    nq[c] = Q;
-  }
+  smhip_chunk_result z;
+  memset(&z, 0, sizeof z);  // the record is zeroed here; later kernels accumulate into it
+  z.status = npk < 2 ? SMHIP_ST_FEW_PEAKS : 0;
+  z.n_events = E;
+  z.n_features = F;
+  z.n_queries = Q;
+  results[c] = z;
+  nq[c] = Q;
 }
 
 // Exclusive scan of n uint32 values by one workgroup (n is a chunk count: small).
@@ -239,7 +289,7 @@ __global__ __launch_bounds__(1024) void ScanKernel(const uint32_t *__restrict__ 
   __shared__ uint64_t part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = tid * per, e = min(n, b + per);
+  const uint32_t b = min(n, tid * per), e = min(n, b + per);
   uint64_t s = 0;
   for (uint32_t i = b; i < e; ++i) s += in[i];
   part[tid] = s;
@@ -263,18 +313,26 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq) {
   if (n_chunks == 0) return hipSuccess;
-  const size_t lds = 4 * (size_t)kLdsStride * sizeof(float) + (size_t)kMaxSamples * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(EventsKernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(EventsKernel, dim3(n_chunks), dim3(kEvThreads), lds, ctx->stream, samples, off,
-                     feat_stride, feat, stdv, results, nq, p.window_length1, p.window_length2,
-                     p.threshold1, p.threshold2, p.peak_height, p.compress_delta, p.min_num_events,
-                     kMaxDim, p.step_size);
+  const size_t row = (size_t)n_chunks * kRowStride;
+  const size_t evn = (size_t)n_chunks * feat_stride;
+  // scratch rows: ps, pss, t1, t2 (f32), event mean / stdv (f32), n_peaks (u32), peaks (u16)
+  hipError_t e = ctx->ev_scratch.Reserve((row * 4 + evn * 2) * sizeof(float) + (size_t)n_chunks * 4 +
+                                         row * sizeof(uint16_t) + 256);
+  if (e != hipSuccess) return e;
+  float *ps = ctx->ev_scratch.as<float>(), *pss = ps + row, *t1 = pss + row, *t2 = t1 + row;
+  float *ev_mean = t2 + row, *ev_stdv = ev_mean + evn;
+  uint32_t *n_peaks = reinterpret_cast<uint32_t *>(ev_stdv + evn);
+  uint16_t *peaks = reinterpret_cast<uint16_t *>(n_peaks + n_chunks);
+  const uint32_t lane_blocks = (n_chunks + 63) / 64;
+  hipLaunchKernelGGL(PrefixKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, samples, off, n_chunks, ps, pss);
+  hipLaunchKernelGGL(TStatKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, t1, t2,
+                     p.window_length1, p.window_length2);
+  hipLaunchKernelGGL(PeakKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, off, n_chunks, t1, t2, peaks, n_peaks,
+                     p.window_length1, p.window_length2, p.threshold1, p.threshold2, p.peak_height);
+  hipLaunchKernelGGL(EventMeanKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, peaks, n_peaks,
+                     ev_mean, ev_stdv, feat_stride);
+  hipLaunchKernelGGL(FeatureKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, n_chunks, n_peaks, ev_mean, ev_stdv,
+                     feat_stride, feat, stdv, results, nq, p.compress_delta, p.min_num_events, kMaxDim, p.step_size);
   return hipGetLastError();
 }
 

@@ -164,7 +164,7 @@ void GenerateMaskedPositions(int kmer_size, float frequency, const SequenceBatch
                              ++num_kmers;
                            }
                          });
-  std::cout << "# " << kmer_size << "mers: " << num_kmers << "\n";
+  std::cerr << "# " << kmer_size << "mers: " << num_kmers << "\n";
   uint64_t num_masked = 0;
   auto mask_strand = [&](const char *seq, uint32_t len, std::vector<bool> &masked) {
     masked.assign(len - kmer_size + 1, false);

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _abi
 
-_ARRAYS = ["nodes", "leaf_pts", "leaf_pos", "leaf_vind", "bbox"]
+_ARRAYS = ["nodes", "leaf_pts", "leaf_vind", "bbox"]
 
 
 def shard_range(n_items, rank, world):
@@ -65,7 +65,7 @@ def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
 
 def replicate_index(dev, ix, rank, world, local_rank, dist):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
-    uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
+    uploads, then each of the four device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive."""
     if world == 1:
         dev.upload_index(ix)
