@@ -37,6 +37,8 @@
 //  * SeedLookupKernel<G> (lanes_per_query = 8/16/32/64): a sub-group of G lanes walks one query
 //    with the stack in LDS and fans out over the points of a leaf (coalesced leaf reads).
 //    Measured slower on MI355X (issue-bound: one traversal step per G lanes); kept for A/B.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace smhip {
@@ -84,13 +86,24 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem,
-                                                               const uint32_t *__restrict__ order) {
+                                                               const uint32_t *__restrict__ order, int xcd_ranges) {
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
-  const uint32_t n_lanes = gridDim.x * kSeedThreads;
+  uint32_t n_lanes = gridDim.x * kSeedThreads;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
-  const uint32_t total = kOverflow ? sink.counters[1] : (n_queries_dev ? *n_queries_dev : n_queries_host);
+  uint32_t total = kOverflow ? sink.counters[1] : (n_queries_dev ? *n_queries_dev : n_queries_host);
   const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
   uint32_t w = gl;
+  if (xcd_ranges) {
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
+    // never correctness).  Give each XCD one contiguous eighth of the visiting order so that its
+    // private L2 only has to hold that part of the tree.
+    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const uint32_t per = (total + 7) / 8;
+    const uint32_t begin = min(total, xcd * per);
+    total = min(total, begin + per);
+    n_lanes = (gridDim.x >> 3) * kSeedThreads;
+    w = begin + slot * kSeedThreads + threadIdx.x;
+  }
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
@@ -492,12 +505,20 @@ template <bool kOverflow>
 hipError_t LaunchWalk(smhip_ctx *ctx, int G, const QueryRec *qrec, const uint32_t *n_queries_dev,
                       uint32_t n_queries_host, const Sink &sink, float radius, const uint32_t *order) {
   if (G == 1) {
-    const uint32_t blocks = 256 * kLaneBlocksPerCU;
+    static int blocks_per_cu = 0, xcd_ranges = 1;
+    if (blocks_per_cu == 0) {
+      const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES");
+      blocks_per_cu = e1 ? atoi(e1) : kLaneBlocksPerCU;
+      if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
+      if (e2) xcd_ranges = atoi(e2);
+    }
+    const uint32_t blocks = 256 * blocks_per_cu;
     const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
     hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((SeedLaneKernel<kOverflow>), dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
-                       qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order);
+                       qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order,
+                       (order && !kOverflow) ? xcd_ranges : 0);
     return hipGetLastError();
   }
   const int blocks_per_cu = G >= 32 ? 8 : (G == 16 ? 5 : 2);
