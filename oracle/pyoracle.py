@@ -105,6 +105,8 @@ def lib():
         L.so_chains_clear.argtypes = [C.POINTER(Chains)]
         L.so_generate_chains.argtypes = [vp, vp, vp, sz, C.c_uint32, C.c_int, C.c_float, sz,
                                          C.POINTER(Chains), C.POINTER(ChainStats)]
+        L.so_generate_chains_ex.argtypes = [vp, vp, vp, sz, C.c_uint32, C.c_int, C.c_float, sz,
+                                            C.POINTER(Chains), C.POINTER(ChainStats), u64]
         L.so_seed_positions.restype = sz
         L.so_seed_positions.argtypes = [sz, C.c_int, C.c_int, vp]
         L.so_default_params.argtypes = [C.POINTER(MapParams)]
@@ -212,7 +214,8 @@ def chains_to_list(ch):
     return out
 
 
-def generate_chains(tree, positions, query, n_refs, query_start_offset=0, step=2, radius=0.08, prev=None):
+def generate_chains(tree, positions, query, n_refs, query_start_offset=0, step=2, radius=0.08, prev=None,
+                    num_nearest_points=5000):
     """prev: list of chain dicts (as returned) to carry over; returns (chains, stats)."""
     query = np.ascontiguousarray(query, dtype=np.float32)
     positions = np.ascontiguousarray(positions, dtype=np.uint64)
@@ -229,8 +232,8 @@ def generate_chains(tree, positions, query, n_refs, query_start_offset=0, step=2
                            C.cast(a, C.POINTER(Anchor)))
         raise NotImplementedError("carry-over through python needs malloc'd anchors; use map_read")
     st = ChainStats()
-    lib().so_generate_chains(tree.h, _p(positions), _p(query), len(query), query_start_offset, step,
-                             radius, n_refs, C.byref(ch), C.byref(st))
+    lib().so_generate_chains_ex(tree.h, _p(positions), _p(query), len(query), query_start_offset, step,
+                                radius, n_refs, C.byref(ch), C.byref(st), num_nearest_points)
     out = chains_to_list(ch)
     lib().so_chains_clear(C.byref(ch))
     return out, st

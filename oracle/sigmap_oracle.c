@@ -1127,8 +1127,15 @@ void so_chain_sorted_anchors(const so_anchor *const *groups, const size_t *count
 void so_generate_chains(const so_kdtree *t, const uint64_t *positions, const float *query,
                         size_t n_query, uint32_t query_start_offset, int step, float radius,
                         size_t n_refs, so_chains *chains, so_chain_stats *st) {
+  so_generate_chains_ex(t, positions, query, n_query, query_start_offset, step, radius, n_refs, chains, st,
+                        5000 /* num_nearest_points, spatial_index.cc:290 */);
+}
+
+void so_generate_chains_ex(const so_kdtree *t, const uint64_t *positions, const float *query,
+                           size_t n_query, uint32_t query_start_offset, int step, float radius,
+                           size_t n_refs, so_chains *chains, so_chain_stats *st,
+                           uint64_t num_nearest_points) {
   const int dim = t->dim;
-  const uint64_t num_nearest_points = 5000;
   so_avec *groups = (so_avec *)calloc(2 * n_refs, sizeof(so_avec)); /* [strand][ref] */
   /* carry anchors of previous chains, spatial_index.cc:301-322 */
   so_chains prev = *chains;

@@ -147,6 +147,13 @@ void so_generate_chains(const so_kdtree *t, const uint64_t *positions, const flo
                         size_t n_query, uint32_t query_start_offset, int step, float radius,
                         size_t n_refs, so_chains *chains, so_chain_stats *st);
 
+/* Same with the reference's hard-coded num_nearest_points (5000) made a parameter, so the
+ * "first N hits in traversal order" truncation can be exercised on small inputs. */
+void so_generate_chains_ex(const so_kdtree *t, const uint64_t *positions, const float *query,
+                           size_t n_query, uint32_t query_start_offset, int step, float radius,
+                           size_t n_refs, so_chains *chains, so_chain_stats *st,
+                           uint64_t num_nearest_points);
+
 /* Lower-level pieces exposed for per-stage parity tests. */
 /* seed positions (spatial_index.cc:326-356,403-408); returns count */
 size_t so_seed_positions(size_t n_query, int dim, int step, uint32_t *pos /*cap n_query*/);

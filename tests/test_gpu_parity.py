@@ -164,28 +164,40 @@ def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
 
 def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     """spatial_index.cc:371-372: only the first num_nearest_points hits IN TRAVERSAL ORDER become
-    anchors.  A repeat-rich reference makes queries exceed a (lowered) cap; the oracle with the
-    same cap must agree, which pins the traversal order end to end."""
+    anchors.  A point cloud that repeats one signal 12 times gives every seed >= 12 hits; with the
+    cap lowered to 5 on both sides the chains only agree if the device keeps exactly the hits the
+    reference's traversal order would keep (which hits survive changes targets and scores)."""
+    lm = small_world["lm"]
     rng = np.random.default_rng(8)
     unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)])
-    genome = [unit * 12 + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20000)])]
-    lm = small_world["lm"]
-    raw, _ = synth.simulate_reads([unit * 3], lm, 6, 2)
+    host = _abi.host_lib()
+    sig = np.zeros(len(unit), np.float32)
+    m = host.smhost_reference_signal(_abi.ptr(np.ascontiguousarray(lm)), 6, unit, len(unit), 0, _abi.ptr(sig))
+    sig = sig[:m]
+    values = np.concatenate([sig + np.float32(1e-4 * k) for k in range(12)]).astype(np.float32)
+    positions = (np.arange(len(values), dtype=np.uint64) << np.uint64(1))  # one contig, + strand
+    ix = pipeline.HostIndex.from_points(positions, values, threads=2)
+    raw, _ = synth.simulate_reads([unit], lm, 6, 2)
     pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
-    ix = pipeline.HostIndex.build(genome, lm, threads=2)
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
     samples, offsets = _batch(pa)
-    res_full = dev.map_chunks(samples, offsets, n_refs=1)
-    assert (res_full["hits_total"] > res_full["n_queries"] * 4).all()   # repeats: many hits per query
     tree = po.OracleTree(ix.values.copy())
-    for i, x in enumerate(pa):
-        f, _ = po.generate_events(x)
-        chains, st = po.generate_chains(tree, ix.positions, f, 1)
-        assert res_full[i]["n_anchors"] == st.anchors and res_full[i]["n_chains"] == len(chains)
-        if chains:
-            assert res_full[i]["chains"][0]["score"] == np.float32(chains[0]["score"])
-            assert res_full[i]["chains"][0]["start"] == chains[0]["start"]
+    for cap in (5, 5000):
+        dev.params.num_nearest_points = cap
+        for fast in (3, 128):   # truncation inside the fast slots and inside the overflow pass
+            dev.params.hits_per_query_fast = fast
+            res = dev.map_chunks(samples, offsets, n_refs=1)
+            assert (res["hits_total"] > res["n_queries"] * 4).sum() >= 2   # repeats: seeds with 12 hits each
+            for i, x in enumerate(pa):
+                f, _ = po.generate_events(x)
+                chains, st = po.generate_chains(tree, ix.positions, f, 1, num_nearest_points=cap)
+                assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits
+                assert res[i]["n_chains"] == len(chains)
+                for k, c in enumerate(chains[:4]):
+                    g = res[i]["chains"][k]
+                    assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
+                    assert g["n_anchors"] == c["n_anchors"]
     tree.close(); dev.close()
 
 
