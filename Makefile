@@ -13,7 +13,7 @@ HIP_OBJS = $(HIP_SRCS:$(CSRC)/%.hip=build/%.o)
 HOST_SRCS = $(HOST)/kdtree.cc $(HOST)/pore_model.cc $(HOST)/sequence_batch.cc $(HOST)/signal_batch.cc \
             $(HOST)/spatial_index.cc $(HOST)/mapping_logic.cc $(HOST)/host_abi.cc
 
-all: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so oracle
+all: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so cli oracle
 
 $(LIBDIR)/libsigmap_host.so: $(HOST_SRCS) $(wildcard $(HOST)/*.h) include/sigmap_host.h include/sigmap_hip.h
 	@mkdir -p $(LIBDIR)

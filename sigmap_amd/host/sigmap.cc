@@ -1,0 +1,300 @@
+// sigmap.cc -- the `sigmap` command line (same flags and defaults as the reference driver,
+// sigmap.cc:1329-1526) over the MI355X hot path.
+//
+//   sigmap -i -r ref.fa -p model.txt -o PREFIX [-d 6] [-l 20]
+//   sigmap -m -r ref.fa -p model.txt -x PREFIX -s READS_DIR -o out.paf [-t N] [development flags]
+//
+// -i is Sigmap::ConstructIndex (sigmap.cc:999-1046).  -m is Sigmap::StreamingMap
+// (sigmap.cc:549-880) with the per-read taskloop turned into chunk rounds: round c sends chunk c
+// of every still-active read to the GPU in one batch (include/sigmap_hip.h), then the unchanged
+// early-stop / output rules run on the host (mapping_logic.cc).  Reads come from this build's
+// .sgr container (signal_batch.h); FAST5/BLOW5 ingestion is not built.
+#include <omp.h>
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sigmap_hip.h"
+#include "mapping_logic.h"
+#include "output_tools.h"
+#include "pore_model.h"
+#include "sequence_batch.h"
+#include "signal_batch.h"
+#include "spatial_index.h"
+#include "utils.h"
+
+namespace sigmap {
+void BuildIndex(SequenceBatch &ref, const PoreModel &pore_model, SpatialIndex &index);  // host_abi.cc
+
+class Sigmap {
+ public:
+  // for index construction
+  Sigmap(int dimension, int max_leaf, const std::string &reference_file_path,
+         const std::string &pore_model_file_path, const std::string &output_file_path)
+      : dimension_(dimension), max_leaf_(max_leaf), reference_file_path_(reference_file_path),
+        pore_model_file_path_(pore_model_file_path), output_file_path_(output_file_path) {}
+  // for mapping
+  Sigmap(const MappingParams &p, int num_threads, const std::string &reference_file_path,
+         const std::string &pore_model_file_path, const std::string &signal_directory,
+         const std::string &reference_index_file_path, const std::string &output_file_path)
+      : params_(p), num_threads_(num_threads), reference_file_path_(reference_file_path),
+        pore_model_file_path_(pore_model_file_path), signal_directory_(signal_directory),
+        reference_index_file_path_(reference_index_file_path), output_file_path_(output_file_path) {}
+
+  void ConstructIndex() {
+    PoreModel pore_model;
+    pore_model.Load(pore_model_file_path_);
+    SequenceBatch reference;
+    reference.InitializeLoading(reference_file_path_);
+    reference.LoadAllSequences();
+    SpatialIndex index(dimension_, max_leaf_, omp_get_max_threads(), output_file_path_);
+    BuildIndex(reference, pore_model, index);
+    index.Save();
+  }
+
+  void StreamingMap(int device, size_t max_batch_chunks) {
+    SignalBatch reads;
+    reads.InitializeLoading(signal_directory_);
+    const size_t num_reads = reads.LoadAllReadSignals();
+    SequenceBatch reference;  // names and lengths for PAF; the pore model is only needed by -i
+    reference.InitializeLoading(reference_file_path_);
+    const uint32_t num_refs = reference.LoadAllSequences();
+    std::vector<uint32_t> ref_lengths(num_refs);
+    for (uint32_t i = 0; i < num_refs; ++i) ref_lengths[i] = reference.GetSequenceLengthAt(i);
+    SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
+    index.Load();
+
+    smhip_ctx *ctx = nullptr;
+    if (smhip_init(device, &ctx) != SMHIP_OK)
+      ExitWithMessage("No usable MI355X GPU (smhip_init failed): this build has no CPU mapping path.");
+    if (smhip_index_upload(ctx, index.dimension(), index.values().data(), index.positions().data(),
+                           index.values().size(), index.tree().vind.data(), index.tree().m_size,
+                           index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
+      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctx));
+    smhip_params dp;
+    smhip_default_params(&dp);
+    dp.search_radius = params_.search_radius;
+    dp.step_size = params_.read_seeding_step_size;
+
+    const uint32_t chunk_size = 4000;
+    struct ReadState {
+      uint32_t chunk_index = 0;  // next chunk to process
+      uint32_t num_events = 0;
+      bool active = true;
+      smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
+      std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
+      double start_time = 0;
+    };
+    std::vector<ReadState> st(num_reads);
+    std::vector<uint32_t> num_chunks(num_reads);
+    for (size_t r = 0; r < num_reads; ++r) {
+      num_chunks[r] = (uint32_t)(reads.GetSignalLengthAt(r) / chunk_size);
+      memset(&st[r].last, 0, sizeof(smhip_chunk_result));
+      if (num_chunks[r] == 0 || params_.max_num_chunks <= 0) st[r].active = false;
+    }
+    const double t_map = GetRealTime();
+    std::vector<size_t> batch;
+    std::vector<float> samples;
+    std::vector<uint32_t> offsets, qstart, carried_off;
+    std::vector<smhip_carried_anchor> carried, out_anchors;
+    std::vector<smhip_chunk_result> results;
+    std::vector<uint64_t> out_off;
+    size_t cursor = 0;  // reads are admitted in order; a read stays in flight until it stops
+    std::vector<size_t> in_flight;
+    while (true) {
+      // admit new reads up to the batch budget
+      while (in_flight.size() < max_batch_chunks && cursor < num_reads) {
+        if (st[cursor].active) {
+          st[cursor].start_time = GetRealTime();
+          in_flight.push_back(cursor);
+        }
+        ++cursor;
+      }
+      if (in_flight.empty()) break;
+      batch = in_flight;
+      samples.clear();
+      offsets.assign(1, 0);
+      qstart.clear();
+      carried.clear();
+      carried_off.assign(1, 0);
+      for (size_t r : batch) {
+        const Signal &sig = reads.GetSignalAt(r);
+        const size_t b = (size_t)chunk_size * st[r].chunk_index;
+        samples.insert(samples.end(), sig.signal_values.begin() + b, sig.signal_values.begin() + b + chunk_size);
+        offsets.push_back((uint32_t)samples.size());
+        qstart.push_back(st[r].num_events);
+        carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
+        carried_off.push_back((uint32_t)carried.size());
+      }
+      results.resize(batch.size());
+      out_off.resize(batch.size() + 1);
+      int rc = smhip_batch_upload(ctx, samples.data(), offsets.data(), (uint32_t)batch.size(), qstart.data(),
+                                  carried.empty() ? nullptr : carried.data(),
+                                  carried.empty() ? nullptr : carried_off.data());
+      if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
+      if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+      uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
+      while (rc == SMHIP_OK) {
+        out_anchors.resize(cap);
+        rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
+        if (rc != SMHIP_ECAP) break;
+        cap *= 4;
+        rc = SMHIP_OK;
+      }
+      if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+      in_flight.clear();
+      for (size_t bi = 0; bi < batch.size(); ++bi) {
+        const size_t r = batch[bi];
+        ReadState &s = st[r];
+        const smhip_chunk_result &res = results[bi];
+        if (res.status & ~SMHIP_ST_FEW_PEAKS)
+          std::cerr << "warning: read " << reads.GetSignalNameAt(r) << ": device capacity flag " << res.status << "\n";
+        bool stop = false;
+        if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
+          s.last = res;
+          s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
+          s.num_events += res.n_features;
+          stop = ShouldStopMapping(res, params_);
+        }
+        if (!stop) {
+          ++s.chunk_index;
+          if (s.chunk_index < num_chunks[r] && s.chunk_index < (uint32_t)params_.max_num_chunks) {
+            in_flight.push_back(r);
+            continue;
+          }
+        }
+        s.active = false;
+        s.anchors.clear();
+        s.anchors.shrink_to_fit();
+        s.start_time = (GetRealTime() - s.start_time) * 1000;
+      }
+    }
+    std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
+
+    // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
+    std::vector<std::vector<std::string>> rows(std::max<uint32_t>(num_refs, 1));
+    for (size_t r = 0; r < num_reads; ++r) {
+      ReadState &s = st[r];
+      uint32_t chunk_index = s.chunk_index;  // sigmap.cc:690-693
+      if (chunk_index > 0 && (chunk_index == num_chunks[r] || chunk_index == (uint32_t)params_.max_num_chunks))
+        --chunk_index;
+      uint32_t bucket = 0;
+      const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
+                                       (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
+                                       params_, true, s.start_time, &bucket);
+      rows[bucket].push_back(FormatPAF(m, num_refs ? reference.GetSequenceNameAt(bucket) : "*",
+                                       num_refs ? ref_lengths[bucket] : 0));
+    }
+    FILE *out = fopen(output_file_path_.c_str(), "w");
+    if (!out) ExitWithMessage("Cannot open output file " + output_file_path_);
+    for (auto &g : rows)
+      for (auto &line : g) fputs(line.c_str(), out);
+    fclose(out);
+    smhip_destroy(ctx);
+  }
+
+ protected:
+  int dimension_ = 6, max_leaf_ = 20;
+  MappingParams params_;
+  int num_threads_ = 1;
+  std::string reference_file_path_, pore_model_file_path_, signal_directory_, reference_index_file_path_,
+      output_file_path_;
+};
+
+namespace {
+struct Args {
+  std::map<std::string, std::string> kv;
+  bool Has(const std::string &k) const { return kv.count(k) != 0; }
+  std::string Str(const std::string &k) const { return kv.at(k); }
+};
+const char *kHelp =
+    "Map ONT raw signal data\nUsage:\n  sigmap [OPTION...]\n\n Indexing options:\n"
+    "  -i, --build-index    Build spatial index for reference\n  -d, --dimension INT  Dimension of spatial index [6]\n"
+    "  -l, --max-leaf INT   Max leaf of spatial index [20]\n\n Mapping options:\n  -m, --map              Map signal data\n"
+    "      --step-size INT    Seeding step size in reads [2]\n  -t, --num-threads INT  # threads for mapping [1] (host side)\n\n"
+    " Input options:\n  -r, --ref FILE         Reference file\n  -p, --pore-model FILE  Pore model file\n"
+    "  -x, --ref-index FILE   Reference index file\n  -s, --sig-dir DIR      Signal data directory (.sgr files)\n\n"
+    " Output options:\n  -o, --output arg  Output file\n\n Development options:\n"
+    "      --search-radius FLT         Search radius for each seed [0.08]\n"
+    "      --max-num-chunks INT        Max # chunks before stop trying to map a read [30]\n"
+    "      --min-num-anchors INT       Min # anchors to stop mapping [10]\n"
+    "      --min-num-anchors-output INT  Min # anchors to output mappings [10]\n"
+    "      --stop-mapping FLOAT        best/second-best chaining score ratio to stop mapping [1.4]\n"
+    "      --stop-mapping-output FLOAT best/second-best ratio to output mappings [1.2]\n"
+    "      --stop-mapping-mean FLOAT   best/mean chaining score ratio to stop mapping [5]\n"
+    "      --stop-mapping-mean-output FLOAT  best/mean ratio to output mappings [5]\n"
+    "      --device INT                GPU ordinal [0]\n      --batch-chunks INT          chunks per GPU batch [16384]\n"
+    "  -h, --help  Print help\n";
+}  // namespace
+
+void ParseArgsAndRun(int argc, char *argv[]) {
+  static const std::map<std::string, std::string> shorts = {
+      {"i", "build-index"}, {"d", "dimension"}, {"l", "max-leaf"}, {"m", "map"}, {"t", "num-threads"},
+      {"r", "ref"}, {"p", "pore-model"}, {"x", "ref-index"}, {"s", "sig-dir"}, {"o", "output"}, {"h", "help"}};
+  static const std::vector<std::string> flags = {"build-index", "map", "help"};
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    std::string k = argv[i];
+    if (k.rfind("--", 0) == 0) k = k.substr(2);
+    else if (k.rfind("-", 0) == 0 && shorts.count(k.substr(1))) k = shorts.at(k.substr(1));
+    else ExitWithMessage("Unknown argument " + k);
+    std::string v = "1";
+    const size_t eq = k.find('=');
+    if (eq != std::string::npos) {
+      v = k.substr(eq + 1);
+      k = k.substr(0, eq);
+    } else if (std::find(flags.begin(), flags.end(), k) == flags.end()) {
+      if (i + 1 >= argc) ExitWithMessage("Missing value for --" + k);
+      v = argv[++i];
+    }
+    a.kv[k] = v;
+  }
+  MappingParams p;
+  if (a.Has("search-radius")) p.search_radius = std::stof(a.Str("search-radius"));
+  if (a.Has("step-size")) p.read_seeding_step_size = std::stoi(a.Str("step-size"));
+  if (a.Has("max-num-chunks")) p.max_num_chunks = std::stoi(a.Str("max-num-chunks"));
+  if (a.Has("min-num-anchors")) p.stop_mapping_min_num_anchors = std::stoi(a.Str("min-num-anchors"));
+  if (a.Has("min-num-anchors-output")) p.output_mapping_min_num_anchors = std::stoi(a.Str("min-num-anchors-output"));
+  if (a.Has("stop-mapping")) p.stop_mapping_ratio = std::stof(a.Str("stop-mapping"));
+  if (a.Has("stop-mapping-output")) p.output_mapping_ratio = std::stof(a.Str("stop-mapping-output"));
+  if (a.Has("stop-mapping-mean")) p.stop_mapping_mean_ratio = std::stof(a.Str("stop-mapping-mean"));
+  if (a.Has("stop-mapping-mean-output")) p.output_mapping_mean_ratio = std::stof(a.Str("stop-mapping-mean-output"));
+  const int num_threads = a.Has("num-threads") ? std::stoi(a.Str("num-threads")) : 1;
+  auto need = [&](const char *k, const char *msg) {
+    if (!a.Has(k)) ExitWithMessage(msg);
+    return a.Str(k);
+  };
+  if (a.Has("build-index")) {
+    const int dimension = a.Has("dimension") ? std::stoi(a.Str("dimension")) : 6;
+    const int max_leaf = a.Has("max-leaf") ? std::stoi(a.Str("max-leaf")) : 20;
+    std::cerr << "Dimension: " << dimension << ", max leaf: " << max_leaf << "\n";
+    const std::string ref = need("ref", "No reference file specified!");
+    const std::string pm = need("pore-model", "No pore model file specified!");
+    const std::string out = need("output", "No output file specified!");
+    Sigmap(dimension, max_leaf, ref, pm, out).ConstructIndex();
+  } else if (a.Has("map")) {
+    std::cerr << "Number of threads: " << num_threads << "\n";
+    const std::string ref = need("ref", "No reference file specified!");
+    const std::string pm = need("pore-model", "No pore model file specified!");
+    const std::string idx = need("ref-index", "No reference index file specified!");
+    const std::string dir = need("sig-dir", "No signal data directory specified!");
+    const std::string out = need("output", "No output file specified!");
+    omp_set_num_threads(std::max(1, num_threads));
+    const int device = a.Has("device") ? std::stoi(a.Str("device")) : 0;
+    const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 16384;
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch);
+  } else {
+    std::cerr << kHelp;
+  }
+}
+}  // namespace sigmap
+
+int main(int argc, char *argv[]) {
+  sigmap::ParseArgsAndRun(argc, argv);
+  return 0;
+}

@@ -90,3 +90,18 @@ def simulate_reads(genome, level_means, n_reads, seed, n_samples=4000, k=6, dwel
     truth = np.zeros(n_reads, dtype=[("contig", "<i4"), ("pos", "<i8"), ("strand", "<i1"), ("span", "<i4")])
     truth["contig"], truth["pos"], truth["strand"], truth["span"] = contig, pos, strand, span
     return raw, truth
+
+
+def write_sgr(path, raw, ids=None, digitisation=DIGITISATION, rng=RANGE, offset=OFFSET):
+    """This build's flat read container (sigmap_amd/host/signal_batch.h): "SGR1" | u32 n | per read
+    { u32 id_len | id | f32 digitisation | f32 range | f32 offset | u32 n_raw | i16 raw[] }."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"SGR1")
+        f.write(struct.pack("<I", len(raw)))
+        for i, r in enumerate(raw):
+            rid = (ids[i] if ids else "read%d" % i).encode()
+            r = np.ascontiguousarray(r, dtype=np.int16)
+            f.write(struct.pack("<I", len(rid)) + rid)
+            f.write(struct.pack("<fffI", digitisation, rng, offset, len(r)))
+            f.write(r.tobytes())

@@ -308,3 +308,51 @@ def test_sdtw_kernel_matches_oracle(device):
         # 1e-4 relative tolerance north_star allows for DTW distance
         assert bits(np.float32(dist[k])) == bits(np.float32(d)), (k, dist[k], d)
         assert end[k] == e
+
+
+# ------------------------------------------------------------------ the CLI end to end
+
+def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
+    """`sigmap -i` then `sigmap -m` (sigmap_amd/bin/sigmap): multi-chunk reads with early stop and
+    chain carry-over; PAF (minus the wall-clock mt tag) must equal the oracle's streaming result,
+    in the reference's output order (reference index, then read order)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "sigmap_amd", "bin", "sigmap")
+    assert os.path.exists(exe), "CLI not built (make cli)"
+    genome, lm = small_world["genome"], small_world["lm"]
+    names = ["contig0", "contig1", "contig2"]
+    synth.write_fasta(str(tmp_path / "ref.fa"), genome, names)
+    synth.write_pore_model(str(tmp_path / "model.txt"), lm)
+    raw3, _ = synth.simulate_reads(genome, lm, 10, 5, n_chunks=3)
+    raw1, _ = synth.simulate_reads(genome, lm, 10, 6, n_chunks=1)
+    raws = [r for r in raw3] + [r for r in raw1] + [np.full(4000, 600, np.int16)]  # + a flat read
+    os.makedirs(tmp_path / "reads")
+    synth.write_sgr(str(tmp_path / "reads" / "a.sgr"), raws)
+    r = subprocess.run([exe, "-i", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-o", str(tmp_path / "idx")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out.paf")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in open(tmp_path / "out.paf").read().splitlines()]
+    strip = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith("mt:f:"))
+    # oracle: index files written by the CLI are read by the oracle's own reader
+    dim, ml, pos, val, n = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    assert po.lib().so_points_load(str(tmp_path / "idx.pt").encode(), C.byref(dim), C.byref(ml), C.byref(pos),
+                                   C.byref(val), C.byref(n)) == 0
+    values = np.ctypeslib.as_array(C.cast(val, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+    positions = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_uint64)), shape=(n.value,)).copy()
+    tree = po.OracleTree.load(str(tmp_path / "idx.si"), values)
+    ref_lens = small_world["ref_lens"]
+    rows = []
+    for i, rw in enumerate(raws):
+        pa = pipeline.raw_to_pa(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        m = po.map_read(tree, positions, pa, 3, ref_lens)
+        rows.append((m.ref, i, po.format_paf(m, "read%d" % i, names, ref_lens).rstrip("\n")))
+    rows.sort(key=lambda t: (t[0], t[1]))
+    exp = [t[2] for t in rows]
+    assert [strip(l) for l in got] == exp
+    assert sum(1 for l in exp if "\t*\t" not in l) >= 18
+    tree.close()

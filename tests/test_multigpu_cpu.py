@@ -1,0 +1,81 @@
+"""N>1 path on CPU: two processes, gloo backend (world_size 2).  Exercises the same
+sigmap_amd.multigpu code bench.py uses for GPUs: index replication by broadcast from rank 0,
+contiguous read sharding, and the (reference index, read index) merge of per-rank rows."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from sigmap_amd import multigpu, pipeline, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        genome = synth.make_genome(3, [20000, 12000])
+        lm = synth.make_pore_model()
+        arrays = None
+        if rank == 0:
+            ix = pipeline.HostIndex.build(genome, lm, threads=2)
+            arrays = dict(values=ix.values, positions=ix.positions, vind=ix.vind, nodes=ix.nodes.view(np.uint8), bbox=ix.bbox)
+        got = multigpu.broadcast_host_index(arrays, rank, dist)
+        # every rank rebuilds independently and must hold byte-identical arrays after the broadcast
+        mine = pipeline.HostIndex.build(genome, lm, threads=1)
+        same = (np.array_equal(got["values"].view(np.uint32), mine.values.view(np.uint32))
+                and np.array_equal(got["positions"], mine.positions) and np.array_equal(got["vind"], mine.vind)
+                and np.array_equal(got["nodes"], mine.nodes.view(np.uint8).reshape(-1))
+                and np.array_equal(got["bbox"].view(np.uint32), mine.bbox.view(np.uint32)))
+        n_reads = 1001
+        lo, hi = multigpu.shard_range(n_reads, rank, world)
+        # fake per-rank rows: (ref bucket, global read index, line)
+        rows = [((i * 7) % 3, i, "r%d" % i) for i in range(lo, hi)]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        merged = multigpu.merge_ranked(gathered)
+        q.put((rank, same, lo, hi, merged if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_index_broadcast_sharding_and_merge():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    assert all(o[1] for o in out), "broadcast index differs from a local build"
+    (r0, _, lo0, hi0, merged), (r1, _, lo1, hi1, _) = out
+    assert lo0 == 0 and hi0 == lo1 and hi1 == 1001          # contiguous, complete, disjoint
+    exp = sorted(range(1001), key=lambda i: ((i * 7) % 3, i))
+    assert merged == ["r%d" % i for i in exp]                # reference -t 1 order
+
+
+def test_shard_range_partitions_everything():
+    from sigmap_amd.multigpu import shard_range
+    for n in (0, 1, 7, 8, 1000, 100003):
+        for world in (1, 2, 4, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
