@@ -200,6 +200,7 @@ def main():
                 "anchors_per_chunk": round(anchors / R, 1),
                 "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
                 "chunks_with_capacity_flags": status_bad,
+                "overflow_queries": int(dev.debug_counters()[1]),
                 "index_build_s": round(t_build, 2),
                 "kernels": kern,
             },

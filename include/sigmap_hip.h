@@ -64,7 +64,7 @@ typedef struct {
   float min_chaining_score;       /* 10 */
   /* device-side capacities (not reference semantics; exceeding one is reported, never
    * silently truncated) */
-  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (128) */
+  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (512) */
   uint32_t lanes_per_query;       /* 1 (default: one lane walks one query) or 8/16/32/64
                                      (a wave sub-group walks one query) */
   uint32_t reserved;
@@ -94,8 +94,9 @@ typedef struct {
   uint32_t pad;
   uint64_t n_nodes, m_size;
   void *nodes;      uint64_t nodes_bytes;      /* smhip_node[n_nodes] */
-  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* 32-byte records in tree (leaf-major) order:
-                                                  float v[6]; uint64 Point.position */
+  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks: n x {v0..v3},
+                                                  then n x {v4, v5, uint64 Point.position}; the
+                                                  block offset is the 4th word of the leaf node */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */
   void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
 } smhip_index_dev;
@@ -170,6 +171,9 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
 /* Mean device time (ms) of the named kernel over the launches since the last
  * smhip_timing_reset(), measured with HIP events on the context stream.
  * names: "events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw". */
+/* Diagnostic counters of the last smhip_map_run: [0] stack-overflow flag, [1] queries that needed
+ * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag. */
+int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
 int smhip_timing_enable(smhip_ctx *ctx, int on);
 int smhip_timing_reset(smhip_ctx *ctx);
 int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64_t *launches);

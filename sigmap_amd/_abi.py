@@ -16,7 +16,7 @@ HIP_SYMBOLS = [
     "smhip_default_params", "smhip_init", "smhip_destroy", "smhip_last_error", "smhip_stream",
     "smhip_index_upload", "smhip_index_export", "smhip_index_attach", "smhip_batch_upload",
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
-    "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
+    "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
     "smhip_seed_lookup", "smhip_sdtw_banded",
 ]
 HOST_SYMBOLS = [
@@ -169,6 +169,7 @@ def hip_lib():
         L.smhip_map_sync.argtypes = [vp]
         L.smhip_map_download.argtypes = [vp, vp, vp, u64, vp]
         L.smhip_map_chunks.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp, vp, vp, vp]
+        L.smhip_debug_counters.argtypes = [vp, vp]
         L.smhip_timing_enable.argtypes = [vp, C.c_int]
         L.smhip_timing_reset.argtypes = [vp]
         L.smhip_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]

@@ -121,7 +121,7 @@ void smhip_default_params(smhip_params *p) {
   p->num_best_chains = 3;
   p->num_nearest_points = 5000;
   p->min_chaining_score = 10;
-  p->hits_per_query_fast = 128;
+  p->hits_per_query_fast = 512;
   p->lanes_per_query = 1;
 }
 
@@ -178,8 +178,24 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(ctx->ix_nodes.Reserve(n_nodes * sizeof(smhip_node)));
-  HIPCHK(ctx->ix_pts.Reserve(m_size * 32 + 64));
-  HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, m_size * 32 + 64, ctx->stream));
+  // leaf blocks: 2 * roundup(n, 8) 16-byte slots each, i.e. whole 128-byte lines; the block
+  // offset goes into the (otherwise unused) 4th word of the leaf's node record
+  std::vector<smhip_node> patched(nodes, nodes + n_nodes);
+  uint64_t n_slots = 0, leaf_points = 0;
+  for (auto &nd : patched) {
+    if (nd.feat >= 0) continue;
+    if (nd.b < nd.a || nd.b > m_size) return Fail(ctx, SMHIP_EINVAL, "leaf range outside the point list");
+    const uint32_t n = nd.b - nd.a;
+    if (n_slots > 0xFFFFFF00ull) return Fail(ctx, SMHIP_EINVAL, "index too large for 32-bit leaf block offsets");
+    nd.child2 = (uint32_t)n_slots;
+    n_slots += 2ull * ((n + 7u) & ~7u);
+    leaf_points += n;
+  }
+  if (leaf_points != m_size) return Fail(ctx, SMHIP_EINVAL, "leaves do not cover the point list exactly");
+  nodes = patched.data();
+  ctx->leaf_pts_bytes = n_slots * 16 + 128;
+  HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
+  HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
   HIPCHK(ctx->ix_vind.Reserve(m_size * sizeof(uint32_t)));
   HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
   // staging copies of the original-order point cloud, freed after the leaf-major gather
@@ -230,7 +246,7 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->nodes = (void *)ctx->index.nodes;
   out->nodes_bytes = ctx->index.n_nodes * sizeof(smhip_node);
   out->leaf_pts = (void *)ctx->index.leaf_pts;
-  out->leaf_pts_bytes = ctx->index.m_size * 32 + 64;  // + read-ahead pad of the 4-wide leaf scan
+  out->leaf_pts_bytes = ctx->leaf_pts_bytes;
   out->leaf_vind = (void *)ctx->index.leaf_vind;
   out->leaf_vind_bytes = ctx->index.m_size * sizeof(uint32_t);
   out->bbox = (void *)ctx->index.bbox;
@@ -243,12 +259,13 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
   if (!in->nodes || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
     return Fail(ctx, SMHIP_EINVAL, "null index array");
-  if (in->nodes_bytes < in->n_nodes * sizeof(smhip_node) || in->leaf_pts_bytes < in->m_size * 32 + 64 ||
+  if (in->nodes_bytes < in->n_nodes * sizeof(smhip_node) || in->leaf_pts_bytes < in->m_size * 32 ||
       in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
     return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");
   ctx->dim = in->dim;
   ctx->index = IndexView{(const smhip_node *)in->nodes, (const float *)in->leaf_pts,
                          (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->m_size};
+  ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->have_index = true;
   ctx->index_owned = false;
   return SMHIP_OK;
@@ -419,7 +436,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();
   {
     ScopedTimer t(ctx, T_CHAIN);
-    HIPCHK(LaunchChain(ctx, *p, ca, R));
+    HIPCHK(LaunchChain(ctx, *p, ca, R, NA));
   }
   hipLaunchKernelGGL(OrStatusKernel, dim3(64), dim3(256), 0, ctx->stream, results, R, ctx->counters.as<uint32_t>());
   HIPCHK(hipGetLastError());
@@ -497,6 +514,16 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, con
   rc = smhip_map_sync(ctx);
   if (rc) return rc;
   return smhip_map_download(ctx, results, nullptr, 0, nullptr);
+}
+
+int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]) {
+  if (!ctx || !out) return SMHIP_EINVAL;
+  memset(out, 0, 16 * sizeof(uint32_t));
+  if (!ctx->counters.p) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(out, ctx->counters.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SMHIP_OK;
 }
 
 int smhip_timing_enable(smhip_ctx *ctx, int on) {

@@ -1,5 +1,5 @@
-// chain.hip -- chaining DP, traceback, primary-chain selection and MAPQ; one wavefront
-// per chunk.
+// chain.hip -- chaining DP, traceback, primary-chain selection and MAPQ (three kernels: DP one
+// lane per bucket, chain ends one wave per chunk, finalisation one lane per chunk).
 //
 // Replaces spatial_index.cc:419-576 (+ TracebackChains :165-220, GeneratePrimaryChains
 // :222-253, ComputeMAPQ :255-274) and the chain-0 statistics of sigmap.cc:714-729.
@@ -12,6 +12,8 @@
 // as chain ends, so it is re-applied after the DP as (prefix max over earlier buckets) +
 // (running max inside the bucket), which is the same sequence of values.
 #include <float.h>
+
+#include <algorithm>
 
 #include "common.h"
 
@@ -40,10 +42,303 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
   return a.end > b.end;
 }
 
-__global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int dim, int max_gap_length,
-                                                  int max_target_gap_length, int chaining_band_length,
-                                                  int max_num_skips, int min_num_anchors, int num_best_chains,
-                                                  float min_chaining_score) {
+constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
+constexpr int kBigGroupMin = 384;  // buckets longer than this are chained by a whole wave ...
+constexpr int kBigGroupCap = 2048; // ... when they fit the LDS staging area (else lane-sequential)
+
+// ---- C0: which anchors can be settled without the sequential DP?  One thread per anchor.
+// The predecessor scan of anchor i (spatial_index.cc:461-540) only looks at predecessor SCORES
+// when a predecessor passes the gap tests (then cur = score[j] + matching); every other evaluated
+// predecessor yields cur = 0, which never beats the anchor's own positive start score and simply
+// counts one skip.  So if the scan -- run on positions alone, counting skips -- reaches one of its
+// exits (26 skips, target gap > 5000, band, bucket start) before meeting a gap-test-passing
+// predecessor, the anchor's result is its start score with itself as predecessor, independent of
+// any other anchor.  Those anchors ("isolated", ~94 % of a noise bucket) are finished here in
+// parallel; the rest are flagged (used = 2) for the sequential kernels.
+__global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float radius, int dim, int max_gap_length,
+                                                           int max_target_gap_length, int chaining_band_length,
+                                                           int max_num_skips) {
+  const uint32_t c = blockIdx.x;
+  const uint64_t base = a.anchor_off[c];
+  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+  const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
+  const float *dist = a.s_dist + base;
+  float *score = a.score + base;
+  uint32_t *pred = a.pred + base;
+  uint8_t *used = a.used + base;
+  for (uint32_t ai = threadIdx.x; ai < n; ai += 256) {
+    const uint32_t g = grp[ai];
+    const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
+    bool isolated = true;
+    int32_t skips = 0;
+    uint32_t steps = 0;
+    for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
+      if (grp[pj] != g) break;  // bucket start
+      const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
+      if (pq == cq || pt == ct) continue;
+      if (pt + max_target_gap_length < ct) break;
+      const int32_t td = ct - pt, qd = cq - pq;
+      if (qd < 0) continue;
+      const int gap_length = abs(td - qd);
+      const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+      if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) {
+        isolated = false;
+        break;
+      }
+      if (++skips > max_num_skips) break;
+    }
+    if (isolated) {
+      const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
+      score[ai] = coef * (float)dim;
+      pred[ai] = ai;
+      used[ai] = 0;
+    } else {
+      used[ai] = 2;
+    }
+  }
+}
+
+// ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER (chunk, bucket), flattened over
+// the whole batch so that the few long buckets (the true locus) are spread over many waves.
+// Predecessor records are fetched kPf at a time so the dependent chain sees one memory latency
+// per block instead of one per predecessor.
+__global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t *__restrict__ goff, uint32_t n_chunks,
+                                                    float radius, int dim, int max_gap_length,
+                                                    int max_target_gap_length, int chaining_band_length,
+                                                    int max_num_skips, uint32_t *__restrict__ big_list,
+                                                    uint32_t *__restrict__ big_count) {
+  const uint32_t total_groups = goff[n_chunks];
+  // grid-stride over buckets (the bucket total is only known on the device)
+  for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_groups; gi += gridDim.x * 64) {
+  uint32_t lo = 0, hi = n_chunks;  // chunk c with goff[c] <= gi < goff[c+1]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (goff[mid] <= gi) lo = mid; else hi = mid;
+  }
+  const uint32_t c = lo, g = gi - goff[c];
+  const uint64_t base = a.anchor_off[c];
+  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+  const uint32_t G = a.n_groups[c];
+  const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base;
+  const float *dist = a.s_dist + base;
+  const uint32_t *gstart = a.group_start + base;
+  float *score = a.score + base;
+  uint32_t *pred = a.pred + base;
+  uint8_t *used = a.used + base;
+  float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
+  const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
+  if (e - s > (uint32_t)kBigGroupMin && e - s <= (uint32_t)kBigGroupCap) {  // long bucket: wave-parallel kernel
+    big_list[atomicAdd(big_count, 1u)] = gi;
+    continue;
+  }
+  float gm = 0.0f;
+  for (uint32_t a0 = s; a0 < e; a0 += 16) {
+   // flags and scores of 16 anchors at a time: settled anchors only feed the bucket maximum
+   uint8_t fl[16];
+   float sc16[16];
+#pragma unroll
+   for (int k = 0; k < 16; ++k) {
+     fl[k] = a0 + k < e ? used[a0 + k] : 0;
+     sc16[k] = a0 + k < e ? score[a0 + k] : 0.0f;
+   }
+#pragma unroll
+   for (int k = 0; k < 16; ++k) {
+    const uint32_t ai = a0 + k;
+    if (ai >= e) break;
+    if (fl[k] != 2) {
+      gm = fmaxf(gm, sc16[k]);
+      continue;
+    }
+    const uint32_t anchor_index = ai - s;
+    const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
+    float best = coef * (float)dim;
+    uint32_t best_pred = anchor_index;
+    const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
+    int32_t start_idx = 0;
+    if (anchor_index > (uint32_t)chaining_band_length) start_idx = (int32_t)anchor_index - chaining_band_length;
+    int32_t num_skips = 0;
+    bool done = false;
+    for (int32_t pj0 = (int32_t)anchor_index - 1; pj0 >= start_idx && !done; pj0 -= kPf) {
+      int32_t pt[kPf], pq[kPf];
+      float ps[kPf];
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) {
+        const int32_t pj = pj0 - k;
+        const bool ok = pj >= start_idx;
+        pt[k] = ok ? (int32_t)tpos[s + pj] : 0;
+        pq[k] = ok ? (int32_t)qpos[s + pj] : 0;
+        ps[k] = ok ? score[s + pj] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) {
+        const int32_t pj = pj0 - k;
+        if (done || pj < start_idx) break;
+        if (pq[k] == cq) continue;
+        if (pt[k] == ct) continue;
+        if (pt[k] + max_target_gap_length < ct) {
+          done = true;
+          break;
+        }
+        const int32_t td = ct - pt[k];
+        const int32_t qd = cq - pq[k];
+        float cur = 0;
+        if (qd < 0) continue;
+        {
+          const int32_t m = min(min(td, qd), dim);
+          const float matching = (float)m * coef;
+          const int gap_length = abs(td - qd);
+          const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+          if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) cur = ps[k] + matching;
+        }
+        if (cur > best) {
+          best = cur;
+          best_pred = (uint32_t)pj;
+          --num_skips;
+        } else {
+          ++num_skips;
+          if (num_skips > max_num_skips) {
+            done = true;
+            break;
+          }
+        }
+      }
+    }
+    score[ai] = best;
+    pred[ai] = s + best_pred;  // chunk-local absolute index
+    used[ai] = 0;
+    gm = fmaxf(gm, best);
+   }
+  }
+  gmax[g] = gm;
+  }
+}
+
+// ---- C1b: the same DP for LONG buckets (the true locus of a read), one WAVE per bucket with the
+// bucket staged in LDS.  The predecessor scan of one anchor is evaluated 64 predecessors at a
+// time; the reference's sequential rules -- running best, `num_skips` +-1 per evaluated
+// predecessor, exit when num_skips > 25, exit at the first predecessor farther than 5000 on the
+// target (spatial_index.cc:461-540) -- are reproduced with an exclusive prefix max (running
+// best), a prefix sum (num_skips) and ballots (first exit), which yields exactly the state the
+// sequential loop would have at its exit.
+__global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ goff,
+                                                       uint32_t n_chunks, float radius, int dim, int max_gap_length,
+                                                       int max_target_gap_length, int chaining_band_length,
+                                                       int max_num_skips, const uint32_t *__restrict__ big_list,
+                                                       const uint32_t *__restrict__ big_count) {
+  __shared__ int32_t l_t[kBigGroupCap], l_q[kBigGroupCap];
+  __shared__ float l_s[kBigGroupCap], l_d[kBigGroupCap];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nbig = *big_count;
+  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    const uint32_t gi = big_list[b];
+    uint32_t lo = 0, hi = n_chunks;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (goff[mid] <= gi) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo, g = gi - goff[c];
+    const uint64_t base = a.anchor_off[c];
+    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+    const uint32_t G = a.n_groups[c];
+    const uint32_t *gstart = a.group_start + base;
+    const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
+    const uint32_t ng = e - s;
+    const uint32_t *tpos = a.s_tpos + base + s, *qpos = a.s_qpos + base + s;
+    const float *dist = a.s_dist + base + s;
+    float *score = a.score + base + s;
+    uint32_t *pred = a.pred + base + s;
+    uint8_t *used = a.used + base + s;
+    float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
+    __syncthreads();
+    for (uint32_t i = lane; i < ng; i += 64) {
+      l_t[i] = (int32_t)tpos[i];
+      l_q[i] = (int32_t)qpos[i];
+      l_d[i] = dist[i];
+      used[i] = 0;
+    }
+    __syncthreads();
+    float gm = 0.0f;
+    for (uint32_t ai = 0; ai < ng; ++ai) {
+      const float coef = (float)(1 - 0.2 * (double)l_d[ai] / (double)radius);
+      float best = coef * (float)dim;
+      uint32_t best_pred = ai;
+      const int32_t ct = l_t[ai], cq = l_q[ai];
+      int32_t start_idx = 0;
+      if (ai > (uint32_t)chaining_band_length) start_idx = (int32_t)ai - chaining_band_length;
+      int32_t num_skips = 0;
+      for (int32_t pj0 = (int32_t)ai - 1; pj0 >= start_idx; pj0 -= 64) {
+        const int32_t pj = pj0 - (int32_t)lane;
+        const bool in_range = pj >= start_idx;
+        int cls = 0;  // 0 = end of range / target-gap exit, 1 = `continue`, 3 = evaluated
+        float cur = 0.0f;
+        if (in_range) {
+          const int32_t pt = l_t[pj], pq = l_q[pj];
+          if (pq == cq || pt == ct) {
+            cls = 1;
+          } else if (pt + max_target_gap_length < ct) {
+            cls = 0;
+          } else {
+            const int32_t td = ct - pt, qd = cq - pq;
+            if (qd < 0) {
+              cls = 1;
+            } else {
+              cls = 3;
+              const int32_t m = min(min(td, qd), dim);
+              const float matching = (float)m * coef;
+              const int gap_length = abs(td - qd);
+              const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+              if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) cur = l_s[pj] + matching;
+            }
+          }
+        }
+        const bool ev = cls == 3;
+        // running best before each lane: max(best, evaluated candidates of earlier lanes)
+        float v = ev ? cur : -FLT_MAX;
+        for (int d = 1; d < 64; d <<= 1) {
+          const float o = __shfl_up(v, d, 64);
+          if ((int)lane >= d) v = fmaxf(v, o);
+        }
+        float before = __shfl_up(v, 1, 64);
+        if (lane == 0) before = -FLT_MAX;
+        before = fmaxf(before, best);
+        const bool improved = ev && cur > before;
+        int delta = ev ? (improved ? -1 : 1) : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(delta, d, 64);
+          if ((int)lane >= d) delta += o;
+        }
+        const int ns_after = num_skips + delta;  // num_skips after this lane's step
+        const unsigned long long m_end = __ballot(cls == 0);
+        const unsigned long long m_skip = __ballot(ev && !improved && ns_after > max_num_skips);
+        const int l_end = m_end ? __ffsll((long long)m_end) - 1 : 64;    // exclusive exit
+        const int l_skip = m_skip ? __ffsll((long long)m_skip) - 1 : 64;  // inclusive exit
+        const int last_valid = min(l_end - 1, l_skip);                    // last lane whose step counts
+        unsigned long long m_imp = __ballot(improved);
+        if (last_valid < 63) m_imp &= (last_valid < 0) ? 0ull : ((2ull << last_valid) - 1ull);
+        if (m_imp) {
+          const int l_last = 63 - __clzll((long long)m_imp);
+          best = __shfl(cur, l_last, 64);
+          best_pred = (uint32_t)(pj0 - l_last);
+        }
+        if (l_end < 64 || l_skip < 64) break;
+        num_skips = __shfl(ns_after, 63, 64);
+      }
+      if (lane == 0) {
+        l_s[ai] = best;
+        score[ai] = best;
+        pred[ai] = s + best_pred;  // chunk-local absolute index
+      }
+      gm = fmaxf(gm, best);
+      __syncthreads();
+    }
+    if (lane == 0) gmax[g] = gm;
+  }
+}
+
+// ---- C2: one wave per chunk: running max_chaining_score across buckets (spatial_index.cc:420,
+// 542-549), chain ends, traceback (spatial_index.cc:165-220, 552-568)
+__global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_anchors, int num_best_chains,
+                                                      float min_chaining_score, uint32_t *__restrict__ n_chains_out) {
   __shared__ uint32_t s_nchains;
   const uint32_t c = blockIdx.x;
   const uint32_t lane = threadIdx.x;
@@ -53,69 +348,19 @@ __global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int
   if (lane == 0) {
     s_nchains = 0;
     a.out_anchor_cnt[c] = 0;
+    n_chains_out[c] = 0;
   }
   __syncthreads();
   if (n == 0 || G == 0) return;
-  const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
-  const float *dist = a.s_dist + base;
+  const uint32_t *tpos = a.s_tpos + base, *grp = a.s_grp + base;
   const uint32_t *gstart = a.group_start + base;
-  float *score = a.score + base;
-  uint32_t *pred = a.pred + base;
+  const float *score = a.score + base;
+  const uint32_t *pred = a.pred + base;
   uint8_t *used = a.used + base;
-  // dead sort scratch (2n keys per chunk) holds the per-bucket maxima and their prefix
   float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
   float *pmax = gmax + n;
-
-  // ---- phase A: DP per bucket (spatial_index.cc:436-541)
-  for (uint32_t g = lane; g < G; g += 64) {
-    const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
-    float gm = 0.0f;
-    for (uint32_t ai = s; ai < e; ++ai) {
-      const uint32_t anchor_index = ai - s;
-      const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
-      float best = coef * (float)dim;
-      uint32_t best_pred = anchor_index;
-      const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
-      int32_t start_idx = 0;
-      if (anchor_index > (uint32_t)chaining_band_length) start_idx = (int32_t)anchor_index - chaining_band_length;
-      int32_t num_skips = 0;
-      for (int32_t pj = (int32_t)anchor_index - 1; pj >= start_idx; --pj) {
-        const int32_t pt = (int32_t)tpos[s + pj], pq = (int32_t)qpos[s + pj];
-        if (pq == cq) continue;
-        if (pt == ct) continue;
-        if (pt + max_target_gap_length < ct) break;
-        const int32_t td = ct - pt;
-        const int32_t qd = cq - pq;
-        float cur = 0;
-        if (qd < 0) continue;
-        {
-          const int32_t m = min(min(td, qd), dim);
-          const float matching = (float)m * coef;
-          const int gap_length = abs(td - qd);
-          const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-          if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) cur = score[s + pj] + matching;
-        }
-        if (cur > best) {
-          best = cur;
-          best_pred = (uint32_t)pj;
-          --num_skips;
-        } else {
-          ++num_skips;
-          if (num_skips > max_num_skips) break;
-        }
-      }
-      score[ai] = best;
-      pred[ai] = best_pred;
-      used[ai] = 0;
-      gm = fmaxf(gm, best);
-    }
-    gmax[g] = gm;
-  }
-  __syncthreads();
-
-  // ---- phase B: max_chaining_score on entry to each bucket = max over all earlier buckets
-  // (order ref0+, ref0-, ref1+, ...; initial value 0, spatial_index.cc:420): exclusive
-  // prefix max by wave shuffles, 64 buckets at a time.
+  // max_chaining_score on entry to each bucket = max over all earlier buckets (order ref0+,
+  // ref0-, ref1+, ...; initial value 0): exclusive prefix max by wave shuffles, 64 at a time.
   {
     float carry = 0.0f;
     for (uint32_t g0 = 0; g0 < G; g0 += 64) {
@@ -132,77 +377,89 @@ __global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int
     }
   }
   __syncthreads();
-
-  // ---- phase C: chain ends, traceback
   for (uint32_t g = lane; g < G; g += 64) {
     const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
     float run_max = pmax[g];  // max_chaining_score on entry to this bucket
     Cand top[3];
     uint32_t ntop = 0;
-    uint32_t ncand = 0;
-    for (uint32_t ai = s; ai < e; ++ai) {
-      const float sc = score[ai];
-      if (sc > run_max) run_max = sc;
-      if (sc >= min_chaining_score && sc > run_max / 2) {  // spatial_index.cc:545-549
-        ++ncand;
-        Cand cnd{sc, ai - s};
-        // keep the best three in sorted order (num_best_chains == 3)
-        uint32_t pos = ntop;
-        while (pos > 0 && CandBefore(cnd, top[pos - 1])) --pos;
-        if (pos < 3) {
-          for (uint32_t k = (ntop < 3 ? ntop : 2); k > pos; --k) top[k] = top[k - 1];
-          top[pos] = cnd;
-          if (ntop < 3) ++ntop;
+    for (uint32_t a0 = s; a0 < e; a0 += kPf) {
+      float sc8[kPf];
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) sc8[k] = a0 + k < e ? score[a0 + k] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) {
+        const uint32_t ai = a0 + k;
+        if (ai >= e) break;
+        const float sc = sc8[k];
+        if (sc > run_max) run_max = sc;
+        if (sc >= min_chaining_score && sc > run_max / 2) {  // spatial_index.cc:545-549
+          Cand cnd{sc, ai - s};
+          uint32_t pos = ntop;  // keep the best three in sorted order (num_best_chains <= 3)
+          while (pos > 0 && CandBefore(cnd, top[pos - 1])) --pos;
+          if (pos < 3) {
+            for (uint32_t kk = (ntop < 3 ? ntop : 2); kk > pos; --kk) top[kk] = top[kk - 1];
+            top[pos] = cnd;
+            if (ntop < 3) ++ntop;
+          }
         }
       }
     }
-    (void)ncand;
     const float max_after = run_max;  // max_chaining_score after the bucket
     const uint32_t grp_id = grp[s];
     const uint32_t ref = grp_id >> 1;
     const uint32_t direction = (grp_id & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
     const uint32_t lim = min(ntop, (uint32_t)min(num_best_chains, 3));
     for (uint32_t k = 0; k < lim; ++k) {
-      // TracebackChains, spatial_index.cc:165-220
-      const uint32_t end_idx = top[k].idx;
-      if (!used[s + end_idx]) {
+      // TracebackChains, spatial_index.cc:165-220 (pred[] holds chunk-local absolute indices)
+      const uint32_t end_abs = s + top[k].idx;
+      if (!used[end_abs]) {
         bool stop_at_used = false;
-        uint32_t cur = end_idx;
-        if (pred[s + cur] != cur && used[s + pred[s + cur]]) stop_at_used = true;
-        used[s + cur] = 1;
+        uint32_t cur = end_abs;
+        if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
+        used[cur] = 1;
         uint32_t num = 1;
-        while (pred[s + cur] != cur && !used[s + pred[s + cur]]) {
-          cur = pred[s + cur];
-          if (pred[s + cur] != cur && used[s + pred[s + cur]]) stop_at_used = true;
-          used[s + cur] = 1;
+        while (pred[cur] != cur && !used[pred[cur]]) {
+          cur = pred[cur];
+          if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
+          used[cur] = 1;
           ++num;
         }
         if (num >= (uint32_t)min_num_anchors) {
-          float adjusted = score[s + end_idx];
-          if (stop_at_used) adjusted -= score[s + pred[s + cur]];
+          float adjusted = score[end_abs];
+          if (stop_at_used) adjusted -= score[pred[cur]];
           const uint32_t slot = atomicAdd(&s_nchains, 1u);
           if (slot < (uint32_t)kChainCap) {
             ChainTmp ch;
             ch.score = adjusted;
             ch.ref = ref;
-            ch.start = tpos[s + cur];
-            ch.end = tpos[s + end_idx];
+            ch.start = tpos[cur];
+            ch.end = tpos[end_abs];
             ch.n_anchors = num;
             ch.direction = direction;
-            ch.end_anchor = s + end_idx;
+            ch.end_anchor = end_abs;
             a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
           }
         }
       }
-      if (score[s + end_idx] < max_after / 2) break;  // spatial_index.cc:563-567
+      if (score[end_abs] < max_after / 2) break;  // spatial_index.cc:563-567
     }
   }
   __syncthreads();
+  if (lane == 0) n_chains_out[c] = s_nchains;
+}
 
-  // ---- phase D: GeneratePrimaryChains + ComputeMAPQ + record (one lane)
-  if (lane != 0) return;
+// ---- C3: GeneratePrimaryChains + ComputeMAPQ + chain statistics + carry-over anchors, ONE LANE
+// PER CHUNK (spatial_index.cc:222-274, sigmap.cc:702-729)
+__global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
+                                                          const uint32_t *__restrict__ n_chains_in) {
+  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uint64_t base = a.anchor_off[c];
+  const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
+  const float *dist = a.s_dist + base;
+  const uint32_t *pred = a.pred + base;
   smhip_chunk_result &res = a.results[c];
-  uint32_t nch = s_nchains;
+  uint32_t nch = n_chains_in[c];
   if (nch > (uint32_t)kChainCap) {
     res.status |= SMHIP_ST_CHAIN_CAP;
     nch = kChainCap;
@@ -268,18 +525,12 @@ __global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int
   uint32_t w = 0;
   smhip_carried_anchor *out = a.out_anchors ? a.out_anchors + base : nullptr;
   for (uint32_t i = 0; i < np; ++i) {
-    // pred[] holds bucket-local indices: recover the bucket start of this chain's anchors
     const uint32_t g_id = grp[ch[i].end_anchor];
-    uint32_t lo = 0, hi = G;  // last group start <= end_anchor
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (gstart[mid] <= ch[i].end_anchor) lo = mid; else hi = mid;
-    }
-    const uint32_t s = gstart[lo];
-    uint32_t cur = ch[i].end_anchor - s;
+    uint32_t cur = ch[i].end_anchor;
     float ad = 0, at = 0, aq = 0;
     for (uint32_t k = 0; k < ch[i].n_anchors; ++k) {
-      const uint32_t ai = s + cur;
+      const uint32_t ai = cur;
+      const uint32_t nx = pred[ai];
       if (out) {
         smhip_carried_anchor o;
         o.ref_strand = g_id;
@@ -294,12 +545,11 @@ __global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int
         if (k == 0) res.c0_first_qpos = qpos[ai];
         if (k + 1 == ch[i].n_anchors) res.c0_last_qpos = qpos[ai];
         if (k + 1 < ch[i].n_anchors) {
-          const uint32_t nx = s + pred[ai];
           at += (float)(uint32_t)(tpos[ai] - tpos[nx]);
           aq += (float)(uint32_t)(qpos[ai] - qpos[nx]);
         }
       }
-      cur = pred[ai];
+      cur = nx;
     }
     if (i == 0) {
       res.c0_sum_dist = ad;
@@ -311,11 +561,32 @@ __global__ __launch_bounds__(64) void ChainKernel(ChainArgs a, float radius, int
 }
 }  // namespace
 
-hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks) {
+hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
+                       uint64_t n_anchors_total) {
   if (n_chunks == 0) return hipSuccess;
-  hipLaunchKernelGGL(ChainKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.search_radius, kMaxDim,
-                     p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
-                     p.min_num_anchors, p.num_best_chains, p.min_chaining_score);
+  // every bucket holds at least one anchor, so the anchor total bounds the bucket total; long
+  // buckets hold > kBigGroupMin anchors each
+  const uint64_t max_big = n_anchors_total / kBigGroupMin + 1;
+  hipError_t e = ctx->chain_cnt.Reserve(((size_t)n_chunks * 2 + 4 + max_big) * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  uint32_t *n_chains = ctx->chain_cnt.as<uint32_t>(), *goff = n_chains + n_chunks;
+  uint32_t *big_count = goff + n_chunks + 1, *big_list = big_count + 1;
+  if ((e = hipMemsetAsync(big_count, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
+  if ((e = LaunchScanU32(ctx, a.n_groups, n_chunks, goff)) != hipSuccess) return e;
+  const uint64_t max_groups = n_anchors_total;
+  const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((max_groups + 63) / 64, 16384);
+  hipLaunchKernelGGL(ChainClassifyKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.search_radius, kMaxDim,
+                     p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+  if (dp_blocks > 0)
+    hipLaunchKernelGGL(ChainDpKernel, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
+                       kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
+                       big_list, big_count);
+  hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
+                     kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
+                     big_list, big_count);
+  hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
+                     p.num_best_chains, p.min_chaining_score, n_chains);
+  hipLaunchKernelGGL(ChainFinalizeKernel, dim3((n_chunks + 63) / 64), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);
   return hipGetLastError();
 }
 }  // namespace smhip

@@ -35,7 +35,7 @@ struct ChainTmp {
 // Device view of the index (all pointers device memory).
 struct IndexView {
   const smhip_node *nodes;
-  const float *leaf_pts;      // [m_size] x 32 B: float v[6]; uint64 position (tree order)
+  const float *leaf_pts;      // per-leaf 128-byte-aligned blocks (layout: seed_lookup.hip header)
   const uint32_t *leaf_vind;  // [m_size]
   const float *bbox;          // [12] low0, high0, ...
   uint64_t n_nodes, m_size;
@@ -81,6 +81,7 @@ struct smhip_ctx {
   int dim = 0;
   smhip::IndexView index{};
   smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox;
+  uint64_t leaf_pts_bytes = 0;
   // batch inputs
   uint32_t n_chunks = 0;
   uint64_t n_samples = 0, n_carried = 0;
@@ -159,7 +160,8 @@ struct ChainArgs {
   smhip_carried_anchor *out_anchors;
   uint32_t *out_anchor_cnt;
 };
-hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks);
+hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
+                       uint64_t n_anchors_total);
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
                       const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n,
                       float *dist, int64_t *end, uint32_t max_t);

@@ -20,6 +20,7 @@ namespace smhip {
 namespace {
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
+constexpr uint32_t kMaxQueriesPerChunk = (kFeatStride - 5) / 1 + 1;  // step >= 1
 
 template <typename KeyPtr>
 __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t tid) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     a.n_groups[c] = 0;
   }
   if (n == 0) return;
-  if (n > (1u << ibits)) {  // the key cannot index this many anchors
+  if (n > (1u << ibits) || nq > kMaxQueriesPerChunk) {  // the key cannot index this many anchors
     if (tid == 0) {
       a.results[c].status |= SMHIP_ST_SORT_CAP;
       a.results[c].n_anchors = 0;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   uint32_t *u_tpos = a.a_tpos + base, *u_qpos = a.a_qpos + base, *u_grp = a.a_grp + base;
   float *u_dist = a.a_dist + base;
 
-  // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts)
+  // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts) into LDS
+  // (the key array is not in use yet: its tail holds the nq+1 offsets during the decode)
+  uint32_t *qoff = reinterpret_cast<uint32_t *>(lds_keys) + 2 * kLdsKeys - (kMaxQueriesPerChunk + 2);
   const uint32_t per = (nq + kSortThreads - 1) / kSortThreads;
   const uint32_t qb = min(nq, tid * per), qe = min(nq, qb + per);
   uint32_t s = 0;
@@ -83,43 +86,62 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     part[tid] += v;
     __syncthreads();
   }
-  // ---- decode: carried anchors, then each query's hits in traversal order
-  const uint64_t idx_mask = (1ull << ibits) - 1;
-  for (uint32_t i = tid; i < ncar; i += kSortThreads) {
-    const smhip_carried_anchor ca = a.carried[a.carried_off[c] + i];
-    u_tpos[i] = ca.target_position;
-    u_qpos[i] = ca.query_position;
-    u_dist[i] = ca.distance;
-    u_grp[i] = ca.ref_strand;
-    const uint64_t key = ((uint64_t)ca.ref_strand << (32 + ibits)) | ((uint64_t)ca.target_position << ibits) | i;
-    if (in_lds) lds_keys[i] = key; else gkeys[i] = key;
-  }
   {
-    uint32_t run = ncar + (tid ? part[tid - 1] : 0);
-    const uint32_t qso = a.qstart ? a.qstart[c] : 0;
+    uint32_t run = tid ? part[tid - 1] : 0;
     for (uint32_t k = qb; k < qe; ++k) {
+      qoff[k] = run;
+      run += min(a.q_count[q0 + k], a.nnp);
+    }
+    if (tid == kSortThreads - 1) qoff[nq] = part[tid];
+  }
+  __syncthreads();
+  // ---- decode: carried anchors, then each query's hits in traversal order.  One thread per
+  // anchor (binary search of its query in the LDS offsets), so the hit records of a query are
+  // read by consecutive lanes.  Keys go to registers first: they overwrite the offsets' LDS.
+  const uint64_t idx_mask = (1ull << ibits) - 1;
+  const uint32_t qso = a.qstart ? a.qstart[c] : 0;
+  constexpr uint32_t kPerThread = (kLdsKeys + kSortThreads - 1) / kSortThreads;  // 16
+  uint64_t mykeys[kPerThread];
+  const bool reg_keys = in_lds;  // LDS path: n <= kLdsKeys, so kPerThread registers suffice
+  for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) {
+    uint32_t tpos, qpos, grp;
+    float dist;
+    if (i < ncar) {
+      const smhip_carried_anchor ca = a.carried[a.carried_off[c] + i];
+      tpos = ca.target_position;
+      qpos = ca.query_position;
+      dist = ca.distance;
+      grp = ca.ref_strand;
+    } else {
+      const uint32_t h0 = i - ncar;
+      uint32_t lo = 0, hi = nq;  // largest k with qoff[k] <= h0
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (qoff[mid] <= h0) lo = mid; else hi = mid;
+      }
+      const uint32_t k = lo, h = h0 - qoff[k];
       const uint32_t qi = q0 + k;
       const uint32_t cnt = a.q_count[qi];
-      const uint32_t m = min(cnt, a.nnp);
       const Hit *src = cnt <= a.fast_cap ? a.region + (size_t)qi * a.fast_cap
                                          : (a.q_ovf_off[qi] != 0xFFFFFFFFu ? a.ovf_pool + a.q_ovf_off[qi] : nullptr);
-      const uint32_t qpos = (k + 1) * a.step + qso;  // position + query_start_offset
-      for (uint32_t h = 0; h < m; ++h) {
-        const uint32_t i = run + h;
-        Hit hit;
-        if (src) hit = src[h]; else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
-        const uint32_t ref = (uint32_t)(hit.position >> 33);
-        const uint32_t tpos = (uint32_t)(hit.position >> 1);
-        const uint32_t grp = (ref << 1) | (uint32_t)(hit.position & 1);
-        u_tpos[i] = tpos;
-        u_qpos[i] = qpos;
-        u_dist[i] = hit.dist;
-        u_grp[i] = grp;
-        const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
-        if (in_lds) lds_keys[i] = key; else gkeys[i] = key;
-      }
-      run += m;
+      Hit hit;
+      if (src) hit = src[h]; else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
+      const uint32_t ref = (uint32_t)(hit.position >> 33);
+      tpos = (uint32_t)(hit.position >> 1);
+      grp = (ref << 1) | (uint32_t)(hit.position & 1);
+      qpos = (k + 1) * a.step + qso;  // position + query_start_offset
+      dist = hit.dist;
     }
+    u_tpos[i] = tpos;
+    u_qpos[i] = qpos;
+    u_dist[i] = dist;
+    u_grp[i] = grp;
+    const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
+    if (reg_keys) mykeys[it] = key; else gkeys[i] = key;
+  }
+  __syncthreads();  // everyone is done with the offsets
+  if (reg_keys) {
+    for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) lds_keys[i] = mykeys[it];
   }
   for (uint32_t i = n + tid; i < npad; i += kSortThreads) {
     if (in_lds) lds_keys[i] = ~0ull; else gkeys[i] = ~0ull;

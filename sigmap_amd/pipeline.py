@@ -146,6 +146,11 @@ class DeviceMapper:
         self.sync()
         return self.download()
 
+    def debug_counters(self):
+        out = np.zeros(16, dtype=np.uint32)
+        self._check(self.L.smhip_debug_counters(self._h, ptr(out)), "smhip_debug_counters")
+        return out
+
     def timing(self, enable=True):
         self._check(self.L.smhip_timing_enable(self._h, 1 if enable else 0), "smhip_timing_enable")
 
