@@ -7,13 +7,14 @@
 //
 // Data layout in HBM (built once per index by LeafGatherKernel):
 //   nodes    : 16-byte pre-order records (smhip_node), child1 = self + 1
-//   leaf_pts : 32 bytes per k-d point, grouped per leaf in TREE order (the order of nanoflann's
-//              vind).  A leaf [left,right) with n points owns the 16-byte slots
-//              [2*left, 2*left + 2n): first the n "first halves" {v0,v1,v2,v3}, then the n
-//              "second halves" {v4, v5, uint64 Point.position}.  One leaf is one contiguous
-//              <= 640-byte block instead of <= 20 scattered (vind -> 6 strided floats) gathers,
-//              the halves that decide most rejections are adjacent, and a hit needs no second
-//              lookup for its reference position.
+//   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf, in TREE order (the order of
+//              nanoflann's vind).  A leaf [left,right) with n points, block offset `boff` (kept
+//              in the leaf node's 4th word): slots [boff, boff+n) hold the "first halves"
+//              {v0,v1,v2,v3}, slots [boff+R, boff+R+n) with R = roundup(n, 8) the "second halves"
+//              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte
+//              line, so every line fetched for a leaf is used whole; this replaces <= 20
+//              scattered (vind -> 6 strided floats) gathers, and a hit needs no second lookup for
+//              its reference position.
 //   qrec     : one 32-byte record per query: float q[6]; uint32 chunk; uint32 k
 //
 // The recursion of searchLevel is replaced by an explicit stack of pending "other child"
@@ -25,11 +26,12 @@
 // Two walkers share that logic:
 //  * SeedLaneKernel (lanes_per_query = 1, default): ONE LANE PER QUERY, written as a state
 //    machine in which every loop iteration issues one batch of 16-byte loads per lane (a node
-//    record, the first halves of up to four leaf points, or one second half) and then retires
-//    it.  A point whose first four squared differences already reach the radius is rejected
+//    record, the first halves of up to eight leaf points = one 128-byte line, or one second half)
+//    and then retires it.  A point whose first four squared differences already reach the radius is rejected
 //    without reading its second half (the partial sum is a lower bound of nanoflann's result:
-//    f32 addition of non-negative terms is monotone).  Stacks live in HBM ([lane][64 entries] x
-//    32 B), so the instruction stream of a wave is amortised over 64 queries.  Queries are
+//    f32 addition of non-negative terms is monotone).  The two newest stack entries of a lane
+//    live in LDS; older ones spill to HBM ([lane][64 entries] x 32 B), so the instruction
+//    stream of a wave is amortised over 64 queries and most push/pop pairs never leave the CU.  Queries are
 //    visited in the order of the leaf that contains them (QueryOrder kernels: a stackless
 //    descent + a counting sort), so the lanes of a wave and the waves of a CU walk the same
 //    part of the tree and share its cache lines; results are indexed by query id, so the
@@ -107,8 +109,13 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
-  float mind = 0, pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0;
-  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, cmask = 0, qi = 0, chunk = 0;
+  float mind = 0;
+  float pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, cmask = 0, qi = 0,
+           chunk = 0;
+  // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
+  __shared__ float4 tos[2][2][kSeedThreads];
+  uint32_t tcnt = 0, thead = 0;
   Hit *out = nullptr;
   uint32_t out_cap = 0;
   for (;;) {
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
       mind = 0.0f;
       SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
       SM_INIT_DIM(5, d5)
-      node = 0; sp = 0; hits = 0; nn = 0; np = 0;
+      node = 0; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
       if (kOverflow) {
         out = sink.region + sink.q_ovf_off[qi];
         out_cap = sink.nnp;
@@ -136,20 +143,22 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
     }
     // ---- one batch of 16-byte loads per lane per iteration
     const uint4 *addr = mode == M_WALK ? reinterpret_cast<const uint4 *>(ix.nodes + node)
-                                       : pts4 + lbase + (mode == M_SCAN2 ? n + j + (uint32_t)(__ffs(cmask) - 1) : j);
+                                       : pts4 + lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
     const uint4 r = addr[0];
-    uint4 r1 = r, r2 = r, r3 = r;
-    if (mode == M_SCAN) {  // first halves of points j .. j+3 (reads past the leaf stay inside the array)
-      r1 = addr[1];
-      r2 = addr[2];
-      r3 = addr[3];
+    uint4 rr[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) rr[t] = r;
+    if (mode == M_SCAN) {  // first halves of points j .. j+7: one aligned 128-byte line
+#pragma unroll
+      for (int t = 0; t < 7; ++t) rr[t] = addr[t + 1];
     }
     bool leaf_end = false;
     if (mode == M_WALK) {
       ++nn;
       if ((int32_t)r.x < 0) {  // leaf: start scanning its points
-        lbase = r.y * 2;
+        lleft = r.y;
         n = r.z - r.y;
+        lbase = r.w;
         j = 0;
         mode = M_SCAN;
         leaf_end = n == 0;
@@ -172,11 +181,19 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
         const float nm = mind + cut - dst;
         if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
-          if (sp < (uint32_t)kStackDepth) {
-            stk[2 * sp] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
-            stk[2 * sp + 1] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
-                                          idx == 5 ? cut : d5);
-            ++sp;
+          if (sp + tcnt < (uint32_t)kStackDepth) {
+            const uint32_t slot = thead ^ 1u;
+            if (tcnt == 2) {  // spill the older cached entry
+              stk[2 * sp] = tos[slot][0][threadIdx.x];
+              stk[2 * sp + 1] = tos[slot][1][threadIdx.x];
+              ++sp;
+            } else {
+              ++tcnt;
+            }
+            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
+            tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
+                                                    idx == 5 ? cut : d5);
+            thead = slot;
           } else {
             atomicOr(&sink.counters[0], 1u);
           }
@@ -184,29 +201,32 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         node = next;
       }
     } else if (mode == M_SCAN) {
-      // nanoflann.hpp:391-401: first group of four differences, for up to four points
+      // nanoflann.hpp:391-401: first group of four differences, for up to eight points
       const uint32_t left_in_leaf = n - j;
-      np += min(4u, left_in_leaf);
-#define SM_PART(rr, out)                                                                     \
+      np += min(8u, left_in_leaf);
+      cmask = 0;
+#define SM_PART(rv, t)                                                                       \
   {                                                                                          \
-    const float f0 = q0 - __uint_as_float(rr.x), f1 = q1 - __uint_as_float(rr.y);           \
-    const float f2 = q2 - __uint_as_float(rr.z), f3 = q3 - __uint_as_float(rr.w);           \
-    out = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */                    \
+    const float f0 = q0 - __uint_as_float(rv.x), f1 = q1 - __uint_as_float(rv.y);           \
+    const float f2 = q2 - __uint_as_float(rv.z), f3 = q3 - __uint_as_float(rv.w);           \
+    const float s4 = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */         \
+    pr[t] = s4;                                                                              \
+    /* result >= partial sum, so partial >= radius cannot be a hit */                        \
+    cmask |= (s4 < radius && left_in_leaf > (uint32_t)t) ? (1u << t) : 0u;                   \
   }
-      SM_PART(r, pr0) SM_PART(r1, pr1) SM_PART(r2, pr2) SM_PART(r3, pr3)
+      SM_PART(r, 0) SM_PART(rr[0], 1) SM_PART(rr[1], 2) SM_PART(rr[2], 3) SM_PART(rr[3], 4) SM_PART(rr[4], 5)
+      SM_PART(rr[5], 6) SM_PART(rr[6], 7)
 #undef SM_PART
-      // result >= partial sum, so partial >= radius cannot be a hit
-      cmask = (pr0 < radius ? 1u : 0u) | ((pr1 < radius && left_in_leaf > 1) ? 2u : 0u) |
-              ((pr2 < radius && left_in_leaf > 2) ? 4u : 0u) | ((pr3 < radius && left_in_leaf > 3) ? 8u : 0u);
       if (cmask) {
         mode = M_SCAN2;
       } else {
-        j += 4;
+        j += 8;
         leaf_end = j >= n;
       }
     } else {  // M_SCAN2, nanoflann.hpp:403-406: two-element tail; r = {v4, v5, position}
       const uint32_t t = (uint32_t)(__ffs(cmask) - 1);
-      const float partial = t == 0 ? pr0 : t == 1 ? pr1 : t == 2 ? pr2 : pr3;
+      const float partial = t == 0 ? pr[0] : t == 1 ? pr[1] : t == 2 ? pr[2] : t == 3 ? pr[3]
+                          : t == 4 ? pr[4] : t == 5 ? pr[5] : t == 6 ? pr[6] : pr[7];
       const float f4 = q4 - __uint_as_float(r.x);
       float res = partial + f4 * f4;
       const float f5 = q5 - __uint_as_float(r.y);
@@ -217,19 +237,19 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
           Hit h;
           h.position = (uint64_t)r.z | ((uint64_t)r.w << 32);
           h.dist = res;
-          h.slot = (lbase >> 1) + j + t;
+          h.slot = lleft + j + t;
           out[ord] = h;
         }
       }
       cmask &= cmask - 1;
       if (cmask == 0) {
-        j += 4;
+        j += 8;
         mode = M_SCAN;
         leaf_end = j >= n;
       }
     }
     if (leaf_end) {
-      if (sp == 0) {  // query complete
+      if (sp + tcnt == 0) {  // query complete
         if (!kOverflow) {
           sink.q_count[qi] = hits;
           if (sink.q_nodes) sink.q_nodes[qi] = nn;
@@ -242,8 +262,17 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         }
         mode = M_FETCH;
       } else {  // return from searchLevel into the innermost pending visit
-        --sp;
-        const float4 a = stk[2 * sp], b = stk[2 * sp + 1];
+        float4 a, b;
+        if (tcnt > 0) {
+          a = tos[thead][0][threadIdx.x];
+          b = tos[thead][1][threadIdx.x];
+          --tcnt;
+          thead ^= 1u;
+        } else {
+          --sp;
+          a = stk[2 * sp];
+          b = stk[2 * sp + 1];
+        }
         node = __float_as_uint(a.x);
         mind = a.y;
         d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
@@ -346,8 +375,8 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLookupKernel(IndexView ix, c
           float dist = 0.0f;
           uint64_t pos = 0;
           if (valid) {
-            const float4 *p = reinterpret_cast<const float4 *>(ix.leaf_pts);
-            const float4 pa = p[(size_t)left * 2 + (i - left)], pb = p[(size_t)left * 2 + (right - left) + (i - left)];
+            const float4 *p = reinterpret_cast<const float4 *>(ix.leaf_pts) + cur.w;
+            const float4 pa = p[i - left], pb = p[((right - left + 7u) & ~7u) + (i - left)];
             const float f0 = q0 - pa.x, f1 = q1 - pa.y, f2 = q2 - pa.z, f3 = q3 - pa.w;
             float r = 0.0f;
             r += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
@@ -443,7 +472,7 @@ __global__ void OverflowPrepareKernel(const uint32_t *__restrict__ n_queries_dev
   }
 }
 
-// Per-leaf blocks of 16-byte slots (layout in the file header): v[d] = values[vind[i] + d]
+// Per-leaf 128-byte-aligned blocks of 16-byte slots (layout in the file header): v[d] = values[vind[i] + d]
 // (sigmap_adaptor.h:94-97: k-d point i is the window values[i..i+dim)), position = Point.position
 // of the window's first element.  One thread per tree node; leaves write their block.
 __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_t *__restrict__ positions,
@@ -454,7 +483,7 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
        k += (uint64_t)gridDim.x * blockDim.x) {
     const smhip_node nd = nodes[k];
     if (nd.feat >= 0) continue;
-    const uint32_t left = nd.a, n = nd.b - nd.a;
+    const uint32_t left = nd.a, n = nd.b - nd.a, boff = nd.child2, rn = (n + 7u) & ~7u;
     for (uint32_t t = 0; t < n; ++t) {
       const uint32_t v = vind[left + t];
       const uint64_t pos = positions[v];
@@ -463,8 +492,8 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
       a.w = values[(uint64_t)v + 3]; b.x = values[(uint64_t)v + 4]; b.y = values[(uint64_t)v + 5];
       b.z = __uint_as_float((uint32_t)pos);
       b.w = __uint_as_float((uint32_t)(pos >> 32));
-      o[(size_t)left * 2 + t] = a;
-      o[(size_t)left * 2 + n + t] = b;
+      o[(size_t)boff + t] = a;
+      o[(size_t)boff + rn + t] = b;
     }
   }
 }
@@ -499,7 +528,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
     order[atomicAdd(&cursor[keys[q]], 1u)] = q;
 }
 
-constexpr int kLaneBlocksPerCU = 8;  // 8 x 256 threads = 32 waves per CU
+constexpr int kLaneBlocksPerCU = 5;  // 5 x 256 threads = 20 waves per CU (what 92 VGPRs admit)
 
 template <bool kOverflow>
 hipError_t LaunchWalk(smhip_ctx *ctx, int G, const QueryRec *qrec, const uint32_t *n_queries_dev,
