@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--fast-cap", type=int, default=0, help="fast hit slots per query (0 = default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
     return ap.parse_args()
 
 
@@ -121,11 +122,19 @@ def main():
     offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
     samples = np.concatenate(pa)
     dev.upload_batch(samples, offsets)  # inputs resident in HBM before the timed region
+    if args.sdtw_band > 0:
+        ref_sig, ref_off = pipeline.reference_signals(genome, lm)
+        dev.upload_reference(ref_sig, ref_off)
 
     def step():
         dev.run(n_refs)
+        if args.sdtw_band > 0:
+            dev.refine(band=args.sdtw_band, pad=32)
         dev.sync()
-        return dev.download()
+        res = dev.download()
+        if args.sdtw_band > 0:
+            step.refined = dev.refine_download()
+        return res
 
     for _ in range(args.warmup):
         res = step()
@@ -151,7 +160,7 @@ def main():
 
     # per-kernel device time (HIP events on the context stream, inside the timed region)
     kern = {}
-    for name in ["events", "seed_lookup", "seed_overflow", "sort", "chain"]:
+    for name in ["events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw"]:
         ms, n = dev.timing_get(name)
         kern[name] = {"mean_ms": round(ms, 4), "launches": int(n)}
 
@@ -189,7 +198,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{R} synthetic 4000-sample reads (1 chunk each) per GPU vs {n_refs} x "
-                            f"{args.contig_len} bp random reference (yeast-sized), event+seed+sort+chain on GPU",
+                            f"{args.contig_len} bp random reference (yeast-sized), event+seed+sort+chain"
+                            f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU",
                 "chunks_per_gpu_per_step": R,
                 "index_points": int(dev_index_points(ix)) if ix is not None else None,
                 "lanes_per_query": int(dev.params.lanes_per_query),
@@ -201,6 +211,8 @@ def main():
                 "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
+                "sdtw_refined_fraction": (round(float((step.refined[1] >= 0).mean()), 4)
+                                          if args.sdtw_band > 0 else None),
                 "index_build_s": round(t_build, 2),
                 "kernels": kern,
             },

@@ -171,6 +171,26 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
 /* Mean device time (ms) of the named kernel over the launches since the last
  * smhip_timing_reset(), measured with HIP events on the context stream.
  * names: "events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw". */
+/* ---- banded sDTW refinement of the best chain ----
+ * The reference computes the z-scored expected signal of every contig strand at map time
+ * (sigmap.cc:566-591) and aligns against it with Sigmap::sDTW (sigmap.cc:1259-1291) in its
+ * DTWAlign/CWTAlign drivers.  Here the same recurrence, restricted to a band around the chain's
+ * diagonal, refines chain 0 of every chunk of the last smhip_map_run; PAF columns 1-12 are not
+ * altered, the distance is reported as an extra tag (dt:f:).
+ * signals: concatenated float arrays in the order contig0 +, contig0 -, contig1 +, ...;
+ * offsets[2*n_refs + 1] in elements. */
+int smhip_reference_upload(smhip_ctx *ctx, const float *signals, const uint64_t *offsets, uint32_t n_refs);
+/* For chunk c with >= 1 chain: target = strand signal[t0, t1) with t0 = max(0, start - pad),
+ * t1 = min(len, end + dim + pad); query = the chunk's feature signal (F values); row t (1-based,
+ * absolute index ta = t0 + t - 1) may use the 1-based columns [centre - band/2, centre + band/2]
+ * clipped to [1, F], centre = 1 + qa + floor((ta - start) * (qb - qa) / max(1, end - start)), where
+ * (start, qa) / (end, qb) are target/query positions of chain 0's first/last anchor (query
+ * positions made chunk-local by subtracting query_start_offset, clamped at 0).
+ * dist[c] = FLT_MAX and end_pos[c] = -1 when the chunk has no chain or the window exceeds 8192
+ * rows; otherwise end_pos = absolute 1-based target row of the best end (t0 + t). */
+int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad);
+int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos);
+
 /* Diagnostic counters of the last smhip_map_run: [0] stack-overflow flag, [1] queries that needed
  * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag. */
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);

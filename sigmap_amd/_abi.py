@@ -16,7 +16,7 @@ HIP_SYMBOLS = [
     "smhip_default_params", "smhip_init", "smhip_destroy", "smhip_last_error", "smhip_stream",
     "smhip_index_upload", "smhip_index_export", "smhip_index_attach", "smhip_batch_upload",
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
-    "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
+    "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
     "smhip_seed_lookup", "smhip_sdtw_banded",
 ]
 HOST_SYMBOLS = [
@@ -169,6 +169,9 @@ def hip_lib():
         L.smhip_map_sync.argtypes = [vp]
         L.smhip_map_download.argtypes = [vp, vp, vp, u64, vp]
         L.smhip_map_chunks.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp, vp, vp, vp]
+        L.smhip_reference_upload.argtypes = [vp, vp, vp, u32]
+        L.smhip_refine_run.argtypes = [vp, u32, u32]
+        L.smhip_refine_download.argtypes = [vp, vp, vp]
         L.smhip_debug_counters.argtypes = [vp, vp]
         L.smhip_timing_enable.argtypes = [vp, C.c_int]
         L.smhip_timing_reset.argtypes = [vp]

@@ -148,7 +148,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
@@ -312,6 +312,7 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   ctx->n_carried = n_carried;
   ctx->batch_ready = true;
   ctx->run_done = false;
+  ctx->refine_done = false;
   return SMHIP_OK;
 }
 
@@ -514,6 +515,59 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, con
   rc = smhip_map_sync(ctx);
   if (rc) return rc;
   return smhip_map_download(ctx, results, nullptr, 0, nullptr);
+}
+
+int smhip_reference_upload(smhip_ctx *ctx, const float *signals, const uint64_t *offsets, uint32_t n_refs) {
+  if (!ctx || !signals || !offsets || n_refs == 0) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  for (uint32_t i = 0; i < 2 * n_refs; ++i)
+    if (offsets[i + 1] < offsets[i]) return Fail(ctx, SMHIP_EINVAL, "offsets must be non-decreasing");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t total = offsets[2 * n_refs];
+  HIPCHK(ctx->ref_sig.Reserve(std::max<uint64_t>(total, 1) * sizeof(float)));
+  HIPCHK(ctx->ref_off.Reserve((2ull * n_refs + 1) * sizeof(uint64_t)));
+  HIPCHK(hipMemcpyAsync(ctx->ref_sig.p, signals, total * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->ref_off.p, offsets, (2ull * n_refs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->ref_n = n_refs;
+  return SMHIP_OK;
+}
+
+int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
+  if (!ctx) return SMHIP_EINVAL;
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_run before smhip_map_run");
+  if (ctx->ref_n == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_run before smhip_reference_upload");
+  if (band == 0) return Fail(ctx, SMHIP_EINVAL, "band must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  ctx->refine_done = false;
+  if (R == 0) {
+    ctx->refine_done = true;
+    return SMHIP_OK;
+  }
+  HIPCHK(ctx->refine_dist.Reserve((uint64_t)R * sizeof(float)));
+  HIPCHK(ctx->refine_end.Reserve((uint64_t)R * sizeof(int64_t)));
+  {
+    ScopedTimer t(ctx, T_SDTW);
+    HIPCHK(LaunchSdtwChains(ctx, ctx->results.as<smhip_chunk_result>(), ctx->feat.as<float>(), kFeatStride,
+                            ctx->qstart.as<uint32_t>(), R, ctx->ref_sig.as<float>(), ctx->ref_off.as<uint64_t>(),
+                            ctx->ref_n, band, pad, ctx->refine_dist.as<float>(), ctx->refine_end.as<int64_t>()));
+  }
+  ctx->refine_done = true;
+  return SMHIP_OK;
+}
+
+int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos) {
+  if (!ctx || !dist || !end_pos) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->refine_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_download before smhip_refine_run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  if (R == 0) return SMHIP_OK;
+  HIPCHK(hipMemcpyAsync(dist, ctx->refine_dist.p, (uint64_t)R * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(end_pos, ctx->refine_end.p, (uint64_t)R * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ResolveTimers(ctx);
+  return SMHIP_OK;
 }
 
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]) {

@@ -95,6 +95,10 @@ struct smhip_ctx {
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
   uint64_t cap_queries = 0, cap_anchors = 0;
+  // sDTW refinement
+  smhip::DevBuf ref_sig, ref_off, refine_dist, refine_end;
+  uint32_t ref_n = 0;
+  bool refine_done = false;
   // host staging
   std::vector<uint64_t> h_anchor_off;
   // timing
@@ -162,6 +166,10 @@ struct ChainArgs {
 };
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
                        uint64_t n_anchors_total);
+hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, const float *feat,
+                            uint32_t feat_stride, const uint32_t *qstart, uint32_t n_chunks, const float *ref_sig,
+                            const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,
+                            int64_t *end_pos);
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
                       const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n,
                       float *dist, int64_t *end, uint32_t max_t);

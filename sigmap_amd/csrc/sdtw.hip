@@ -106,6 +106,144 @@ __global__ __launch_bounds__(64) void SdtwKernel(const float *__restrict__ targe
     }
   }
 }
+
+__device__ __forceinline__ int64_t FloorDiv(int64_t a, int64_t b) {  // b > 0
+  int64_t q = a / b;
+  if ((a % b) != 0 && a < 0) --q;
+  return q;
+}
+
+// Refinement of chain 0 of every chunk (contract: include/sigmap_hip.h smhip_refine_run).
+// Same sweep as SdtwKernel; the band is the linear diagonal through the chain's end anchors.
+__global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *__restrict__ results,
+                                                      const float *__restrict__ feat, uint32_t feat_stride,
+                                                      const uint32_t *__restrict__ qstart,
+                                                      const float *__restrict__ ref_sig,
+                                                      const uint64_t *__restrict__ ref_off, uint32_t n_refs,
+                                                      uint32_t band, uint32_t pad, int dim,
+                                                      float *__restrict__ dist, int64_t *__restrict__ end_pos,
+                                                      uint32_t max_rows, int second_pass) {
+  extern __shared__ float sm[];
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  // pass 1 runs with LDS for max_rows rows and leaves longer windows (end_pos = -2) to pass 2
+  if (second_pass && end_pos[c] != -2) return;
+  const smhip_chunk_result &res = results[c];
+  bool ok = res.n_chains >= 1 && res.chains[0].ref < n_refs;
+  uint32_t T = 0, Q = res.n_features;
+  int64_t t0 = 0, start = 0, den = 1, qa = 0, qb = 0;
+  const float *tg = nullptr;
+  if (ok) {
+    const smhip_chain ch = res.chains[0];
+    const uint32_t strand = ch.direction == 1 ? 0u : 1u;
+    const uint64_t so = ref_off[2 * ch.ref + strand], se = ref_off[2 * ch.ref + strand + 1];
+    const int64_t len = (int64_t)(se - so);
+    start = ch.start;
+    const int64_t endp = ch.end;
+    t0 = start - (int64_t)pad < 0 ? 0 : start - (int64_t)pad;
+    int64_t t1 = endp + dim + (int64_t)pad;
+    if (t1 > len) t1 = len;
+    const uint32_t qs = qstart ? qstart[c] : 0;
+    qa = (int64_t)res.c0_last_qpos - qs;
+    qb = (int64_t)res.c0_first_qpos - qs;
+    if (qa < 0) qa = 0;
+    if (qb < 0) qb = 0;
+    den = endp - start > 0 ? endp - start : 1;
+    if (t1 <= t0 || t1 - t0 > (int64_t)kSdtwMaxT || Q == 0) {
+      ok = false;
+    } else if (t1 - t0 > (int64_t)max_rows) {
+      if (lane == 0) {
+        dist[c] = FLT_MAX;
+        end_pos[c] = -2;
+      }
+      return;
+    } else {
+      T = (uint32_t)(t1 - t0);
+      tg = ref_sig + so + t0;
+    }
+  }
+  if (!ok) {
+    if (lane == 0) {
+      dist[c] = FLT_MAX;
+      end_pos[c] = -1;
+    }
+    return;
+  }
+  const float *qr = feat + (size_t)c * feat_stride;
+  const uint32_t stride = T + 2;
+  float *d0 = sm, *d1 = sm + stride, *d2 = sm + 2 * stride;  // cells with t >= 1, q >= 1 only
+  int32_t *cen = reinterpret_cast<int32_t *>(sm + 3 * stride);  // band centre of every row
+  const int64_t half = band / 2;
+  float best = FLT_MAX;
+  uint32_t best_t = 0xFFFFFFFFu;
+  for (uint32_t t = lane; t < stride; t += 64) {
+    d0[t] = FLT_MAX;
+    d1[t] = FLT_MAX;
+    d2[t] = FLT_MAX;
+    const int64_t ta = t0 + (int64_t)t - 1;
+    cen[t] = (int32_t)(1 + qa + FloorDiv((ta - start) * (qb - qa), den));
+  }
+  __syncthreads();
+  // g(t) = t + centre(t) is strictly increasing, and cell (t, q) is inside the band only if
+  // |t + q - g(t)| <= half, so on diagonal d = t + q the band is the short row interval that
+  // starts at tb = first t with g(t) + half >= d; tb only moves forward as d grows.  Each
+  // diagonal writes that interval plus a margin of FLT_MAX cells, which is all the next two
+  // diagonals can read.  Row 0 and column 0 are constants (FLT_MAX / 0) and are never stored.
+  uint32_t tb = 1;
+  for (uint32_t d = 2; d <= T + Q; ++d) {
+    while (tb <= T && (int64_t)tb + cen[tb] + half < (int64_t)d) ++tb;
+    const uint32_t t_min = d > Q ? d - Q : 1, t_max = d - 1 < T ? d - 1 : T;  // q in [1, Q], t in [1, T]
+    const uint32_t w_lo = max(t_min, tb > 3 ? tb - 3 : 1u);
+    const uint32_t w_hi = min(t_max, tb + band + 6);
+    for (uint32_t t = w_lo + lane; t <= w_hi && w_lo <= w_hi; t += 64) {
+      const uint32_t q = d - t;
+      float v = FLT_MAX;
+      const int64_t centre = cen[t];
+      int64_t lo = centre - half, hi = centre + half;
+      if (lo < 1) lo = 1;
+      if (hi > (int64_t)Q) hi = Q;
+      if ((int64_t)q >= lo && (int64_t)q <= hi) {
+        const float cost = fabsf(tg[t - 1] - qr[q - 1]);
+        // (t-1, q-1), (t-1, q), (t, q-1) with the boundary constants of sigmap.cc:1263-1271
+        const float a = t == 1 ? (q == 1 ? 0.0f : FLT_MAX) : (q == 1 ? 0.0f : d0[t - 1]);
+        const float b = t == 1 ? FLT_MAX : d1[t - 1];
+        const float cc = q == 1 ? 0.0f : d1[t];
+        float m = a;
+        if (b < m) m = b;
+        if (cc < m) m = cc;
+        v = cost + m;
+      }
+      d2[t] = v;
+      if (q == Q) {
+        if (v < best || (v == best && t < best_t)) {
+          best = v;
+          best_t = t;
+        }
+      }
+    }
+    __syncthreads();
+    float *tmp = d0;
+    d0 = d1;
+    d1 = d2;
+    d2 = tmp;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_down(best, off, 64);
+    const uint32_t ot = __shfl_down(best_t, off, 64);
+    if (ob < best || (ob == best && ot < best_t)) {
+      best = ob;
+      best_t = ot;
+    }
+  }
+  if (lane == 0) {
+    if (best < FLT_MAX) {
+      dist[c] = best;
+      end_pos[c] = t0 + (int64_t)best_t;
+    } else {
+      dist[c] = FLT_MAX;
+      end_pos[c] = -1;
+    }
+  }
+}
 }  // namespace
 
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
@@ -124,6 +262,30 @@ hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off
   }
   hipLaunchKernelGGL(SdtwKernel, dim3(n), dim3(64), lds, ctx->stream, target, t_off, query, q_off, lo, hi,
                      dist, end);
+  return hipGetLastError();
+}
+hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, const float *feat,
+                            uint32_t feat_stride, const uint32_t *qstart, uint32_t n_chunks, const float *ref_sig,
+                            const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,
+                            int64_t *end_pos) {
+  if (n_chunks == 0) return hipSuccess;
+  // rows of a window = chain span + dim + 2*pad (a 4000-sample chunk spans a few hundred events):
+  // pass 1 sizes LDS for 1021 rows (16 KB => 10 workgroups per CU); the rare longer windows are
+  // redone by pass 2 with the full 8192-row LDS.
+  const size_t lds_full = 4 * (size_t)(kSdtwMaxT + 2) * sizeof(float);
+  const uint32_t fast_rows = 1021;
+  const size_t lds_fast = 4 * (size_t)(fast_rows + 2) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
+                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0);
+  hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_full, ctx->stream, results, feat, feat_stride,
+                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, (uint32_t)kSdtwMaxT, 1);
   return hipGetLastError();
 }
 }  // namespace smhip

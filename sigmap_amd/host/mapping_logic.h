@@ -31,9 +31,12 @@ bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p);
 // chunk_index = index of the last chunk counted the way the reference counts it
 // (sigmap.cc:690-693), num_events = features consumed over all chunks with > 50 features.
 // include_time_tag: prepend "mt:f:<ms>" like the reference (wall clock; excluded from parity).
+// sdtw_distance: when given, appended as the extra tag dt:f: (banded sDTW refinement of chain 0;
+// not part of the reference's PAF).
 PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std::string &read_name,
                        uint32_t read_length, uint32_t chunk_index, uint32_t num_events,
                        const std::vector<uint32_t> &ref_lengths, const MappingParams &p,
-                       bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket);
+                       bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket,
+                       const float *sdtw_distance = nullptr);
 }  // namespace sigmap
 #endif

@@ -57,7 +57,7 @@ class Sigmap {
     index.Save();
   }
 
-  void StreamingMap(int device, size_t max_batch_chunks) {
+  void StreamingMap(int device, size_t max_batch_chunks, int sdtw_band) {
     SignalBatch reads;
     reads.InitializeLoading(signal_directory_);
     const size_t num_reads = reads.LoadAllReadSignals();
@@ -76,6 +76,24 @@ class Sigmap {
                            index.values().size(), index.tree().vind.data(), index.tree().m_size,
                            index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
       ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctx));
+    if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
+      PoreModel pore_model;
+      pore_model.Load(pore_model_file_path_);
+      SignalBatch ref_signals;
+      for (uint32_t i = 0; i < num_refs; ++i) reference.PrepareNegativeSequenceAt(i);
+      ref_signals.ConvertSequencesToSignals(reference, pore_model, num_refs);
+      std::vector<float> sig;
+      std::vector<uint64_t> off(1, 0);
+      for (uint32_t i = 0; i < num_refs; ++i) {
+        const Signal &s = ref_signals.GetSignalAt(i);
+        ZscoreNormalize(s.signal_values.data(), s.signal_values.size(), sig);
+        off.push_back(sig.size());
+        ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
+        off.push_back(sig.size());
+      }
+      if (smhip_reference_upload(ctx, sig.data(), off.data(), num_refs) != SMHIP_OK)
+        ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(ctx));
+    }
     smhip_params dp;
     smhip_default_params(&dp);
     dp.search_radius = params_.search_radius;
@@ -87,6 +105,8 @@ class Sigmap {
       uint32_t num_events = 0;
       bool active = true;
       smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
+      float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
+      bool has_dt = false;
       std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
       double start_time = 0;
     };
@@ -137,7 +157,11 @@ class Sigmap {
                                   carried.empty() ? nullptr : carried.data(),
                                   carried.empty() ? nullptr : carried_off.data());
       if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
+      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
       if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+      std::vector<float> dts(batch.size());
+      std::vector<int64_t> dte(batch.size());
+      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
       uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
       while (rc == SMHIP_OK) {
         out_anchors.resize(cap);
@@ -157,6 +181,8 @@ class Sigmap {
         bool stop = false;
         if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
           s.last = res;
+          s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
+          s.dt = dts[bi];
           s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
           s.num_events += res.n_features;
           stop = ShouldStopMapping(res, params_);
@@ -186,7 +212,7 @@ class Sigmap {
       uint32_t bucket = 0;
       const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
                                        (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
-                                       params_, true, s.start_time, &bucket);
+                                       params_, true, s.start_time, &bucket, s.has_dt ? &s.dt : nullptr);
       rows[bucket].push_back(FormatPAF(m, num_refs ? reference.GetSequenceNameAt(bucket) : "*",
                                        num_refs ? ref_lengths[bucket] : 0));
     }
@@ -228,6 +254,7 @@ const char *kHelp =
     "      --stop-mapping-output FLOAT best/second-best ratio to output mappings [1.2]\n"
     "      --stop-mapping-mean FLOAT   best/mean chaining score ratio to stop mapping [5]\n"
     "      --stop-mapping-mean-output FLOAT  best/mean ratio to output mappings [5]\n"
+    "      --sdtw-band INT             banded sDTW refinement of the best chain, adds dt:f: [0 = off]\n"
     "      --device INT                GPU ordinal [0]\n      --batch-chunks INT          chunks per GPU batch [16384]\n"
     "  -h, --help  Print help\n";
 }  // namespace
@@ -287,7 +314,8 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     omp_set_num_threads(std::max(1, num_threads));
     const int device = a.Has("device") ? std::stoi(a.Str("device")) : 0;
     const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 16384;
-    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch);
+    const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch, sdtw_band);
   } else {
     std::cerr << kHelp;
   }

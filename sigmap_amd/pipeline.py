@@ -71,6 +71,21 @@ def raw_to_pa(raw, digitisation, rng, offset):
     return out[:n]
 
 
+def reference_signals(genome, level_means, k=6):
+    """Z-scored expected signal of every contig strand (the sDTW target), concatenated in the order
+    contig0 +, contig0 -, contig1 +, ... plus the 2*n+1 element offsets."""
+    L = _abi.host_lib()
+    lm = np.ascontiguousarray(level_means, dtype=np.float32)
+    parts, offs = [], [0]
+    for g in genome:
+        for strand in (0, 1):
+            out = np.zeros(len(g), dtype=np.float32)
+            m = L.smhost_reference_signal(ptr(lm), k, g, len(g), strand, ptr(out))
+            parts.append(out[:m].copy())
+            offs.append(offs[-1] + int(m))
+    return np.concatenate(parts), np.array(offs, dtype=np.uint64)
+
+
 def default_params():
     p = _abi.Params()
     _abi.hip_lib().smhip_default_params(C.byref(p))
@@ -146,6 +161,22 @@ class DeviceMapper:
         self.sync()
         return self.download()
 
+    def upload_reference(self, signals, offsets):
+        """signals: concatenated z-scored expected signals (contig0 +, contig0 -, contig1 +, ...)."""
+        signals = np.ascontiguousarray(signals, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.L.smhip_reference_upload(self._h, ptr(signals), ptr(offsets), (len(offsets) - 1) // 2),
+                    "smhip_reference_upload")
+
+    def refine(self, band=64, pad=32):
+        self._check(self.L.smhip_refine_run(self._h, band, pad), "smhip_refine_run")
+
+    def refine_download(self):
+        dist = np.zeros(self.n_chunks, dtype=np.float32)
+        end = np.zeros(self.n_chunks, dtype=np.int64)
+        self._check(self.L.smhip_refine_download(self._h, ptr(dist), ptr(end)), "smhip_refine_download")
+        return dist, end
+
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint32)
         self._check(self.L.smhip_debug_counters(self._h, ptr(out)), "smhip_debug_counters")
@@ -162,7 +193,7 @@ class DeviceMapper:
         self._check(self.L.smhip_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)), "smhip_timing_get")
         return ms.value, n.value
 
-    def events(self, samples, offsets, feat_stride=2672):
+    def events(self, samples, offsets, feat_stride=2736):
         samples = np.ascontiguousarray(samples, dtype=np.float32)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
         n = len(offsets) - 1

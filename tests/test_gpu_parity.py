@@ -356,3 +356,63 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     assert [strip(l) for l in got] == exp
     assert sum(1 for l in exp if "\t*\t" not in l) >= 18
     tree.close()
+    # --sdtw-band adds a dt:f: tag to rows that have a chain and changes nothing else
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out2.paf"),
+                        "--sdtw-band", "64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got2 = open(tmp_path / "out2.paf").read().splitlines()
+    nodt = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith(("mt:f:", "dt:f:")))
+    assert [nodt(l) for l in got2] == exp
+    assert sum(1 for l in got2 if "\tdt:f:" in l) >= 18
+
+
+# ------------------------------------------------------------------ sDTW refinement of chain 0 (D4/D5)
+
+@pytest.mark.parametrize("band", [32, 64, 128])
+def test_refine_matches_oracle(device, small_world, band):
+    """smhip_refine_run: banded sDTW of the chunk's features against the z-scored reference signal
+    around chain 0 (window + band exactly as include/sigmap_hip.h states) == the oracle's banded
+    sDTW on the same window.  Also: refinement does not touch the mapping results."""
+    genome, lm, pa = small_world["genome"], small_world["lm"], small_world["pa"][:24]
+    sig, offs = pipeline.reference_signals(genome, lm)
+    device.upload_reference(sig, offs)
+    samples, offsets = _batch(pa)
+    device.upload_batch(samples, offsets)
+    device.run(3); device.sync()
+    before = device.download()
+    pad = 32
+    device.refine(band=band, pad=pad); device.sync()
+    dist, end = device.refine_download()
+    assert before.tobytes() == device.download().tobytes()
+    feat, _, nf, _, _ = device.events(samples, offsets)
+    checked = 0
+    for i in range(len(pa)):
+        r = before[i]
+        if r["n_chains"] == 0:
+            assert end[i] == -1
+            continue
+        c0 = r["chains"][0]
+        strand = 0 if c0["direction"] == 1 else 1
+        so, se = int(offs[2 * c0["ref"] + strand]), int(offs[2 * c0["ref"] + strand + 1])
+        start, endp = int(c0["start"]), int(c0["end"])
+        t0 = max(0, start - pad); t1 = min(se - so, endp + 6 + pad)
+        target = sig[so + t0:so + t1]
+        q = feat[i, :nf[i]]
+        qa, qb = int(r["c0_last_qpos"]), int(r["c0_first_qpos"])
+        den = max(1, endp - start)
+        ta = np.arange(t0, t1, dtype=np.int64)
+        centre = 1 + qa + ((ta - start) * (qb - qa)) // den       # floor division
+        lo = np.clip(centre - band // 2, 1, None).astype(np.int64)
+        hi = np.clip(centre + band // 2, None, len(q)).astype(np.int64)
+        hi = np.maximum(hi, 0)
+        d, e = po.sdtw_banded(target, q, lo.astype(np.uint32), hi.astype(np.uint32))
+        if e < 0:
+            assert end[i] == -1
+        else:
+            assert bits(np.float32(dist[i])) == bits(np.float32(d)), (i, dist[i], d)
+            assert end[i] == t0 + e
+            # the refined end lies near the chain's end on the reference
+            assert abs(int(end[i]) - (endp + 6)) < 64
+        checked += 1
+    assert checked >= 20
