@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--reads", type=int, default=10000, help="chunks per GPU per step")
     ap.add_argument("--contigs", type=int, default=16)
     ap.add_argument("--contig-len", type=int, default=750000)
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per query (0 = library default)")
+    ap.add_argument("--walk-blocks", type=int, default=0, help="tree-walker workgroups per CU (0 = default)")
     ap.add_argument("--fast-cap", type=int, default=0, help="fast hit slots per query (0 = default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -105,8 +105,8 @@ def main():
     lm = synth.make_pore_model()
     genome = synth.make_genome(7, genome_lens)  # every rank: cheap, and reads are cut from it
     dev = pipeline.DeviceMapper(local_rank)
-    if args.lanes:
-        dev.params.lanes_per_query = args.lanes
+    if args.walk_blocks:
+        dev.params.walk_blocks_per_cu = args.walk_blocks
     if args.fast_cap:
         dev.params.hits_per_query_fast = args.fast_cap
     ix = None
@@ -202,7 +202,6 @@ def main():
                             f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU",
                 "chunks_per_gpu_per_step": R,
                 "index_points": int(dev_index_points(ix)) if ix is not None else None,
-                "lanes_per_query": int(dev.params.lanes_per_query),
                 "mapped_fraction": round(float((res["n_chains"] > 0).mean()), 4),
                 "queries_per_chunk": round(queries / R, 2),
                 "nodes_per_query": round(nodes / max(queries, 1), 1),

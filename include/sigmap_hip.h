@@ -65,8 +65,8 @@ typedef struct {
   /* device-side capacities (not reference semantics; exceeding one is reported, never
    * silently truncated) */
   uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (512) */
-  uint32_t lanes_per_query;       /* 1 (default: one lane walks one query) or 8/16/32/64
-                                     (a wave sub-group walks one query) */
+  uint32_t walk_blocks_per_cu;    /* resident 256-thread workgroups per CU of the tree walker
+                                     (0 = default 5; speed only) */
   uint32_t reserved;
 } smhip_params;
 
@@ -88,15 +88,18 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
                        const smhip_node *nodes, uint64_t n_nodes, const float *root_bbox);
 
 /* Device-resident index arrays, for replication to peer GPUs by one RCCL broadcast per
- * array.  The caller owns the transport (torch.distributed / RCCL). */
+ * array.  The caller owns the transport (torch.distributed / RCCL).
+ * These are the walker's own structures, derived from the smhip_node array at upload. */
 typedef struct {
   int32_t dim;
-  uint32_t pad;
-  uint64_t n_nodes, m_size;
-  void *nodes;      uint64_t nodes_bytes;      /* smhip_node[n_nodes] */
-  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks: n x {v0..v3},
-                                                  then n x {v4, v5, uint64 Point.position}; the
-                                                  block offset is the 4th word of the leaf node */
+  uint32_t root_ref;            /* inner index, or 0x80000000 | leaf ordinal for a one-leaf tree */
+  uint64_t n_inner, n_leaves, m_size;
+  void *inner;      uint64_t inner_bytes;      /* 32 B per inner node (pre-order): {feat, divlow,
+                                                  divhigh, child1 ref, child2 ref, pad x3} */
+  void *leaf_recs;  uint64_t leaf_recs_bytes;  /* 64 B per leaf: {left, n, boff, pad, lo[6], hi[6]}
+                                                  (tight box of the leaf's points) */
+  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks at slot `boff`:
+                                                  n x {v0..v3}, then n x {v4, v5, uint64 position} */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */
   void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
 } smhip_index_dev;

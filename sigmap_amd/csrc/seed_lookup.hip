@@ -5,40 +5,44 @@
 // (nanoflann.hpp:1278-1301, 1221-1242, 1006-1023, 1346-1410, 383-408, 249-253) as called
 // from SpatialIndex::GenerateChains (spatial_index.cc:351-409).
 //
-// Data layout in HBM (built once per index by LeafGatherKernel):
-//   nodes    : 16-byte pre-order records (smhip_node), child1 = self + 1
-//   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf, in TREE order (the order of
-//              nanoflann's vind).  A leaf [left,right) with n points, block offset `boff` (kept
-//              in the leaf node's 4th word): slots [boff, boff+n) hold the "first halves"
-//              {v0,v1,v2,v3}, slots [boff+R, boff+R+n) with R = roundup(n, 8) the "second halves"
-//              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte
-//              line, so every line fetched for a leaf is used whole; this replaces <= 20
-//              scattered (vind -> 6 strided floats) gathers, and a hit needs no second lookup for
-//              its reference position.
+// Data layout in HBM (built once per index from the pre-order smhip_node array + point cloud):
+//   inner    : 32-byte records of the INNER nodes only, in pre-order:
+//              {feat, divlow, divhigh, child1 ref, child2 ref, pad}.  A child ref is either an
+//              inner index or kLeafTag | leaf ordinal, so reaching a leaf costs no node read.
+//   leaf_recs: one 64-byte (one sector) record per leaf, in tree order: {left, n, boff, pad,
+//              lo[6], hi[6]} where lo/hi is the TIGHT bounding box of the leaf's points.
+//   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf at slot offset `boff`: n "first
+//              halves" {v0,v1,v2,v3}, then (from slot boff + roundup(n, 8)) n "second halves"
+//              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte line.
+//              This replaces <= 20 scattered (vind -> 6 strided floats) gathers per leaf
+//              (sigmap_adaptor.h:94-97), and a hit needs no second lookup for its position.
 //   qrec     : one 32-byte record per query: float q[6]; uint32 chunk; uint32 k
 //
-// The recursion of searchLevel is replaced by an explicit stack of pending "other child"
-// visits (node, mindistsq, dists[6] = 32 bytes per entry).  That reproduces nanoflann's visiting
-// order exactly, so hits come out in the reference's traversal order; the k-th hit of a query
-// is stored at slot k, and k >= num_nearest_points (5000, spatial_index.cc:371-372) is dropped
-// exactly like the reference.
+// The recursion of searchLevel is replaced by an explicit stack of pending "other child" visits
+// (child ref, mindistsq, dists[6] = 32 bytes per entry).  That reproduces nanoflann's visiting
+// order and pruning arithmetic (`mindistsq + cut_dist - dists[idx]`, same operation order)
+// exactly, so hits come out in the reference's traversal order; the k-th hit of a query is stored
+// at slot k, and k >= num_nearest_points (5000, spatial_index.cc:371-372) is dropped exactly like
+// the reference.
 //
-// Two walkers share that logic:
-//  * SeedLaneKernel (lanes_per_query = 1, default): ONE LANE PER QUERY, written as a state
-//    machine in which every loop iteration issues one batch of 16-byte loads per lane (a node
-//    record, the first halves of up to eight leaf points = one 128-byte line, or one second half)
-//    and then retires it.  A point whose first four squared differences already reach the radius is rejected
-//    without reading its second half (the partial sum is a lower bound of nanoflann's result:
-//    f32 addition of non-negative terms is monotone).  The two newest stack entries of a lane
-//    live in LDS; older ones spill to HBM ([lane][64 entries] x 32 B), so the instruction
-//    stream of a wave is amortised over 64 queries and most push/pop pairs never leave the CU.  Queries are
-//    visited in the order of the leaf that contains them (QueryOrder kernels: a stackless
-//    descent + a counting sort), so the lanes of a wave and the waves of a CU walk the same
-//    part of the tree and share its cache lines; results are indexed by query id, so the
-//    visiting order never shows in the output.
-//  * SeedLookupKernel<G> (lanes_per_query = 8/16/32/64): a sub-group of G lanes walks one query
-//    with the stack in LDS and fans out over the points of a leaf (coalesced leaf reads).
-//    Measured slower on MI355X (issue-bound: one traversal step per G lanes); kept for A/B.
+// What is NOT read although nanoflann reads it (results are identical, argument in place):
+//  * a visited leaf whose tight box is at squared distance >= radius from the query is skipped:
+//    the box distance is accumulated with nanoflann's own association order, and every f32
+//    operation involved is monotone, so it is a lower bound of the f32 distance nanoflann would
+//    compute for any point of the leaf -- no point of that leaf can pass `dist < radius`
+//    (measured: 86 % of the visited leaves, 83 % of the points);
+//  * the second half of a point whose first four squared differences already reach the radius.
+// The per-chunk counters still report the reference's work (nodes visited, points it tests).
+//
+// Mapping: ONE LANE PER QUERY, a state machine in which every loop iteration issues one batch of
+// 16-byte loads per lane (an inner node, a leaf record = one sector, the first halves of up to
+// eight points = one line, or one second half) and then retires it, so the instruction stream
+// of a wave is amortised over 64 queries.  The two newest stack entries of a lane live in LDS,
+// older ones spill to HBM ([lane][64] x 32 B).  Queries are visited in the order of the leaf that
+// contains them (QueryKey/QueryScatter: a stackless descent + a counting sort), each XCD taking
+// one contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the
+// same part of the tree and share its cache lines; results are indexed by query id, so the
+// visiting order never shows in the output.
 #include <stdlib.h>
 
 #include "common.h"
@@ -80,8 +84,7 @@ struct Sink {
     }                                                         \
   }
 
-// ------------------------------------------------------------------ lane-per-query walker
-enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_SCAN = 2, M_SCAN2 = 3 };
+enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3, M_SCAN2 = 4 };
 
 template <bool kOverflow>
 __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
       mind = 0.0f;
       SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
       SM_INIT_DIM(5, d5)
-      node = 0; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
+      node = ix.root_ref; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
       if (kOverflow) {
         out = sink.region + sink.q_ovf_off[qi];
         out_cap = sink.nnp;
@@ -139,71 +142,97 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         out = sink.region + (size_t)qi * sink.fast_cap;
         out_cap = sink.fast_cap;
       }
-      mode = M_WALK;
+      mode = (node & kLeafTag) ? M_LEAF : M_WALK;
     }
     // ---- one batch of 16-byte loads per lane per iteration
-    const uint4 *addr = mode == M_WALK ? reinterpret_cast<const uint4 *>(ix.nodes + node)
-                                       : pts4 + lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
+    const uint4 *addr;
+    if (mode == M_WALK) addr = ix.inner + (size_t)node * 2;
+    else if (mode == M_LEAF) addr = ix.leaf_recs + (size_t)(node & ~kLeafTag) * 4;
+    else addr = pts4 + lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
     const uint4 r = addr[0];
     uint4 rr[7];
 #pragma unroll
     for (int t = 0; t < 7; ++t) rr[t] = r;
-    if (mode == M_SCAN) {  // first halves of points j .. j+7: one aligned 128-byte line
+    if (mode == M_WALK) {
+      rr[0].x = reinterpret_cast<const uint32_t *>(addr)[4];  // child2 ref
+    } else if (mode == M_LEAF) {  // rest of the 64-byte leaf record: the tight box
+      rr[0] = addr[1];
+      rr[1] = addr[2];
+      rr[2] = addr[3];
+    } else if (mode == M_SCAN) {  // first halves of points j .. j+7: one aligned 128-byte line
 #pragma unroll
       for (int t = 0; t < 7; ++t) rr[t] = addr[t + 1];
     }
     bool leaf_end = false;
-    if (mode == M_WALK) {
+    if (mode == M_WALK) {  // nanoflann.hpp:1371-1408
       ++nn;
-      if ((int32_t)r.x < 0) {  // leaf: start scanning its points
-        lleft = r.y;
-        n = r.z - r.y;
-        lbase = r.w;
-        j = 0;
-        mode = M_SCAN;
-        leaf_end = n == 0;
-      } else {  // nanoflann.hpp:1371-1408
-        const int idx = (int)r.x;
-        const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
-        const float divlow = __uint_as_float(r.y), divhigh = __uint_as_float(r.z);
-        const float diff1 = val - divlow, diff2 = val - divhigh;
-        uint32_t next, other;
-        float cut;
-        if ((diff1 + diff2) < 0) {
-          next = node + 1;
-          other = r.w;
-          cut = (val - divhigh) * (val - divhigh);
-        } else {
-          next = r.w;
-          other = node + 1;
-          cut = (val - divlow) * (val - divlow);
-        }
-        const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
-        const float nm = mind + cut - dst;
-        if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
-          if (sp + tcnt < (uint32_t)kStackDepth) {
-            const uint32_t slot = thead ^ 1u;
-            if (tcnt == 2) {  // spill the older cached entry
-              stk[2 * sp] = tos[slot][0][threadIdx.x];
-              stk[2 * sp + 1] = tos[slot][1][threadIdx.x];
-              ++sp;
-            } else {
-              ++tcnt;
-            }
-            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
-            tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
-                                                    idx == 5 ? cut : d5);
-            thead = slot;
+      const int idx = (int)r.x;
+      const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
+      const float divlow = __uint_as_float(r.y), divhigh = __uint_as_float(r.z);
+      const float diff1 = val - divlow, diff2 = val - divhigh;
+      uint32_t next, other;
+      float cut;
+      if ((diff1 + diff2) < 0) {
+        next = r.w;
+        other = rr[0].x;
+        cut = (val - divhigh) * (val - divhigh);
+      } else {
+        next = rr[0].x;
+        other = r.w;
+        cut = (val - divlow) * (val - divlow);
+      }
+      const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
+      const float nm = mind + cut - dst;
+      if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
+        if (sp + tcnt < (uint32_t)kStackDepth) {
+          const uint32_t slot = thead ^ 1u;
+          if (tcnt == 2) {  // spill the older cached entry
+            stk[2 * sp] = tos[slot][0][threadIdx.x];
+            stk[2 * sp + 1] = tos[slot][1][threadIdx.x];
+            ++sp;
           } else {
-            atomicOr(&sink.counters[0], 1u);
+            ++tcnt;
           }
+          tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
+          tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
+                                                  idx == 5 ? cut : d5);
+          thead = slot;
+        } else {
+          atomicOr(&sink.counters[0], 1u);
         }
-        node = next;
+      }
+      node = next;
+      mode = (node & kLeafTag) ? M_LEAF : M_WALK;
+    } else if (mode == M_LEAF) {
+      // a leaf visit of searchLevel (nanoflann.hpp:1350-1369); r = {left, n, boff, -},
+      // rr[0..2] = lo[0..5], hi[0..5]
+      ++nn;
+      lleft = r.x;
+      n = r.y;
+      lbase = r.z;
+      np += n;  // the reference evaluates every point of a visited leaf
+      // squared distance from the query to the leaf's tight box, accumulated like evalMetric
+      // (nanoflann.hpp:391-406): a lower bound of every point's f32 distance (monotone ops)
+      const float l0 = __uint_as_float(rr[0].x), l1 = __uint_as_float(rr[0].y), l2 = __uint_as_float(rr[0].z),
+                  l3 = __uint_as_float(rr[0].w), l4 = __uint_as_float(rr[1].x), l5 = __uint_as_float(rr[1].y);
+      const float h0 = __uint_as_float(rr[1].z), h1 = __uint_as_float(rr[1].w), h2 = __uint_as_float(rr[2].x),
+                  h3 = __uint_as_float(rr[2].y), h4 = __uint_as_float(rr[2].z), h5 = __uint_as_float(rr[2].w);
+#define SM_BOX(qq, ll, hh) ((qq) > (hh) ? (qq) - (hh) : ((qq) < (ll) ? (qq) - (ll) : 0.0f))
+      const float e0 = SM_BOX(q0, l0, h0), e1 = SM_BOX(q1, l1, h1), e2 = SM_BOX(q2, l2, h2);
+      const float e3 = SM_BOX(q3, l3, h3), e4 = SM_BOX(q4, l4, h4), e5 = SM_BOX(q5, l5, h5);
+#undef SM_BOX
+      float lb = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      lb += e4 * e4;
+      lb += e5 * e5;
+      j = 0;
+      if (lb < radius && n > 0) {
+        mode = M_SCAN;
+      } else {
+        leaf_end = true;  // no point of this leaf can satisfy dist < radius
       }
     } else if (mode == M_SCAN) {
       // nanoflann.hpp:391-401: first group of four differences, for up to eight points
       const uint32_t left_in_leaf = n - j;
-      np += min(8u, left_in_leaf);
       cmask = 0;
 #define SM_PART(rv, t)                                                                       \
   {                                                                                          \
@@ -276,143 +305,7 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         node = __float_as_uint(a.x);
         mind = a.y;
         d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
-        mode = M_WALK;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ G-lanes-per-query walker
-template <int G, bool kOverflow>
-__global__ __launch_bounds__(kSeedThreads) void SeedLookupKernel(IndexView ix, const QueryRec *__restrict__ qrec,
-                                                                 const uint32_t *__restrict__ n_queries_dev,
-                                                                 uint32_t n_queries_host, Sink sink, float radius) {
-  extern __shared__ __align__(16) float4 stack_mem[];
-  constexpr int kGroupsPerBlock = kSeedThreads / G;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t group_in_block = tid / G;
-  const uint32_t lig = tid % G;
-  const uint32_t group_shift = (tid & 63) / G * G;
-  float4 *stack = stack_mem + (size_t)group_in_block * kStackDepth * 2;
-  const uint32_t n_groups_total = gridDim.x * kGroupsPerBlock;
-  const uint32_t total = kOverflow ? sink.counters[1] : (n_queries_dev ? *n_queries_dev : n_queries_host);
-  for (uint32_t w = blockIdx.x * kGroupsPerBlock + group_in_block; w < total; w += n_groups_total) {
-    const uint32_t qi = kOverflow ? sink.ovf_list[w] : w;
-    const QueryRec qr = qrec[qi];
-    const float q0 = qr.q[0], q1 = qr.q[1], q2 = qr.q[2], q3 = qr.q[3], q4 = qr.q[4], q5 = qr.q[5];
-    const uint32_t chunk = qr.chunk;
-    Hit *out;
-    uint32_t out_cap;
-    if (kOverflow) {
-      out = sink.region + sink.q_ovf_off[qi];
-      out_cap = sink.nnp;
-    } else {
-      out = sink.region + (size_t)qi * sink.fast_cap;
-      out_cap = sink.fast_cap;
-    }
-    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
-    float mind = 0.0f;
-    SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
-    SM_INIT_DIM(5, d5)
-    uint32_t hit_count = 0, n_nodes = 0, n_points = 0;
-    uint32_t sp = 0, node = 0;
-    bool alive = ix.n_nodes > 0;
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (alive) rec = *reinterpret_cast<const uint4 *>(&ix.nodes[0]);
-    while (alive) {
-      ++n_nodes;
-      const uint4 cur = rec;
-      const bool is_leaf = (int32_t)cur.x < 0;
-      uint32_t next = 0;
-      if (is_leaf) {
-        if (sp == 0) {
-          alive = false;
-        } else {
-          --sp;
-          const float4 a = stack[2 * sp], b = stack[2 * sp + 1];
-          next = __float_as_uint(a.x);
-          mind = a.y;
-          d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
-        }
-      } else {
-        const int idx = (int)cur.x;
-        const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
-        const float divlow = __uint_as_float(cur.y), divhigh = __uint_as_float(cur.z);
-        const float diff1 = val - divlow, diff2 = val - divhigh;
-        uint32_t other;
-        float cut;
-        if ((diff1 + diff2) < 0) {
-          next = node + 1;
-          other = cur.w;
-          cut = (val - divhigh) * (val - divhigh);
-        } else {
-          next = cur.w;
-          other = node + 1;
-          cut = (val - divlow) * (val - divlow);
-        }
-        const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
-        const float nm = mind + cut - dst;
-        if (nm <= radius) {
-          if (sp < (uint32_t)kStackDepth) {
-            if (lig == 0) {
-              stack[2 * sp] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
-              stack[2 * sp + 1] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
-                                              idx == 5 ? cut : d5);
-            }
-            ++sp;
-          } else if (lig == 0) {
-            atomicOr(&sink.counters[0], 1u);
-          }
-        }
-      }
-      node = next;
-      if (alive) rec = *reinterpret_cast<const uint4 *>(&ix.nodes[node]);  // in flight during the leaf scan
-      if (is_leaf) {
-        const uint32_t left = cur.y, right = cur.z;
-        for (uint32_t base = left; base < right; base += G) {
-          const uint32_t i = base + lig;
-          const bool valid = i < right;
-          float dist = 0.0f;
-          uint64_t pos = 0;
-          if (valid) {
-            const float4 *p = reinterpret_cast<const float4 *>(ix.leaf_pts) + cur.w;
-            const float4 pa = p[i - left], pb = p[((right - left + 7u) & ~7u) + (i - left)];
-            const float f0 = q0 - pa.x, f1 = q1 - pa.y, f2 = q2 - pa.z, f3 = q3 - pa.w;
-            float r = 0.0f;
-            r += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
-            const float f4 = q4 - pb.x;
-            r += f4 * f4;
-            const float f5 = q5 - pb.y;
-            r += f5 * f5;
-            dist = r;
-            pos = (uint64_t)__float_as_uint(pb.z) | ((uint64_t)__float_as_uint(pb.w) << 32);
-          }
-          const bool hit = valid && dist < radius;
-          const uint64_t wave_mask = __ballot(hit);
-          const uint64_t gmask = G == 64 ? wave_mask : ((wave_mask >> group_shift) & ((1ull << (G & 63)) - 1));
-          const uint32_t rank = __popcll(gmask & ((1ull << lig) - 1));
-          const uint32_t ord = hit_count + rank;
-          if (hit && ord < sink.nnp && ord < out_cap) {
-            Hit h;
-            h.position = pos;
-            h.dist = dist;
-            h.slot = i;
-            out[ord] = h;
-          }
-          hit_count += __popcll(gmask);
-          n_points += min((uint32_t)G, right - base);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      }
-    }
-    if (lig == 0 && !kOverflow) {
-      sink.q_count[qi] = hit_count;
-      if (sink.q_nodes) sink.q_nodes[qi] = n_nodes;
-      if (sink.q_points) sink.q_points[qi] = n_points;
-      if (sink.results) {
-        atomicAdd((unsigned long long *)&sink.results[chunk].nodes_visited, (unsigned long long)n_nodes);
-        atomicAdd((unsigned long long *)&sink.results[chunk].points_tested, (unsigned long long)n_points);
-        atomicAdd((unsigned long long *)&sink.results[chunk].hits_total, (unsigned long long)hit_count);
+        mode = (node & kLeafTag) ? M_LEAF : M_WALK;
       }
     }
   }
@@ -472,33 +365,45 @@ __global__ void OverflowPrepareKernel(const uint32_t *__restrict__ n_queries_dev
   }
 }
 
-// Per-leaf 128-byte-aligned blocks of 16-byte slots (layout in the file header): v[d] = values[vind[i] + d]
-// (sigmap_adaptor.h:94-97: k-d point i is the window values[i..i+dim)), position = Point.position
-// of the window's first element.  One thread per tree node; leaves write their block.
+// One thread per leaf: writes the leaf's point block (layout in the file header) and the tight
+// bounding box into its record.  v[d] = values[vind[i] + d] (sigmap_adaptor.h:94-97: k-d point i is
+// the window values[i..i+dim)), position = Point.position of the window's first element.
 __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_t *__restrict__ positions,
-                                 const uint32_t *__restrict__ vind, const smhip_node *__restrict__ nodes,
-                                 uint64_t n_nodes, float *__restrict__ leaf_pts) {
+                                 const uint32_t *__restrict__ vind, uint4 *__restrict__ leaf_recs,
+                                 uint64_t n_leaves, float *__restrict__ leaf_pts) {
   float4 *o = reinterpret_cast<float4 *>(leaf_pts);
-  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_nodes;
+  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_leaves;
        k += (uint64_t)gridDim.x * blockDim.x) {
-    const smhip_node nd = nodes[k];
-    if (nd.feat >= 0) continue;
-    const uint32_t left = nd.a, n = nd.b - nd.a, boff = nd.child2, rn = (n + 7u) & ~7u;
+    const uint4 hd = leaf_recs[k * 4];
+    const uint32_t left = hd.x, n = hd.y, boff = hd.z, rn = (n + 7u) & ~7u;
+    float lo[6], hi[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      lo[d] = 3.402823466e38f;
+      hi[d] = -3.402823466e38f;
+    }
     for (uint32_t t = 0; t < n; ++t) {
       const uint32_t v = vind[left + t];
       const uint64_t pos = positions[v];
-      float4 a, b;
-      a.x = values[(uint64_t)v + 0]; a.y = values[(uint64_t)v + 1]; a.z = values[(uint64_t)v + 2];
-      a.w = values[(uint64_t)v + 3]; b.x = values[(uint64_t)v + 4]; b.y = values[(uint64_t)v + 5];
-      b.z = __uint_as_float((uint32_t)pos);
-      b.w = __uint_as_float((uint32_t)(pos >> 32));
-      o[(size_t)boff + t] = a;
-      o[(size_t)boff + rn + t] = b;
+      float p[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        p[d] = values[(uint64_t)v + d];
+        lo[d] = fminf(lo[d], p[d]);
+        hi[d] = fmaxf(hi[d], p[d]);
+      }
+      o[(size_t)boff + t] = make_float4(p[0], p[1], p[2], p[3]);
+      o[(size_t)boff + rn + t] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
+                                             __uint_as_float((uint32_t)(pos >> 32)));
     }
+    float4 *rec = reinterpret_cast<float4 *>(leaf_recs + k * 4);
+    rec[1] = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    rec[2] = make_float4(lo[4], lo[5], hi[0], hi[1]);
+    rec[3] = make_float4(hi[2], hi[3], hi[4], hi[5]);
   }
 }
 
-// ---- visiting order of the queries: key = tree-order index of the leaf that contains the
+// ---- visiting order of the queries: key = ordinal (tree order) of the leaf that contains the
 // query point (a stackless best-child descent), then a counting sort on key >> shift.
 __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
@@ -506,15 +411,15 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
-    uint32_t node = 0;
-    uint4 rec = *reinterpret_cast<const uint4 *>(&ix.nodes[0]);
-    while ((int32_t)rec.x >= 0) {
+    uint32_t node = ix.root_ref;
+    while (!(node & kLeafTag)) {
+      const uint4 rec = ix.inner[(size_t)node * 2];
+      const uint32_t c2 = reinterpret_cast<const uint32_t *>(ix.inner + (size_t)node * 2)[4];
       const float val = r.q[rec.x];
       const float diff1 = val - __uint_as_float(rec.y), diff2 = val - __uint_as_float(rec.z);
-      node = (diff1 + diff2) < 0 ? node + 1 : rec.w;
-      rec = *reinterpret_cast<const uint4 *>(&ix.nodes[node]);
+      node = (diff1 + diff2) < 0 ? rec.w : c2;
     }
-    const uint32_t key = rec.y >> shift;
+    const uint32_t key = (node & ~kLeafTag) >> shift;
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
   }
@@ -528,60 +433,36 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
     order[atomicAdd(&cursor[keys[q]], 1u)] = q;
 }
 
-constexpr int kLaneBlocksPerCU = 5;  // 5 x 256 threads = 20 waves per CU (what 92 VGPRs admit)
+constexpr int kLaneBlocksPerCU = 5;  // 5 x 256 threads = 20 waves per CU (what ~92 VGPRs admit)
 
 template <bool kOverflow>
-hipError_t LaunchWalk(smhip_ctx *ctx, int G, const QueryRec *qrec, const uint32_t *n_queries_dev,
-                      uint32_t n_queries_host, const Sink &sink, float radius, const uint32_t *order) {
-  if (G == 1) {
-    static int blocks_per_cu = 0, xcd_ranges = 1;
-    if (blocks_per_cu == 0) {
-      const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES");
-      blocks_per_cu = e1 ? atoi(e1) : kLaneBlocksPerCU;
-      if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
-      if (e2) xcd_ranges = atoi(e2);
-    }
-    const uint32_t blocks = 256 * blocks_per_cu;
-    const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
-    hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((SeedLaneKernel<kOverflow>), dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
-                       qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order,
-                       (order && !kOverflow) ? xcd_ranges : 0);
-    return hipGetLastError();
+hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryRec *qrec,
+                      const uint32_t *n_queries_dev, uint32_t n_queries_host, const Sink &sink, float radius,
+                      const uint32_t *order) {
+  static int env_blocks = -1, xcd_ranges = 1;
+  if (env_blocks < 0) {
+    const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES");
+    env_blocks = e1 ? atoi(e1) : 0;
+    if (e2) xcd_ranges = atoi(e2);
   }
-  const int blocks_per_cu = G >= 32 ? 8 : (G == 16 ? 5 : 2);
-  const dim3 grid(256 * blocks_per_cu), block(kSeedThreads);
-  const size_t lds = (size_t)(kSeedThreads / G) * kStackDepth * 2 * sizeof(float4);
-#define SM_LAUNCH(GG)                                                                                  \
-  {                                                                                                    \
-    static bool attr = false;                                                                          \
-    if (!attr && lds > 48 * 1024) {                                                                    \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SeedLookupKernel<GG, kOverflow>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-      if (e != hipSuccess) return e;                                                                   \
-      attr = true;                                                                                     \
-    }                                                                                                  \
-    hipLaunchKernelGGL((SeedLookupKernel<GG, kOverflow>), grid, block, lds, ctx->stream, ctx->index,   \
-                       qrec, n_queries_dev, n_queries_host, sink, radius);                             \
-  }
-  switch (G) {
-    case 8: SM_LAUNCH(8) break;
-    case 16: SM_LAUNCH(16) break;
-    case 32: SM_LAUNCH(32) break;
-    case 64: SM_LAUNCH(64) break;
-    default: return hipErrorInvalidValue;
-  }
-#undef SM_LAUNCH
+  int blocks_per_cu = blocks_per_cu_param ? (int)blocks_per_cu_param : (env_blocks ? env_blocks : kLaneBlocksPerCU);
+  if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
+  const uint32_t blocks = 256 * blocks_per_cu;
+  const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
+  hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((SeedLaneKernel<kOverflow>), dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
+                     qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order,
+                     (order && !kOverflow) ? xcd_ranges : 0);
   return hipGetLastError();
 }
 }  // namespace
 
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, const smhip_node *nodes, uint64_t n_nodes, float *leaf_pts) {
+                            const uint32_t *vind, void *leaf_recs, uint64_t n_leaves, float *leaf_pts) {
   if (dim != 6) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind, nodes,
-                     n_nodes, leaf_pts);
+  hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind,
+                     reinterpret_cast<uint4 *>(leaf_recs), n_leaves, leaf_pts);
   return hipGetLastError();
 }
 
@@ -593,13 +474,13 @@ hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float 
 }
 
 namespace {
-// Visiting order for the lane walker (see file header).  n_max bounds the query count.
+// Visiting order for the walker (see file header).  n_max bounds the query count.
 hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t *n_queries_dev,
                            uint32_t n_queries_host, uint64_t n_max, const uint32_t **order_out) {
   uint32_t bits = 1;
-  while ((1ull << bits) < ctx->index.m_size) ++bits;
+  while ((1ull << bits) < ctx->index.n_leaves) ++bits;
   const uint32_t shift = bits > 17 ? bits - 17 : 0;
-  const uint32_t n_buckets = (uint32_t)(ctx->index.m_size >> shift) + 1;
+  const uint32_t n_buckets = (uint32_t)(ctx->index.n_leaves >> shift) + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
   if ((e = ctx->q_order.Reserve(n_max * 4)) != hipSuccess) return e;
@@ -623,11 +504,9 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
             results, counters, nullptr, nullptr};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr;
-  if (p.lanes_per_query == 1) {
-    hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
-    if (e != hipSuccess) return e;
-  }
-  return LaunchWalk<false>(ctx, (int)p.lanes_per_query, qr, q_off + n_chunks, 0, sink, p.search_radius, order);
+  hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
+  if (e != hipSuccess) return e;
+  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, qr, q_off + n_chunks, 0, sink, p.search_radius, order);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -638,10 +517,10 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const uint32_t *order = nullptr;
-  if (p.lanes_per_query == 1 && (e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
+  if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
   // the test entry point reports every hit up to `cap`: no 5000 truncation here
   Sink sink{region, cap, 0xFFFFFFFFu, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr};
-  return LaunchWalk<false>(ctx, (int)p.lanes_per_query, qr, nullptr, n, sink, p.search_radius, order);
+  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, qr, nullptr, n, sink, p.search_radius, order);
 }
 
 hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
@@ -655,7 +534,7 @@ hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void 
   if (e != hipSuccess) return e;
   Sink sink{ovf_pool, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, nullptr, nullptr,
             results, counters, ovf_list, q_ovf_off};
-  return LaunchWalk<true>(ctx, (int)p.lanes_per_query, reinterpret_cast<const QueryRec *>(qrec), nullptr, 0, sink,
+  return LaunchWalk<true>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(qrec), nullptr, 0, sink,
                           p.search_radius, nullptr);
 }
 }  // namespace smhip

@@ -7,7 +7,7 @@ from oracle import pyoracle as po
 
 def main():
     nreads = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    G = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     genome = synth.make_genome(7, [150000, 100000, 50000])
     lm = synth.make_pore_model()
     raw, truth = synth.simulate_reads(genome, lm, nreads, 11)
@@ -15,7 +15,7 @@ def main():
     ix = pipeline.HostIndex.build(genome, lm, threads=0)
     print("index", ix.n_points, ix.n_nodes, ix.depth, "%.2fs" % (time.time() - t0))
     dev = pipeline.DeviceMapper(0)
-    dev.params.lanes_per_query = G
+    dev.params.walk_blocks_per_cu = G
     dev.upload_index(ix)
     pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
