@@ -148,7 +148,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->ix_inner, &ctx->ix_leafrec, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->ix_inner, &ctx->ix_leafrec, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
@@ -381,6 +381,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   const uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
   HIPCHK(ctx->q_count.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * sizeof(uint32_t)));
+  HIPCHK(ctx->q_nodes.Reserve(nq_cap * sizeof(uint32_t)));
+  HIPCHK(ctx->q_points.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_list.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
@@ -391,8 +393,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   {
     ScopedTimer t(ctx, T_SEED);
     HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap,
-                            ctx->region.as<Hit>(), ctx->q_count.as<uint32_t>(), results,
-                            ctx->counters.as<uint32_t>()));
+                            ctx->region.as<Hit>(), ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(),
+                            ctx->q_points.as<uint32_t>(), ctx->counters.as<uint32_t>()));
   }
   {
     ScopedTimer t(ctx, T_OVF);
@@ -402,7 +404,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
                               ctx->counters.as<uint32_t>(), nq_cap));
   }
   HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
-                           ctx->carried_off.as<uint32_t>(), R, ctx->chunk_anchor_cnt.as<uint32_t>()));
+                           ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(), R,
+                           ctx->chunk_anchor_cnt.as<uint32_t>(), results));
   HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
   uint64_t NA = 0;
   HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

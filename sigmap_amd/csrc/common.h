@@ -94,7 +94,7 @@ struct smhip_ctx {
   // per-chunk intermediates
   smhip::DevBuf ev_scratch, feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
   // per-query
-  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist;
+  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
@@ -126,7 +126,7 @@ hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float 
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
-                            smhip_chunk_result *results, uint32_t *counters);
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters);
 // explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
                                uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
@@ -136,8 +136,9 @@ hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void 
                               Hit *ovf_pool, uint64_t pool_cap, smhip_chunk_result *results, uint32_t *counters,
                               uint64_t max_queries);
 hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
-                             const uint32_t *q_count, const uint32_t *carried_off, uint32_t n_chunks,
-                             uint32_t *chunk_cnt);
+                             const uint32_t *q_count, const uint32_t *q_nodes, const uint32_t *q_points,
+                             const uint32_t *carried_off, uint32_t n_chunks, uint32_t *chunk_cnt,
+                             smhip_chunk_result *results);
 hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *out_excl);
 struct SortArgs {
   const uint32_t *q_off, *q_count, *q_ovf_off, *qstart, *carried_off;

@@ -36,7 +36,7 @@
 //
 // Mapping: ONE LANE PER QUERY, a state machine in which every loop iteration issues one batch of
 // 16-byte loads per lane (an inner node, a leaf record = one sector, the first halves of up to
-// eight points = one line, or one second half) and then retires it, so the instruction stream
+// four points = one sector, or one second half) and then retires it, so the instruction stream
 // of a wave is amortised over 64 queries.  The two newest stack entries of a lane live in LDS,
 // older ones spill to HBM ([lane][64] x 32 B).  Queries are visited in the order of the leaf that
 // contains them (QueryKey/QueryScatter: a stackless descent + a counting sort), each XCD taking
@@ -87,7 +87,7 @@ struct Sink {
 enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3, M_SCAN2 = 4 };
 
 template <bool kOverflow>
-__global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
+__global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem,
@@ -113,14 +113,12 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
   float mind = 0;
-  float pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, cmask = 0, qi = 0,
-           chunk = 0;
+  float pr[4] = {0, 0, 0, 0};
+  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, cmask = 0, qi = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
   uint32_t tcnt = 0, thead = 0;
-  Hit *out = nullptr;
-  uint32_t out_cap = 0;
+  const uint32_t out_cap = kOverflow ? sink.nnp : sink.fast_cap;
   for (;;) {
     if (mode == M_FETCH) {
       if (w >= total) break;
@@ -129,19 +127,11 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
       const float4 a = *reinterpret_cast<const float4 *>(&qrec[qi]);
       const float4 b = *(reinterpret_cast<const float4 *>(&qrec[qi]) + 1);
       q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
-      chunk = __float_as_uint(b.z);
       d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
       mind = 0.0f;
       SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
       SM_INIT_DIM(5, d5)
       node = ix.root_ref; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
-      if (kOverflow) {
-        out = sink.region + sink.q_ovf_off[qi];
-        out_cap = sink.nnp;
-      } else {
-        out = sink.region + (size_t)qi * sink.fast_cap;
-        out_cap = sink.fast_cap;
-      }
       mode = (node & kLeafTag) ? M_LEAF : M_WALK;
     }
     // ---- one batch of 16-byte loads per lane per iteration
@@ -150,18 +140,18 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
     else if (mode == M_LEAF) addr = ix.leaf_recs + (size_t)(node & ~kLeafTag) * 4;
     else addr = pts4 + lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
     const uint4 r = addr[0];
-    uint4 rr[7];
+    uint4 rr[3];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) rr[t] = r;
+    for (int t = 0; t < 3; ++t) rr[t] = r;
     if (mode == M_WALK) {
       rr[0].x = reinterpret_cast<const uint32_t *>(addr)[4];  // child2 ref
     } else if (mode == M_LEAF) {  // rest of the 64-byte leaf record: the tight box
       rr[0] = addr[1];
       rr[1] = addr[2];
       rr[2] = addr[3];
-    } else if (mode == M_SCAN) {  // first halves of points j .. j+7: one aligned 128-byte line
+    } else if (mode == M_SCAN) {  // first halves of points j .. j+3: half of an aligned 128-byte line
 #pragma unroll
-      for (int t = 0; t < 7; ++t) rr[t] = addr[t + 1];
+      for (int t = 0; t < 3; ++t) rr[t] = addr[t + 1];
     }
     bool leaf_end = false;
     if (mode == M_WALK) {  // nanoflann.hpp:1371-1408
@@ -231,7 +221,7 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
         leaf_end = true;  // no point of this leaf can satisfy dist < radius
       }
     } else if (mode == M_SCAN) {
-      // nanoflann.hpp:391-401: first group of four differences, for up to eight points
+      // nanoflann.hpp:391-401: first group of four differences, for up to four points
       const uint32_t left_in_leaf = n - j;
       cmask = 0;
 #define SM_PART(rv, t)                                                                       \
@@ -243,19 +233,17 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
     /* result >= partial sum, so partial >= radius cannot be a hit */                        \
     cmask |= (s4 < radius && left_in_leaf > (uint32_t)t) ? (1u << t) : 0u;                   \
   }
-      SM_PART(r, 0) SM_PART(rr[0], 1) SM_PART(rr[1], 2) SM_PART(rr[2], 3) SM_PART(rr[3], 4) SM_PART(rr[4], 5)
-      SM_PART(rr[5], 6) SM_PART(rr[6], 7)
+      SM_PART(r, 0) SM_PART(rr[0], 1) SM_PART(rr[1], 2) SM_PART(rr[2], 3)
 #undef SM_PART
       if (cmask) {
         mode = M_SCAN2;
       } else {
-        j += 8;
+        j += 4;
         leaf_end = j >= n;
       }
     } else {  // M_SCAN2, nanoflann.hpp:403-406: two-element tail; r = {v4, v5, position}
       const uint32_t t = (uint32_t)(__ffs(cmask) - 1);
-      const float partial = t == 0 ? pr[0] : t == 1 ? pr[1] : t == 2 ? pr[2] : t == 3 ? pr[3]
-                          : t == 4 ? pr[4] : t == 5 ? pr[5] : t == 6 ? pr[6] : pr[7];
+      const float partial = t == 0 ? pr[0] : t == 1 ? pr[1] : t == 2 ? pr[2] : pr[3];
       const float f4 = q4 - __uint_as_float(r.x);
       float res = partial + f4 * f4;
       const float f5 = q5 - __uint_as_float(r.y);
@@ -267,12 +255,13 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
           h.position = (uint64_t)r.z | ((uint64_t)r.w << 32);
           h.dist = res;
           h.slot = lleft + j + t;
+          Hit *out = kOverflow ? sink.region + sink.q_ovf_off[qi] : sink.region + (size_t)qi * sink.fast_cap;
           out[ord] = h;
         }
       }
       cmask &= cmask - 1;
       if (cmask == 0) {
-        j += 8;
+        j += 4;
         mode = M_SCAN;
         leaf_end = j >= n;
       }
@@ -280,14 +269,10 @@ __global__ __launch_bounds__(kSeedThreads) void SeedLaneKernel(IndexView ix, con
     if (leaf_end) {
       if (sp + tcnt == 0) {  // query complete
         if (!kOverflow) {
+          // per-query counters (plain stores; the per-chunk sums are formed by AnchorCountKernel)
           sink.q_count[qi] = hits;
           if (sink.q_nodes) sink.q_nodes[qi] = nn;
           if (sink.q_points) sink.q_points[qi] = np;
-          if (sink.results) {
-            atomicAdd((unsigned long long *)&sink.results[chunk].nodes_visited, (unsigned long long)nn);
-            atomicAdd((unsigned long long *)&sink.results[chunk].points_tested, (unsigned long long)np);
-            atomicAdd((unsigned long long *)&sink.results[chunk].hits_total, (unsigned long long)hits);
-          }
         }
         mode = M_FETCH;
       } else {  // return from searchLevel into the innermost pending visit
@@ -433,7 +418,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
     order[atomicAdd(&cursor[keys[q]], 1u)] = q;
 }
 
-constexpr int kLaneBlocksPerCU = 5;  // 5 x 256 threads = 20 waves per CU (what ~92 VGPRs admit)
+constexpr int kLaneBlocksPerCU = 7;  // 7 x 256 threads = 28 waves per CU (72 allocated VGPRs)
 
 template <bool kOverflow>
 hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryRec *qrec,
@@ -499,9 +484,9 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
 
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
-                            smhip_chunk_result *results, uint32_t *counters) {
-  Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, nullptr, nullptr,
-            results, counters, nullptr, nullptr};
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters) {
+  Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
+            nullptr, counters, nullptr, nullptr};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr;
   hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);

@@ -205,31 +205,53 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   (void)s_total;
 }
 
-// anchors per chunk = carried + sum over its queries of min(hits, num_nearest_points)
+// anchors per chunk = carried + sum over its queries of min(hits, num_nearest_points); also the
+// chunk's search counters (nodes visited, points tested, hits) from the per-query values
 __global__ __launch_bounds__(256) void AnchorCountKernel(const uint32_t *__restrict__ q_off,
                                                          const uint32_t *__restrict__ q_count,
+                                                         const uint32_t *__restrict__ q_nodes,
+                                                         const uint32_t *__restrict__ q_points,
                                                          const uint32_t *__restrict__ carried_off,
-                                                         uint32_t nnp, uint32_t *__restrict__ chunk_cnt) {
-  __shared__ uint32_t red[256];
+                                                         uint32_t nnp, uint32_t *__restrict__ chunk_cnt,
+                                                         smhip_chunk_result *__restrict__ results) {
+  __shared__ unsigned long long red[4][256];
   const uint32_t c = blockIdx.x, tid = threadIdx.x;
   const uint32_t q0 = q_off[c], q1 = q_off[c + 1];
-  uint32_t s = 0;
-  for (uint32_t q = q0 + tid; q < q1; q += 256) s += min(q_count[q], nnp);
-  red[tid] = s;
+  unsigned long long s = 0, sn = 0, sp = 0, sh = 0;
+  for (uint32_t q = q0 + tid; q < q1; q += 256) {
+    const uint32_t h = q_count[q];
+    s += min(h, nnp);
+    sh += h;
+    sn += q_nodes[q];
+    sp += q_points[q];
+  }
+  red[0][tid] = s;
+  red[1][tid] = sn;
+  red[2][tid] = sp;
+  red[3][tid] = sh;
   __syncthreads();
   for (uint32_t d = 128; d > 0; d >>= 1) {
-    if (tid < d) red[tid] += red[tid + d];
+    if (tid < d) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + d];
+    }
     __syncthreads();
   }
-  if (tid == 0) chunk_cnt[c] = red[0] + (carried_off ? carried_off[c + 1] - carried_off[c] : 0);
+  if (tid == 0) {
+    chunk_cnt[c] = (uint32_t)red[0][0] + (carried_off ? carried_off[c + 1] - carried_off[c] : 0);
+    results[c].nodes_visited = red[1][0];
+    results[c].points_tested = red[2][0];
+    results[c].hits_total = red[3][0];
+  }
 }
 }  // namespace
 
 hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
-                             const uint32_t *q_count, const uint32_t *carried_off, uint32_t n_chunks,
-                             uint32_t *chunk_cnt) {
-  hipLaunchKernelGGL(AnchorCountKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, q_off, q_count,
-                     carried_off, (uint32_t)p.num_nearest_points, chunk_cnt);
+                             const uint32_t *q_count, const uint32_t *q_nodes, const uint32_t *q_points,
+                             const uint32_t *carried_off, uint32_t n_chunks, uint32_t *chunk_cnt,
+                             smhip_chunk_result *results) {
+  hipLaunchKernelGGL(AnchorCountKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, q_off, q_count, q_nodes, q_points,
+                     carried_off, (uint32_t)p.num_nearest_points, chunk_cnt, results);
   return hipGetLastError();
 }
 
