@@ -211,7 +211,7 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   }
   if (leaf_points != m_size) return Fail(ctx, SMHIP_EINVAL, "leaves do not cover the point list exactly");
   ctx->leaf_pts_bytes = n_slots * 16 + 128;
-  HIPCHK(ctx->ix_inner.Reserve(std::max<uint64_t>(n_inner, 1) * 32));
+  HIPCHK(ctx->ix_inner.Reserve(std::max<uint64_t>(n_inner, 1) * 32 + 64));  // + read-ahead of the 64-byte window
   HIPCHK(ctx->ix_leafrec.Reserve(n_leaves * 64));
   HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
@@ -267,7 +267,7 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->n_leaves = ctx->index.n_leaves;
   out->m_size = ctx->index.m_size;
   out->inner = (void *)ctx->index.inner;
-  out->inner_bytes = std::max<uint64_t>(ctx->index.n_inner, 1) * 32;
+  out->inner_bytes = std::max<uint64_t>(ctx->index.n_inner, 1) * 32 + 64;
   out->leaf_recs = (void *)ctx->index.leaf_recs;
   out->leaf_recs_bytes = ctx->index.n_leaves * 64;
   out->leaf_pts = (void *)ctx->index.leaf_pts;
@@ -284,7 +284,7 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
   if (!in->inner || !in->leaf_recs || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_leaves == 0)
     return Fail(ctx, SMHIP_EINVAL, "null index array");
-  if (in->inner_bytes < in->n_inner * 32 || in->leaf_recs_bytes < in->n_leaves * 64 ||
+  if (in->inner_bytes < in->n_inner * 32 + 64 || in->leaf_recs_bytes < in->n_leaves * 64 ||
       in->leaf_pts_bytes < in->m_size * 32 ||
       in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
     return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");

@@ -39,7 +39,8 @@
 // four points = one sector, or one second half) and then retires it, so the instruction stream
 // of a wave is amortised over 64 queries.  The two newest stack entries of a lane live in LDS,
 // older ones spill to HBM ([lane][64] x 32 B).  Queries are visited in the order of the leaf that
-// contains them (QueryKey/QueryScatter: a stackless descent + a counting sort), each XCD taking
+// contains them (QueryKey/QueryScatter: a stackless descent + a counting sort that permutes the
+// query records), each XCD taking
 // one contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the
 // same part of the tree and share its cache lines; results are indexed by query id, so the
 // visiting order never shows in the output.
@@ -122,10 +123,13 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
   for (;;) {
     if (mode == M_FETCH) {
       if (w >= total) break;
-      qi = kOverflow ? sink.ovf_list[w] : (order ? order[w] : w);
+      // the fast pass reads records already permuted into visiting order (one round trip);
+      // the record's last word is the query id
+      const uint32_t ri = kOverflow ? sink.ovf_list[w] : w;
       w += n_lanes;
-      const float4 a = *reinterpret_cast<const float4 *>(&qrec[qi]);
-      const float4 b = *(reinterpret_cast<const float4 *>(&qrec[qi]) + 1);
+      const float4 a = *reinterpret_cast<const float4 *>(&qrec[ri]);
+      const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
+      qi = kOverflow ? ri : __float_as_uint(b.w);
       q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
       d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
       mind = 0.0f;
@@ -134,27 +138,34 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
       node = ix.root_ref; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
       mode = (node & kLeafTag) ? M_LEAF : M_WALK;
     }
-    // ---- one batch of 16-byte loads per lane per iteration
-    const uint4 *addr;
-    if (mode == M_WALK) addr = ix.inner + (size_t)node * 2;
-    else if (mode == M_LEAF) addr = ix.leaf_recs + (size_t)(node & ~kLeafTag) * 4;
-    else addr = pts4 + lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
-    const uint4 r = addr[0];
-    uint4 rr[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) rr[t] = r;
-    if (mode == M_WALK) {
-      rr[0].x = reinterpret_cast<const uint32_t *>(addr)[4];  // child2 ref
-    } else if (mode == M_LEAF) {  // rest of the 64-byte leaf record: the tight box
-      rr[0] = addr[1];
-      rr[1] = addr[2];
-      rr[2] = addr[3];
-    } else if (mode == M_SCAN) {  // first halves of points j .. j+3: half of an aligned 128-byte line
-#pragma unroll
-      for (int t = 0; t < 3; ++t) rr[t] = addr[t + 1];
+    // ---- one batch of 16-byte loads per lane per iteration: a 64-byte window at `wa`, the same
+    // four load instructions whatever the lane's mode (node: 32 of them used; leaf record: all;
+    // four first halves: all; second half: 16).  The address is formed with selects and made
+    // opaque, and all results are pinned right after the loads, so that the compiler keeps ONE
+    // memory round trip per iteration instead of sinking a load + wait into every mode's branch.
+    uint64_t wa;
+    {
+      const uint64_t a_walk = (uint64_t)ix.inner + (uint64_t)node * 32;
+      const uint64_t a_leaf = (uint64_t)ix.leaf_recs + (uint64_t)(node & ~kLeafTag) * 64;
+      const uint32_t slot = lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
+      const uint64_t a_pts = (uint64_t)pts4 + (uint64_t)slot * 16;
+      wa = mode == M_WALK ? a_walk : (mode == M_LEAF ? a_leaf : a_pts);
+      uint32_t lo32 = (uint32_t)wa, hi32 = (uint32_t)(wa >> 32);
+      asm volatile("" : "+v"(lo32), "+v"(hi32));
+      wa = ((uint64_t)hi32 << 32) | lo32;
     }
+    const uint4 *addr = reinterpret_cast<const uint4 *>(wa);
+    uint4 r = addr[0];
+    uint4 rr[3];
+    rr[0] = addr[1];
+    rr[1] = addr[2];
+    rr[2] = addr[3];
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w), "+v"(rr[0].x), "+v"(rr[0].y), "+v"(rr[0].z),
+                 "+v"(rr[0].w));
+    asm volatile("" : "+v"(rr[1].x), "+v"(rr[1].y), "+v"(rr[1].z), "+v"(rr[1].w), "+v"(rr[2].x), "+v"(rr[2].y),
+                 "+v"(rr[2].z), "+v"(rr[2].w));
     bool leaf_end = false;
-    if (mode == M_WALK) {  // nanoflann.hpp:1371-1408
+    if (mode == M_WALK) {  // nanoflann.hpp:1371-1408; r = {feat, divlow, divhigh, c1}, rr[0].x = c2
       ++nn;
       const int idx = (int)r.x;
       const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
@@ -412,10 +423,13 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
 
 __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
                                    const uint32_t *__restrict__ keys, uint32_t *__restrict__ cursor,
-                                   uint32_t *__restrict__ order) {
+                                   const QueryRec *__restrict__ qrec, QueryRec *__restrict__ sorted) {
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x)
-    order[atomicAdd(&cursor[keys[q]], 1u)] = q;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    QueryRec r = qrec[q];
+    r.k = q;  // the walker needs the query id; (chunk, k) stay available in the unsorted array
+    sorted[atomicAdd(&cursor[keys[q]], 1u)] = r;
+  }
 }
 
 constexpr int kLaneBlocksPerCU = 7;  // 7 x 256 threads = 28 waves per CU (72 allocated VGPRs)
@@ -468,7 +482,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
   const uint32_t n_buckets = (uint32_t)(ctx->index.n_leaves >> shift) + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
-  if ((e = ctx->q_order.Reserve(n_max * 4)) != hipSuccess) return e;
+  if ((e = ctx->q_order.Reserve(n_max * 32)) != hipSuccess) return e;
   if ((e = ctx->q_hist.Reserve(((size_t)n_buckets + 1) * 8)) != hipSuccess) return e;
   uint32_t *hist = ctx->q_hist.as<uint32_t>(), *cursor = hist + n_buckets + 1;
   if ((e = hipMemsetAsync(hist, 0, (size_t)n_buckets * 4, ctx->stream)) != hipSuccess) return e;
@@ -476,7 +490,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
                      n_queries_host, shift, ctx->q_keys.as<uint32_t>(), hist);
   if ((e = LaunchScanU32(ctx, hist, n_buckets - 1, cursor)) != hipSuccess) return e;
   hipLaunchKernelGGL(QueryScatterKernel, dim3(2048), dim3(256), 0, ctx->stream, n_queries_dev, n_queries_host,
-                     ctx->q_keys.as<uint32_t>(), cursor, ctx->q_order.as<uint32_t>());
+                     ctx->q_keys.as<uint32_t>(), cursor, qrec, ctx->q_order.as<QueryRec>());
   *order_out = ctx->q_order.as<uint32_t>();
   return hipGetLastError();
 }
@@ -491,7 +505,8 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   const uint32_t *order = nullptr;
   hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
   if (e != hipSuccess) return e;
-  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, qr, q_off + n_chunks, 0, sink, p.search_radius, order);
+  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0,
+                           sink, p.search_radius, order);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -505,7 +520,8 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
   // the test entry point reports every hit up to `cap`: no 5000 truncation here
   Sink sink{region, cap, 0xFFFFFFFFu, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr};
-  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, qr, nullptr, n, sink, p.search_radius, order);
+  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink,
+                           p.search_radius, order);
 }
 
 hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
