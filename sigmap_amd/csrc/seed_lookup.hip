@@ -31,12 +31,11 @@
 //    operation involved is monotone, so it is a lower bound of the f32 distance nanoflann would
 //    compute for any point of the leaf -- no point of that leaf can pass `dist < radius`
 //    (measured: 86 % of the visited leaves, 83 % of the points);
-//  * the second half of a point whose first four squared differences already reach the radius.
 // The per-chunk counters still report the reference's work (nodes visited, points it tests).
 //
 // Mapping: ONE LANE PER QUERY, a state machine in which every loop iteration issues one batch of
-// 16-byte loads per lane (an inner node, a leaf record = one sector, the first halves of up to
-// four points = one sector, or one second half) and then retires it, so the instruction stream
+// 16-byte loads per lane (an inner node, a leaf record = one sector, or four points of a leaf that
+// passed the box test: one sector of first halves + one of second halves) and then retires it, so the instruction stream
 // of a wave is amortised over 64 queries.  The two newest stack entries of a lane live in LDS,
 // older ones spill to HBM ([lane][64] x 32 B).  Queries are visited in the order of the leaf that
 // contains them (QueryKey/QueryScatter: a stackless descent + a counting sort that permutes the
@@ -85,10 +84,10 @@ struct Sink {
     }                                                         \
   }
 
-enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3, M_SCAN2 = 4 };
+enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3 };
 
 template <bool kOverflow>
-__global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
+__global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem,
@@ -114,8 +113,7 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
   float mind = 0;
-  float pr[4] = {0, 0, 0, 0};
-  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, cmask = 0, qi = 0;
+  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, qi = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
   uint32_t tcnt = 0, thead = 0;
@@ -147,8 +145,7 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
     {
       const uint64_t a_walk = (uint64_t)ix.inner + (uint64_t)node * 32;
       const uint64_t a_leaf = (uint64_t)ix.leaf_recs + (uint64_t)(node & ~kLeafTag) * 64;
-      const uint32_t slot = lbase + (mode == M_SCAN2 ? ((n + 7u) & ~7u) + j + (uint32_t)(__ffs(cmask) - 1) : j);
-      const uint64_t a_pts = (uint64_t)pts4 + (uint64_t)slot * 16;
+      const uint64_t a_pts = (uint64_t)pts4 + (uint64_t)(lbase + j) * 16;
       wa = mode == M_WALK ? a_walk : (mode == M_LEAF ? a_leaf : a_pts);
       uint32_t lo32 = (uint32_t)wa, hi32 = (uint32_t)(wa >> 32);
       asm volatile("" : "+v"(lo32), "+v"(hi32));
@@ -160,6 +157,19 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
     rr[0] = addr[1];
     rr[1] = addr[2];
     rr[2] = addr[3];
+    // scanning lanes also fetch the four second halves {v4, v5, position} of the same points
+    uint4 rs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rs[t] = r;
+    if (mode == M_SCAN) {
+      const uint4 *sh = addr + ((n + 7u) & ~7u);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rs[t] = sh[t];
+    }
+    asm volatile("" : "+v"(rs[0].x), "+v"(rs[0].y), "+v"(rs[0].z), "+v"(rs[0].w), "+v"(rs[1].x), "+v"(rs[1].y),
+                 "+v"(rs[1].z), "+v"(rs[1].w));
+    asm volatile("" : "+v"(rs[2].x), "+v"(rs[2].y), "+v"(rs[2].z), "+v"(rs[2].w), "+v"(rs[3].x), "+v"(rs[3].y),
+                 "+v"(rs[3].z), "+v"(rs[3].w));
     asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w), "+v"(rr[0].x), "+v"(rr[0].y), "+v"(rr[0].z),
                  "+v"(rr[0].w));
     asm volatile("" : "+v"(rr[1].x), "+v"(rr[1].y), "+v"(rr[1].z), "+v"(rr[1].w), "+v"(rr[2].x), "+v"(rr[2].y),
@@ -231,51 +241,33 @@ __global__ __launch_bounds__(kSeedThreads, 7) void SeedLaneKernel(IndexView ix, 
       } else {
         leaf_end = true;  // no point of this leaf can satisfy dist < radius
       }
-    } else if (mode == M_SCAN) {
-      // nanoflann.hpp:391-401: first group of four differences, for up to four points
+    } else {  // M_SCAN: nanoflann.hpp:391-406 for up to four points of the leaf
       const uint32_t left_in_leaf = n - j;
-      cmask = 0;
-#define SM_PART(rv, t)                                                                       \
-  {                                                                                          \
-    const float f0 = q0 - __uint_as_float(rv.x), f1 = q1 - __uint_as_float(rv.y);           \
-    const float f2 = q2 - __uint_as_float(rv.z), f3 = q3 - __uint_as_float(rv.w);           \
-    const float s4 = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */         \
-    pr[t] = s4;                                                                              \
-    /* result >= partial sum, so partial >= radius cannot be a hit */                        \
-    cmask |= (s4 < radius && left_in_leaf > (uint32_t)t) ? (1u << t) : 0u;                   \
+#define SM_POINT(rv, sv, t)                                                                   \
+  if (left_in_leaf > (uint32_t)t) {                                                           \
+    const float f0 = q0 - __uint_as_float(rv.x), f1 = q1 - __uint_as_float(rv.y);            \
+    const float f2 = q2 - __uint_as_float(rv.z), f3 = q3 - __uint_as_float(rv.w);            \
+    float res = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */               \
+    const float f4 = q4 - __uint_as_float(sv.x);                                              \
+    res += f4 * f4;                                                                           \
+    const float f5 = q5 - __uint_as_float(sv.y);                                              \
+    res += f5 * f5;                                                                           \
+    if (res < radius) { /* RadiusResultSet::addPoint */                                       \
+      const uint32_t ord = hits++;                                                            \
+      if (ord < sink.nnp && ord < out_cap) {                                                  \
+        Hit h;                                                                                \
+        h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);                                 \
+        h.dist = res;                                                                         \
+        h.slot = lleft + j + t;                                                               \
+        Hit *out = kOverflow ? sink.region + sink.q_ovf_off[qi] : sink.region + (size_t)qi * sink.fast_cap; \
+        out[ord] = h;                                                                         \
+      }                                                                                       \
+    }                                                                                         \
   }
-      SM_PART(r, 0) SM_PART(rr[0], 1) SM_PART(rr[1], 2) SM_PART(rr[2], 3)
-#undef SM_PART
-      if (cmask) {
-        mode = M_SCAN2;
-      } else {
-        j += 4;
-        leaf_end = j >= n;
-      }
-    } else {  // M_SCAN2, nanoflann.hpp:403-406: two-element tail; r = {v4, v5, position}
-      const uint32_t t = (uint32_t)(__ffs(cmask) - 1);
-      const float partial = t == 0 ? pr[0] : t == 1 ? pr[1] : t == 2 ? pr[2] : pr[3];
-      const float f4 = q4 - __uint_as_float(r.x);
-      float res = partial + f4 * f4;
-      const float f5 = q5 - __uint_as_float(r.y);
-      res += f5 * f5;
-      if (res < radius) {  // RadiusResultSet::addPoint
-        const uint32_t ord = hits++;
-        if (ord < sink.nnp && ord < out_cap) {
-          Hit h;
-          h.position = (uint64_t)r.z | ((uint64_t)r.w << 32);
-          h.dist = res;
-          h.slot = lleft + j + t;
-          Hit *out = kOverflow ? sink.region + sink.q_ovf_off[qi] : sink.region + (size_t)qi * sink.fast_cap;
-          out[ord] = h;
-        }
-      }
-      cmask &= cmask - 1;
-      if (cmask == 0) {
-        j += 4;
-        mode = M_SCAN;
-        leaf_end = j >= n;
-      }
+      SM_POINT(r, rs[0], 0) SM_POINT(rr[0], rs[1], 1) SM_POINT(rr[1], rs[2], 2) SM_POINT(rr[2], rs[3], 3)
+#undef SM_POINT
+      j += 4;
+      leaf_end = j >= n;
     }
     if (leaf_end) {
       if (sp + tcnt == 0) {  // query complete
@@ -432,7 +424,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
   }
 }
 
-constexpr int kLaneBlocksPerCU = 7;  // 7 x 256 threads = 28 waves per CU (72 allocated VGPRs)
+constexpr int kLaneBlocksPerCU = 6;  // 6 x 256 threads = 24 waves per CU (<= 80 allocated VGPRs)
 
 template <bool kOverflow>
 hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryRec *qrec,
