@@ -160,7 +160,7 @@ def main():
 
     # per-kernel device time (HIP events on the context stream, inside the timed region)
     kern = {}
-    for name in ["events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw"]:
+    for name in ["events", "seed_lookup", "sort", "chain", "sdtw"]:
         ms, n = dev.timing_get(name)
         kern[name] = {"mean_ms": round(ms, 4), "launches": int(n)}
 

@@ -173,7 +173,7 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
                      const uint32_t *carried_offsets, smhip_chunk_result *results);
 /* Mean device time (ms) of the named kernel over the launches since the last
  * smhip_timing_reset(), measured with HIP events on the context stream.
- * names: "events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw". */
+ * names: "events", "seed_lookup", "sort", "chain", "sdtw". */
 /* ---- banded sDTW refinement of the best chain ----
  * The reference computes the z-scored expected signal of every contig strand at map time
  * (sigmap.cc:566-591) and aligns against it with Sigmap::sDTW (sigmap.cc:1259-1291) in its

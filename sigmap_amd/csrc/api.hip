@@ -387,21 +387,16 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
   HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
-  const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 32 + (1u << 20), 0xFFFF0000ull);
+  const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 64 + (1u << 22), 0xFFFF0000ull);
   HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
   HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+  HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
   {
     ScopedTimer t(ctx, T_SEED);
-    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap,
-                            ctx->region.as<Hit>(), ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(),
-                            ctx->q_points.as<uint32_t>(), ctx->counters.as<uint32_t>()));
-  }
-  {
-    ScopedTimer t(ctx, T_OVF);
-    HIPCHK(LaunchSeedOverflow(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R,
-                              ctx->q_count.as<uint32_t>(), ctx->q_ovf_off.as<uint32_t>(),
-                              ctx->ovf_list.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), pool_cap, results,
-                              ctx->counters.as<uint32_t>(), nq_cap));
+    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
+                            ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
+                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
+                            pool_cap));
   }
   HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
                            ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(), R,
@@ -420,7 +415,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   SortArgs sa;
   sa.q_off = ctx->q_off.as<uint32_t>();
   sa.q_count = ctx->q_count.as<uint32_t>();
-  sa.q_ovf_off = ctx->q_ovf_off.as<uint32_t>();
+  sa.ovf_tab = ctx->q_ovf_off.as<uint32_t>();
   sa.qstart = ctx->qstart.as<uint32_t>();
   sa.carried_off = ctx->carried_off.as<uint32_t>();
   sa.carried = ctx->carried.as<smhip_carried_anchor>();

@@ -18,6 +18,7 @@ constexpr int kMaxDim = 6;           // device kernels are specialised for the i
 constexpr int kMaxSamples = 4096;    // samples per chunk held in LDS (reference chunk = 4000)
 constexpr int kFeatStride = 2736;    // >= 2/3 * kMaxSamples + 2: upper bound on events per chunk
 constexpr int kStackDepth = 64;      // pending "other child" entries per tree walk
+constexpr int kOvfLevels = 16;       // overflow segments per query (sizes fast_cap << level)
 constexpr int kChainCap = 128;       // candidate chains per chunk before the primary filter
 
 struct Hit {  // 16 B: one radius-search result
@@ -126,22 +127,19 @@ hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float 
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
-                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters);
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
+                            uint32_t *ovf_tab, uint64_t pool_cap);
 // explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
                                uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
                                uint32_t *q_points, uint32_t *counters, void *qrec);
-hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
-                              uint32_t n_chunks, uint32_t *q_count, uint32_t *q_ovf_off, uint32_t *ovf_list,
-                              Hit *ovf_pool, uint64_t pool_cap, smhip_chunk_result *results, uint32_t *counters,
-                              uint64_t max_queries);
 hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
                              const uint32_t *q_count, const uint32_t *q_nodes, const uint32_t *q_points,
                              const uint32_t *carried_off, uint32_t n_chunks, uint32_t *chunk_cnt,
                              smhip_chunk_result *results);
 hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *out_excl);
 struct SortArgs {
-  const uint32_t *q_off, *q_count, *q_ovf_off, *qstart, *carried_off;
+  const uint32_t *q_off, *q_count, *ovf_tab, *qstart, *carried_off;
   const smhip_carried_anchor *carried;
   const Hit *region, *ovf_pool;
   const uint64_t *anchor_off;

@@ -66,8 +66,9 @@ struct Sink {
   uint32_t *q_points;
   smhip_chunk_result *results;  // optional per-chunk accumulation
   uint32_t *counters;   // [0] stack overflow flag, [1] #overflow queries, [2] pool top, [3] pool full
-  const uint32_t *ovf_list;
-  const uint32_t *q_ovf_off;
+  Hit *pool;            // overflow pool: hits beyond the fast slots, in geometric segments
+  uint32_t *ovf_tab;    // [n_queries][kOvfLevels] pool offset of each segment
+  uint64_t pool_cap;
 };
 
 // nanoflann.hpp:1006-1023 computeInitialDistances (low test, then high test, per dimension)
@@ -86,7 +87,33 @@ struct Sink {
 
 enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3 };
 
-template <bool kOverflow>
+// Hit number `ord` of query `qi` (0-based, in traversal order): the first fast_cap hits go to the
+// query's own slots; later ones go to segments of the shared pool whose sizes double
+// (fast_cap, 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a
+// query with many hits never has to be searched twice.
+__device__ __forceinline__ void EmitHit(const Sink &sink, uint32_t qi, uint32_t ord, const Hit &h,
+                                        uint32_t &ovf_base) {
+  if (ord < sink.fast_cap) {
+    sink.region[(size_t)qi * sink.fast_cap + ord] = h;
+    return;
+  }
+  const uint32_t k = ord - sink.fast_cap;
+  const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
+  const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
+  if (k == first) {  // first hit of this segment: allocate it
+    const uint32_t size = sink.fast_cap << level;
+    const uint32_t base = atomicAdd(&sink.counters[2], size);
+    ovf_base = base;
+    if (level == 0) atomicAdd(&sink.counters[1], 1u);
+    if ((uint64_t)base + size > sink.pool_cap || level >= (uint32_t)kOvfLevels) {
+      atomicOr(&sink.counters[3], 1u);  // reported as SMHIP_ST_HIT_POOL_FULL
+      ovf_base = 0xFFFFFFFFu;
+    }
+    if (level < (uint32_t)kOvfLevels) sink.ovf_tab[(size_t)qi * kOvfLevels + level] = ovf_base;
+  }
+  if (ovf_base != 0xFFFFFFFFu) sink.pool[(size_t)ovf_base + (k - first)] = h;
+}
+
 __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
@@ -95,7 +122,7 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
   uint32_t n_lanes = gridDim.x * kSeedThreads;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
-  uint32_t total = kOverflow ? sink.counters[1] : (n_queries_dev ? *n_queries_dev : n_queries_host);
+  uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
   uint32_t w = gl;
   if (xcd_ranges) {
@@ -117,17 +144,17 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
   uint32_t tcnt = 0, thead = 0;
-  const uint32_t out_cap = kOverflow ? sink.nnp : sink.fast_cap;
+  uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
   for (;;) {
     if (mode == M_FETCH) {
       if (w >= total) break;
       // the fast pass reads records already permuted into visiting order (one round trip);
       // the record's last word is the query id
-      const uint32_t ri = kOverflow ? sink.ovf_list[w] : w;
+      const uint32_t ri = w;
       w += n_lanes;
       const float4 a = *reinterpret_cast<const float4 *>(&qrec[ri]);
       const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
-      qi = kOverflow ? ri : __float_as_uint(b.w);
+      qi = __float_as_uint(b.w);
       q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
       d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
       mind = 0.0f;
@@ -254,13 +281,12 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
     res += f5 * f5;                                                                           \
     if (res < radius) { /* RadiusResultSet::addPoint */                                       \
       const uint32_t ord = hits++;                                                            \
-      if (ord < sink.nnp && ord < out_cap) {                                                  \
+      if (ord < sink.nnp) {                                                                   \
         Hit h;                                                                                \
         h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);                                 \
         h.dist = res;                                                                         \
         h.slot = lleft + j + t;                                                               \
-        Hit *out = kOverflow ? sink.region + sink.q_ovf_off[qi] : sink.region + (size_t)qi * sink.fast_cap; \
-        out[ord] = h;                                                                         \
+        EmitHit(sink, qi, ord, h, ovf_base);                                                  \
       }                                                                                       \
     }                                                                                         \
   }
@@ -271,12 +297,10 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
     }
     if (leaf_end) {
       if (sp + tcnt == 0) {  // query complete
-        if (!kOverflow) {
-          // per-query counters (plain stores; the per-chunk sums are formed by AnchorCountKernel)
-          sink.q_count[qi] = hits;
-          if (sink.q_nodes) sink.q_nodes[qi] = nn;
-          if (sink.q_points) sink.q_points[qi] = np;
-        }
+        // per-query counters (plain stores; the per-chunk sums are formed by AnchorCountKernel)
+        sink.q_count[qi] = hits;
+        if (sink.q_nodes) sink.q_nodes[qi] = nn;
+        if (sink.q_points) sink.q_points[qi] = np;
         mode = M_FETCH;
       } else {  // return from searchLevel into the innermost pending visit
         float4 a, b;
@@ -326,30 +350,6 @@ __global__ void QueryExpandRawKernel(const float *__restrict__ queries, uint32_t
     r.chunk = 0;
     r.k = k;
     qrec[k] = r;
-  }
-}
-
-// Queries whose hit count exceeded the fast slots get an exact-size segment in the pool.
-__global__ void OverflowPrepareKernel(const uint32_t *__restrict__ n_queries_dev,
-                                      const uint32_t *__restrict__ q_count, uint32_t fast_cap, uint32_t nnp,
-                                      uint32_t *__restrict__ q_ovf_off, uint32_t *__restrict__ ovf_list,
-                                      uint32_t *__restrict__ counters, uint64_t pool_cap,
-                                      uint64_t max_queries) {
-  const uint32_t total = *n_queries_dev;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
-    const uint32_t c = q_count[q];
-    if (c > fast_cap) {
-      const uint32_t need = min(c, nnp);
-      const uint32_t off = atomicAdd(&counters[2], need);
-      if ((uint64_t)off + need > pool_cap) {
-        atomicOr(&counters[3], 1u);  // pool exhausted: reported as SMHIP_ST_HIT_POOL_FULL
-        q_ovf_off[q] = 0xFFFFFFFFu;
-        continue;
-      }
-      q_ovf_off[q] = off;
-      const uint32_t k = atomicAdd(&counters[1], 1u);
-      if (k < max_queries) ovf_list[k] = q;
-    }
   }
 }
 
@@ -426,7 +426,6 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 
 constexpr int kLaneBlocksPerCU = 6;  // 6 x 256 threads = 24 waves per CU (<= 80 allocated VGPRs)
 
-template <bool kOverflow>
 hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryRec *qrec,
                       const uint32_t *n_queries_dev, uint32_t n_queries_host, const Sink &sink, float radius,
                       const uint32_t *order) {
@@ -442,9 +441,9 @@ hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryR
   const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((SeedLaneKernel<kOverflow>), dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
+  hipLaunchKernelGGL(SeedLaneKernel, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
                      qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order,
-                     (order && !kOverflow) ? xcd_ranges : 0);
+                     order ? xcd_ranges : 0);
   return hipGetLastError();
 }
 }  // namespace
@@ -490,15 +489,16 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
 
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
-                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters) {
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
+                            uint32_t *ovf_tab, uint64_t pool_cap) {
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
-            nullptr, counters, nullptr, nullptr};
+            nullptr, counters, pool, ovf_tab, pool_cap};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr;
   hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
   if (e != hipSuccess) return e;
-  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0,
-                           sink, p.search_radius, order);
+  return LaunchWalk(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink,
+                    p.search_radius, order);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -510,24 +510,9 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if (e != hipSuccess) return e;
   const uint32_t *order = nullptr;
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
-  // the test entry point reports every hit up to `cap`: no 5000 truncation here
-  Sink sink{region, cap, 0xFFFFFFFFu, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr};
-  return LaunchWalk<false>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink,
-                           p.search_radius, order);
-}
-
-hipError_t LaunchSeedOverflow(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
-                              uint32_t n_chunks, uint32_t *q_count, uint32_t *q_ovf_off, uint32_t *ovf_list,
-                              Hit *ovf_pool, uint64_t pool_cap, smhip_chunk_result *results, uint32_t *counters,
-                              uint64_t max_queries) {
-  hipLaunchKernelGGL(OverflowPrepareKernel, dim3(1024), dim3(256), 0, ctx->stream, q_off + n_chunks, q_count,
-                     p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_ovf_off, ovf_list, counters,
-                     pool_cap, max_queries);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  Sink sink{ovf_pool, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, nullptr, nullptr,
-            results, counters, ovf_list, q_ovf_off};
-  return LaunchWalk<true>(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(qrec), nullptr, 0, sink,
-                          p.search_radius, nullptr);
+  // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
+  Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
+  return LaunchWalk(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink,
+                    p.search_radius, order);
 }
 }  // namespace smhip

@@ -122,10 +122,18 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       const uint32_t k = lo, h = h0 - qoff[k];
       const uint32_t qi = q0 + k;
       const uint32_t cnt = a.q_count[qi];
-      const Hit *src = cnt <= a.fast_cap ? a.region + (size_t)qi * a.fast_cap
-                                         : (a.q_ovf_off[qi] != 0xFFFFFFFFu ? a.ovf_pool + a.q_ovf_off[qi] : nullptr);
+      (void)cnt;
       Hit hit;
-      if (src) hit = src[h]; else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
+      if (h < a.fast_cap) {
+        hit = a.region[(size_t)qi * a.fast_cap + h];
+      } else {  // geometric overflow segments (seed_lookup.hip EmitHit)
+        const uint32_t kk = h - a.fast_cap;
+        const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+        const uint32_t first = a.fast_cap * ((1u << level) - 1u);
+        const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
+        if (seg != 0xFFFFFFFFu) hit = a.ovf_pool[(size_t)seg + (kk - first)];
+        else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
+      }
       const uint32_t ref = (uint32_t)(hit.position >> 33);
       tpos = (uint32_t)(hit.position >> 1);
       grp = (ref << 1) | (uint32_t)(hit.position & 1);
