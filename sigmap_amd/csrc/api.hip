@@ -455,6 +455,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   ca.used = ctx->used.as<uint8_t>();
   ca.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
   ca.scratch = ctx->keys.as<uint64_t>();
+  ca.pending = ctx->a_tpos.as<uint32_t>();  // the unsorted SoA is dead after the sort
+  ca.lists = ctx->a_qpos.as<uint32_t>();
   ca.results = results;
   ca.out_anchors = ctx->out_anchors.as<smhip_carried_anchor>();
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();

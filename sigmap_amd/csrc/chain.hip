@@ -43,7 +43,7 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 }
 
 constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
-constexpr int kBigGroupMin = 384;  // buckets longer than this are chained by a whole wave ...
+constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
 constexpr int kBigGroupCap = 2048; // ... when they fit the LDS staging area (else lane-sequential)
 
 // ---- C0: which anchors can be settled without the sequential DP?  One thread per anchor.
@@ -54,48 +54,89 @@ constexpr int kBigGroupCap = 2048; // ... when they fit the LDS staging area (el
 // exits (26 skips, target gap > 5000, band, bucket start) before meeting a gap-test-passing
 // predecessor, the anchor's result is its start score with itself as predecessor, independent of
 // any other anchor.  Those anchors ("isolated", ~94 % of a noise bucket) are finished here in
-// parallel; the rest are flagged (used = 2) for the sequential kernels.
+// parallel (score, predecessor, bucket maximum); the rest are flagged (used = 2) and listed in
+// index order for the sequential kernels.
+constexpr uint32_t kLdsGroups = 4096;  // bucket maxima kept in LDS by the classify kernel
+
 __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float radius, int dim, int max_gap_length,
                                                            int max_target_gap_length, int chaining_band_length,
-                                                           int max_num_skips) {
-  const uint32_t c = blockIdx.x;
+                                                           int max_num_skips, uint32_t *__restrict__ n_pending) {
+  __shared__ uint32_t s_gmax[kLdsGroups];  // positive floats order like their bit patterns
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_run;
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
   const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+  const uint32_t G = a.n_groups[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
+  const uint32_t *gstart = a.group_start + base;
   const float *dist = a.s_dist + base;
   float *score = a.score + base;
   uint32_t *pred = a.pred + base;
   uint8_t *used = a.used + base;
-  for (uint32_t ai = threadIdx.x; ai < n; ai += 256) {
-    const uint32_t g = grp[ai];
-    const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
-    bool isolated = true;
-    int32_t skips = 0;
-    uint32_t steps = 0;
-    for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-      if (grp[pj] != g) break;  // bucket start
-      const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
-      if (pq == cq || pt == ct) continue;
-      if (pt + max_target_gap_length < ct) break;
-      const int32_t td = ct - pt, qd = cq - pq;
-      if (qd < 0) continue;
-      const int gap_length = abs(td - qd);
-      const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-      if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) {
-        isolated = false;
-        break;
-      }
-      if (++skips > max_num_skips) break;
-    }
-    if (isolated) {
-      const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
-      score[ai] = coef * (float)dim;
-      pred[ai] = ai;
-      used[ai] = 0;
-    } else {
-      used[ai] = 2;
-    }
+  uint32_t *pending = a.pending + base;
+  uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
+  const bool lds_max = G <= kLdsGroups;
+  for (uint32_t g = tid; g < G; g += 256) {
+    if (lds_max) s_gmax[g] = 0; else gmax_g[g] = 0;
   }
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+    const uint32_t ai = t0 + tid;
+    bool pend = false;
+    if (ai < n) {
+      const uint32_t g = grp[ai];
+      const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
+      bool isolated = true;
+      int32_t skips = 0;
+      uint32_t steps = 0;
+      for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
+        if (grp[pj] != g) break;  // bucket start
+        const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
+        if (pq == cq || pt == ct) continue;
+        if (pt + max_target_gap_length < ct) break;
+        const int32_t td = ct - pt, qd = cq - pq;
+        if (qd < 0) continue;
+        const int gap_length = abs(td - qd);
+        const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+        if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) {
+          isolated = false;
+          break;
+        }
+        if (++skips > max_num_skips) break;
+      }
+      if (isolated) {
+        const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
+        const float sc = coef * (float)dim;
+        score[ai] = sc;
+        pred[ai] = ai;
+        used[ai] = 0;
+        uint32_t lo = 0, hi = G;  // bucket ordinal: last bucket start <= ai
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (gstart[mid] <= ai) lo = mid; else hi = mid;
+        }
+        if (lds_max) atomicMax(&s_gmax[lo], __float_as_uint(sc)); else atomicMax(&gmax_g[lo], __float_as_uint(sc));
+      } else {
+        used[ai] = 2;
+        pend = true;
+      }
+    }
+    // ordered compaction of the pending anchors of this tile
+    const unsigned long long m = __ballot(pend);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = s_run;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+    if (pend) pending[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ai;
+    __syncthreads();
+    if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (lds_max)
+    for (uint32_t g = tid; g < G; g += 256) gmax_g[g] = s_gmax[g];
+  if (tid == 0) n_pending[c] = s_run;
 }
 
 // ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER (chunk, bucket), flattened over
@@ -106,7 +147,8 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
                                                     float radius, int dim, int max_gap_length,
                                                     int max_target_gap_length, int chaining_band_length,
                                                     int max_num_skips, uint32_t *__restrict__ big_list,
-                                                    uint32_t *__restrict__ big_count) {
+                                                    uint32_t *__restrict__ big_count,
+                                                    const uint32_t *__restrict__ n_pending) {
   const uint32_t total_groups = goff[n_chunks];
   // grid-stride over buckets (the bucket total is only known on the device)
   for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_groups; gi += gridDim.x * 64) {
@@ -127,28 +169,27 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
   uint8_t *used = a.used + base;
   float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
   const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
-  if (e - s > (uint32_t)kBigGroupMin && e - s <= (uint32_t)kBigGroupCap) {  // long bucket: wave-parallel kernel
+  // this bucket's slice of the chunk's pending list (sorted by anchor index)
+  const uint32_t *pending = a.pending + base;
+  const uint32_t npend = n_pending[c];
+  uint32_t p0, p1;
+  {
+    uint32_t lo2 = 0, hi2 = npend;
+    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
+    p0 = lo2;
+    hi2 = npend;
+    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < e) lo2 = mid + 1; else hi2 = mid; }
+    p1 = lo2;
+  }
+  // a bucket with many unsettled anchors (the true locus of a read) goes to the wave-parallel kernel
+  if (p1 - p0 > (uint32_t)kBigPendingMin && e - s <= (uint32_t)kBigGroupCap) {
     big_list[atomicAdd(big_count, 1u)] = gi;
     continue;
   }
   float gm = 0.0f;
-  for (uint32_t a0 = s; a0 < e; a0 += 16) {
-   // flags and scores of 16 anchors at a time: settled anchors only feed the bucket maximum
-   uint8_t fl[16];
-   float sc16[16];
-#pragma unroll
-   for (int k = 0; k < 16; ++k) {
-     fl[k] = a0 + k < e ? used[a0 + k] : 0;
-     sc16[k] = a0 + k < e ? score[a0 + k] : 0.0f;
-   }
-#pragma unroll
-   for (int k = 0; k < 16; ++k) {
-    const uint32_t ai = a0 + k;
-    if (ai >= e) break;
-    if (fl[k] != 2) {
-      gm = fmaxf(gm, sc16[k]);
-      continue;
-    }
+  for (uint32_t pi = p0; pi < p1; ++pi) {
+   {
+    const uint32_t ai = pending[pi];
     const uint32_t anchor_index = ai - s;
     const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
     float best = coef * (float)dim;
@@ -209,7 +250,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     gm = fmaxf(gm, best);
    }
   }
-  gmax[g] = gm;
+  if (gm > gmax[g]) gmax[g] = gm;  // the classify kernel stored the maximum over the settled anchors
   }
 }
 
@@ -227,6 +268,7 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
                                                        const uint32_t *__restrict__ big_count) {
   __shared__ int32_t l_t[kBigGroupCap], l_q[kBigGroupCap];
   __shared__ float l_s[kBigGroupCap], l_d[kBigGroupCap];
+  __shared__ uint8_t l_f[kBigGroupCap];
   const uint32_t lane = threadIdx.x;
   const uint32_t nbig = *big_count;
   for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
@@ -254,11 +296,17 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
       l_t[i] = (int32_t)tpos[i];
       l_q[i] = (int32_t)qpos[i];
       l_d[i] = dist[i];
+      l_f[i] = used[i];
+      l_s[i] = score[i];  // valid for the anchors the classify kernel settled
       used[i] = 0;
     }
     __syncthreads();
     float gm = 0.0f;
     for (uint32_t ai = 0; ai < ng; ++ai) {
+      if (l_f[ai] != 2) {  // settled: its own start score, itself as predecessor
+        gm = fmaxf(gm, l_s[ai]);
+        continue;
+      }
       const float coef = (float)(1 - 0.2 * (double)l_d[ai] / (double)radius);
       float best = coef * (float)dim;
       uint32_t best_pred = ai;
@@ -357,6 +405,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
   const float *score = a.score + base;
   const uint32_t *pred = a.pred + base;
   uint8_t *used = a.used + base;
+  uint32_t *lists = a.lists + base;
   float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
   float *pmax = gmax + n;
   // max_chaining_score on entry to each bucket = max over all earlier buckets (order ref0+,
@@ -409,17 +458,21 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
     const uint32_t ref = grp_id >> 1;
     const uint32_t direction = (grp_id & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
     const uint32_t lim = min(ntop, (uint32_t)min(num_best_chains, 3));
+    uint32_t cursor = s;  // chain anchor lists are packed into this bucket's own slice of `lists`
     for (uint32_t k = 0; k < lim; ++k) {
       // TracebackChains, spatial_index.cc:165-220 (pred[] holds chunk-local absolute indices)
       const uint32_t end_abs = s + top[k].idx;
       if (!used[end_abs]) {
         bool stop_at_used = false;
         uint32_t cur = end_abs;
+        const uint32_t list_off = cursor;
+        lists[cursor++] = cur;
         if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
         used[cur] = 1;
         uint32_t num = 1;
         while (pred[cur] != cur && !used[pred[cur]]) {
           cur = pred[cur];
+          lists[cursor++] = cur;
           if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
           used[cur] = 1;
           ++num;
@@ -437,6 +490,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
             ch.n_anchors = num;
             ch.direction = direction;
             ch.end_anchor = end_abs;
+            ch.list_off = list_off;
             a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
           }
         }
@@ -457,7 +511,7 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
   const uint64_t base = a.anchor_off[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
   const float *dist = a.s_dist + base;
-  const uint32_t *pred = a.pred + base;
+  const uint32_t *lists = a.lists + base;
   smhip_chunk_result &res = a.results[c];
   uint32_t nch = n_chains_in[c];
   if (nch > (uint32_t)kChainCap) {
@@ -526,30 +580,45 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
   smhip_carried_anchor *out = a.out_anchors ? a.out_anchors + base : nullptr;
   for (uint32_t i = 0; i < np; ++i) {
     const uint32_t g_id = grp[ch[i].end_anchor];
-    uint32_t cur = ch[i].end_anchor;
+    const uint32_t *lst = lists + ch[i].list_off;  // anchors of this chain, end -> start
+    const uint32_t na = ch[i].n_anchors;
     float ad = 0, at = 0, aq = 0;
-    for (uint32_t k = 0; k < ch[i].n_anchors; ++k) {
-      const uint32_t ai = cur;
-      const uint32_t nx = pred[ai];
-      if (out) {
-        smhip_carried_anchor o;
-        o.ref_strand = g_id;
-        o.target_position = tpos[ai];
-        o.query_position = qpos[ai];
-        o.distance = dist[ai];
-        out[w] = o;
+    uint32_t pt_prev = 0, pq_prev = 0;
+    for (uint32_t k0 = 0; k0 < na; k0 += kPf) {
+      uint32_t t8[kPf], q8[kPf];
+      float d8[kPf];
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) {
+        const uint32_t ai = k0 + k < na ? lst[k0 + k] : lst[0];
+        t8[k] = tpos[ai];
+        q8[k] = qpos[ai];
+        d8[k] = dist[ai];
       }
-      ++w;
-      if (i == 0) {
-        ad += dist[ai];
-        if (k == 0) res.c0_first_qpos = qpos[ai];
-        if (k + 1 == ch[i].n_anchors) res.c0_last_qpos = qpos[ai];
-        if (k + 1 < ch[i].n_anchors) {
-          at += (float)(uint32_t)(tpos[ai] - tpos[nx]);
-          aq += (float)(uint32_t)(qpos[ai] - qpos[nx]);
+#pragma unroll
+      for (int k = 0; k < kPf; ++k) {
+        if (k0 + k >= na) break;
+        if (out) {
+          smhip_carried_anchor o;
+          o.ref_strand = g_id;
+          o.target_position = t8[k];
+          o.query_position = q8[k];
+          o.distance = d8[k];
+          out[w] = o;
+        }
+        ++w;
+        if (i == 0) {
+          // sigmap.cc:717-725: distance of every anchor, gaps between consecutive anchors
+          ad += d8[k];
+          if (k0 + k == 0) res.c0_first_qpos = q8[k];
+          if (k0 + k + 1 == na) res.c0_last_qpos = q8[k];
+          if (k0 + k > 0) {
+            at += (float)(uint32_t)(pt_prev - t8[k]);
+            aq += (float)(uint32_t)(pq_prev - q8[k]);
+          }
+          pt_prev = t8[k];
+          pq_prev = q8[k];
         }
       }
-      cur = nx;
     }
     if (i == 0) {
       res.c0_sum_dist = ad;
@@ -564,23 +633,24 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
                        uint64_t n_anchors_total) {
   if (n_chunks == 0) return hipSuccess;
-  // every bucket holds at least one anchor, so the anchor total bounds the bucket total; long
-  // buckets hold > kBigGroupMin anchors each
-  const uint64_t max_big = n_anchors_total / kBigGroupMin + 1;
-  hipError_t e = ctx->chain_cnt.Reserve(((size_t)n_chunks * 2 + 4 + max_big) * sizeof(uint32_t));
+  // every bucket holds at least one anchor, so the anchor total bounds the bucket total; buckets
+  // sent to the wave-parallel kernel hold > kBigPendingMin anchors each
+  const uint64_t max_big = n_anchors_total / kBigPendingMin + 1;
+  hipError_t e = ctx->chain_cnt.Reserve(((size_t)n_chunks * 3 + 4 + max_big) * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   uint32_t *n_chains = ctx->chain_cnt.as<uint32_t>(), *goff = n_chains + n_chunks;
-  uint32_t *big_count = goff + n_chunks + 1, *big_list = big_count + 1;
+  uint32_t *n_pending = goff + n_chunks + 1;
+  uint32_t *big_count = n_pending + n_chunks, *big_list = big_count + 1;
   if ((e = hipMemsetAsync(big_count, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   if ((e = LaunchScanU32(ctx, a.n_groups, n_chunks, goff)) != hipSuccess) return e;
   const uint64_t max_groups = n_anchors_total;
   const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((max_groups + 63) / 64, 16384);
   hipLaunchKernelGGL(ChainClassifyKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.search_radius, kMaxDim,
-                     p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+                     p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips, n_pending);
   if (dp_blocks > 0)
     hipLaunchKernelGGL(ChainDpKernel, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
                        kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
-                       big_list, big_count);
+                       big_list, big_count, n_pending);
   hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
                      kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
                      big_list, big_count);

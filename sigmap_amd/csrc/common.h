@@ -31,6 +31,7 @@ struct ChainTmp {
   float score;
   uint32_t ref, start, end, n_anchors, direction;
   uint32_t end_anchor;  // chunk-local index of the chain's last (highest target) anchor
+  uint32_t list_off;    // chunk-local offset of the chain's anchor index list (end -> start)
 };
 
 constexpr uint32_t kLeafTag = 0x80000000u;  // child ref: kLeafTag | leaf ordinal, else inner index
@@ -163,6 +164,8 @@ struct ChainArgs {
   uint8_t *used;
   ChainTmp *chain_tmp;
   uint64_t *scratch;  // the sort's key buffer (2 keys per anchor), dead by now
+  uint32_t *pending;  // per chunk: anchors that need the sequential DP, in index order (dead a_tpos)
+  uint32_t *lists;    // per chunk: anchor index lists of the traced chains (dead a_qpos)
   smhip_chunk_result *results;
   smhip_carried_anchor *out_anchors;
   uint32_t *out_anchor_cnt;
