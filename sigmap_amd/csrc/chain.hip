@@ -502,131 +502,158 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
   if (lane == 0) n_chains_out[c] = s_nchains;
 }
 
-// ---- C3: GeneratePrimaryChains + ComputeMAPQ + chain statistics + carry-over anchors, ONE LANE
-// PER CHUNK (spatial_index.cc:222-274, sigmap.cc:702-729)
+// ---- C3: GeneratePrimaryChains + ComputeMAPQ + chain statistics + carry-over anchors, one wave
+// per chunk (spatial_index.cc:222-274, sigmap.cc:702-729).  Lane 0 orders and filters the (few)
+// candidate chains; all lanes gather the chains' anchors through the recorded index lists; lane 0
+// then adds chain 0's statistics in the reference's order (f32 sums are order-sensitive).
+constexpr uint32_t kStatLds = 1024;  // anchors of chain 0 staged in LDS for the sequential sums
+
 __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
                                                           const uint32_t *__restrict__ n_chains_in) {
-  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= n_chunks) return;
+  __shared__ uint32_t s_np;
+  __shared__ uint32_t l_t[kStatLds], l_q[kStatLds];
+  __shared__ float l_d[kStatLds];
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
   const uint64_t base = a.anchor_off[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
   const float *dist = a.s_dist + base;
   const uint32_t *lists = a.lists + base;
   smhip_chunk_result &res = a.results[c];
-  uint32_t nch = n_chains_in[c];
-  if (nch > (uint32_t)kChainCap) {
-    res.status |= SMHIP_ST_CHAIN_CAP;
-    nch = kChainCap;
-  }
-  if (nch == 0) return;
   ChainTmp *ch = a.chain_tmp + (size_t)c * kChainCap;
-  for (uint32_t i = 1; i < nch; ++i) {  // insertion sort, descending by operator>
-    const ChainTmp x = ch[i];
-    uint32_t j = i;
-    while (j > 0 && ChainGreater(x, ch[j - 1])) {
-      ch[j] = ch[j - 1];
-      --j;
+  if (lane == 0) {
+    uint32_t nch = n_chains_in[c];
+    if (nch > (uint32_t)kChainCap) {
+      res.status |= SMHIP_ST_CHAIN_CAP;
+      nch = kChainCap;
     }
-    ch[j] = x;
-  }
-  // spatial_index.cc:222-253: primaries are compacted to the front of ch[]
-  uint32_t np = 1;
-  for (uint32_t ci = 1; ci < nch; ++ci) {
-    bool is_primary = true;
-    if (ch[ci].score < ch[np - 1].score / 3) break;
-    for (uint32_t pi = 0; pi < np; ++pi) {
-      if (ch[ci].ref == ch[pi].ref) {
-        if (max(ch[ci].start, ch[pi].start) > min(ch[ci].end, ch[pi].end)) {
-        } else {
-          is_primary = false;
-          break;
+    uint32_t np = 0;
+    if (nch > 0) {
+      for (uint32_t i = 1; i < nch; ++i) {  // insertion sort, descending by operator>
+        const ChainTmp x = ch[i];
+        uint32_t j = i;
+        while (j > 0 && ChainGreater(x, ch[j - 1])) {
+          ch[j] = ch[j - 1];
+          --j;
+        }
+        ch[j] = x;
+      }
+      // spatial_index.cc:222-253: primaries are compacted to the front of ch[]
+      np = 1;
+      for (uint32_t ci = 1; ci < nch; ++ci) {
+        bool is_primary = true;
+        if (ch[ci].score < ch[np - 1].score / 3) break;
+        for (uint32_t pi = 0; pi < np; ++pi) {
+          if (ch[ci].ref == ch[pi].ref) {
+            if (max(ch[ci].start, ch[pi].start) > min(ch[ci].end, ch[pi].end)) {
+            } else {
+              is_primary = false;
+              break;
+            }
+          }
+        }
+        if (is_primary) {
+          const ChainTmp x = ch[ci];
+          ch[np++] = x;
         }
       }
+      // spatial_index.cc:255-274
+      uint32_t mapq;
+      if (np == 1) {
+        mapq = 60;
+      } else {
+        int m = (int)(40 * (1 - ch[1].score / ch[0].score));
+        if (m > 60) m = 60;
+        if (m < 0) m = 0;
+        mapq = (uint32_t)m;
+      }
+      res.n_chains = np;
+      float sum = 0;
+      for (uint32_t i = 0; i < np; ++i) sum += ch[i].score;  // sigmap.cc:702-705
+      res.sum_score = sum;
+      for (uint32_t i = 0; i < np && i < SMHIP_TOPK; ++i) {
+        smhip_chain o;
+        o.score = ch[i].score;
+        o.ref = ch[i].ref;
+        o.start = ch[i].start;
+        o.end = ch[i].end;
+        o.n_anchors = ch[i].n_anchors;
+        o.mapq = i == 0 ? mapq : 0;
+        o.direction = ch[i].direction;
+        o.pad = 0;
+        res.chains[i] = o;
+      }
     }
-    if (is_primary) {
-      const ChainTmp x = ch[ci];
-      ch[np++] = x;
-    }
+    s_np = np;
   }
-  // spatial_index.cc:255-274
-  uint32_t mapq;
-  if (np == 1) {
-    mapq = 60;
-  } else {
-    int m = (int)(40 * (1 - ch[1].score / ch[0].score));
-    if (m > 60) m = 60;
-    if (m < 0) m = 0;
-    mapq = (uint32_t)m;
+  __syncthreads();
+  const uint32_t np = s_np;
+  if (np == 0) {
+    if (lane == 0) a.out_anchor_cnt[c] = 0;
+    return;
   }
-  res.n_chains = np;
-  float sum = 0;
-  for (uint32_t i = 0; i < np; ++i) sum += ch[i].score;  // sigmap.cc:702-705
-  res.sum_score = sum;
-  for (uint32_t i = 0; i < np && i < SMHIP_TOPK; ++i) {
-    smhip_chain o;
-    o.score = ch[i].score;
-    o.ref = ch[i].ref;
-    o.start = ch[i].start;
-    o.end = ch[i].end;
-    o.n_anchors = ch[i].n_anchors;
-    o.mapq = i == 0 ? mapq : 0;
-    o.direction = ch[i].direction;
-    o.pad = 0;
-    res.chains[i] = o;
-  }
-  // anchors of every primary chain, end -> start (the order TracebackChains pushes them),
-  // for the next chunk's carry-over; chain 0 statistics as sigmap.cc:714-729 accumulates them
+  // anchors of every primary chain, end -> start (the order TracebackChains pushes them), for the
+  // next chunk's carry-over
   uint32_t w = 0;
   smhip_carried_anchor *out = a.out_anchors ? a.out_anchors + base : nullptr;
   for (uint32_t i = 0; i < np; ++i) {
-    const uint32_t g_id = grp[ch[i].end_anchor];
-    const uint32_t *lst = lists + ch[i].list_off;  // anchors of this chain, end -> start
-    const uint32_t na = ch[i].n_anchors;
-    float ad = 0, at = 0, aq = 0;
-    uint32_t pt_prev = 0, pq_prev = 0;
-    for (uint32_t k0 = 0; k0 < na; k0 += kPf) {
-      uint32_t t8[kPf], q8[kPf];
-      float d8[kPf];
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) {
-        const uint32_t ai = k0 + k < na ? lst[k0 + k] : lst[0];
-        t8[k] = tpos[ai];
-        q8[k] = qpos[ai];
-        d8[k] = dist[ai];
+    const ChainTmp ci = ch[i];
+    const uint32_t g_id = grp[ci.end_anchor];
+    const uint32_t *lst = lists + ci.list_off;
+    const uint32_t na = ci.n_anchors;
+    for (uint32_t k = lane; k < na; k += 64) {
+      const uint32_t ai = lst[k];
+      const uint32_t t = tpos[ai], q = qpos[ai];
+      const float d = dist[ai];
+      if (out) {
+        smhip_carried_anchor o;
+        o.ref_strand = g_id;
+        o.target_position = t;
+        o.query_position = q;
+        o.distance = d;
+        out[w + k] = o;
       }
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) {
-        if (k0 + k >= na) break;
-        if (out) {
-          smhip_carried_anchor o;
-          o.ref_strand = g_id;
-          o.target_position = t8[k];
-          o.query_position = q8[k];
-          o.distance = d8[k];
-          out[w] = o;
-        }
-        ++w;
-        if (i == 0) {
-          // sigmap.cc:717-725: distance of every anchor, gaps between consecutive anchors
-          ad += d8[k];
-          if (k0 + k == 0) res.c0_first_qpos = q8[k];
-          if (k0 + k + 1 == na) res.c0_last_qpos = q8[k];
-          if (k0 + k > 0) {
-            at += (float)(uint32_t)(pt_prev - t8[k]);
-            aq += (float)(uint32_t)(pq_prev - q8[k]);
-          }
-          pt_prev = t8[k];
-          pq_prev = q8[k];
-        }
+      if (i == 0 && k < kStatLds) {
+        l_t[k] = t;
+        l_q[k] = q;
+        l_d[k] = d;
       }
     }
+    w += na;
     if (i == 0) {
-      res.c0_sum_dist = ad;
-      res.c0_sum_tgap = at;
-      res.c0_sum_qgap = aq;
+      __syncthreads();
+      if (lane == 0) {  // sigmap.cc:714-729 in the reference's accumulation order
+        float ad = 0, at = 0, aq = 0;
+        uint32_t pt_prev = 0, pq_prev = 0;
+        for (uint32_t k = 0; k < na; ++k) {
+          uint32_t t, q;
+          float d;
+          if (k < kStatLds) {
+            t = l_t[k];
+            q = l_q[k];
+            d = l_d[k];
+          } else {
+            const uint32_t ai = lst[k];
+            t = tpos[ai];
+            q = qpos[ai];
+            d = dist[ai];
+          }
+          ad += d;
+          if (k == 0) res.c0_first_qpos = q;
+          if (k + 1 == na) res.c0_last_qpos = q;
+          if (k > 0) {
+            at += (float)(uint32_t)(pt_prev - t);
+            aq += (float)(uint32_t)(pq_prev - q);
+          }
+          pt_prev = t;
+          pq_prev = q;
+        }
+        res.c0_sum_dist = ad;
+        res.c0_sum_tgap = at;
+        res.c0_sum_qgap = aq;
+      }
     }
   }
-  a.out_anchor_cnt[c] = w;
+  if (lane == 0) a.out_anchor_cnt[c] = w;
 }
 }  // namespace
 
@@ -656,7 +683,7 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
                      big_list, big_count);
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
                      p.num_best_chains, p.min_chaining_score, n_chains);
-  hipLaunchKernelGGL(ChainFinalizeKernel, dim3((n_chunks + 63) / 64), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);
+  hipLaunchKernelGGL(ChainFinalizeKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);
   return hipGetLastError();
 }
 }  // namespace smhip
