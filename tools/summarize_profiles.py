@@ -21,8 +21,8 @@ def short(name):
 
 def main(tag):
     os.makedirs(DST, exist_ok=True)
-    ks = glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv"))
-    rows = list(csv.DictReader(open(ks[0])))
+    ks = sorted(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(ks[-1])))  # newest run
     with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
@@ -32,9 +32,10 @@ def main(tag):
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
         if not os.path.isdir(d):
             continue
-        cc = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+        cc = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
         if not cc:
             continue
+        cc = cc[-1:]
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(set)
         for r in csv.DictReader(open(cc[0])):
@@ -50,7 +51,7 @@ def main(tag):
         w.writerow(["kernel"] + counters)
         for k in sorted(per, key=lambda k: -per[k].get("SQ_WAVE_CYCLES", 0)):
             w.writerow([k] + ["%.6g" % per[k].get(c, float("nan")) for c in counters])
-    seed = next((k for k in per if k.startswith("SeedLaneKernel<false>")), None)
+    seed = next((k for k in per if k.startswith("SeedLaneKernel")), None)
     out = {}
     if seed and "FETCH_SIZE" in per[seed]:
         fetch_kb, write_kb = per[seed]["FETCH_SIZE"], per[seed].get("WRITE_SIZE", 0.0)
