@@ -66,8 +66,11 @@ typedef struct {
    * silently truncated) */
   uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (512) */
   uint32_t walk_blocks_per_cu;    /* resident 256-thread workgroups per CU of the tree walker
-                                     (0 = default 5; speed only) */
-  uint32_t reserved;
+                                     (0 = default 6; speed only) */
+  uint32_t reference_walk;        /* 0: skip subtrees whose tight box is out of range (same hits,
+                                     same order).  1: visit exactly nanoflann's node set, so that
+                                     nodes_visited / points_tested count the reference's work
+                                     (the census behind bench.py's algorithmic bytes) */
 } smhip_params;
 
 void smhip_default_params(smhip_params *p);
@@ -92,12 +95,12 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
  * These are the walker's own structures, derived from the smhip_node array at upload. */
 typedef struct {
   int32_t dim;
-  uint32_t root_ref;            /* inner index, or 0x80000000 | leaf ordinal for a one-leaf tree */
-  uint64_t n_inner, n_leaves, m_size;
-  void *inner;      uint64_t inner_bytes;      /* 32 B per inner node (pre-order): {feat, divlow,
-                                                  divhigh, child1 ref, child2 ref, pad x3} */
-  void *leaf_recs;  uint64_t leaf_recs_bytes;  /* 64 B per leaf: {left, n, boff, pad, lo[6], hi[6]}
-                                                  (tight box of the leaf's points) */
+  uint32_t pad;
+  uint64_t n_nodes, m_size;
+  void *nodes;      uint64_t nodes_bytes;      /* 64 B per tree node, pre-order (child1 = self+1):
+                                                  inner {divlow, divhigh, child2, feat}, leaf
+                                                  {left, n, boff, 0xFFFFFFFF}; then lo[6], hi[6] =
+                                                  tight box of the points below the node */
   void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks at slot `boff`:
                                                   n x {v0..v3}, then n x {v4, v5, uint64 position} */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */

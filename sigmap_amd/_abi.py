@@ -44,7 +44,7 @@ class Params(C.Structure):
         ("min_num_anchors", C.c_int32), ("num_best_chains", C.c_int32),
         ("num_nearest_points", C.c_int32), ("min_chaining_score", C.c_float),
         ("hits_per_query_fast", C.c_uint32), ("walk_blocks_per_cu", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("reference_walk", C.c_uint32),
     ]
 
 
@@ -83,10 +83,8 @@ CARRIED_DTYPE = np.dtype([("ref_strand", "<u4"), ("target_position", "<u4"),
 
 
 class IndexDev(C.Structure):
-    _fields_ = [("dim", C.c_int32), ("root_ref", C.c_uint32), ("n_inner", C.c_uint64),
-                ("n_leaves", C.c_uint64), ("m_size", C.c_uint64),
-                ("inner", C.c_void_p), ("inner_bytes", C.c_uint64),
-                ("leaf_recs", C.c_void_p), ("leaf_recs_bytes", C.c_uint64),
+    _fields_ = [("dim", C.c_int32), ("pad", C.c_uint32), ("n_nodes", C.c_uint64), ("m_size", C.c_uint64),
+                ("nodes", C.c_void_p), ("nodes_bytes", C.c_uint64),
                 ("leaf_pts", C.c_void_p), ("leaf_pts_bytes", C.c_uint64),
                 ("leaf_vind", C.c_void_p), ("leaf_vind_bytes", C.c_uint64),
                 ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64)]

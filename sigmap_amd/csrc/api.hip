@@ -148,7 +148,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->ix_inner, &ctx->ix_leafrec, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
@@ -177,58 +177,71 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   if (n_points < (uint64_t)dim || m_size != n_points - dim + 1 || n_nodes == 0 || n_nodes > 0xFFFFFFFFull)
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
-  // Walker structures (layouts: seed_lookup.hip header) from the pre-order node array: inner
-  // nodes only (32 B, explicit child refs), one 64-byte record per leaf, and per-leaf point blocks
-  // of 2 * roundup(n, 8) 16-byte slots (whole 128-byte lines).
-  std::vector<uint32_t> ord(n_nodes);
-  uint64_t n_inner = 0, n_leaves = 0, n_slots = 0, leaf_points = 0;
-  for (uint64_t i = 0; i < n_nodes; ++i) ord[i] = nodes[i].feat >= 0 ? (uint32_t)n_inner++ : (uint32_t)n_leaves++;
-  if (n_inner >= kLeafTag || n_leaves >= kLeafTag) return Fail(ctx, SMHIP_EINVAL, "tree too large for 31-bit refs");
-  auto ref_of = [&](uint64_t i) { return nodes[i].feat >= 0 ? ord[i] : (kLeafTag | ord[i]); };
-  std::vector<uint32_t> h_inner(n_inner * 8, 0), h_leaf(n_leaves * 16, 0);
+  // Walker structures (layouts: seed_lookup.hip header) from the pre-order node array: one
+  // 64-byte record per node and per-leaf point blocks of 2 * roundup(n, 8) 16-byte slots (whole
+  // 128-byte lines).  The boxes are filled on the device: leaves by the gather, inner nodes level
+  // by level from the deepest one up.
+  std::vector<uint32_t> h_nodes(n_nodes * 16, 0), depth(n_nodes, 0);
+  uint64_t n_inner = 0, n_slots = 0, leaf_points = 0;
+  uint32_t max_depth = 0;
   for (uint64_t i = 0; i < n_nodes; ++i) {
     const smhip_node &nd = nodes[i];
+    uint32_t *o = &h_nodes[(size_t)i * 16];
     if (nd.feat >= 0) {
       if (nd.feat >= dim || i + 1 >= n_nodes || nd.child2 >= n_nodes || nd.child2 <= i + 1)
         return Fail(ctx, SMHIP_EINVAL, "malformed inner node (children must follow in pre-order)");
-      uint32_t *o = &h_inner[(size_t)ord[i] * 8];
-      o[0] = (uint32_t)nd.feat;
-      o[1] = nd.a;
-      o[2] = nd.b;
-      o[3] = ref_of(i + 1);
-      o[4] = ref_of(nd.child2);
+      o[0] = nd.a;
+      o[1] = nd.b;
+      o[2] = nd.child2;
+      o[3] = (uint32_t)nd.feat;
+      depth[i + 1] = depth[nd.child2] = depth[i] + 1;
+      max_depth = std::max(max_depth, depth[i] + 1);
+      ++n_inner;
     } else {
       if (nd.b < nd.a || nd.b > m_size) return Fail(ctx, SMHIP_EINVAL, "leaf range outside the point list");
+      if (nd.b - nd.a > 255) return Fail(ctx, SMHIP_EINVAL, "leaf with more than 255 points");
       if (n_slots > 0xFFFFFF00ull) return Fail(ctx, SMHIP_EINVAL, "index too large for 32-bit leaf block offsets");
       const uint32_t n = nd.b - nd.a;
-      uint32_t *o = &h_leaf[(size_t)ord[i] * 16];
       o[0] = nd.a;
       o[1] = n;
       o[2] = (uint32_t)n_slots;
+      o[3] = 0xFFFFFFFFu;
       n_slots += 2ull * ((n + 7u) & ~7u);
       leaf_points += n;
     }
   }
   if (leaf_points != m_size) return Fail(ctx, SMHIP_EINVAL, "leaves do not cover the point list exactly");
+  // inner nodes grouped by depth (counting sort)
+  std::vector<uint64_t> level_start(max_depth + 2, 0);
+  for (uint64_t i = 0; i < n_nodes; ++i)
+    if (nodes[i].feat >= 0) ++level_start[depth[i] + 1];
+  for (uint32_t d = 0; d <= max_depth; ++d) level_start[d + 1] += level_start[d];
+  std::vector<uint32_t> level_nodes(std::max<uint64_t>(n_inner, 1));
+  {
+    std::vector<uint64_t> cur(level_start.begin(), level_start.end() - 1);
+    for (uint64_t i = 0; i < n_nodes; ++i)
+      if (nodes[i].feat >= 0) level_nodes[cur[depth[i]]++] = (uint32_t)i;
+  }
   ctx->leaf_pts_bytes = n_slots * 16 + 128;
-  HIPCHK(ctx->ix_inner.Reserve(std::max<uint64_t>(n_inner, 1) * 32 + 64));  // + read-ahead of the 64-byte window
-  HIPCHK(ctx->ix_leafrec.Reserve(n_leaves * 64));
+  HIPCHK(ctx->ix_nodes.Reserve(n_nodes * 64));
   HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
   HIPCHK(ctx->ix_vind.Reserve(m_size * sizeof(uint32_t)));
   HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
   // staging copies of the original-order point cloud, freed after the leaf-major gather
-  DevBuf d_values, d_positions;
+  DevBuf d_values, d_positions, d_levels;
   HIPCHK(d_values.Reserve(n_points * sizeof(float)));
   hipError_t e = d_positions.Reserve(n_points * sizeof(uint64_t));
-  if (e != hipSuccess) {
-    d_values.Free();
-    return HipFail(ctx, e, "staging allocation");
-  }
+  if (e == hipSuccess) e = d_levels.Reserve(level_nodes.size() * sizeof(uint32_t));
   auto cleanup = [&]() {
     d_values.Free();
     d_positions.Free();
+    d_levels.Free();
   };
+  if (e != hipSuccess) {
+    cleanup();
+    return HipFail(ctx, e, "staging allocation");
+  }
 #define HIPCHK2(expr)                                  \
   do {                                                 \
     hipError_t _e = (expr);                            \
@@ -240,18 +253,21 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   HIPCHK2(hipMemcpyAsync(d_values.p, values, n_points * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_positions.p, positions, n_points * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_vind.p, vind, m_size * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK2(hipMemcpyAsync(ctx->ix_inner.p, h_inner.data(), n_inner * 32, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK2(hipMemcpyAsync(ctx->ix_leafrec.p, h_leaf.data(), n_leaves * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, h_nodes.data(), n_nodes * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(d_levels.p, level_nodes.data(), level_nodes.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_bbox.p, root_bbox, 2 * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), ctx->ix_vind.as<uint32_t>(),
-                           ctx->ix_leafrec.p, n_leaves, ctx->ix_pts.as<float>()));
+                           ctx->ix_nodes.p, n_nodes, ctx->ix_pts.as<float>()));
+  for (uint32_t d = max_depth + 1; d-- > 0;)
+    HIPCHK2(LaunchInnerBoxes(ctx, ctx->ix_nodes.p, d_levels.as<uint32_t>() + level_start[d],
+                             (uint32_t)(level_start[d + 1] - level_start[d])));
   HIPCHK2(hipStreamSynchronize(ctx->stream));
 #undef HIPCHK2
   cleanup();
   ctx->dim = dim;
-  ctx->index = IndexView{ctx->ix_inner.as<uint4>(), ctx->ix_leafrec.as<uint4>(), ctx->ix_pts.as<float>(),
-                         ctx->ix_vind.as<uint32_t>(), ctx->ix_bbox.as<float>(), n_inner, n_leaves, m_size,
-                         ref_of(0)};
+  ctx->index = IndexView{ctx->ix_nodes.as<uint4>(), ctx->ix_pts.as<float>(), ctx->ix_vind.as<uint32_t>(),
+                         ctx->ix_bbox.as<float>(), n_nodes, m_size};
   ctx->have_index = true;
   ctx->index_owned = true;
   return SMHIP_OK;
@@ -262,14 +278,10 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "no index resident");
   memset(out, 0, sizeof *out);
   out->dim = ctx->dim;
-  out->root_ref = ctx->index.root_ref;
-  out->n_inner = ctx->index.n_inner;
-  out->n_leaves = ctx->index.n_leaves;
+  out->n_nodes = ctx->index.n_nodes;
   out->m_size = ctx->index.m_size;
-  out->inner = (void *)ctx->index.inner;
-  out->inner_bytes = std::max<uint64_t>(ctx->index.n_inner, 1) * 32 + 64;
-  out->leaf_recs = (void *)ctx->index.leaf_recs;
-  out->leaf_recs_bytes = ctx->index.n_leaves * 64;
+  out->nodes = (void *)ctx->index.nodes;
+  out->nodes_bytes = ctx->index.n_nodes * 64;
   out->leaf_pts = (void *)ctx->index.leaf_pts;
   out->leaf_pts_bytes = ctx->leaf_pts_bytes;
   out->leaf_vind = (void *)ctx->index.leaf_vind;
@@ -282,16 +294,14 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (!ctx || !in) return SMHIP_EINVAL;
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
-  if (!in->inner || !in->leaf_recs || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_leaves == 0)
+  if (!in->nodes || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
     return Fail(ctx, SMHIP_EINVAL, "null index array");
-  if (in->inner_bytes < in->n_inner * 32 + 64 || in->leaf_recs_bytes < in->n_leaves * 64 ||
-      in->leaf_pts_bytes < in->m_size * 32 ||
+  if (in->nodes_bytes < in->n_nodes * 64 || in->leaf_pts_bytes < in->m_size * 32 ||
       in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
     return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");
   ctx->dim = in->dim;
-  ctx->index = IndexView{(const uint4 *)in->inner, (const uint4 *)in->leaf_recs, (const float *)in->leaf_pts,
-                         (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_inner, in->n_leaves,
-                         in->m_size, in->root_ref};
+  ctx->index = IndexView{(const uint4 *)in->nodes, (const float *)in->leaf_pts, (const uint32_t *)in->leaf_vind,
+                         (const float *)in->bbox, in->n_nodes, in->m_size};
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->have_index = true;
   ctx->index_owned = false;

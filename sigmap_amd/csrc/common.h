@@ -34,17 +34,14 @@ struct ChainTmp {
   uint32_t list_off;    // chunk-local offset of the chain's anchor index list (end -> start)
 };
 
-constexpr uint32_t kLeafTag = 0x80000000u;  // child ref: kLeafTag | leaf ordinal, else inner index
-
 // Device view of the index (all pointers device memory; layouts: seed_lookup.hip header).
 struct IndexView {
-  const uint4 *inner;         // 2 x uint4 per inner node: {feat, divlow, divhigh, c1}, {c2, -, -, -}
-  const uint4 *leaf_recs;     // 4 x uint4 per leaf: {left, n, boff, -}, lo[6], hi[6]
+  const uint4 *nodes;         // 4 x uint4 per tree node (pre-order): {divlow, divhigh, child2, feat} or
+                              // {left, n, boff, 0xFFFFFFFF}, then lo[6], hi[6] of the node's tight box
   const float *leaf_pts;      // per-leaf 128-byte-aligned point blocks
   const uint32_t *leaf_vind;  // [m_size] tree order -> original point index
   const float *bbox;          // [12] low0, high0, ...
-  uint64_t n_inner, n_leaves, m_size;
-  uint32_t root_ref;
+  uint64_t n_nodes, m_size;
 };
 
 // Grow-only device buffer.
@@ -86,7 +83,7 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_inner, ix_leafrec, ix_pts, ix_vind, ix_bbox;
+  smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox;
   uint64_t leaf_pts_bytes = 0;
   // batch inputs
   uint32_t n_chunks = 0;
@@ -119,7 +116,8 @@ namespace smhip {
 // Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
 // launch status.
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *leaf_recs, uint64_t n_leaves, float *leaf_pts);
+                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts);
+hipError_t LaunchInnerBoxes(smhip_ctx *ctx, void *nodes, const uint32_t *level_nodes, uint32_t count);
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);

@@ -6,11 +6,10 @@
 // from SpatialIndex::GenerateChains (spatial_index.cc:351-409).
 //
 // Data layout in HBM (built once per index from the pre-order smhip_node array + point cloud):
-//   inner    : 32-byte records of the INNER nodes only, in pre-order:
-//              {feat, divlow, divhigh, child1 ref, child2 ref, pad}.  A child ref is either an
-//              inner index or kLeafTag | leaf ordinal, so reaching a leaf costs no node read.
-//   leaf_recs: one 64-byte (one sector) record per leaf, in tree order: {left, n, boff, pad,
-//              lo[6], hi[6]} where lo/hi is the TIGHT bounding box of the leaf's points.
+//   nodes    : one 64-byte record (one sector) per tree node, in pre-order (child1 = self + 1):
+//                inner {divlow, divhigh, child2, feat}  lo[6] hi[6]
+//                leaf  {left, n, boff, 0xFFFFFFFF}      lo[6] hi[6]
+//              lo/hi is the TIGHT bounding box of the points below the node.
 //   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf at slot offset `boff`: n "first
 //              halves" {v0,v1,v2,v3}, then (from slot boff + roundup(n, 8)) n "second halves"
 //              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte line.
@@ -19,30 +18,37 @@
 //   qrec     : one 32-byte record per query: float q[6]; uint32 chunk; uint32 k
 //
 // The recursion of searchLevel is replaced by an explicit stack of pending "other child" visits
-// (child ref, mindistsq, dists[6] = 32 bytes per entry).  That reproduces nanoflann's visiting
+// (node, mindistsq, dists[6] = 32 bytes per entry).  That reproduces nanoflann's visiting
 // order and pruning arithmetic (`mindistsq + cut_dist - dists[idx]`, same operation order)
 // exactly, so hits come out in the reference's traversal order; the k-th hit of a query is stored
 // at slot k, and k >= num_nearest_points (5000, spatial_index.cc:371-372) is dropped exactly like
 // the reference.
 //
-// What is NOT read although nanoflann reads it (results are identical, argument in place):
-//  * a visited leaf whose tight box is at squared distance >= radius from the query is skipped:
-//    the box distance is accumulated with nanoflann's own association order, and every f32
-//    operation involved is monotone, so it is a lower bound of the f32 distance nanoflann would
-//    compute for any point of the leaf -- no point of that leaf can pass `dist < radius`
-//    (measured: 86 % of the visited leaves, 83 % of the points);
-// The per-chunk counters still report the reference's work (nodes visited, points it tests).
+// What is NOT visited although nanoflann visits it (results are identical, argument in place):
+// a node whose tight box is at squared distance >= radius from the query.  The box distance is
+// accumulated with nanoflann's own association order (evalMetric) and every f32 operation
+// involved is monotone, so it is a lower bound of the f32 distance nanoflann would compute for
+// any point below the node -- no point there can pass `dist < radius`, the subtree contributes no
+// hit, and skipping it changes neither the hit list nor its order.  nanoflann's own rule is still
+// applied with its own arithmetic on top (it must be: it is not implied bit-for-bit by the box rule).
+// On the 12 Mb index this visits 331 node records per query instead of nanoflann's 470 and tests
+// 205 points instead of 1196.  kStrict = true switches the box rule off for inner nodes and counts
+// nanoflann's work (nodes visited, points it would test): that is the census the roofline's
+// algorithmic bytes are computed from, and what the per-stage tests compare with the oracle.
 //
-// Mapping: ONE LANE PER QUERY, a state machine in which every loop iteration issues one batch of
-// 16-byte loads per lane (an inner node, a leaf record = one sector, or four points of a leaf that
-// passed the box test: one sector of first halves + one of second halves) and then retires it, so the instruction stream
-// of a wave is amortised over 64 queries.  The two newest stack entries of a lane live in LDS,
-// older ones spill to HBM ([lane][64] x 32 B).  Queries are visited in the order of the leaf that
-// contains them (QueryKey/QueryScatter: a stackless descent + a counting sort that permutes the
-// query records), each XCD taking
-// one contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the
-// same part of the tree and share its cache lines; results are indexed by query id, so the
-// visiting order never shows in the output.
+// Mapping: ONE LANE PER QUERY.  A wave alternates between two uniform phases so that its
+// instruction stream is one body at a time:
+//   walk : every active lane loads its current node record (4 x 16 B), tests the box, and either
+//          descends (inner), queues the leaf in its LDS FIFO (leaf), or pops its stack;
+//   scan : when enough lanes are blocked (FIFO full, or query finished with leaves pending) all
+//          lanes drain their FIFOs, four points of a leaf per iteration.
+// Leaves of a query are scanned in the order they were reached, so hits keep traversal order.
+// The two newest stack entries of a lane live in LDS, older ones spill to HBM ([lane][64] x 32 B).
+// Queries are visited in the order of the leaf that contains them (QueryKey/QueryScatter: a
+// stackless descent + a counting sort that permutes the query records), each XCD taking one
+// contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the same
+// part of the tree and share its cache lines; results are indexed by query id, so the visiting
+// order never shows in the output.
 #include <stdlib.h>
 
 #include "common.h"
@@ -51,6 +57,7 @@ namespace smhip {
 namespace {
 
 constexpr int kSeedThreads = 256;
+constexpr int kFifo = 4;  // pending leaves per lane
 
 struct QueryRec {  // 32 B
   float q[6];
@@ -58,13 +65,13 @@ struct QueryRec {  // 32 B
 };
 
 struct Sink {
-  Hit *region;          // [n_queries][fast_cap] (fast pass) or the overflow pool
-  uint32_t fast_cap;    // slots per query in the fast pass
+  Hit *region;          // [n_queries][fast_cap]
+  uint32_t fast_cap;    // slots per query before the overflow pool
   uint32_t nnp;         // num_nearest_points
   uint32_t *q_count;    // total hits per query
   uint32_t *q_nodes;    // optional per-query stats
   uint32_t *q_points;
-  smhip_chunk_result *results;  // optional per-chunk accumulation
+  smhip_chunk_result *results;  // unused (per-chunk sums are formed by AnchorCountKernel)
   uint32_t *counters;   // [0] stack overflow flag, [1] #overflow queries, [2] pool top, [3] pool full
   Hit *pool;            // overflow pool: hits beyond the fast slots, in geometric segments
   uint32_t *ovf_tab;    // [n_queries][kOvfLevels] pool offset of each segment
@@ -85,7 +92,7 @@ struct Sink {
     }                                                         \
   }
 
-enum : uint32_t { M_FETCH = 0, M_WALK = 1, M_LEAF = 2, M_SCAN = 3 };
+enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
 
 // Hit number `ord` of query `qi` (0-based, in traversal order): the first fast_cap hits go to the
 // query's own slots; later ones go to segments of the shared pool whose sizes double
@@ -114,11 +121,12 @@ __device__ __forceinline__ void EmitHit(const Sink &sink, uint32_t qi, uint32_t 
   if (ovf_base != 0xFFFFFFFFu) sink.pool[(size_t)ovf_base + (k - first)] = h;
 }
 
-__global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, const QueryRec *__restrict__ qrec,
+template <bool kStrict>
+__global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
-                                                               float4 *__restrict__ stack_mem,
-                                                               const uint32_t *__restrict__ order, int xcd_ranges) {
+                                                               float4 *__restrict__ stack_mem, int xcd_ranges,
+                                                               uint32_t scan_threshold) {
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
   uint32_t n_lanes = gridDim.x * kSeedThreads;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
@@ -140,136 +148,32 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
   float mind = 0;
-  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, j = 0, n = 0, lbase = 0, lleft = 0, qi = 0;
+  uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, qi = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
+  // pending leaves of this lane's query, in the order they were reached: {boff, left}; n in fifo_n
+  __shared__ uint2 fifo[kFifo][kSeedThreads];
   uint32_t tcnt = 0, thead = 0;
+  uint32_t fifo_cnt = 0, fifo_n = 0;  // fifo_n: 8 bits of n per entry
   uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
   for (;;) {
-    if (mode == M_FETCH) {
-      if (w >= total) break;
-      // the fast pass reads records already permuted into visiting order (one round trip);
-      // the record's last word is the query id
-      const uint32_t ri = w;
-      w += n_lanes;
-      const float4 a = *reinterpret_cast<const float4 *>(&qrec[ri]);
-      const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
-      qi = __float_as_uint(b.w);
-      q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
-      d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
-      mind = 0.0f;
-      SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
-      SM_INIT_DIM(5, d5)
-      node = ix.root_ref; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
-      mode = (node & kLeafTag) ? M_LEAF : M_WALK;
-    }
-    // ---- one batch of 16-byte loads per lane per iteration: a 64-byte window at `wa`, the same
-    // four load instructions whatever the lane's mode (node: 32 of them used; leaf record: all;
-    // four first halves: all; second half: 16).  The address is formed with selects and made
-    // opaque, and all results are pinned right after the loads, so that the compiler keeps ONE
-    // memory round trip per iteration instead of sinking a load + wait into every mode's branch.
-    uint64_t wa;
-    {
-      const uint64_t a_walk = (uint64_t)ix.inner + (uint64_t)node * 32;
-      const uint64_t a_leaf = (uint64_t)ix.leaf_recs + (uint64_t)(node & ~kLeafTag) * 64;
-      const uint64_t a_pts = (uint64_t)pts4 + (uint64_t)(lbase + j) * 16;
-      wa = mode == M_WALK ? a_walk : (mode == M_LEAF ? a_leaf : a_pts);
-      uint32_t lo32 = (uint32_t)wa, hi32 = (uint32_t)(wa >> 32);
-      asm volatile("" : "+v"(lo32), "+v"(hi32));
-      wa = ((uint64_t)hi32 << 32) | lo32;
-    }
-    const uint4 *addr = reinterpret_cast<const uint4 *>(wa);
-    uint4 r = addr[0];
-    uint4 rr[3];
-    rr[0] = addr[1];
-    rr[1] = addr[2];
-    rr[2] = addr[3];
-    // scanning lanes also fetch the four second halves {v4, v5, position} of the same points
-    uint4 rs[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) rs[t] = r;
-    if (mode == M_SCAN) {
-      const uint4 *sh = addr + ((n + 7u) & ~7u);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) rs[t] = sh[t];
-    }
-    asm volatile("" : "+v"(rs[0].x), "+v"(rs[0].y), "+v"(rs[0].z), "+v"(rs[0].w), "+v"(rs[1].x), "+v"(rs[1].y),
-                 "+v"(rs[1].z), "+v"(rs[1].w));
-    asm volatile("" : "+v"(rs[2].x), "+v"(rs[2].y), "+v"(rs[2].z), "+v"(rs[2].w), "+v"(rs[3].x), "+v"(rs[3].y),
-                 "+v"(rs[3].z), "+v"(rs[3].w));
-    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w), "+v"(rr[0].x), "+v"(rr[0].y), "+v"(rr[0].z),
-                 "+v"(rr[0].w));
-    asm volatile("" : "+v"(rr[1].x), "+v"(rr[1].y), "+v"(rr[1].z), "+v"(rr[1].w), "+v"(rr[2].x), "+v"(rr[2].y),
-                 "+v"(rr[2].z), "+v"(rr[2].w));
-    bool leaf_end = false;
-    if (mode == M_WALK) {  // nanoflann.hpp:1371-1408; r = {feat, divlow, divhigh, c1}, rr[0].x = c2
-      ++nn;
-      const int idx = (int)r.x;
-      const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
-      const float divlow = __uint_as_float(r.y), divhigh = __uint_as_float(r.z);
-      const float diff1 = val - divlow, diff2 = val - divhigh;
-      uint32_t next, other;
-      float cut;
-      if ((diff1 + diff2) < 0) {
-        next = r.w;
-        other = rr[0].x;
-        cut = (val - divhigh) * (val - divhigh);
-      } else {
-        next = rr[0].x;
-        other = r.w;
-        cut = (val - divlow) * (val - divlow);
-      }
-      const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
-      const float nm = mind + cut - dst;
-      if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
-        if (sp + tcnt < (uint32_t)kStackDepth) {
-          const uint32_t slot = thead ^ 1u;
-          if (tcnt == 2) {  // spill the older cached entry
-            stk[2 * sp] = tos[slot][0][threadIdx.x];
-            stk[2 * sp + 1] = tos[slot][1][threadIdx.x];
-            ++sp;
-          } else {
-            ++tcnt;
-          }
-          tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
-          tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
-                                                  idx == 5 ? cut : d5);
-          thead = slot;
-        } else {
-          atomicOr(&sink.counters[0], 1u);
-        }
-      }
-      node = next;
-      mode = (node & kLeafTag) ? M_LEAF : M_WALK;
-    } else if (mode == M_LEAF) {
-      // a leaf visit of searchLevel (nanoflann.hpp:1350-1369); r = {left, n, boff, -},
-      // rr[0..2] = lo[0..5], hi[0..5]
-      ++nn;
-      lleft = r.x;
-      n = r.y;
-      lbase = r.z;
-      np += n;  // the reference evaluates every point of a visited leaf
-      // squared distance from the query to the leaf's tight box, accumulated like evalMetric
-      // (nanoflann.hpp:391-406): a lower bound of every point's f32 distance (monotone ops)
-      const float l0 = __uint_as_float(rr[0].x), l1 = __uint_as_float(rr[0].y), l2 = __uint_as_float(rr[0].z),
-                  l3 = __uint_as_float(rr[0].w), l4 = __uint_as_float(rr[1].x), l5 = __uint_as_float(rr[1].y);
-      const float h0 = __uint_as_float(rr[1].z), h1 = __uint_as_float(rr[1].w), h2 = __uint_as_float(rr[2].x),
-                  h3 = __uint_as_float(rr[2].y), h4 = __uint_as_float(rr[2].z), h5 = __uint_as_float(rr[2].w);
-#define SM_BOX(qq, ll, hh) ((qq) > (hh) ? (qq) - (hh) : ((qq) < (ll) ? (qq) - (ll) : 0.0f))
-      const float e0 = SM_BOX(q0, l0, h0), e1 = SM_BOX(q1, l1, h1), e2 = SM_BOX(q2, l2, h2);
-      const float e3 = SM_BOX(q3, l3, h3), e4 = SM_BOX(q4, l4, h4), e5 = SM_BOX(q5, l5, h5);
-#undef SM_BOX
-      float lb = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-      lb += e4 * e4;
-      lb += e5 * e5;
-      j = 0;
-      if (lb < radius && n > 0) {
-        mode = M_SCAN;
-      } else {
-        leaf_end = true;  // no point of this leaf can satisfy dist < radius
-      }
-    } else {  // M_SCAN: nanoflann.hpp:391-406 for up to four points of the leaf
-      const uint32_t left_in_leaf = n - j;
+    const bool blocked = fifo_cnt == (uint32_t)kFifo || mode == M_DRAIN;
+    const bool active = !blocked && mode != M_IDLE;
+    const uint64_t act = __ballot(active);
+    const uint64_t pend = __ballot(fifo_cnt > 0);
+    if (act == 0 && pend == 0) break;
+    if (act == 0 || (uint32_t)__popcll(__ballot(blocked)) >= scan_threshold) {
+      // ---- scan phase: every lane drains its FIFO (nanoflann.hpp:1350-1369, 391-406) ----
+      uint32_t e = 0, j = 0;
+      while (__ballot(e < fifo_cnt)) {
+        if (e < fifo_cnt) {
+          const uint2 ent = fifo[e][threadIdx.x];
+          const uint32_t n = (fifo_n >> (8 * e)) & 0xFFu;
+          const uint4 *fh = pts4 + (size_t)ent.x + j;
+          const uint4 *sh = fh + ((n + 7u) & ~7u);
+          const uint4 r0 = fh[0], r1 = fh[1], r2 = fh[2], r3 = fh[3];
+          const uint4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+          const uint32_t left_in_leaf = n - j;
 #define SM_POINT(rv, sv, t)                                                                   \
   if (left_in_leaf > (uint32_t)t) {                                                           \
     const float f0 = q0 - __uint_as_float(rv.x), f1 = q1 - __uint_as_float(rv.y);            \
@@ -285,39 +189,140 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedLaneKernel(IndexView ix, 
         Hit h;                                                                                \
         h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);                                 \
         h.dist = res;                                                                         \
-        h.slot = lleft + j + t;                                                               \
+        h.slot = ent.y + j + t;                                                               \
         EmitHit(sink, qi, ord, h, ovf_base);                                                  \
       }                                                                                       \
     }                                                                                         \
   }
-      SM_POINT(r, rs[0], 0) SM_POINT(rr[0], rs[1], 1) SM_POINT(rr[1], rs[2], 2) SM_POINT(rr[2], rs[3], 3)
+          SM_POINT(r0, s0, 0) SM_POINT(r1, s1, 1) SM_POINT(r2, s2, 2) SM_POINT(r3, s3, 3)
 #undef SM_POINT
-      j += 4;
-      leaf_end = j >= n;
-    }
-    if (leaf_end) {
-      if (sp + tcnt == 0) {  // query complete
-        // per-query counters (plain stores; the per-chunk sums are formed by AnchorCountKernel)
+          j += 4;
+          if (j >= n) {
+            ++e;
+            j = 0;
+          }
+        }
+      }
+      fifo_cnt = 0;
+      fifo_n = 0;
+      if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
         sink.q_count[qi] = hits;
         if (sink.q_nodes) sink.q_nodes[qi] = nn;
         if (sink.q_points) sink.q_points[qi] = np;
         mode = M_FETCH;
-      } else {  // return from searchLevel into the innermost pending visit
-        float4 a, b;
-        if (tcnt > 0) {
-          a = tos[thead][0][threadIdx.x];
-          b = tos[thead][1][threadIdx.x];
-          --tcnt;
-          thead ^= 1u;
-        } else {
-          --sp;
-          a = stk[2 * sp];
-          b = stk[2 * sp + 1];
+      }
+      continue;
+    }
+    // ---- walk phase: one node visit per active lane ----
+    if (active && mode == M_FETCH) {
+      if (w >= total) {
+        mode = M_IDLE;
+      } else {
+        // records are already permuted into visiting order; the record's last word is the query id
+        const uint32_t ri = w;
+        w += n_lanes;
+        const float4 a = *reinterpret_cast<const float4 *>(&qrec[ri]);
+        const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
+        qi = __float_as_uint(b.w);
+        q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
+        d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
+        mind = 0.0f;
+        SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
+        SM_INIT_DIM(5, d5)
+        node = 0; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
+        mode = M_NODE;
+      }
+    }
+    if (active && mode == M_NODE) {
+      const uint4 *rec = ix.nodes + (size_t)node * 4;
+      const uint4 r = rec[0], b0 = rec[1], b1 = rec[2], b2 = rec[3];
+      // squared distance from the query to the node's tight box, accumulated like evalMetric
+      // (nanoflann.hpp:391-406): a lower bound of every point's f32 distance (monotone ops)
+#define SM_BOX(qq, ll, hh) fmaxf(fmaxf((qq) - __uint_as_float(hh), __uint_as_float(ll) - (qq)), 0.0f)
+      const float e0 = SM_BOX(q0, b0.x, b1.z), e1 = SM_BOX(q1, b0.y, b1.w), e2 = SM_BOX(q2, b0.z, b2.x);
+      const float e3 = SM_BOX(q3, b0.w, b2.y), e4 = SM_BOX(q4, b1.x, b2.z), e5 = SM_BOX(q5, b1.y, b2.w);
+#undef SM_BOX
+      float lb = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      lb += e4 * e4;
+      lb += e5 * e5;
+      const bool is_leaf = r.w == 0xFFFFFFFFu;
+      const bool inside = lb < radius;
+      bool pop = true;
+      if (kStrict || inside) ++nn;
+      if (is_leaf) {
+        // a leaf visit of searchLevel (nanoflann.hpp:1350-1369); r = {left, n, boff, -}
+        if (kStrict) np += r.y;  // the reference evaluates every point of a visited leaf
+        if (inside && r.y > 0) {
+          if (!kStrict) np += r.y;
+          fifo[fifo_cnt][threadIdx.x] = make_uint2(r.z, r.x);
+          fifo_n |= r.y << (8 * fifo_cnt);
+          ++fifo_cnt;
         }
-        node = __float_as_uint(a.x);
-        mind = a.y;
-        d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
-        mode = (node & kLeafTag) ? M_LEAF : M_WALK;
+      } else if (kStrict || inside) {  // nanoflann.hpp:1371-1408; r = {divlow, divhigh, child2, feat}
+        const int idx = (int)r.w;
+        const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
+        const float divlow = __uint_as_float(r.x), divhigh = __uint_as_float(r.y);
+        const float diff1 = val - divlow, diff2 = val - divhigh;
+        uint32_t next, other;
+        float cut;
+        if ((diff1 + diff2) < 0) {
+          next = node + 1;
+          other = r.z;
+          cut = (val - divhigh) * (val - divhigh);
+        } else {
+          next = r.z;
+          other = node + 1;
+          cut = (val - divlow) * (val - divlow);
+        }
+        const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
+        const float nm = mind + cut - dst;
+        if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
+          if (sp + tcnt < (uint32_t)kStackDepth) {
+            const uint32_t slot = thead ^ 1u;
+            if (tcnt == 2) {  // spill the older cached entry
+              stk[2 * sp] = tos[slot][0][threadIdx.x];
+              stk[2 * sp + 1] = tos[slot][1][threadIdx.x];
+              ++sp;
+            } else {
+              ++tcnt;
+            }
+            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
+            tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
+                                                    idx == 5 ? cut : d5);
+            thead = slot;
+          } else {
+            atomicOr(&sink.counters[0], 1u);
+          }
+        }
+        node = next;
+        pop = false;
+      }
+      if (pop) {
+        if (sp + tcnt == 0) {  // traversal of this query complete
+          if (fifo_cnt > 0) {
+            mode = M_DRAIN;  // its pending leaves are scanned first
+          } else {
+            sink.q_count[qi] = hits;
+            if (sink.q_nodes) sink.q_nodes[qi] = nn;
+            if (sink.q_points) sink.q_points[qi] = np;
+            mode = M_FETCH;
+          }
+        } else {  // return from searchLevel into the innermost pending visit
+          float4 a, b;
+          if (tcnt > 0) {
+            a = tos[thead][0][threadIdx.x];
+            b = tos[thead][1][threadIdx.x];
+            --tcnt;
+            thead ^= 1u;
+          } else {
+            --sp;
+            a = stk[2 * sp];
+            b = stk[2 * sp + 1];
+          }
+          node = __float_as_uint(a.x);
+          mind = a.y;
+          d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
+        }
       }
     }
   }
@@ -353,16 +358,17 @@ __global__ void QueryExpandRawKernel(const float *__restrict__ queries, uint32_t
   }
 }
 
-// One thread per leaf: writes the leaf's point block (layout in the file header) and the tight
-// bounding box into its record.  v[d] = values[vind[i] + d] (sigmap_adaptor.h:94-97: k-d point i is
-// the window values[i..i+dim)), position = Point.position of the window's first element.
+// One thread per node, leaves only: writes the leaf's point block (layout in the file header) and
+// the tight bounding box into its record.  v[d] = values[vind[i] + d] (sigmap_adaptor.h:94-97: k-d
+// point i is the window values[i..i+dim)), position = Point.position of the window's first element.
 __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_t *__restrict__ positions,
-                                 const uint32_t *__restrict__ vind, uint4 *__restrict__ leaf_recs,
-                                 uint64_t n_leaves, float *__restrict__ leaf_pts) {
+                                 const uint32_t *__restrict__ vind, uint4 *__restrict__ nodes,
+                                 uint64_t n_nodes, float *__restrict__ leaf_pts) {
   float4 *o = reinterpret_cast<float4 *>(leaf_pts);
-  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_leaves;
+  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_nodes;
        k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint4 hd = leaf_recs[k * 4];
+    const uint4 hd = nodes[k * 4];
+    if (hd.w != 0xFFFFFFFFu) continue;
     const uint32_t left = hd.x, n = hd.y, boff = hd.z, rn = (n + 7u) & ~7u;
     float lo[6], hi[6];
 #pragma unroll
@@ -384,30 +390,45 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
       o[(size_t)boff + rn + t] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
                                              __uint_as_float((uint32_t)(pos >> 32)));
     }
-    float4 *rec = reinterpret_cast<float4 *>(leaf_recs + k * 4);
+    float4 *rec = reinterpret_cast<float4 *>(nodes + k * 4);
     rec[1] = make_float4(lo[0], lo[1], lo[2], lo[3]);
     rec[2] = make_float4(lo[4], lo[5], hi[0], hi[1]);
     rec[3] = make_float4(hi[2], hi[3], hi[4], hi[5]);
   }
 }
 
-// ---- visiting order of the queries: key = ordinal (tree order) of the leaf that contains the
-// query point (a stackless best-child descent), then a counting sort on key >> shift.
+// Boxes of the inner nodes of one tree level (deepest level first): the union of the children's.
+__global__ void InnerBoxKernel(uint4 *__restrict__ nodes, const uint32_t *__restrict__ level_nodes, uint32_t count) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+    const uint64_t i = level_nodes[t];
+    float4 *rec = reinterpret_cast<float4 *>(nodes + i * 4);
+    const uint32_t c2 = nodes[i * 4].z;
+    const float4 *a = reinterpret_cast<const float4 *>(nodes + (i + 1) * 4);
+    const float4 *b = reinterpret_cast<const float4 *>(nodes + (uint64_t)c2 * 4);
+    const float4 a1 = a[1], a2 = a[2], a3 = a[3], b1 = b[1], b2 = b[2], b3 = b[3];
+    rec[1] = make_float4(fminf(a1.x, b1.x), fminf(a1.y, b1.y), fminf(a1.z, b1.z), fminf(a1.w, b1.w));
+    rec[2] = make_float4(fminf(a2.x, b2.x), fminf(a2.y, b2.y), fmaxf(a2.z, b2.z), fmaxf(a2.w, b2.w));
+    rec[3] = make_float4(fmaxf(a3.x, b3.x), fmaxf(a3.y, b3.y), fmaxf(a3.z, b3.z), fmaxf(a3.w, b3.w));
+  }
+}
+
+// ---- visiting order of the queries: key = pre-order index of the leaf that contains the query
+// point (a stackless best-child descent), then a counting sort on key >> shift.
 __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
                                uint32_t shift, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
-    uint32_t node = ix.root_ref;
-    while (!(node & kLeafTag)) {
-      const uint4 rec = ix.inner[(size_t)node * 2];
-      const uint32_t c2 = reinterpret_cast<const uint32_t *>(ix.inner + (size_t)node * 2)[4];
-      const float val = r.q[rec.x];
-      const float diff1 = val - __uint_as_float(rec.y), diff2 = val - __uint_as_float(rec.z);
-      node = (diff1 + diff2) < 0 ? rec.w : c2;
+    uint32_t node = 0;
+    for (;;) {
+      const uint4 rec = ix.nodes[(size_t)node * 4];
+      if (rec.w == 0xFFFFFFFFu) break;
+      const float val = r.q[rec.w];
+      const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
+      node = (diff1 + diff2) < 0 ? node + 1 : rec.z;
     }
-    const uint32_t key = (node & ~kLeafTag) >> shift;
+    const uint32_t key = node >> shift;
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
   }
@@ -425,34 +446,52 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 }
 
 constexpr int kLaneBlocksPerCU = 6;  // 6 x 256 threads = 24 waves per CU (<= 80 allocated VGPRs)
+constexpr int kScanThreshold = 8;    // blocked lanes of a wave that trigger a scan phase
 
-hipError_t LaunchWalk(smhip_ctx *ctx, uint32_t blocks_per_cu_param, const QueryRec *qrec,
-                      const uint32_t *n_queries_dev, uint32_t n_queries_host, const Sink &sink, float radius,
-                      const uint32_t *order) {
-  static int env_blocks = -1, xcd_ranges = 1;
+hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qrec, const uint32_t *n_queries_dev,
+                      uint32_t n_queries_host, const Sink &sink) {
+  static int env_blocks = -1, xcd_ranges = 1, env_thr = 0;
   if (env_blocks < 0) {
-    const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES");
+    const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES"),
+               *e3 = getenv("SMHIP_SCAN_THRESHOLD");
     env_blocks = e1 ? atoi(e1) : 0;
     if (e2) xcd_ranges = atoi(e2);
+    if (e3) env_thr = atoi(e3);
   }
-  int blocks_per_cu = blocks_per_cu_param ? (int)blocks_per_cu_param : (env_blocks ? env_blocks : kLaneBlocksPerCU);
+  int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
+  int thr = env_thr > 0 ? env_thr : kScanThreshold;
+  if (thr < 1) thr = 1;
+  if (thr > 64) thr = 64;
   const uint32_t blocks = 256 * blocks_per_cu;
   const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(SeedLaneKernel, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index,
-                     qrec, n_queries_dev, n_queries_host, sink, radius, ctx->walk_stack.as<float4>(), order,
-                     order ? xcd_ranges : 0);
+  if (p.reference_walk)
+    hipLaunchKernelGGL(SeedWalkKernel<true>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
+                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
+                       xcd_ranges, (uint32_t)thr);
+  else
+    hipLaunchKernelGGL(SeedWalkKernel<false>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
+                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
+                       xcd_ranges, (uint32_t)thr);
   return hipGetLastError();
 }
 }  // namespace
 
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *leaf_recs, uint64_t n_leaves, float *leaf_pts) {
+                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts) {
   if (dim != 6) return hipErrorInvalidValue;
   hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind,
-                     reinterpret_cast<uint4 *>(leaf_recs), n_leaves, leaf_pts);
+                     reinterpret_cast<uint4 *>(nodes), n_nodes, leaf_pts);
+  return hipGetLastError();
+}
+
+hipError_t LaunchInnerBoxes(smhip_ctx *ctx, void *nodes, const uint32_t *level_nodes, uint32_t count) {
+  if (count == 0) return hipSuccess;
+  const uint32_t blocks = std::min<uint32_t>((count + 255) / 256, 4096);
+  hipLaunchKernelGGL(InnerBoxKernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(nodes),
+                     level_nodes, count);
   return hipGetLastError();
 }
 
@@ -468,9 +507,9 @@ namespace {
 hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t *n_queries_dev,
                            uint32_t n_queries_host, uint64_t n_max, const uint32_t **order_out) {
   uint32_t bits = 1;
-  while ((1ull << bits) < ctx->index.n_leaves) ++bits;
+  while ((1ull << bits) < ctx->index.n_nodes) ++bits;
   const uint32_t shift = bits > 17 ? bits - 17 : 0;
-  const uint32_t n_buckets = (uint32_t)(ctx->index.n_leaves >> shift) + 1;
+  const uint32_t n_buckets = (uint32_t)(ctx->index.n_nodes >> shift) + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
   if ((e = ctx->q_order.Reserve(n_max * 32)) != hipSuccess) return e;
@@ -497,8 +536,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   const uint32_t *order = nullptr;
   hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
   if (e != hipSuccess) return e;
-  return LaunchWalk(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink,
-                    p.search_radius, order);
+  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -512,7 +550,6 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
   Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
-  return LaunchWalk(ctx, p.walk_blocks_per_cu, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink,
-                    p.search_radius, order);
+  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink);
 }
 }  // namespace smhip

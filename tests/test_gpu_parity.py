@@ -63,25 +63,30 @@ def test_events_edge_cases(device):
 
 # ------------------------------------------------------------------ seed lookup (A10)
 
-@pytest.mark.parametrize("blocks", [0, 1, 8])
-def test_seed_lookup_matches_oracle(device, small_world, oracle_tree, blocks):
+@pytest.mark.parametrize("blocks,strict", [(0, 0), (0, 1), (1, 0), (8, 1), (8, 0)])
+def test_seed_lookup_matches_oracle(device, small_world, oracle_tree, blocks, strict):
     qs = []
     for x in small_world["pa"][:12]:
         f, _ = po.generate_events(x)
         qs += [f[p:p + 6] for p in range(2, len(f) - 5, 2)]
     qs = np.array(qs, np.float32)
     device.params.walk_blocks_per_cu = blocks   # occupancy of the walker must not change results
+    device.params.reference_walk = strict       # nor may the box pruning: same hits, same order
     try:
         counts, idx, dist, nodes, pts = device.seed_lookup(qs, cap=1024)
     finally:
         device.params.walk_blocks_per_cu = 0
+        device.params.reference_walk = 0
     total = 0
     for k in range(len(qs)):
         n, oi, od, stt = oracle_tree.radius_search(qs[k], 0.08)
         assert counts[k] == n
         assert np.array_equal(idx[k, :n], oi)                      # traversal order, point ids
         assert np.array_equal(bits(dist[k, :n]), bits(od))
-        assert nodes[k] == stt[0] and pts[k] == stt[2]             # same nodes / points visited
+        if strict:
+            assert nodes[k] == stt[0] and pts[k] == stt[2]         # same nodes / points visited
+        else:
+            assert nodes[k] <= stt[0] and pts[k] <= stt[2]         # a subset of the reference's work
         total += n
     assert total > 1000
 
@@ -118,15 +123,17 @@ def _paf_lines(res, pa_list, names, ref_lens):
     return out
 
 
-@pytest.mark.parametrize("blocks", [0, 2])
-def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, blocks):
+@pytest.mark.parametrize("blocks,strict", [(0, 0), (2, 1), (2, 0)])
+def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, blocks, strict):
     pa, ix, ref_lens = small_world["pa"], small_world["ix"], small_world["ref_lens"]
     samples, offsets = _batch(pa)
     device.params.walk_blocks_per_cu = blocks
+    device.params.reference_walk = strict
     try:
         res = device.map_chunks(samples, offsets, n_refs=3)
     finally:
         device.params.walk_blocks_per_cu = 0
+        device.params.reference_walk = 0
     names = ["contig0", "contig1", "contig2"]
     lines = _paf_lines(res, pa, names, ref_lens)
     mapped = 0
@@ -135,7 +142,10 @@ def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, bloc
         assert res[i]["status"] == 0
         assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)   # cols 1-12 + every tag
         assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
-        assert res[i]["nodes_visited"] == m.stats.search.nodes and res[i]["points_tested"] == m.stats.search.points
+        if strict:   # the census mode counts exactly the reference's node visits / point tests
+            assert res[i]["nodes_visited"] == m.stats.search.nodes and res[i]["points_tested"] == m.stats.search.points
+        else:
+            assert res[i]["nodes_visited"] <= m.stats.search.nodes and res[i]["points_tested"] <= m.stats.search.points
         mapped += m.mapped
     assert mapped >= len(pa) - 2
     # mapped locus agrees with the generator's truth (sanity of the whole setup)
