@@ -210,6 +210,7 @@ def main():
                 "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
+                "walker_phase_stats": walker_stats(dev),
                 "sdtw_refined_fraction": (round(float((step.refined[1] >= 0).mean()), 4)
                                           if args.sdtw_band > 0 else None),
                 "index_build_s": round(t_build, 2),
@@ -233,6 +234,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     del keepalive
+
+
+def walker_stats(dev):
+    """Wave-iterations and mean active lanes of the walker's two phases in the last launch."""
+    c = dev.debug_counters()[8:16].view(np.uint64)
+    return {"walk_iters": int(c[0]), "walk_lanes": round(float(c[1]) / max(int(c[0]), 1), 1),
+            "scan_iters": int(c[2]), "scan_lanes": round(float(c[3]) / max(int(c[2]), 1), 1)}
 
 
 def dev_index_points(ix):

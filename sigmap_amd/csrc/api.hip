@@ -377,7 +377,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->n_groups.Reserve((uint64_t)R * sizeof(uint32_t)));
   HIPCHK(ctx->chain_tmp.Reserve((uint64_t)R * kChainCap * sizeof(ChainTmp)));
   HIPCHK(ctx->out_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
-  HIPCHK(ctx->counters.Reserve(16 * sizeof(uint32_t)));
+  HIPCHK(ctx->counters.Reserve(32 * sizeof(uint32_t)));
   smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
   {
     ScopedTimer t(ctx, T_EVENTS);
@@ -399,7 +399,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
   const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 64 + (1u << 22), 0xFFFF0000ull);
   HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
-  HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
   {
     ScopedTimer t(ctx, T_SEED);
@@ -703,9 +703,9 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   step(d_idx.Reserve(total * 8));
   step(d_dist.Reserve(total * 4));
   step(d_qrec.Reserve((uint64_t)n_queries * 32));
-  step(ctx->counters.Reserve(16 * sizeof(uint32_t)));
+  step(ctx->counters.Reserve(32 * sizeof(uint32_t)));
   if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+  if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   if (e == hipSuccess) {
     ScopedTimer t(ctx, T_SEED);
     step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, d_region.as<Hit>(), d_cnt.as<uint32_t>(),

@@ -81,7 +81,7 @@ struct Sink {
 // nanoflann.hpp:1006-1023 computeInitialDistances (low test, then high test, per dimension)
 #define SM_INIT_DIM(k, dk)                                    \
   {                                                           \
-    const float lo = ix.bbox[2 * k], hi = ix.bbox[2 * k + 1]; \
+    const float lo = root_box[2 * k], hi = root_box[2 * k + 1]; \
     if (q##k < lo) {                                          \
       dk = (q##k - lo) * (q##k - lo);                         \
       mind += dk;                                             \
@@ -122,28 +122,26 @@ __device__ __forceinline__ void EmitHit(const Sink &sink, uint32_t qi, uint32_t 
 }
 
 template <bool kStrict>
-__global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
+__global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem, int xcd_ranges,
                                                                uint32_t scan_threshold) {
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
-  uint32_t n_lanes = gridDim.x * kSeedThreads;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
-  uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
+  const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
-  uint32_t w = gl;
-  if (xcd_ranges) {
-    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
-    // never correctness).  Give each XCD one contiguous eighth of the visiting order so that its
-    // private L2 only has to hold that part of the tree.
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t per = (total + 7) / 8;
-    const uint32_t begin = min(total, xcd * per);
-    total = min(total, begin + per);
-    n_lanes = (gridDim.x >> 3) * kSeedThreads;
-    w = begin + slot * kSeedThreads + threadIdx.x;
-  }
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
+  // never correctness).  Each XCD starts on its own contiguous eighth of the visiting order so
+  // that its private L2 only has to hold that part of the tree.
+  const uint32_t n_ranges = xcd_ranges ? 8u : 1u;
+  const uint32_t first_range = xcd_ranges ? (blockIdx.x & 7u) : 0u;
+  const uint32_t per = (total + n_ranges - 1) / n_ranges;
+  uint32_t *cursors = sink.counters + 16;
+  float root_box[12];  // wave-uniform: kept in scalar registers
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    root_box[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[k])));
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
@@ -153,9 +151,27 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
   __shared__ float4 tos[2][2][kSeedThreads];
   // pending leaves of this lane's query, in the order they were reached: {boff, left}; n in fifo_n
   __shared__ uint2 fifo[kFifo][kSeedThreads];
+  // staging of the cooperative node fetch: 64 records x 64 B per wave
+  __shared__ uint4 stage[kSeedThreads / 64][256];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint4 *stage_w = stage[threadIdx.x >> 6];
   uint32_t tcnt = 0, thead = 0;
   uint32_t fifo_cnt = 0, fifo_n = 0;  // fifo_n: 8 bits of n per entry
   uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
+  uint32_t st_walk = 0, st_walk_lanes = 0, st_scan = 0, st_scan_lanes = 0;  // wave-uniform statistics
+#ifdef SM_PROF
+  uint64_t pf_fetch = 0, pf_wait = 0, pf_body = 0, ps_load = 0, ps_rest = 0;
+  const uint64_t pk0 = __builtin_amdgcn_s_memtime();
+#endif
+  // A load that would otherwise add a dependent round trip to an iteration is issued one
+  // iteration early and retires with the next node fetch: the newest spilled stack entry,
+  // whenever a pop leaves room in the LDS cache (rf_*).
+  float4 rf_a = make_float4(0, 0, 0, 0), rf_b = rf_a;
+  bool rf_pending = false;
+  // Queries are handed out dynamically, 64 at a time per wave, from one cursor per XCD range
+  // (a wave whose own range is exhausted takes from the other ranges), so that neither a lane nor
+  // a wave nor an XCD idles while another still has a backlog.
+  uint32_t pool_next = 0, pool_end = 0, victim = 0;
   for (;;) {
     const bool blocked = fifo_cnt == (uint32_t)kFifo || mode == M_DRAIN;
     const bool active = !blocked && mode != M_IDLE;
@@ -165,14 +181,26 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
     if (act == 0 || (uint32_t)__popcll(__ballot(blocked)) >= scan_threshold) {
       // ---- scan phase: every lane drains its FIFO (nanoflann.hpp:1350-1369, 391-406) ----
       uint32_t e = 0, j = 0;
-      while (__ballot(e < fifo_cnt)) {
+      for (;;) {
+        const uint64_t busy = __ballot(e < fifo_cnt);
+        if (!busy) break;
+        ++st_scan;
+        st_scan_lanes += (uint32_t)__popcll(busy);
         if (e < fifo_cnt) {
           const uint2 ent = fifo[e][threadIdx.x];
           const uint32_t n = (fifo_n >> (8 * e)) & 0xFFu;
           const uint4 *fh = pts4 + (size_t)ent.x + j;
           const uint4 *sh = fh + ((n + 7u) & ~7u);
-          const uint4 r0 = fh[0], r1 = fh[1], r2 = fh[2], r3 = fh[3];
-          const uint4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+#ifdef SM_PROF
+          const uint64_t ps0 = __builtin_amdgcn_s_memtime();
+#endif
+          uint4 r0 = fh[0], r1 = fh[1], r2 = fh[2], r3 = fh[3];
+          uint4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+#ifdef SM_PROF
+          asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x), "+v"(r3.x), "+v"(s0.x), "+v"(s1.x), "+v"(s2.x), "+v"(s3.x));
+          const uint64_t ps1 = __builtin_amdgcn_s_memtime();
+          ps_load += ps1 - ps0;
+#endif
           const uint32_t left_in_leaf = n - j;
 #define SM_POINT(rv, sv, t)                                                                   \
   if (left_in_leaf > (uint32_t)t) {                                                           \
@@ -201,6 +229,9 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
             ++e;
             j = 0;
           }
+#ifdef SM_PROF
+          ps_rest += __builtin_amdgcn_s_memtime() - ps1;
+#endif
         }
       }
       fifo_cnt = 0;
@@ -214,13 +245,38 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
       continue;
     }
     // ---- walk phase: one node visit per active lane ----
-    if (active && mode == M_FETCH) {
-      if (w >= total) {
-        mode = M_IDLE;
-      } else {
+    ++st_walk;
+    st_walk_lanes += (uint32_t)__popcll(act);
+#ifdef SM_PROF
+    const uint64_t pt0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint64_t need = __ballot(active && mode == M_FETCH); need;) {
+      if (pool_next >= pool_end) {  // wave-uniform: take the next 64 queries of a range
+        bool got = false;
+        while (victim < n_ranges) {
+          const uint32_t xx = (first_range + victim) % n_ranges;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&cursors[xx], 64u);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t rb = min(total, xx * per), re = min(total, rb + per);
+          if (base < re - rb) {
+            pool_next = rb + base;
+            pool_end = min(re, pool_next + 64u);
+            got = true;
+            break;
+          }
+          ++victim;
+        }
+        if (!got) {  // nothing left anywhere
+          if (active && mode == M_FETCH) mode = M_IDLE;
+          break;
+        }
+      }
+      const uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(need));
+      const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+      if (((need >> lane) & 1ull) && rank < take) {
         // records are already permuted into visiting order; the record's last word is the query id
-        const uint32_t ri = w;
-        w += n_lanes;
+        const uint32_t ri = pool_next + rank;
         const float4 a = *reinterpret_cast<const float4 *>(&qrec[ri]);
         const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
         qi = __float_as_uint(b.w);
@@ -232,10 +288,46 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
         node = 0; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
         mode = M_NODE;
       }
+      pool_next += take;
+      need = __ballot(active && mode == M_FETCH);
+    }
+#ifdef SM_PROF
+    uint64_t pt1 = 0, pt2 = 0;
+#endif
+    {
+      const uint32_t want = (active && mode == M_NODE) ? node : 0xFFFFFFFFu;
+#ifdef SM_PROF
+      pt1 = __builtin_amdgcn_s_memtime();
+#endif
+      uint32_t nsrc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        nsrc[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)r * 16u + (lane >> 2)) * 4u), (int)want);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t src = (uint32_t)r * 16u + (lane >> 2);
+        if (nsrc[r] != 0xFFFFFFFFu) {
+          const uint4 *g = ix.nodes + (size_t)nsrc[r] * 4 + ((lane & 3u) ^ ((src >> 2) & 3u));
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                           (__attribute__((address_space(3))) void *)(stage_w + r * 64), 16, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
+#ifdef SM_PROF
+      pt2 = __builtin_amdgcn_s_memtime();
+#endif
+    }
+    if (rf_pending) {  // the refill issued by the previous pop has landed too: it is the oldest cached entry
+      const uint32_t slot = tcnt == 0 ? thead : thead ^ 1u;
+      tos[slot][0][threadIdx.x] = rf_a;
+      tos[slot][1][threadIdx.x] = rf_b;
+      ++tcnt;
+      rf_pending = false;
     }
     if (active && mode == M_NODE) {
-      const uint4 *rec = ix.nodes + (size_t)node * 4;
-      const uint4 r = rec[0], b0 = rec[1], b1 = rec[2], b2 = rec[3];
+      const uint32_t rot = (lane >> 2) & 3u;
+      const uint4 *mine = stage_w + lane * 4;
+      const uint4 r = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
       // squared distance from the query to the node's tight box, accumulated like evalMetric
       // (nanoflann.hpp:391-406): a lower bound of every point's f32 distance (monotone ops)
 #define SM_BOX(qq, ll, hh) fmaxf(fmaxf((qq) - __uint_as_float(hh), __uint_as_float(ll) - (qq)), 0.0f)
@@ -322,9 +414,41 @@ __global__ __launch_bounds__(kSeedThreads, 6) void SeedWalkKernel(IndexView ix, 
           node = __float_as_uint(a.x);
           mind = a.y;
           d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
+          if (tcnt < 2 && sp > 0) {  // refill the cache from the spill area, without waiting
+            --sp;
+            rf_a = stk[2 * sp];
+            rf_b = stk[2 * sp + 1];
+            rf_pending = true;
+          }
         }
       }
     }
+#ifdef SM_PROF
+    {
+      const uint64_t pt3 = __builtin_amdgcn_s_memtime();
+      pf_fetch += (uint32_t)(pt1 - pt0);
+      pf_wait += (uint32_t)(pt2 - pt1);
+      pf_body += (uint32_t)(pt3 - pt2);
+    }
+#endif
+  }
+#ifdef SM_PROF
+  if (lane == 0) {
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(sink.counters + 8);
+    const unsigned long long dur = __builtin_amdgcn_s_memtime() - pk0;
+    atomicAdd(&st[0], 1ull);
+    atomicAdd(&st[1], dur);
+    atomicMax(&st[2], dur);
+    atomicAdd(&st[3], (unsigned long long)(dur > 30000000ull ? 1 : 0));
+  }
+  return;
+#endif
+  if (lane == 0) {  // occupancy statistics of the two phases (smhip_debug_counters)
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(sink.counters + 8);
+    atomicAdd(&st[0], (unsigned long long)st_walk);
+    atomicAdd(&st[1], (unsigned long long)st_walk_lanes);
+    atomicAdd(&st[2], (unsigned long long)st_scan);
+    atomicAdd(&st[3], (unsigned long long)st_scan_lanes);
   }
 }
 #undef SM_INIT_DIM
@@ -445,7 +569,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
   }
 }
 
-constexpr int kLaneBlocksPerCU = 6;  // 6 x 256 threads = 24 waves per CU (<= 80 allocated VGPRs)
+constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 8;    // blocked lanes of a wave that trigger a scan phase
 
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qrec, const uint32_t *n_queries_dev,
