@@ -103,7 +103,8 @@ typedef struct {
                                                   tight box of the points below the node */
   void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks at slot `boff`:
                                                   n x {v0..v3}, then n x {v4, v5, uint64 position} */
-  void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[m_size], original point index */
+  void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[slots / 2]: original point index of the
+                                                  point in first-half slot boff + t at (boff >> 1) + t */
   void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
 } smhip_index_dev;
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);

@@ -226,17 +226,21 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   HIPCHK(ctx->ix_nodes.Reserve(n_nodes * 64));
   HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
-  HIPCHK(ctx->ix_vind.Reserve(m_size * sizeof(uint32_t)));
+  ctx->leaf_vind_bytes = (n_slots / 2 + 32) * sizeof(uint32_t);
+  HIPCHK(ctx->ix_vind.Reserve(ctx->leaf_vind_bytes));
+  HIPCHK(hipMemsetAsync(ctx->ix_vind.p, 0, ctx->leaf_vind_bytes, ctx->stream));
   HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
   // staging copies of the original-order point cloud, freed after the leaf-major gather
-  DevBuf d_values, d_positions, d_levels;
+  DevBuf d_values, d_positions, d_levels, d_vind;
   HIPCHK(d_values.Reserve(n_points * sizeof(float)));
   hipError_t e = d_positions.Reserve(n_points * sizeof(uint64_t));
   if (e == hipSuccess) e = d_levels.Reserve(level_nodes.size() * sizeof(uint32_t));
+  if (e == hipSuccess) e = d_vind.Reserve(m_size * sizeof(uint32_t));
   auto cleanup = [&]() {
     d_values.Free();
     d_positions.Free();
     d_levels.Free();
+    d_vind.Free();
   };
   if (e != hipSuccess) {
     cleanup();
@@ -252,13 +256,13 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   } while (0)
   HIPCHK2(hipMemcpyAsync(d_values.p, values, n_points * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_positions.p, positions, n_points * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK2(hipMemcpyAsync(ctx->ix_vind.p, vind, m_size * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(d_vind.p, vind, m_size * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, h_nodes.data(), n_nodes * 64, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_levels.p, level_nodes.data(), level_nodes.size() * sizeof(uint32_t),
                          hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_bbox.p, root_bbox, 2 * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), ctx->ix_vind.as<uint32_t>(),
-                           ctx->ix_nodes.p, n_nodes, ctx->ix_pts.as<float>()));
+  HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), d_vind.as<uint32_t>(),
+                           ctx->ix_nodes.p, n_nodes, ctx->ix_pts.as<float>(), ctx->ix_vind.as<uint32_t>()));
   for (uint32_t d = max_depth + 1; d-- > 0;)
     HIPCHK2(LaunchInnerBoxes(ctx, ctx->ix_nodes.p, d_levels.as<uint32_t>() + level_start[d],
                              (uint32_t)(level_start[d + 1] - level_start[d])));
@@ -285,7 +289,7 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->leaf_pts = (void *)ctx->index.leaf_pts;
   out->leaf_pts_bytes = ctx->leaf_pts_bytes;
   out->leaf_vind = (void *)ctx->index.leaf_vind;
-  out->leaf_vind_bytes = ctx->index.m_size * sizeof(uint32_t);
+  out->leaf_vind_bytes = ctx->leaf_vind_bytes;
   out->bbox = (void *)ctx->index.bbox;
   out->bbox_bytes = 2 * ctx->dim * sizeof(float);
   return SMHIP_OK;
@@ -303,6 +307,7 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   ctx->index = IndexView{(const uint4 *)in->nodes, (const float *)in->leaf_pts, (const uint32_t *)in->leaf_vind,
                          (const float *)in->bbox, in->n_nodes, in->m_size};
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
+  ctx->leaf_vind_bytes = in->leaf_vind_bytes;
   ctx->have_index = true;
   ctx->index_owned = false;
   return SMHIP_OK;

@@ -39,7 +39,7 @@ struct IndexView {
   const uint4 *nodes;         // 4 x uint4 per tree node (pre-order): {divlow, divhigh, child2, feat} or
                               // {left, n, boff, 0xFFFFFFFF}, then lo[6], hi[6] of the node's tight box
   const float *leaf_pts;      // per-leaf 128-byte-aligned point blocks
-  const uint32_t *leaf_vind;  // [m_size] tree order -> original point index
+  const uint32_t *leaf_vind;  // [n_slots / 2] Hit.slot -> original point index
   const float *bbox;          // [12] low0, high0, ...
   uint64_t n_nodes, m_size;
 };
@@ -84,7 +84,7 @@ struct smhip_ctx {
   int dim = 0;
   smhip::IndexView index{};
   smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox;
-  uint64_t leaf_pts_bytes = 0;
+  uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   // batch inputs
   uint32_t n_chunks = 0;
   uint64_t n_samples = 0, n_carried = 0;
@@ -116,7 +116,8 @@ namespace smhip {
 // Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
 // launch status.
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts);
+                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts,
+                            uint32_t *slot_vind);
 hipError_t LaunchInnerBoxes(smhip_ctx *ctx, void *nodes, const uint32_t *level_nodes, uint32_t count);
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,

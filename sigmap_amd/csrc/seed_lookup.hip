@@ -15,6 +15,8 @@
 //              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte line.
 //              This replaces <= 20 scattered (vind -> 6 strided floats) gathers per leaf
 //              (sigmap_adaptor.h:94-97), and a hit needs no second lookup for its position.
+//   leaf_vind: uint32[n_slots / 2]: original point index of first-half slot s at [(boff >> 1) + t]
+//              (Hit.slot; only the per-stage test entry point reads it)
 //   qrec     : one 32-byte record per query: float q[6]; uint32 chunk; uint32 k
 //
 // The recursion of searchLevel is replaced by an explicit stack of pending "other child" visits
@@ -94,16 +96,12 @@ struct Sink {
 
 enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
 
-// Hit number `ord` of query `qi` (0-based, in traversal order): the first fast_cap hits go to the
-// query's own slots; later ones go to segments of the shared pool whose sizes double
-// (fast_cap, 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a
-// query with many hits never has to be searched twice.
-__device__ __forceinline__ void EmitHit(const Sink &sink, uint32_t qi, uint32_t ord, const Hit &h,
-                                        uint32_t &ovf_base) {
-  if (ord < sink.fast_cap) {
-    sink.region[(size_t)qi * sink.fast_cap + ord] = h;
-    return;
-  }
+// Hit number `ord` >= fast_cap of query `qi` (0-based, in traversal order; the first fast_cap hits
+// go to the query's own slots): segments of the shared pool whose sizes double (fast_cap,
+// 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a query with
+// many hits never has to be searched twice.  Called for one hit at a time in ordinal order.
+__device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint32_t ord, const Hit &h,
+                                             uint32_t &ovf_base) {
   const uint32_t k = ord - sink.fast_cap;
   const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
   const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
@@ -149,8 +147,9 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, qi = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
-  // pending leaves of this lane's query, in the order they were reached: {boff, left}; n in fifo_n
-  __shared__ uint2 fifo[kFifo][kSeedThreads];
+  // pending leaves of this lane's query, in the order they were reached: boff; n in fifo_n
+  __shared__ uint32_t fifo[kFifo][kSeedThreads];
+  __shared__ uint32_t ovf_lds[kSeedThreads];  // scan phase: overflow segment base of each lane's query
   // staging of the cooperative node fetch: 64 records x 64 B per wave
   __shared__ uint4 stage[kSeedThreads / 64][256];
   const uint32_t lane = threadIdx.x & 63u;
@@ -179,60 +178,105 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     const uint64_t pend = __ballot(fifo_cnt > 0);
     if (act == 0 && pend == 0) break;
     if (act == 0 || (uint32_t)__popcll(__ballot(blocked)) >= scan_threshold) {
-      // ---- scan phase: every lane drains its FIFO (nanoflann.hpp:1350-1369, 391-406) ----
-      uint32_t e = 0, j = 0;
-      for (;;) {
-        const uint64_t busy = __ballot(e < fifo_cnt);
-        if (!busy) break;
+      // ---- scan phase (nanoflann.hpp:1350-1369, 391-406): the pending leaves of all lanes are
+      // listed in (lane, arrival) order and scanned three per iteration, 21 lanes each, ONE POINT
+      // PER LANE (a leaf holds <= 20 points), so the loads of a leaf are one contiguous run and
+      // every lane that works tests a point.  A hit's ordinal within its query = the query's hits
+      // so far + hits of the same query in earlier leaves of this iteration + its rank among the
+      // leaf's hits (ballot), i.e. exactly the order in which searchLevel reports them.
+      const uint32_t c = fifo_cnt;
+      const uint64_t lt = (1ull << lane) - 1ull;
+      const uint64_t cb0 = __ballot(c & 1u), cb1 = __ballot(c & 2u), cb2 = __ballot(c & 4u);
+      const uint32_t my_first = (uint32_t)__popcll(cb0 & lt) + 2u * (uint32_t)__popcll(cb1 & lt) +
+                                4u * (uint32_t)__popcll(cb2 & lt);
+      const uint32_t n_ent = (uint32_t)__popcll(cb0) + 2u * (uint32_t)__popcll(cb1) + 4u * (uint32_t)__popcll(cb2);
+      uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {boff, owner lane | n << 8}
+      float4 *own_a = reinterpret_cast<float4 *>(stage_w + 128);  // [64] q0..q3 of the owning lane
+      uint4 *own_b = stage_w + 192;                                // [64] q4, q5, query id, hits so far
+#pragma unroll
+      for (int e = 0; e < kFifo; ++e)
+        if ((uint32_t)e < c)
+          ents[my_first + e] = make_uint2(fifo[e][threadIdx.x], lane | (((fifo_n >> (8 * e)) & 0xFFu) << 8));
+      if (c > 0) {
+        own_a[lane] = make_float4(q0, q1, q2, q3);
+        own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
+        ovf_lds[threadIdx.x] = ovf_base;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t grp = lane / 21u, t = lane - grp * 21u;  // lane 63: grp 3, idle
+      const uint32_t hits_word = 3;
+      for (uint32_t it = 0; it < n_ent; it += 3) {
         ++st_scan;
-        st_scan_lanes += (uint32_t)__popcll(busy);
-        if (e < fifo_cnt) {
-          const uint2 ent = fifo[e][threadIdx.x];
-          const uint32_t n = (fifo_n >> (8 * e)) & 0xFFu;
-          const uint4 *fh = pts4 + (size_t)ent.x + j;
-          const uint4 *sh = fh + ((n + 7u) & ~7u);
-#ifdef SM_PROF
-          const uint64_t ps0 = __builtin_amdgcn_s_memtime();
-#endif
-          uint4 r0 = fh[0], r1 = fh[1], r2 = fh[2], r3 = fh[3];
-          uint4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
-#ifdef SM_PROF
-          asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x), "+v"(r3.x), "+v"(s0.x), "+v"(s1.x), "+v"(s2.x), "+v"(s3.x));
-          const uint64_t ps1 = __builtin_amdgcn_s_memtime();
-          ps_load += ps1 - ps0;
-#endif
-          const uint32_t left_in_leaf = n - j;
-#define SM_POINT(rv, sv, t)                                                                   \
-  if (left_in_leaf > (uint32_t)t) {                                                           \
-    const float f0 = q0 - __uint_as_float(rv.x), f1 = q1 - __uint_as_float(rv.y);            \
-    const float f2 = q2 - __uint_as_float(rv.z), f3 = q3 - __uint_as_float(rv.w);            \
-    float res = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */               \
-    const float f4 = q4 - __uint_as_float(sv.x);                                              \
-    res += f4 * f4;                                                                           \
-    const float f5 = q5 - __uint_as_float(sv.y);                                              \
-    res += f5 * f5;                                                                           \
-    if (res < radius) { /* RadiusResultSet::addPoint */                                       \
-      const uint32_t ord = hits++;                                                            \
-      if (ord < sink.nnp) {                                                                   \
-        Hit h;                                                                                \
-        h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);                                 \
-        h.dist = res;                                                                         \
-        h.slot = ent.y + j + t;                                                               \
-        EmitHit(sink, qi, ord, h, ovf_base);                                                  \
-      }                                                                                       \
-    }                                                                                         \
-  }
-          SM_POINT(r0, s0, 0) SM_POINT(r1, s1, 1) SM_POINT(r2, s2, 2) SM_POINT(r3, s3, 3)
-#undef SM_POINT
-          j += 4;
-          if (j >= n) {
-            ++e;
-            j = 0;
-          }
-#ifdef SM_PROF
-          ps_rest += __builtin_amdgcn_s_memtime() - ps1;
-#endif
+        // the three entries of this iteration (uniform addresses: LDS broadcasts); a missing one
+        // repeats its predecessor with n = 0
+        const uint2 e0 = ents[it];
+        uint2 e1 = it + 1 < n_ent ? ents[it + 1] : make_uint2(e0.x, e0.y & 0xFFu);
+        uint2 e2 = it + 2 < n_ent ? ents[it + 2] : make_uint2(e1.x, e1.y & 0xFFu);
+        const uint2 mine = grp == 0 ? e0 : (grp == 1 ? e1 : e2);
+        const uint32_t owner = mine.y & 0xFFu, n = grp < 3 ? (mine.y >> 8) : 0u;
+        const bool pt = t < n;
+        st_scan_lanes += (uint32_t)__popcll(__ballot(pt));
+        bool hit = false;
+        float res = 0.0f;
+        uint4 sv = make_uint4(0, 0, 0, 0);
+        uint32_t oqi = 0;
+        if (pt) {
+          const uint4 *fh = pts4 + (size_t)mine.x + t;
+          const uint4 rv = fh[0];
+          sv = fh[(n + 7u) & ~7u];
+          const float4 oa = own_a[owner];
+          const uint4 ob = own_b[owner];
+          oqi = ob.z;
+          const float f0 = oa.x - __uint_as_float(rv.x), f1 = oa.y - __uint_as_float(rv.y);
+          const float f2 = oa.z - __uint_as_float(rv.z), f3 = oa.w - __uint_as_float(rv.w);
+          res = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */
+          const float f4 = __uint_as_float(ob.x) - __uint_as_float(sv.x);
+          res += f4 * f4;
+          const float f5 = __uint_as_float(ob.y) - __uint_as_float(sv.y);
+          res += f5 * f5;
+          hit = res < radius; /* RadiusResultSet::addPoint */
         }
+        const uint64_t hb = __ballot(hit);
+        const uint32_t m21 = 0x1FFFFFu;
+        const uint32_t c0 = (uint32_t)__popc((uint32_t)hb & m21), c1 = (uint32_t)__popc((uint32_t)(hb >> 21) & m21),
+                       c2 = (uint32_t)__popc((uint32_t)(hb >> 42) & m21);
+        const uint32_t o0 = e0.y & 0xFFu, o1 = e1.y & 0xFFu, o2 = e2.y & 0xFFu;
+        uint32_t *h0 = reinterpret_cast<uint32_t *>(&own_b[o0]) + hits_word;
+        uint32_t *h1 = reinterpret_cast<uint32_t *>(&own_b[o1]) + hits_word;
+        uint32_t *h2 = reinterpret_cast<uint32_t *>(&own_b[o2]) + hits_word;
+        const uint32_t base0 = *h0;
+        const uint32_t base1 = o1 == o0 ? base0 + c0 : *h1;
+        const uint32_t base2 = o2 == o1 ? base1 + c1 : *h2;
+        if (lane == 0) {  // in this order: equal owners end with the full sum
+          *h0 = base0 + c0;
+          *h1 = base1 + c1;
+          *h2 = base2 + c2;
+        }
+        const uint32_t ord = (grp == 0 ? base0 : (grp == 1 ? base1 : base2)) +
+                             (uint32_t)__popc((uint32_t)(hb >> (21u * grp)) & m21 & ((1u << t) - 1u));
+        Hit h;
+        h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);
+        h.dist = res;
+        h.slot = (mine.x >> 1) + t;
+        const bool emit = hit && ord < sink.nnp;
+        if (emit && ord < sink.fast_cap) sink.region[(size_t)oqi * sink.fast_cap + ord] = h;
+        // rare: hits beyond the query's own slots, one lane at a time in ordinal order
+        for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
+          if (lane == (uint32_t)__builtin_ctzll(ovm)) {
+            uint32_t ob = ovf_lds[(threadIdx.x & ~63u) + owner];
+            EmitOverflow(sink, oqi, ord, h, ob);
+            ovf_lds[(threadIdx.x & ~63u) + owner] = ob;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (c > 0) {
+        hits = own_b[lane].w;
+        ovf_base = ovf_lds[threadIdx.x];
       }
       fifo_cnt = 0;
       fifo_n = 0;
@@ -346,7 +390,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         if (kStrict) np += r.y;  // the reference evaluates every point of a visited leaf
         if (inside && r.y > 0) {
           if (!kStrict) np += r.y;
-          fifo[fifo_cnt][threadIdx.x] = make_uint2(r.z, r.x);
+          fifo[fifo_cnt][threadIdx.x] = r.z;
           fifo_n |= r.y << (8 * fifo_cnt);
           ++fifo_cnt;
         }
@@ -487,7 +531,7 @@ __global__ void QueryExpandRawKernel(const float *__restrict__ queries, uint32_t
 // point i is the window values[i..i+dim)), position = Point.position of the window's first element.
 __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_t *__restrict__ positions,
                                  const uint32_t *__restrict__ vind, uint4 *__restrict__ nodes,
-                                 uint64_t n_nodes, float *__restrict__ leaf_pts) {
+                                 uint64_t n_nodes, float *__restrict__ leaf_pts, uint32_t *__restrict__ slot_vind) {
   float4 *o = reinterpret_cast<float4 *>(leaf_pts);
   for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_nodes;
        k += (uint64_t)gridDim.x * blockDim.x) {
@@ -510,6 +554,7 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
         lo[d] = fminf(lo[d], p[d]);
         hi[d] = fmaxf(hi[d], p[d]);
       }
+      slot_vind[(size_t)(boff >> 1) + t] = v;  // Hit.slot -> original point index
       o[(size_t)boff + t] = make_float4(p[0], p[1], p[2], p[3]);
       o[(size_t)boff + rn + t] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
                                              __uint_as_float((uint32_t)(pos >> 32)));
@@ -604,10 +649,11 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qre
 }  // namespace
 
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts) {
+                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts,
+                            uint32_t *slot_vind) {
   if (dim != 6) return hipErrorInvalidValue;
   hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind,
-                     reinterpret_cast<uint4 *>(nodes), n_nodes, leaf_pts);
+                     reinterpret_cast<uint4 *>(nodes), n_nodes, leaf_pts, slot_vind);
   return hipGetLastError();
 }
 
