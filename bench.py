@@ -136,6 +136,13 @@ def main():
             step.refined = dev.refine_download()
         return res
 
+    # Census (untimed): one pass with the walker restricted to exactly nanoflann's node set, so
+    # that nodes_visited / points_tested count the REFERENCE's work on these inputs (SURVEY 8d:
+    # "counted on the actual inputs").  The timed passes skip subtrees whose tight box is out of
+    # range (same hits, same order) and therefore touch fewer bytes than the algorithmic figure.
+    dev.params.reference_walk = 1
+    census = step()
+    dev.params.reference_walk = 0
     for _ in range(args.warmup):
         res = step()
     dev.timing(True)
@@ -167,8 +174,10 @@ def main():
     if rank == 0:
         R = args.reads
         status_bad = int((res["status"] & ~np.uint32(1)).astype(bool).sum())
-        nodes = int(res["nodes_visited"].sum())
-        points = int(res["points_tested"].sum())
+        nodes = int(census["nodes_visited"].sum())
+        points = int(census["points_tested"].sum())
+        same = all(np.array_equal(census[k], res[k]) for k in census.dtype.names
+                   if k not in ("nodes_visited", "points_tested"))
         anchors = int(res["n_anchors"].sum())
         queries = int(res["n_queries"].sum())
         # B_chunk = 2*S + Q*(Nn*16 + Np*28) + 24*A + 64, counted on the actual inputs
@@ -206,6 +215,9 @@ def main():
                 "queries_per_chunk": round(queries / R, 2),
                 "nodes_per_query": round(nodes / max(queries, 1), 1),
                 "points_per_query": round(points / max(queries, 1), 1),
+                "walker_nodes_per_query": round(int(res["nodes_visited"].sum()) / max(queries, 1), 1),
+                "walker_points_per_query": round(int(res["points_tested"].sum()) / max(queries, 1), 1),
+                "census_results_identical": bool(same),
                 "anchors_per_chunk": round(anchors / R, 1),
                 "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
                 "chunks_with_capacity_flags": status_bad,

@@ -9,10 +9,11 @@
 // (spatial_index.cc:421-423), so the device produces ONE array per chunk ordered by
 // (group = ref*2 + strand, target, query, distance) plus the list of group boundaries.
 //
-// Method: 64-bit keys [group | target_position | unsorted index] sorted by a bitonic network
-// (in LDS when the padded count fits 16384 keys, otherwise in an HBM scratch region that
-// stays L2-resident for the workgroup), then runs of equal (group, target) - short - are
-// ordered by (query, distance) in place.  Every comparison key is total, so the result is
+// Method: 64-bit keys [group | target_position | unsorted index].  Up to 16384 keys per chunk are
+// sorted in LDS in two levels (counting sort into 256 buckets of a dense monotone key, then a
+// rank sort of every bucket by one wave); a chunk with a heavy bucket or more keys falls back to
+// a bitonic network (in LDS, or in an HBM scratch region that stays L2-resident).  Runs of equal
+// (group, target) - short - are then ordered by (query, distance) in place.  Every comparison key is total, so the result is
 // the unique sorted sequence the reference's std::sort produces.
 #include "common.h"
 
@@ -21,6 +22,8 @@ namespace {
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
 constexpr uint32_t kMaxQueriesPerChunk = (kFeatStride - 5) / 1 + 1;  // step >= 1
+constexpr uint32_t kBuckets = 256;    // buckets of the two-level sort
+constexpr uint32_t kMaxBucket = 512;  // largest bucket one wave rank-sorts (8 keys per lane)
 
 template <typename KeyPtr>
 __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t tid) {
@@ -45,7 +48,8 @@ __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t
 __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t gbits, uint32_t ibits) {
   extern __shared__ __align__(16) uint64_t lds_keys[];
   __shared__ uint32_t part[kSortThreads];
-  __shared__ uint32_t s_total;
+  __shared__ uint32_t hist[kBuckets + 1], bstart[kBuckets + 1];
+  __shared__ uint32_t s_maxt, s_maxb;
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const uint64_t base = a.anchor_off[c];
@@ -55,6 +59,8 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   if (tid == 0) {
     a.results[c].n_anchors = n;
     a.n_groups[c] = 0;
+    s_maxt = 0;
+    s_maxb = 0;
   }
   if (n == 0) return;
   if (n > (1u << ibits) || nq > kMaxQueriesPerChunk) {  // the key cannot index this many anchors
@@ -103,6 +109,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   constexpr uint32_t kPerThread = (kLdsKeys + kSortThreads - 1) / kSortThreads;  // 16
   uint64_t mykeys[kPerThread];
   const bool reg_keys = in_lds;  // LDS path: n <= kLdsKeys, so kPerThread registers suffice
+  uint32_t local_maxt = 0;
   for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) {
     uint32_t tpos, qpos, grp;
     float dist;
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       qpos = (k + 1) * a.step + qso;  // position + query_start_offset
       dist = hit.dist;
     }
+    local_maxt = max(local_maxt, tpos);
     u_tpos[i] = tpos;
     u_qpos[i] = qpos;
     u_dist[i] = dist;
@@ -147,15 +155,96 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
     if (reg_keys) mykeys[it] = key; else gkeys[i] = key;
   }
-  __syncthreads();  // everyone is done with the offsets
-  if (reg_keys) {
-    for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) lds_keys[i] = mykeys[it];
+  // ---- two-level sort (LDS path): counting sort of the keys into <= 256 buckets of the dense
+  // key grp * (max target + 1) + target (monotone in the key), then every bucket - a few dozen
+  // keys - is rank-sorted by one wave (keys are unique: rank = number of smaller keys), without
+  // workgroup barriers.  A chunk with a heavy bucket (many equal targets) takes the bitonic path.
+  bool bucketed = false;
+  if (in_lds) {
+    atomicMax(&s_maxt, local_maxt);
+    if (tid < kBuckets + 1) hist[tid] = 0;
+    __syncthreads();  // everyone is done with the offsets; s_maxt, hist ready
+    const uint64_t span = (uint64_t)s_maxt + 1ull;
+    const uint64_t range = span << gbits;  // dense keys are < range
+    const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
+    const uint32_t shift = rbits > 8u ? rbits - 8u : 0u;
+    uint32_t myb[kPerThread];
+    for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) {
+      const uint64_t key = mykeys[it];
+      const uint64_t dense = (key >> (32 + ibits)) * span + ((key >> ibits) & 0xFFFFFFFFull);
+      myb[it] = (uint32_t)(dense >> shift);
+      atomicAdd(&hist[myb[it]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 256 bucket sizes (first 256 threads, Hillis-Steele in `part`)
+    if (tid < kBuckets) {
+      part[tid] = hist[tid];
+      atomicMax(&s_maxb, hist[tid]);
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < kBuckets; d <<= 1) {
+      const uint32_t v = (tid < kBuckets && tid >= d) ? part[tid - d] : 0;
+      __syncthreads();
+      if (tid < kBuckets) part[tid] += v;
+      __syncthreads();
+    }
+    if (tid < kBuckets) {
+      bstart[tid] = part[tid] - hist[tid];
+      hist[tid] = 0;  // becomes the insertion cursor
+    }
+    if (tid == 0) bstart[kBuckets] = n;
+    __syncthreads();
+    bucketed = s_maxb <= kMaxBucket;
+    if (bucketed) {
+      for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it)
+        lds_keys[bstart[myb[it]] + atomicAdd(&hist[myb[it]], 1u)] = mykeys[it];
+      __syncthreads();
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      for (uint32_t b = wave; b < kBuckets; b += kSortThreads / 64) {
+        const uint32_t b0 = bstart[b], m = bstart[b + 1] - b0;
+        if (m < 2) continue;
+        if (m <= 64) {  // the common case: one key per lane
+          const uint64_t mine = lane < m ? lds_keys[b0 + lane] : ~0ull;
+          uint32_t rank = 0;
+          for (uint32_t x = 0; x < m; ++x) rank += lds_keys[b0 + x] < mine ? 1u : 0u;  // LDS broadcasts
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // all reads of the bucket precede the permuting writes
+          if (lane < m) lds_keys[b0 + rank] = mine;
+          continue;
+        }
+        uint64_t mine[kMaxBucket / 64];
+        uint32_t rank[kMaxBucket / 64];
+#pragma unroll
+        for (uint32_t r = 0; r < kMaxBucket / 64; ++r) {
+          mine[r] = lane + 64 * r < m ? lds_keys[b0 + lane + 64 * r] : ~0ull;
+          rank[r] = 0;
+        }
+        for (uint32_t x = 0; x < m; ++x) {
+          const uint64_t other = lds_keys[b0 + x];
+#pragma unroll
+          for (uint32_t r = 0; r < kMaxBucket / 64; ++r) rank[r] += other < mine[r] ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t r = 0; r < kMaxBucket / 64; ++r)
+          if (lane + 64 * r < m) lds_keys[b0 + rank[r]] = mine[r];
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();  // everyone is done with the offsets
   }
-  for (uint32_t i = n + tid; i < npad; i += kSortThreads) {
-    if (in_lds) lds_keys[i] = ~0ull; else gkeys[i] = ~0ull;
+  if (!bucketed) {
+    if (reg_keys) {
+      for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) lds_keys[i] = mykeys[it];
+    }
+    for (uint32_t i = n + tid; i < npad; i += kSortThreads) {
+      if (in_lds) lds_keys[i] = ~0ull; else gkeys[i] = ~0ull;
+    }
+    __syncthreads();
+    if (in_lds) BitonicSort(lds_keys, npad, tid); else BitonicSort(gkeys, npad, tid);
   }
-  __syncthreads();
-  if (in_lds) BitonicSort(lds_keys, npad, tid); else BitonicSort(gkeys, npad, tid);
 
   // ---- scatter into sorted order
   uint32_t *s_tpos = a.s_tpos + base, *s_qpos = a.s_qpos + base, *s_grp = a.s_grp + base;
@@ -210,7 +299,6 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       if (i == 0 || s_grp[i - 1] != s_grp[i]) gs[w++] = i;
     if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
   }
-  (void)s_total;
 }
 
 // anchors per chunk = carried + sum over its queries of min(hits, num_nearest_points); also the
