@@ -123,8 +123,9 @@ template <bool kStrict>
 __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
-                                                               float4 *__restrict__ stack_mem, int xcd_ranges,
-                                                               uint32_t scan_threshold) {
+                                                               float4 *__restrict__ stack_mem,
+                                                               const uint32_t *__restrict__ range_end,
+                                                               uint32_t range_stride, uint32_t scan_threshold) {
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
   // never correctness).  Each XCD starts on its own contiguous eighth of the visiting order so
   // that its private L2 only has to hold that part of the tree.
-  const uint32_t n_ranges = xcd_ranges ? 8u : 1u;
-  const uint32_t first_range = xcd_ranges ? (blockIdx.x & 7u) : 0u;
-  const uint32_t per = (total + n_ranges - 1) / n_ranges;
+  // (range_end[(r + 1) * range_stride - 1] = end of range r of the visiting order.)
+  const uint32_t n_ranges = range_end ? 8u : 1u;
+  const uint32_t first_range = range_end ? (blockIdx.x & 7u) : 0u;
   uint32_t *cursors = sink.counters + 16;
   float root_box[12];  // wave-uniform: kept in scalar registers
 #pragma unroll
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(&cursors[xx], 64u);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          const uint32_t rb = min(total, xx * per), re = min(total, rb + per);
+          const uint32_t rb = (range_end && xx) ? range_end[xx * range_stride - 1] : 0u;
+          const uint32_t re = range_end ? range_end[(xx + 1) * range_stride - 1] : total;
           if (base < re - rb) {
             pool_next = rb + base;
             pool_end = min(re, pool_next + 64u);
@@ -581,11 +583,18 @@ __global__ void InnerBoxKernel(uint4 *__restrict__ nodes, const uint32_t *__rest
   }
 }
 
-// ---- visiting order of the queries: key = pre-order index of the leaf that contains the query
-// point (a stackless best-child descent), then a counting sort on key >> shift.
+// ---- visiting order of the queries.  Bucket = pre-order index of the leaf that contains the
+// query point (a stackless best-child descent) >> shift; the buckets are cut into 8 equal ranges
+// (one per XCD), and inside a range the queries are visited in 4 cost classes, most expensive
+// first, each class in bucket order.  The class is |q|^2 (the windows are z-scored, so density -
+// and with it the number of nodes a search visits - falls with the distance from the origin:
+// measured correlation -0.8); visiting the cheap queries last keeps the tail of the launch, when
+// lanes run out of work one by one, short.  Counting sort on (range, class, bucket in range).
+constexpr uint32_t kCostClasses = 4;
 __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
-                               uint32_t shift, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
+                               uint32_t shift, uint32_t per_range, uint32_t *__restrict__ keys,
+                               uint32_t *__restrict__ hist) {
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
@@ -597,7 +606,11 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
       const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
       node = (diff1 + diff2) < 0 ? node + 1 : rec.z;
     }
-    const uint32_t key = node >> shift;
+    const uint32_t lb = node >> shift, range = lb / per_range;
+    const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
+                     r.q[5] * r.q[5];
+    const uint32_t cls = r2 < 2.2f ? 0u : (r2 < 3.8f ? 1u : (r2 < 6.2f ? 2u : 3u));
+    const uint32_t key = (range * kCostClasses + cls) * per_range + (lb - range * per_range);
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
   }
@@ -615,10 +628,10 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 }
 
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
-constexpr int kScanThreshold = 8;    // blocked lanes of a wave that trigger a scan phase
+constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
 
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qrec, const uint32_t *n_queries_dev,
-                      uint32_t n_queries_host, const Sink &sink) {
+                      uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride) {
   static int env_blocks = -1, xcd_ranges = 1, env_thr = 0;
   if (env_blocks < 0) {
     const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES"),
@@ -639,11 +652,11 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qre
   if (p.reference_walk)
     hipLaunchKernelGGL(SeedWalkKernel<true>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
                        n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
-                       xcd_ranges, (uint32_t)thr);
+                       xcd_ranges ? range_end : nullptr, range_stride, (uint32_t)thr);
   else
     hipLaunchKernelGGL(SeedWalkKernel<false>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
                        n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
-                       xcd_ranges, (uint32_t)thr);
+                       xcd_ranges ? range_end : nullptr, range_stride, (uint32_t)thr);
   return hipGetLastError();
 }
 }  // namespace
@@ -675,11 +688,13 @@ hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float 
 namespace {
 // Visiting order for the walker (see file header).  n_max bounds the query count.
 hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t *n_queries_dev,
-                           uint32_t n_queries_host, uint64_t n_max, const uint32_t **order_out) {
+                           uint32_t n_queries_host, uint64_t n_max, const uint32_t **order_out,
+                           const uint32_t **range_end_out, uint32_t *range_stride_out) {
   uint32_t bits = 1;
   while ((1ull << bits) < ctx->index.n_nodes) ++bits;
   const uint32_t shift = bits > 17 ? bits - 17 : 0;
-  const uint32_t n_buckets = (uint32_t)(ctx->index.n_nodes >> shift) + 1;
+  const uint32_t per_range = ((uint32_t)(ctx->index.n_nodes >> shift) + 8) / 8;  // leaf buckets per XCD range
+  const uint32_t n_buckets = 8 * kCostClasses * per_range + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
   if ((e = ctx->q_order.Reserve(n_max * 32)) != hipSuccess) return e;
@@ -687,11 +702,15 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
   uint32_t *hist = ctx->q_hist.as<uint32_t>(), *cursor = hist + n_buckets + 1;
   if ((e = hipMemsetAsync(hist, 0, (size_t)n_buckets * 4, ctx->stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(QueryKeyKernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->index, qrec, n_queries_dev,
-                     n_queries_host, shift, ctx->q_keys.as<uint32_t>(), hist);
+                     n_queries_host, shift, per_range, ctx->q_keys.as<uint32_t>(), hist);
   if ((e = LaunchScanU32(ctx, hist, n_buckets - 1, cursor)) != hipSuccess) return e;
   hipLaunchKernelGGL(QueryScatterKernel, dim3(2048), dim3(256), 0, ctx->stream, n_queries_dev, n_queries_host,
                      ctx->q_keys.as<uint32_t>(), cursor, qrec, ctx->q_order.as<QueryRec>());
   *order_out = ctx->q_order.as<uint32_t>();
+  // after the scatter cursor[k] = end of bucket k, so range r of the order ends at
+  // cursor[(r + 1) * kCostClasses * per_range - 1]
+  *range_end_out = cursor;
+  *range_stride_out = kCostClasses * per_range;
   return hipGetLastError();
 }
 }  // namespace
@@ -703,10 +722,12 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
             nullptr, counters, pool, ovf_tab, pool_cap};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
-  const uint32_t *order = nullptr;
-  hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order);
+  const uint32_t *order = nullptr, *range_end = nullptr;
+  uint32_t range_stride = 0;
+  hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order, &range_end, &range_stride);
   if (e != hipSuccess) return e;
-  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink);
+  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+                    range_stride);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -716,10 +737,11 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   hipLaunchKernelGGL(QueryExpandRawKernel, dim3(256), dim3(256), 0, ctx->stream, queries, n, qr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const uint32_t *order = nullptr;
-  if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order)) != hipSuccess) return e;
+  const uint32_t *order = nullptr, *range_end = nullptr;
+  uint32_t range_stride = 0;
+  if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
   Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
-  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink);
+  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
 }
 }  // namespace smhip
