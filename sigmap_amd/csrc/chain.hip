@@ -44,7 +44,7 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 
 constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
-constexpr int kBigGroupCap = 2048; // ... when they fit the LDS staging area (else lane-sequential)
+constexpr int kBigGroupCap = 1024; // ... staged in LDS when they fit (else the wave reads them from L2)
 
 // ---- C0: which anchors can be settled without the sequential DP?  One thread per anchor.
 // The predecessor scan of anchor i (spatial_index.cc:461-540) only looks at predecessor SCORES
@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
   __shared__ uint32_t s_gmax[kLdsGroups];  // positive floats order like their bit patterns
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_run;
+  __shared__ int32_t s_t[512], s_q[512];
+  __shared__ uint32_t s_g[512];
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
   const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
@@ -83,17 +85,30 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
   if (tid == 0) s_run = 0;
   __syncthreads();
   for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+    // the tile and the 256 anchors before it in LDS: the backward scans rarely leave that window
+    const uint32_t w0 = t0 >= 256 ? t0 - 256 : 0;
+    __syncthreads();
+    for (uint32_t k = tid; k < 512; k += 256) {
+      const uint32_t gi = w0 + k;
+      if (gi < n && gi < t0 + 256) {
+        s_t[k] = (int32_t)tpos[gi];
+        s_q[k] = (int32_t)qpos[gi];
+        s_g[k] = grp[gi];
+      }
+    }
+    __syncthreads();
     const uint32_t ai = t0 + tid;
     bool pend = false;
     if (ai < n) {
-      const uint32_t g = grp[ai];
-      const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
+      const uint32_t g = s_g[ai - w0];
+      const int32_t ct = s_t[ai - w0], cq = s_q[ai - w0];
       bool isolated = true;
       int32_t skips = 0;
       uint32_t steps = 0;
       for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-        if (grp[pj] != g) break;  // bucket start
-        const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
+        const bool in_lds = pj >= w0;
+        if ((in_lds ? s_g[pj - w0] : grp[pj]) != g) break;  // bucket start
+        const int32_t pt = in_lds ? s_t[pj - w0] : (int32_t)tpos[pj], pq = in_lds ? s_q[pj - w0] : (int32_t)qpos[pj];
         if (pq == cq || pt == ct) continue;
         if (pt + max_target_gap_length < ct) break;
         const int32_t td = ct - pt, qd = cq - pq;
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     p1 = lo2;
   }
   // a bucket with many unsettled anchors (the true locus of a read) goes to the wave-parallel kernel
-  if (p1 - p0 > (uint32_t)kBigPendingMin && e - s <= (uint32_t)kBigGroupCap) {
+  if (p1 - p0 > (uint32_t)kBigPendingMin) {
     big_list[atomicAdd(big_count, 1u)] = gi;
     continue;
   }
@@ -261,14 +276,101 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
 // target (spatial_index.cc:461-540) -- are reproduced with an exclusive prefix max (running
 // best), a prefix sum (num_skips) and ballots (first exit), which yields exactly the state the
 // sequential loop would have at its exit.
+template <bool kLds>
+__device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t s, const uint32_t *__restrict__ pend,
+                                            uint32_t npend, int32_t *l_t, int32_t *l_q, float *l_s, float *l_d,
+                                            const uint32_t *tpos, const uint32_t *qpos, const float *dist,
+                                            float *score, uint32_t *pred, float *gmax_slot, float radius, int dim,
+                                            int max_gap_length, int max_target_gap_length, int chaining_band_length,
+                                            int max_num_skips) {
+  float gm = *gmax_slot;  // maximum over the anchors the classify kernel settled
+  for (uint32_t pi = 0; pi < npend; ++pi) {
+    const uint32_t ai = pend[pi] - s;  // bucket-local index of the next unsettled anchor
+    const float coef = (float)(1 - 0.2 * (double)(kLds ? l_d[ai] : dist[ai]) / (double)radius);
+    float best = coef * (float)dim;
+    uint32_t best_pred = ai;
+    const int32_t ct = kLds ? l_t[ai] : (int32_t)tpos[ai], cq = kLds ? l_q[ai] : (int32_t)qpos[ai];
+    int32_t start_idx = 0;
+    if (ai > (uint32_t)chaining_band_length) start_idx = (int32_t)ai - chaining_band_length;
+    int32_t num_skips = 0;
+    for (int32_t pj0 = (int32_t)ai - 1; pj0 >= start_idx; pj0 -= 64) {
+      const int32_t pj = pj0 - (int32_t)lane;
+      const bool in_range = pj >= start_idx;
+      int cls = 0;  // 0 = end of range / target-gap exit, 1 = `continue`, 3 = evaluated
+      float cur = 0.0f;
+      if (in_range) {
+        const int32_t pt = kLds ? l_t[pj] : (int32_t)tpos[pj], pq = kLds ? l_q[pj] : (int32_t)qpos[pj];
+        if (pq == cq || pt == ct) {
+          cls = 1;
+        } else if (pt + max_target_gap_length < ct) {
+          cls = 0;
+        } else {
+          const int32_t td = ct - pt, qd = cq - pq;
+          if (qd < 0) {
+            cls = 1;
+          } else {
+            cls = 3;
+            const int32_t m = min(min(td, qd), dim);
+            const float matching = (float)m * coef;
+            const int gap_length = abs(td - qd);
+            const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+            if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f)
+              cur = (kLds ? l_s[pj] : score[pj]) + matching;
+          }
+        }
+      }
+      const bool ev = cls == 3;
+      // running best before each lane: max(best, evaluated candidates of earlier lanes)
+      float v = ev ? cur : -FLT_MAX;
+      for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v = fmaxf(v, o);
+      }
+      float before = __shfl_up(v, 1, 64);
+      if (lane == 0) before = -FLT_MAX;
+      before = fmaxf(before, best);
+      const bool improved = ev && cur > before;
+      int delta = ev ? (improved ? -1 : 1) : 0;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(delta, d, 64);
+        if ((int)lane >= d) delta += o;
+      }
+      const int ns_after = num_skips + delta;  // num_skips after this lane's step
+      const unsigned long long m_end = __ballot(cls == 0);
+      const unsigned long long m_skip = __ballot(ev && !improved && ns_after > max_num_skips);
+      const int l_end = m_end ? __ffsll((long long)m_end) - 1 : 64;    // exclusive exit
+      const int l_skip = m_skip ? __ffsll((long long)m_skip) - 1 : 64;  // inclusive exit
+      const int last_valid = min(l_end - 1, l_skip);                    // last lane whose step counts
+      unsigned long long m_imp = __ballot(improved);
+      if (last_valid < 63) m_imp &= (last_valid < 0) ? 0ull : ((2ull << last_valid) - 1ull);
+      if (m_imp) {
+        const int l_last = 63 - __clzll((long long)m_imp);
+        best = __shfl(cur, l_last, 64);
+        best_pred = (uint32_t)(pj0 - l_last);
+      }
+      if (l_end < 64 || l_skip < 64) break;
+      num_skips = __shfl(ns_after, 63, 64);
+    }
+    if (lane == 0) {
+      if (kLds) l_s[ai] = best;
+      score[ai] = best;
+      pred[ai] = s + best_pred;  // chunk-local absolute index
+    }
+    gm = fmaxf(gm, best);
+    __syncthreads();  // (one wave per workgroup) the new score is visible to the next anchor's scan
+    if (!kLds) __threadfence_block();
+  }
+  if (lane == 0) *gmax_slot = gm;
+}
+
 __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ goff,
                                                        uint32_t n_chunks, float radius, int dim, int max_gap_length,
                                                        int max_target_gap_length, int chaining_band_length,
                                                        int max_num_skips, const uint32_t *__restrict__ big_list,
-                                                       const uint32_t *__restrict__ big_count) {
+                                                       const uint32_t *__restrict__ big_count,
+                                                       const uint32_t *__restrict__ n_pending) {
   __shared__ int32_t l_t[kBigGroupCap], l_q[kBigGroupCap];
   __shared__ float l_s[kBigGroupCap], l_d[kBigGroupCap];
-  __shared__ uint8_t l_f[kBigGroupCap];
   const uint32_t lane = threadIdx.x;
   const uint32_t nbig = *big_count;
   for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
@@ -291,102 +393,45 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
     uint32_t *pred = a.pred + base + s;
     uint8_t *used = a.used + base + s;
     float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
+    // this bucket's slice of the chunk's pending list (sorted by anchor index)
+    const uint32_t *pending = a.pending + base;
+    const uint32_t npend = n_pending[c];
+    uint32_t p0, p1;
+    {
+      uint32_t lo2 = 0, hi2 = npend;
+      while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
+      p0 = lo2;
+      hi2 = npend;
+      while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < e) lo2 = mid + 1; else hi2 = mid; }
+      p1 = lo2;
+    }
+    const bool in_lds = ng <= (uint32_t)kBigGroupCap;
     __syncthreads();
     for (uint32_t i = lane; i < ng; i += 64) {
-      l_t[i] = (int32_t)tpos[i];
-      l_q[i] = (int32_t)qpos[i];
-      l_d[i] = dist[i];
-      l_f[i] = used[i];
-      l_s[i] = score[i];  // valid for the anchors the classify kernel settled
+      if (in_lds) {
+        l_t[i] = (int32_t)tpos[i];
+        l_q[i] = (int32_t)qpos[i];
+        l_d[i] = dist[i];
+        l_s[i] = score[i];  // valid for the anchors the classify kernel settled
+      }
       used[i] = 0;
     }
     __syncthreads();
-    float gm = 0.0f;
-    for (uint32_t ai = 0; ai < ng; ++ai) {
-      if (l_f[ai] != 2) {  // settled: its own start score, itself as predecessor
-        gm = fmaxf(gm, l_s[ai]);
-        continue;
-      }
-      const float coef = (float)(1 - 0.2 * (double)l_d[ai] / (double)radius);
-      float best = coef * (float)dim;
-      uint32_t best_pred = ai;
-      const int32_t ct = l_t[ai], cq = l_q[ai];
-      int32_t start_idx = 0;
-      if (ai > (uint32_t)chaining_band_length) start_idx = (int32_t)ai - chaining_band_length;
-      int32_t num_skips = 0;
-      for (int32_t pj0 = (int32_t)ai - 1; pj0 >= start_idx; pj0 -= 64) {
-        const int32_t pj = pj0 - (int32_t)lane;
-        const bool in_range = pj >= start_idx;
-        int cls = 0;  // 0 = end of range / target-gap exit, 1 = `continue`, 3 = evaluated
-        float cur = 0.0f;
-        if (in_range) {
-          const int32_t pt = l_t[pj], pq = l_q[pj];
-          if (pq == cq || pt == ct) {
-            cls = 1;
-          } else if (pt + max_target_gap_length < ct) {
-            cls = 0;
-          } else {
-            const int32_t td = ct - pt, qd = cq - pq;
-            if (qd < 0) {
-              cls = 1;
-            } else {
-              cls = 3;
-              const int32_t m = min(min(td, qd), dim);
-              const float matching = (float)m * coef;
-              const int gap_length = abs(td - qd);
-              const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-              if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) cur = l_s[pj] + matching;
-            }
-          }
-        }
-        const bool ev = cls == 3;
-        // running best before each lane: max(best, evaluated candidates of earlier lanes)
-        float v = ev ? cur : -FLT_MAX;
-        for (int d = 1; d < 64; d <<= 1) {
-          const float o = __shfl_up(v, d, 64);
-          if ((int)lane >= d) v = fmaxf(v, o);
-        }
-        float before = __shfl_up(v, 1, 64);
-        if (lane == 0) before = -FLT_MAX;
-        before = fmaxf(before, best);
-        const bool improved = ev && cur > before;
-        int delta = ev ? (improved ? -1 : 1) : 0;
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(delta, d, 64);
-          if ((int)lane >= d) delta += o;
-        }
-        const int ns_after = num_skips + delta;  // num_skips after this lane's step
-        const unsigned long long m_end = __ballot(cls == 0);
-        const unsigned long long m_skip = __ballot(ev && !improved && ns_after > max_num_skips);
-        const int l_end = m_end ? __ffsll((long long)m_end) - 1 : 64;    // exclusive exit
-        const int l_skip = m_skip ? __ffsll((long long)m_skip) - 1 : 64;  // inclusive exit
-        const int last_valid = min(l_end - 1, l_skip);                    // last lane whose step counts
-        unsigned long long m_imp = __ballot(improved);
-        if (last_valid < 63) m_imp &= (last_valid < 0) ? 0ull : ((2ull << last_valid) - 1ull);
-        if (m_imp) {
-          const int l_last = 63 - __clzll((long long)m_imp);
-          best = __shfl(cur, l_last, 64);
-          best_pred = (uint32_t)(pj0 - l_last);
-        }
-        if (l_end < 64 || l_skip < 64) break;
-        num_skips = __shfl(ns_after, 63, 64);
-      }
-      if (lane == 0) {
-        l_s[ai] = best;
-        score[ai] = best;
-        pred[ai] = s + best_pred;  // chunk-local absolute index
-      }
-      gm = fmaxf(gm, best);
-      __syncthreads();
-    }
-    if (lane == 0) gmax[g] = gm;
+    if (in_lds)
+      DpBigBucket<true>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, &gmax[g],
+                        radius, dim, max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
+    else
+      DpBigBucket<false>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred,
+                         &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length,
+                         max_num_skips);
   }
 }
 
 // ---- C2: one wave per chunk: running max_chaining_score across buckets (spatial_index.cc:420,
 // 542-549), chain ends, traceback (spatial_index.cc:165-220, 552-568)
 __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_anchors, int num_best_chains,
-                                                      float min_chaining_score, uint32_t *__restrict__ n_chains_out) {
+                                                      float min_chaining_score, uint32_t *__restrict__ n_chains_out,
+                                                      const uint32_t *__restrict__ n_pending, int dim) {
   __shared__ uint32_t s_nchains;
   const uint32_t c = blockIdx.x;
   const uint32_t lane = threadIdx.x;
@@ -408,6 +453,9 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
   uint32_t *lists = a.lists + base;
   float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
   float *pmax = gmax + n;
+  const uint32_t *pending = a.pending + base;
+  const uint32_t npend = n_pending[c];
+  const bool pending_only = min_chaining_score > (float)dim;
   // max_chaining_score on entry to each bucket = max over all earlier buckets (order ref0+,
   // ref0-, ref1+, ...; initial value 0): exclusive prefix max by wave shuffles, 64 at a time.
   {
@@ -431,28 +479,45 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
     float run_max = pmax[g];  // max_chaining_score on entry to this bucket
     Cand top[3];
     uint32_t ntop = 0;
-    for (uint32_t a0 = s; a0 < e; a0 += kPf) {
-      float sc8[kPf];
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) sc8[k] = a0 + k < e ? score[a0 + k] : 0.0f;
-#pragma unroll
-      for (int k = 0; k < kPf; ++k) {
-        const uint32_t ai = a0 + k;
+    auto consider = [&](uint32_t ai, float sc) {
+      if (sc > run_max) run_max = sc;
+      if (sc >= min_chaining_score && sc > run_max / 2) {  // spatial_index.cc:545-549
+        Cand cnd{sc, ai - s};
+        uint32_t pos = ntop;  // keep the best three in sorted order (num_best_chains <= 3)
+        while (pos > 0 && CandBefore(cnd, top[pos - 1])) --pos;
+        if (pos < 3) {
+          for (uint32_t kk = (ntop < 3 ? ntop : 2); kk > pos; --kk) top[kk] = top[kk - 1];
+          top[pos] = cnd;
+          if (ntop < 3) ++ntop;
+        }
+      }
+    };
+    if (pending_only) {
+      // Settled anchors score at most `dim` (their own start score) < min_chaining_score: none is
+      // a chain end, and a running maximum they alone raised is <= dim, so it cannot fail the
+      // `sc > max / 2` test of a candidate (sc >= min_chaining_score > dim).  Only the anchors the
+      // DP kernels scored need to be looked at.
+      uint32_t lo2 = 0, hi2 = npend;
+      while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
+      for (uint32_t pi = lo2; pi < npend; ++pi) {
+        const uint32_t ai = pending[pi];
         if (ai >= e) break;
-        const float sc = sc8[k];
-        if (sc > run_max) run_max = sc;
-        if (sc >= min_chaining_score && sc > run_max / 2) {  // spatial_index.cc:545-549
-          Cand cnd{sc, ai - s};
-          uint32_t pos = ntop;  // keep the best three in sorted order (num_best_chains <= 3)
-          while (pos > 0 && CandBefore(cnd, top[pos - 1])) --pos;
-          if (pos < 3) {
-            for (uint32_t kk = (ntop < 3 ? ntop : 2); kk > pos; --kk) top[kk] = top[kk - 1];
-            top[pos] = cnd;
-            if (ntop < 3) ++ntop;
-          }
+        consider(ai, score[ai]);
+      }
+    } else {
+      for (uint32_t a0 = s; a0 < e; a0 += kPf) {
+        float sc8[kPf];
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) sc8[k] = a0 + k < e ? score[a0 + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) {
+          const uint32_t ai = a0 + k;
+          if (ai >= e) break;
+          consider(ai, sc8[k]);
         }
       }
     }
+    run_max = fmaxf(run_max, gmax[g]);  // (the bucket maximum includes the settled anchors)
     const float max_after = run_max;  // max_chaining_score after the bucket
     const uint32_t grp_id = grp[s];
     const uint32_t ref = grp_id >> 1;
@@ -519,7 +584,13 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
   const float *dist = a.s_dist + base;
   const uint32_t *lists = a.lists + base;
   smhip_chunk_result &res = a.results[c];
-  ChainTmp *ch = a.chain_tmp + (size_t)c * kChainCap;
+  __shared__ ChainTmp ch[kChainCap];  // the chunk's candidate chains, staged for lane 0's ordering
+  {
+    const ChainTmp *gch = a.chain_tmp + (size_t)c * kChainCap;
+    const uint32_t nch0 = min(n_chains_in[c], (uint32_t)kChainCap);
+    for (uint32_t i = lane; i < nch0; i += 64) ch[i] = gch[i];
+  }
+  __syncthreads();
   if (lane == 0) {
     uint32_t nch = n_chains_in[c];
     if (nch > (uint32_t)kChainCap) {
@@ -680,9 +751,9 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
                        big_list, big_count, n_pending);
   hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
                      kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
-                     big_list, big_count);
+                     big_list, big_count, n_pending);
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
-                     p.num_best_chains, p.min_chaining_score, n_chains);
+                     p.num_best_chains, p.min_chaining_score, n_chains, n_pending, kMaxDim);
   hipLaunchKernelGGL(ChainFinalizeKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);
   return hipGetLastError();
 }
