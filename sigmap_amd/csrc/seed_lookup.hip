@@ -159,10 +159,6 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   uint32_t fifo_cnt = 0, fifo_n = 0;  // fifo_n: 8 bits of n per entry
   uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
   uint32_t st_walk = 0, st_walk_lanes = 0, st_scan = 0, st_scan_lanes = 0;  // wave-uniform statistics
-#ifdef SM_PROF
-  uint64_t pf_fetch = 0, pf_wait = 0, pf_body = 0, ps_load = 0, ps_rest = 0;
-  const uint64_t pk0 = __builtin_amdgcn_s_memtime();
-#endif
   // A load that would otherwise add a dependent round trip to an iteration is issued one
   // iteration early and retires with the next node fetch: the newest spilled stack entry,
   // whenever a pop leaves room in the LDS cache (rf_*).
@@ -292,9 +288,6 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     // ---- walk phase: one node visit per active lane ----
     ++st_walk;
     st_walk_lanes += (uint32_t)__popcll(act);
-#ifdef SM_PROF
-    const uint64_t pt0 = __builtin_amdgcn_s_memtime();
-#endif
     for (uint64_t need = __ballot(active && mode == M_FETCH); need;) {
       if (pool_next >= pool_end) {  // wave-uniform: take the next 64 queries of a range
         bool got = false;
@@ -337,14 +330,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       pool_next += take;
       need = __ballot(active && mode == M_FETCH);
     }
-#ifdef SM_PROF
-    uint64_t pt1 = 0, pt2 = 0;
-#endif
     {
       const uint32_t want = (active && mode == M_NODE) ? node : 0xFFFFFFFFu;
-#ifdef SM_PROF
-      pt1 = __builtin_amdgcn_s_memtime();
-#endif
       uint32_t nsrc[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -359,9 +346,6 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
-#ifdef SM_PROF
-      pt2 = __builtin_amdgcn_s_memtime();
-#endif
     }
     if (rf_pending) {  // the refill issued by the previous pop has landed too: it is the oldest cached entry
       const uint32_t slot = tcnt == 0 ? thead : thead ^ 1u;
@@ -397,22 +381,25 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           ++fifo_cnt;
         }
       } else if (kStrict || inside) {  // nanoflann.hpp:1371-1408; r = {divlow, divhigh, child2, feat}
-        const int idx = (int)r.w;
-        const float val = idx == 0 ? q0 : idx == 1 ? q1 : idx == 2 ? q2 : idx == 3 ? q3 : idx == 4 ? q4 : q5;
+        const uint32_t idx = r.w;
+        // q[idx], dists[idx]: a balanced tree of bit-selects (v_bfi_b32) on the bits of idx, 5 per
+        // value; written on integers so that the compiler keeps them branch-free
+        const uint32_t m0 = 0u - (idx & 1u), m1 = 0u - ((idx >> 1) & 1u), m2 = 0u - ((idx >> 2) & 1u);
+#define SM_SEL(m, a, b) (((m) & (a)) | (~(m) & (b))) /* m ? a : b */
+#define SM_PICK(x0, x1, x2, x3, x4, x5)                                                                  \
+  SM_SEL(m2, SM_SEL(m0, __float_as_uint(x5), __float_as_uint(x4)),                                       \
+         SM_SEL(m1, SM_SEL(m0, __float_as_uint(x3), __float_as_uint(x2)),                                \
+                SM_SEL(m0, __float_as_uint(x1), __float_as_uint(x0))))
+        const float val = __uint_as_float(SM_PICK(q0, q1, q2, q3, q4, q5));
+        const float dst = __uint_as_float(SM_PICK(d0, d1, d2, d3, d4, d5));
+#undef SM_PICK
+#undef SM_SEL
         const float divlow = __uint_as_float(r.x), divhigh = __uint_as_float(r.y);
         const float diff1 = val - divlow, diff2 = val - divhigh;
-        uint32_t next, other;
-        float cut;
-        if ((diff1 + diff2) < 0) {
-          next = node + 1;
-          other = r.z;
-          cut = (val - divhigh) * (val - divhigh);
-        } else {
-          next = r.z;
-          other = node + 1;
-          cut = (val - divlow) * (val - divlow);
-        }
-        const float dst = idx == 0 ? d0 : idx == 1 ? d1 : idx == 2 ? d2 : idx == 3 ? d3 : idx == 4 ? d4 : d5;
+        const bool low_side = (diff1 + diff2) < 0;
+        const uint32_t next = low_side ? node + 1 : r.z, other = low_side ? r.z : node + 1;
+        const float dcut = low_side ? diff2 : diff1;
+        const float cut = dcut * dcut;
         const float nm = mind + cut - dst;
         if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
           if (sp + tcnt < (uint32_t)kStackDepth) {
@@ -424,9 +411,12 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
             } else {
               ++tcnt;
             }
-            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, idx == 0 ? cut : d0, idx == 1 ? cut : d1);
-            tos[slot][1][threadIdx.x] = make_float4(idx == 2 ? cut : d2, idx == 3 ? cut : d3, idx == 4 ? cut : d4,
-                                                    idx == 5 ? cut : d5);
+            // the entry is the current dists with dists[idx] = cut: written whole, then one word
+            // replaced (words 2..7 of the entry are dists[0..5])
+            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, d0, d1);
+            tos[slot][1][threadIdx.x] = make_float4(d2, d3, d4, d5);
+            const uint32_t word = idx + 2u;
+            reinterpret_cast<float *>(&tos[slot][word >> 2][threadIdx.x])[word & 3u] = cut;
             thead = slot;
           } else {
             atomicOr(&sink.counters[0], 1u);
@@ -469,26 +459,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         }
       }
     }
-#ifdef SM_PROF
-    {
-      const uint64_t pt3 = __builtin_amdgcn_s_memtime();
-      pf_fetch += (uint32_t)(pt1 - pt0);
-      pf_wait += (uint32_t)(pt2 - pt1);
-      pf_body += (uint32_t)(pt3 - pt2);
-    }
-#endif
   }
-#ifdef SM_PROF
-  if (lane == 0) {
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(sink.counters + 8);
-    const unsigned long long dur = __builtin_amdgcn_s_memtime() - pk0;
-    atomicAdd(&st[0], 1ull);
-    atomicAdd(&st[1], dur);
-    atomicMax(&st[2], dur);
-    atomicAdd(&st[3], (unsigned long long)(dur > 30000000ull ? 1 : 0));
-  }
-  return;
-#endif
   if (lane == 0) {  // occupancy statistics of the two phases (smhip_debug_counters)
     unsigned long long *st = reinterpret_cast<unsigned long long *>(sink.counters + 8);
     atomicAdd(&st[0], (unsigned long long)st_walk);
