@@ -51,7 +51,7 @@ def main(tag):
         w.writerow(["kernel"] + counters)
         for k in sorted(per, key=lambda k: -per[k].get("SQ_WAVE_CYCLES", 0)):
             w.writerow([k] + ["%.6g" % per[k].get(c, float("nan")) for c in counters])
-    seed = next((k for k in per if k.startswith("SeedLaneKernel")), None)
+    seed = next((k for k in per if k.startswith("SeedWalkKernel<false>")), None)
     out = {}
     if seed and "FETCH_SIZE" in per[seed]:
         fetch_kb, write_kb = per[seed]["FETCH_SIZE"], per[seed].get("WRITE_SIZE", 0.0)
