@@ -272,6 +272,15 @@ def test_full_size_properties():
     dev.params.walk_blocks_per_cu = 2
     c = dev.map_chunks(samples, offsets, n_refs=16)
     assert a.tobytes() == c.tobytes()
+    dev.params.walk_blocks_per_cu = 0
+    dev.params.reference_walk = 1   # nanoflann's exact node set: same records, larger work counters
+    r = dev.map_chunks(samples, offsets, n_refs=16)
+    dev.params.reference_walk = 0
+    for k in a.dtype.names:
+        if k in ("nodes_visited", "points_tested"):
+            assert (r[k] >= a[k]).all() and r[k].sum() > a[k].sum()
+        else:
+            assert np.array_equal(r[k], a[k]), k
     assert (a["status"] == 0).all()
     c0 = a["chains"][:, 0]
     ok = (a["n_chains"] > 0) & (c0["ref"] == truth["contig"]) & ((c0["direction"] == 1) == (truth["strand"] == 0))
@@ -285,6 +294,39 @@ def test_full_size_properties():
         m = po.map_read(tree, ix.positions, pa[i], 16, ref_lens)
         assert lines[k] == po.format_paf(m, "read%d" % k, names, ref_lens)
     tree.close(); dev.close()
+
+
+def test_band_sweep_properties():
+    """BASELINE configs[3] shape (one 4.6 Mb contig, band 32/64/128) on 4000 reads: a wider band
+    admits a superset of warping paths, so the refined distance can only shrink, and the mapping
+    records do not depend on the refinement at all."""
+    genome = synth.make_genome(11, [4600000])
+    lm = synth.make_pore_model()
+    raw, truth = synth.simulate_reads(genome, lm, 4000, 77)
+    ix = pipeline.HostIndex.build(genome, lm, threads=0)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    ref_sig, ref_off = pipeline.reference_signals(genome, lm)
+    dev.upload_reference(ref_sig, ref_off)
+    pa = [pipeline.raw_to_pa(x, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for x in raw]
+    samples, offsets = _batch(pa)
+    dev.upload_batch(samples, offsets)
+    dev.run(1); dev.sync()
+    res = dev.download()
+    assert (res["status"] == 0).all()
+    c0 = res["chains"][:, 0]
+    ok = (res["n_chains"] > 0) & ((c0["direction"] == 1) == (truth["strand"] == 0))
+    assert ok.mean() > 0.95
+    d = {}
+    for band in (32, 64, 128):
+        dev.refine(band=band, pad=32); dev.sync()
+        d[band] = dev.refine_download()
+        assert np.array_equal(dev.download().tobytes(), res.tobytes())
+    refined = d[32][1] >= 0   # a path that fits the narrow band also fits the wider ones
+    assert refined.mean() > 0.9 and (d[64][1] >= 0)[refined].all() and (d[128][1] >= 0)[d[64][1] >= 0].all()
+    assert (d[64][0][refined] <= d[32][0][refined]).all() and (d[128][0][refined] <= d[64][0][refined]).all()
+    assert (d[128][0][refined] < d[32][0][refined]).any()
+    dev.close()
 
 
 # ------------------------------------------------------------------ banded sDTW (D4/D5)
