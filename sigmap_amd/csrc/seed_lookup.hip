@@ -450,7 +450,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           node = __float_as_uint(a.x);
           mind = a.y;
           d0 = a.z; d1 = a.w; d2 = b.x; d3 = b.y; d4 = b.z; d5 = b.w;
-          if (tcnt < 2 && sp > 0) {  // refill the cache from the spill area, without waiting
+          if (tcnt == 0 && sp > 0) {  // cache empty: refill from the spill area, without waiting
+            // (not at tcnt == 1: a pop / push pair around the top would then spill and refill every time)
             --sp;
             rf_a = stk[2 * sp];
             rf_b = stk[2 * sp + 1];
