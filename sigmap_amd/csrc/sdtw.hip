@@ -13,6 +13,8 @@
 // lanes sweep a diagonal in parallel (no MFMA: min-plus DP, not a contraction).
 #include <float.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace smhip {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
                                                       const uint64_t *__restrict__ ref_off, uint32_t n_refs,
                                                       uint32_t band, uint32_t pad, int dim,
                                                       float *__restrict__ dist, int64_t *__restrict__ end_pos,
-                                                      uint32_t max_rows, int second_pass) {
+                                                      uint32_t max_rows, int second_pass, uint32_t ring) {
   extern __shared__ float sm[];
   const uint32_t c = blockIdx.x, lane = threadIdx.x;
   // pass 1 runs with LDS for max_rows rows and leaves longer windows (end_pos = -2) to pass 2
@@ -170,15 +172,23 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
   }
   const float *qr = feat + (size_t)c * feat_stride;
   const uint32_t stride = T + 2;
-  float *d0 = sm, *d1 = sm + stride, *d2 = sm + 2 * stride;  // cells with t >= 1, q >= 1 only
-  int32_t *cen = reinterpret_cast<int32_t *>(sm + 3 * stride);  // band centre of every row
+  // The three live diagonals are rings of `ring` (a power of two >= band + 16) cells indexed by
+  // t mod ring: a diagonal only ever touches the rows [tb - 3, tb + band + 6] (below), and every
+  // cell a later diagonal reads was written by the diagonal it belongs to, so rows a ring apart
+  // never meet.  That keeps LDS at ~6 KB per wave whatever the window length (occupancy is what
+  // this latency-bound sweep lives on).  Cells with t >= 1, q >= 1 only.
+  const uint32_t rmask = ring - 1;
+  float *d0 = sm, *d1 = sm + ring, *d2 = sm + 2 * ring;
+  int32_t *cen = reinterpret_cast<int32_t *>(sm + 3 * ring);  // band centre of every row
   const int64_t half = band / 2;
   float best = FLT_MAX;
   uint32_t best_t = 0xFFFFFFFFu;
-  for (uint32_t t = lane; t < stride; t += 64) {
+  for (uint32_t t = lane; t < ring; t += 64) {
     d0[t] = FLT_MAX;
     d1[t] = FLT_MAX;
     d2[t] = FLT_MAX;
+  }
+  for (uint32_t t = lane; t < stride; t += 64) {
     const int64_t ta = t0 + (int64_t)t - 1;
     cen[t] = (int32_t)(1 + qa + FloorDiv((ta - start) * (qb - qa), den));
   }
@@ -204,15 +214,15 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
       if ((int64_t)q >= lo && (int64_t)q <= hi) {
         const float cost = fabsf(tg[t - 1] - qr[q - 1]);
         // (t-1, q-1), (t-1, q), (t, q-1) with the boundary constants of sigmap.cc:1263-1271
-        const float a = t == 1 ? (q == 1 ? 0.0f : FLT_MAX) : (q == 1 ? 0.0f : d0[t - 1]);
-        const float b = t == 1 ? FLT_MAX : d1[t - 1];
-        const float cc = q == 1 ? 0.0f : d1[t];
+        const float a = t == 1 ? (q == 1 ? 0.0f : FLT_MAX) : (q == 1 ? 0.0f : d0[(t - 1) & rmask]);
+        const float b = t == 1 ? FLT_MAX : d1[(t - 1) & rmask];
+        const float cc = q == 1 ? 0.0f : d1[t & rmask];
         float m = a;
         if (b < m) m = b;
         if (cc < m) m = cc;
         v = cost + m;
       }
-      d2[t] = v;
+      d2[t & rmask] = v;
       if (q == Q) {
         if (v < best || (v == best && t < best_t)) {
           best = v;
@@ -269,23 +279,28 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
                             const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,
                             int64_t *end_pos) {
   if (n_chunks == 0) return hipSuccess;
-  // rows of a window = chain span + dim + 2*pad (a 4000-sample chunk spans a few hundred events):
-  // pass 1 sizes LDS for 1021 rows (16 KB => 10 workgroups per CU); the rare longer windows are
-  // redone by pass 2 with the full 8192-row LDS.
-  const size_t lds_full = 4 * (size_t)(kSdtwMaxT + 2) * sizeof(float);
+  // rows of a window = chain span + dim + 2*pad (a 4000-sample chunk spans ~600 events).  The sweep
+  // is a chain of LDS round trips per diagonal, so it lives on occupancy: with the diagonals kept
+  // in rings, pass 1 needs (3 * ring + 1023) * 4 B = 6.6 KB at band 64 (24 single-wave workgroups
+  // per CU); windows longer than 1021 rows (end_pos = -2) are redone by pass 2 with room for 8192.
+  // (Whole diagonals in LDS, 16 KB per workgroup: 3.0 ms; 9.7 KB: 2.1 ms.)
+  uint32_t ring = 64;
+  while (ring < band + 16) ring <<= 1;
   const uint32_t fast_rows = 1021;
-  const size_t lds_fast = 4 * (size_t)(fast_rows + 2) * sizeof(float);
+  const size_t lds_fast = (3 * (size_t)ring + fast_rows + 2) * sizeof(float);
+  const size_t lds_full = (3 * (size_t)ring + kSdtwMaxT + 2) * sizeof(float);
+  if (lds_full > 160 * 1024) return hipErrorInvalidValue;  // band beyond what the LDS rings hold
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
   hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
-                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0);
+                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0, ring);
   hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_full, ctx->stream, results, feat, feat_stride,
-                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, (uint32_t)kSdtwMaxT, 1);
+                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, (uint32_t)kSdtwMaxT, 1, ring);
   return hipGetLastError();
 }
 }  // namespace smhip
