@@ -44,7 +44,7 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 
 constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
-constexpr int kBigGroupCap = 1024; // ... staged in LDS when they fit (else the wave reads them from L2)
+constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit (else the wave reads them from L2)
 
 // ---- C0: which anchors can be settled without the sequential DP?  One thread per anchor.
 // The predecessor scan of anchor i (spatial_index.cc:461-540) only looks at predecessor SCORES
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
 // per chunk (spatial_index.cc:222-274, sigmap.cc:702-729).  Lane 0 orders and filters the (few)
 // candidate chains; all lanes gather the chains' anchors through the recorded index lists; lane 0
 // then adds chain 0's statistics in the reference's order (f32 sums are order-sensitive).
-constexpr uint32_t kStatLds = 1024;  // anchors of chain 0 staged in LDS for the sequential sums
+constexpr uint32_t kStatLds = 384;   // anchors of chain 0 staged in LDS for the sequential sums
 
 __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
                                                           const uint32_t *__restrict__ n_chains_in) {
