@@ -148,7 +148,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,

@@ -83,7 +83,7 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox;
+  smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox, scan_tmp;
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   // batch inputs
   uint32_t n_chunks = 0;

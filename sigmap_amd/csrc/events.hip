@@ -307,6 +307,47 @@ __global__ __launch_bounds__(1024) void ScanKernel(const uint32_t *__restrict__ 
   }
   if (tid == 1023) out[n] = (OutT)part[1023];
 }
+// Large inputs (the walker's query-order histogram: ~0.5 M bins): three coalesced launches --
+// per-block sums, scan of the sums, per-block rescan with the block's offset.
+constexpr uint32_t kScanTile = 4096;  // elements per 256-thread block
+__global__ __launch_bounds__(256) void ScanReduceKernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                        uint32_t *__restrict__ sums) {
+  __shared__ uint32_t red[256];
+  const uint32_t base = blockIdx.x * kScanTile, tid = threadIdx.x;
+  uint32_t s = 0;
+  for (uint32_t i = base + tid; i < min(n, base + kScanTile); i += 256) s += in[i];
+  red[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 128; d > 0; d >>= 1) {
+    if (tid < d) red[tid] += red[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) sums[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void ScanApplyKernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                       const uint32_t *__restrict__ block_excl,
+                                                       uint32_t *__restrict__ out) {
+  __shared__ uint32_t part[256];
+  const uint32_t base = blockIdx.x * kScanTile, tid = threadIdx.x;
+  uint32_t carry = block_excl[blockIdx.x];
+  for (uint32_t t0 = base; t0 < min(n, base + kScanTile); t0 += 256) {  // 256 elements at a time, coalesced
+    const uint32_t i = t0 + tid;
+    const uint32_t v = i < n ? in[i] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      const uint32_t o = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += o;
+      __syncthreads();
+    }
+    if (i < n) out[i] = carry + part[tid] - v;
+    carry += part[255];
+    __syncthreads();
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) out[n] = carry;
+}
 }  // namespace
 
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
@@ -337,7 +378,21 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
 }
 
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl) {
-  hipLaunchKernelGGL(ScanKernel<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, in, n, out_excl);
+  if (n <= 16384) {
+    hipLaunchKernelGGL(ScanKernel<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, in, n, out_excl);
+    return hipGetLastError();
+  }
+  const uint32_t blocks = (n + kScanTile - 1) / kScanTile;
+  hipError_t e = ctx->scan_tmp.Reserve(((size_t)blocks * 2 + 2) * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  uint32_t *sums = ctx->scan_tmp.as<uint32_t>(), *excl = sums + blocks;
+  hipLaunchKernelGGL(ScanReduceKernel, dim3(blocks), dim3(256), 0, ctx->stream, in, n, sums);
+  if (blocks <= 16384) {
+    hipLaunchKernelGGL(ScanKernel<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, sums, blocks, excl);
+  } else {
+    return hipErrorInvalidValue;  // > 64 M elements: not a size this path produces
+  }
+  hipLaunchKernelGGL(ScanApplyKernel, dim3(blocks), dim3(256), 0, ctx->stream, in, n, excl, out_excl);
   return hipGetLastError();
 }
 
