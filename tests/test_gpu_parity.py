@@ -91,6 +91,29 @@ def test_seed_lookup_matches_oracle(device, small_world, oracle_tree, blocks, st
     assert total > 1000
 
 
+@pytest.mark.parametrize("npts", [6, 7, 15, 21, 45, 300])
+def test_seed_lookup_tiny_trees(npts):
+    """Degenerate trees: a single leaf (the root), a handful of nodes; every query of the cloud."""
+    rng = np.random.default_rng(5)
+    vals = rng.normal(size=npts).astype(np.float32)
+    ix = pipeline.HostIndex.from_points(np.arange(npts, dtype=np.uint64) << 1, vals, threads=1)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    tree = po.OracleTree(ix.values.copy())
+    qs = np.array([vals[i:i + 6] + rng.normal(scale=0.05, size=6).astype(np.float32)
+                   for i in range(0, max(1, npts - 5))], np.float32)
+    for strict in (0, 1):
+        dev.params.reference_walk = strict
+        counts, idx, dist, nodes, pts = dev.seed_lookup(qs, cap=64)
+        for k in range(len(qs)):
+            n, oi, od, stt = tree.radius_search(qs[k], 0.08)
+            assert counts[k] == n and np.array_equal(idx[k, :n], oi) and np.array_equal(bits(dist[k, :n]), bits(od))
+            if strict:
+                assert nodes[k] == stt[0] and pts[k] == stt[2]
+    assert counts.sum() >= len(qs)
+    dev.close(); tree.close()
+
+
 def test_seed_lookup_matches_reference_golden():
     g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
     ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=2)
