@@ -149,21 +149,54 @@ __device__ __forceinline__ void DetectorStep(Detector *d, int k, float cur, uint
   }
 }
 
-// E3 -- event.h:117-182: sequential in i, short detector first.
-__global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ off, uint32_t n_chunks,
-                                                 const float *__restrict__ t1_all, const float *__restrict__ t2_all,
-                                                 uint16_t *__restrict__ peaks_all, uint32_t *__restrict__ n_peaks,
-                                                 uint32_t w1, uint32_t w2, float thr1, float thr2, float peak_height) {
-  const uint32_t c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= n_chunks) return;
-  uint32_t n = off[c + 1] - off[c];
-  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
-  const float *t1 = t1_all + (size_t)c * kRowStride, *t2 = t2_all + (size_t)c * kRowStride;
-  uint16_t *peaks = peaks_all + (size_t)c * kRowStride;
-  Detector d[2] = {{thr1, w1, 0, -1, FLT_MAX, false}, {thr2, w2, 0, -1, FLT_MAX, false}};
-  uint32_t np = 0;
-  uint32_t i = 0;
-  for (; i + kBlk <= n; i += kBlk) {
+// E3 -- event.h:117-182: sequential in i, short detector first.  A lane per chunk would leave the
+// chip idle (10 000 chunks = 157 waves, each a chain of 8000 dependent detector steps), so a chunk
+// is cut into kPeakSegs segments run by different lanes of one wave, speculatively: a segment
+// starts kPeakWarm samples early from the initial state, which almost always reaches the state
+// the sequential scan has at the segment boundary (both detectors re-synchronise at the next peak).
+// The speculation is then CHECKED, exactly: a segment whose predecessor's end state differs from
+// the state it started from is re-run from the true state, round after round until nothing
+// changes (at most kPeakSegs - 1 rounds = the sequential order), so the peak list is the one the
+// reference's loop produces whatever the signal looks like.
+constexpr int kPeakSegs = 8;
+constexpr uint32_t kPeakWarm = 96;
+
+struct PeakState {  // the varying part of the two detectors (det 0 is never masked)
+  int p0, p1;
+  float v0, v1;
+  uint32_t ok0, ok1;
+  uint64_t m1;
+};
+__device__ __forceinline__ PeakState SaveState(const Detector *d) {
+  return PeakState{d[0].peak_pos, d[1].peak_pos, d[0].peak_value, d[1].peak_value, d[0].valid_peak ? 1u : 0u,
+                   d[1].valid_peak ? 1u : 0u, d[1].masked_to};
+}
+__device__ __forceinline__ void LoadState(Detector *d, const PeakState &s) {
+  d[0].peak_pos = s.p0; d[1].peak_pos = s.p1;
+  d[0].peak_value = s.v0; d[1].peak_value = s.v1;
+  d[0].valid_peak = s.ok0 != 0; d[1].valid_peak = s.ok1 != 0;
+  d[0].masked_to = 0; d[1].masked_to = s.m1;
+}
+__device__ __forceinline__ bool SameState(const PeakState &a, const PeakState &b) {
+  return a.p0 == b.p0 && a.p1 == b.p1 && __float_as_uint(a.v0) == __float_as_uint(b.v0) &&
+         __float_as_uint(a.v1) == __float_as_uint(b.v1) && a.ok0 == b.ok0 && a.ok1 == b.ok1 && a.m1 == b.m1;
+}
+__device__ __forceinline__ PeakState ShflUpState(const PeakState &s, int delta) {
+  PeakState r;
+  r.p0 = __shfl_up(s.p0, delta, 64); r.p1 = __shfl_up(s.p1, delta, 64);
+  r.v0 = __shfl_up(s.v0, delta, 64); r.v1 = __shfl_up(s.v1, delta, 64);
+  r.ok0 = __shfl_up(s.ok0, delta, 64); r.ok1 = __shfl_up(s.ok1, delta, 64);
+  const uint32_t lo = __shfl_up((uint32_t)s.m1, delta, 64), hi = __shfl_up((uint32_t)(s.m1 >> 32), delta, 64);
+  r.m1 = ((uint64_t)hi << 32) | lo;
+  return r;
+}
+
+// steps [ib, ie) of both detectors; peaks go to out[np++] when out != nullptr
+__device__ __forceinline__ void RunSteps(Detector *d, const float *__restrict__ t1, const float *__restrict__ t2,
+                                         uint32_t ib, uint32_t ie, float peak_height, uint16_t *out, uint32_t &np) {
+  uint16_t sink[1];
+  uint32_t i = ib;
+  for (; i + kBlk <= ie; i += kBlk) {
     float a[kBlk], b[kBlk];
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
@@ -172,15 +205,80 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ of
     }
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
-      DetectorStep(d, 0, a[k], i + k, peak_height, peaks, np);
-      DetectorStep(d, 1, b[k], i + k, peak_height, peaks, np);
+      if (out) {
+        DetectorStep(d, 0, a[k], i + k, peak_height, out, np);
+        DetectorStep(d, 1, b[k], i + k, peak_height, out, np);
+      } else {
+        uint32_t z = 0;
+        DetectorStep(d, 0, a[k], i + k, peak_height, sink, z);
+        z = 0;
+        DetectorStep(d, 1, b[k], i + k, peak_height, sink, z);
+      }
     }
   }
-  for (; i < n; ++i) {
-    DetectorStep(d, 0, t1[i], i, peak_height, peaks, np);
-    DetectorStep(d, 1, t2[i], i, peak_height, peaks, np);
+  for (; i < ie; ++i) {
+    if (out) {
+      DetectorStep(d, 0, t1[i], i, peak_height, out, np);
+      DetectorStep(d, 1, t2[i], i, peak_height, out, np);
+    } else {
+      uint32_t z = 0;
+      DetectorStep(d, 0, t1[i], i, peak_height, sink, z);
+      z = 0;
+      DetectorStep(d, 1, t2[i], i, peak_height, sink, z);
+    }
   }
-  n_peaks[c] = np;
+}
+
+__global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ off, uint32_t n_chunks,
+                                                 const float *__restrict__ t1_all, const float *__restrict__ t2_all,
+                                                 uint16_t *__restrict__ peaks_all, uint32_t *__restrict__ n_peaks,
+                                                 uint16_t *__restrict__ seg_peaks_all, uint32_t w1, uint32_t w2,
+                                                 float thr1, float thr2, float peak_height) {
+  constexpr int kChunksPerWave = 64 / kPeakSegs;
+  const uint32_t lane = threadIdx.x, cl = lane % kChunksPerWave, seg = lane / kChunksPerWave;
+  const uint32_t c = blockIdx.x * kChunksPerWave + cl;
+  const bool live = c < n_chunks;
+  uint32_t n = 0;
+  if (live) {
+    n = off[c + 1] - off[c];
+    if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
+  }
+  const size_t row = (size_t)(live ? c : 0) * kRowStride;
+  const float *t1 = t1_all + row, *t2 = t2_all + row;
+  const uint32_t S = (n + kPeakSegs - 1) / kPeakSegs;
+  const uint32_t beg = min(n, seg * S), end = min(n, beg + S);
+  uint16_t *mine = seg_peaks_all + row + beg;  // a segment of S steps emits at most S peaks
+  Detector d[2] = {{thr1, w1, 0, -1, FLT_MAX, false}, {thr2, w2, 0, -1, FLT_MAX, false}};
+  uint32_t np = 0;
+  // speculative run: warm-up from the initial state, then the segment
+  RunSteps(d, t1, t2, beg > kPeakWarm ? beg - kPeakWarm : 0u, beg, peak_height, nullptr, np);
+  PeakState start = SaveState(d);
+  RunSteps(d, t1, t2, beg, end, peak_height, mine, np);
+  PeakState fin = SaveState(d);
+  // check against the predecessor segment's end state; re-run what started from a wrong state
+  for (int round = 0; round < kPeakSegs; ++round) {
+    const PeakState prev = ShflUpState(fin, kChunksPerWave);
+    const bool redo = seg > 0 && !SameState(prev, start);
+    if (!__ballot(redo)) break;
+    if (redo) {
+      start = prev;
+      LoadState(d, prev);
+      np = 0;
+      RunSteps(d, t1, t2, beg, end, peak_height, mine, np);
+      fin = SaveState(d);
+    }
+  }
+  // concatenate the segments' peaks in order
+  uint32_t before = 0;  // peaks of the earlier segments of this chunk
+  for (int k = 1; k < kPeakSegs; ++k) {
+    const uint32_t o = __shfl_up(np, k * kChunksPerWave, 64);
+    if ((int)seg >= k) before += o;
+  }
+  if (live) {
+    uint16_t *peaks = peaks_all + row;
+    for (uint32_t k = 0; k < np; ++k) peaks[before + k] = mine[k];
+    if (seg == kPeakSegs - 1) n_peaks[c] = before + np;
+  }
 }
 
 // E4 -- event.h:184-224: event e spans [peaks[e-1], peaks[e]) (first from 0, last to n; the
@@ -358,17 +456,18 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
   const size_t evn = (size_t)n_chunks * feat_stride;
   // scratch rows: ps, pss, t1, t2 (f32), event mean / stdv (f32), n_peaks (u32), peaks (u16)
   hipError_t e = ctx->ev_scratch.Reserve((row * 4 + evn * 2) * sizeof(float) + (size_t)n_chunks * 4 +
-                                         row * sizeof(uint16_t) + 256);
+                                         2 * row * sizeof(uint16_t) + 256);
   if (e != hipSuccess) return e;
   float *ps = ctx->ev_scratch.as<float>(), *pss = ps + row, *t1 = pss + row, *t2 = t1 + row;
   float *ev_mean = t2 + row, *ev_stdv = ev_mean + evn;
   uint32_t *n_peaks = reinterpret_cast<uint32_t *>(ev_stdv + evn);
-  uint16_t *peaks = reinterpret_cast<uint16_t *>(n_peaks + n_chunks);
+  uint16_t *peaks = reinterpret_cast<uint16_t *>(n_peaks + n_chunks), *seg_peaks = peaks + row;
   const uint32_t lane_blocks = (n_chunks + 63) / 64;
   hipLaunchKernelGGL(PrefixKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, samples, off, n_chunks, ps, pss);
   hipLaunchKernelGGL(TStatKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, t1, t2,
                      p.window_length1, p.window_length2);
-  hipLaunchKernelGGL(PeakKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, off, n_chunks, t1, t2, peaks, n_peaks,
+  hipLaunchKernelGGL(PeakKernel, dim3((n_chunks * kPeakSegs + 63) / 64), dim3(64), 0, ctx->stream, off, n_chunks, t1,
+                     t2, peaks, n_peaks, seg_peaks,
                      p.window_length1, p.window_length2, p.threshold1, p.threshold2, p.peak_height);
   hipLaunchKernelGGL(EventMeanKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, peaks, n_peaks,
                      ev_mean, ev_stdv, feat_stride);

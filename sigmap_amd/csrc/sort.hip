@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   while (npad < n) npad <<= 1;
   const bool in_lds = npad <= kLdsKeys;
   uint64_t *gkeys = a.keys + 2 * base;  // per-chunk scratch of 2n >= npad keys
-  uint32_t *u_tpos = a.a_tpos + base, *u_qpos = a.a_qpos + base, *u_grp = a.a_grp + base;
+  uint32_t *u_qpos = a.a_qpos + base;  // (target and group travel in the key)
   float *u_dist = a.a_dist + base;
 
   // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts) into LDS
@@ -148,10 +148,8 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       dist = hit.dist;
     }
     local_maxt = max(local_maxt, tpos);
-    u_tpos[i] = tpos;
     u_qpos[i] = qpos;
     u_dist[i] = dist;
-    u_grp[i] = grp;
     const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
     if (reg_keys) mykeys[it] = key; else gkeys[i] = key;
   }
