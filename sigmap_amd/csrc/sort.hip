@@ -204,7 +204,15 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
         if (m <= 64) {  // the common case: one key per lane
           const uint64_t mine = lane < m ? lds_keys[b0 + lane] : ~0ull;
           uint32_t rank = 0;
-          for (uint32_t x = 0; x < m; ++x) rank += lds_keys[b0 + x] < mine ? 1u : 0u;  // LDS broadcasts
+          uint32_t x = 0;
+          for (; x + 8 <= m; x += 8) {  // LDS broadcasts, eight in flight
+            uint64_t o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = lds_keys[b0 + x + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rank += o[k] < mine ? 1u : 0u;
+          }
+          for (; x < m; ++x) rank += lds_keys[b0 + x] < mine ? 1u : 0u;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();  // all reads of the bucket precede the permuting writes
           if (lane < m) lds_keys[b0 + rank] = mine;
@@ -258,11 +266,13 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   __syncthreads();
   // ---- order runs of equal (group, target) by (query, distance): insertion sort by the
   // thread that owns the run's first element
+  // ((group, target) of sorted element i = key >> ibits; the sorted keys are still in LDS / scratch)
   for (uint32_t i = tid; i < n; i += kSortThreads) {
-    const bool run_start = i == 0 || s_tpos[i - 1] != s_tpos[i] || s_grp[i - 1] != s_grp[i];
+    const uint64_t gt = (in_lds ? lds_keys[i] : gkeys[i]) >> ibits;
+    const bool run_start = i == 0 || ((in_lds ? lds_keys[i - 1] : gkeys[i - 1]) >> ibits) != gt;
     if (!run_start) continue;
     uint32_t e = i + 1;
-    while (e < n && s_tpos[e] == s_tpos[i] && s_grp[e] == s_grp[i]) ++e;
+    while (e < n && ((in_lds ? lds_keys[e] : gkeys[e]) >> ibits) == gt) ++e;
     for (uint32_t x = i + 1; x < e; ++x) {
       const uint32_t kq = s_qpos[x];
       const float kd = s_dist[x];
@@ -281,7 +291,9 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     const uint32_t per_a = (n + kSortThreads - 1) / kSortThreads;
     const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
     uint32_t cnt = 0;
-    for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || s_grp[i - 1] != s_grp[i]) ? 1 : 0;
+    const uint32_t gsh = 32 + ibits;
+    auto grp_of = [&](uint32_t i) { return (uint32_t)((in_lds ? lds_keys[i] : gkeys[i]) >> gsh); };
+    for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1 : 0;
     __syncthreads();
     part[tid] = cnt;
     __syncthreads();
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     uint32_t w = tid ? part[tid - 1] : 0;
     uint32_t *gs = a.group_start + base;
     for (uint32_t i = ab; i < ae; ++i)
-      if (i == 0 || s_grp[i - 1] != s_grp[i]) gs[w++] = i;
+      if (i == 0 || grp_of(i - 1) != grp_of(i)) gs[w++] = i;
     if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
   }
 }
