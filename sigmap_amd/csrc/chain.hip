@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_run;
   __shared__ int32_t s_t[512], s_q[512];
-  __shared__ uint32_t s_g[512];
+  __shared__ uint32_t s_g[512], s_gstart[1024];
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
   const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
   uint32_t *pending = a.pending + base;
   uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
   const bool lds_max = G <= kLdsGroups;
+  const bool lds_gs = G <= 1024;  // bucket starts staged for the ordinal search
   for (uint32_t g = tid; g < G; g += 256) {
     if (lds_max) s_gmax[g] = 0; else gmax_g[g] = 0;
+    if (lds_gs) s_gstart[g] = gstart[g];
   }
   if (tid == 0) s_run = 0;
   __syncthreads();
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
         uint32_t lo = 0, hi = G;  // bucket ordinal: last bucket start <= ai
         while (hi - lo > 1) {
           const uint32_t mid = (lo + hi) >> 1;
-          if (gstart[mid] <= ai) lo = mid; else hi = mid;
+          if ((lds_gs ? s_gstart[mid] : gstart[mid]) <= ai) lo = mid; else hi = mid;
         }
         if (lds_max) atomicMax(&s_gmax[lo], __float_as_uint(sc)); else atomicMax(&gmax_g[lo], __float_as_uint(sc));
       } else {
