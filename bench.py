@@ -113,7 +113,8 @@ def main():
     t_build = 0.0
     if rank == 0:
         t0 = time.perf_counter()
-        ix = pipeline.HostIndex.build(genome, lm, threads=0)
+        # (torch.distributed.run exports OMP_NUM_THREADS=1: ask for the cores explicitly)
+        ix = pipeline.HostIndex.build(genome, lm, threads=max(1, (os.cpu_count() or 1) // max(world, 1)))
         t_build = time.perf_counter() - t0
     keepalive = replicate_index(dev, ix, rank, world, local_rank, dist)  # RCCL broadcast when world > 1
 
