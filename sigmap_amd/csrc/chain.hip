@@ -221,11 +221,12 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
       float ps[kPf];
 #pragma unroll
       for (int k = 0; k < kPf; ++k) {
-        const int32_t pj = pj0 - k;
-        const bool ok = pj >= start_idx;
-        pt[k] = ok ? (int32_t)tpos[s + pj] : 0;
-        pq[k] = ok ? (int32_t)qpos[s + pj] : 0;
-        ps[k] = ok ? score[s + pj] : 0.0f;
+        // unconditional loads from a clamped index: a conditional load compiles to a branch with
+        // its own s_waitcnt, i.e. one memory round trip per predecessor instead of one per block
+        const int32_t pj = max(pj0 - k, start_idx);
+        pt[k] = (int32_t)tpos[s + pj];
+        pq[k] = (int32_t)qpos[s + pj];
+        ps[k] = score[s + pj];
       }
 #pragma unroll
       for (int k = 0; k < kPf; ++k) {
