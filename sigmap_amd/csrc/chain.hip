@@ -502,10 +502,25 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
       // DP kernels scored need to be looked at.
       uint32_t lo2 = 0, hi2 = npend;
       while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
-      for (uint32_t pi = lo2; pi < npend; ++pi) {
-        const uint32_t ai = pending[pi];
-        if (ai >= e) break;
-        consider(ai, score[ai]);
+      // kPf list entries, then their kPf scores, per pair of memory round trips (clamped
+      // unconditional loads: a conditional one would wait on its own)
+      bool more = lo2 < npend;
+      for (uint32_t pi = lo2; more; pi += kPf) {
+        uint32_t ids[kPf];
+        float sc8[kPf];
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) ids[k] = pending[min(pi + k, npend - 1)];
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) sc8[k] = score[ids[k]];
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) {
+          if (!more) break;
+          if (pi + k >= npend || ids[k] >= e) {
+            more = false;
+            break;
+          }
+          consider(ids[k], sc8[k]);
+        }
       }
     } else {
       for (uint32_t a0 = s; a0 < e; a0 += kPf) {
@@ -531,23 +546,30 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
       // TracebackChains, spatial_index.cc:165-220 (pred[] holds chunk-local absolute indices)
       const uint32_t end_abs = s + top[k].idx;
       if (!used[end_abs]) {
+        // (the loop below is the reference's, with pred[p] fetched beside used[p]: one memory
+        // round trip per chain anchor instead of two dependent ones)
         bool stop_at_used = false;
         uint32_t cur = end_abs;
         const uint32_t list_off = cursor;
-        lists[cursor++] = cur;
-        if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
-        used[cur] = 1;
-        uint32_t num = 1;
-        while (pred[cur] != cur && !used[pred[cur]]) {
-          cur = pred[cur];
+        uint32_t num = 0;
+        uint32_t pc = pred[cur];
+        for (;;) {
           lists[cursor++] = cur;
-          if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
           used[cur] = 1;
           ++num;
+          if (pc == cur) break;
+          const uint8_t up = used[pc];
+          const uint32_t pp = pred[pc];
+          if (up) {
+            stop_at_used = true;
+            break;
+          }
+          cur = pc;
+          pc = pp;
         }
         if (num >= (uint32_t)min_num_anchors) {
           float adjusted = score[end_abs];
-          if (stop_at_used) adjusted -= score[pred[cur]];
+          if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
           const uint32_t slot = atomicAdd(&s_nchains, 1u);
           if (slot < (uint32_t)kChainCap) {
             ChainTmp ch;
