@@ -402,24 +402,37 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
   HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
-  const uint64_t pool_cap = std::min<uint64_t>(nq_cap * 64 + (1u << 22), 0xFFFF0000ull);
-  HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
-  HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+  // Overflow pool (hits beyond a query's fast slots).  The walker keeps adding the sizes of the
+  // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
+  // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
+  // the size is remembered for the following batches).
+  uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(nq_cap * 64 + (1u << 22), ctx->pool_hint), 0xFFFF0000ull);
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
-  {
-    ScopedTimer t(ctx, T_SEED);
-    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
-                            ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
-                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
-                            pool_cap));
-  }
-  HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
-                           ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(), R,
-                           ctx->chunk_anchor_cnt.as<uint32_t>(), results));
-  HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
   uint64_t NA = 0;
-  HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int attempt = 0;; ++attempt) {
+    HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+    {
+      ScopedTimer t(ctx, T_SEED);
+      HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
+                              ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
+                              ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
+                              pool_cap));
+    }
+    HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
+                             ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(),
+                             R, ctx->chunk_anchor_cnt.as<uint32_t>(), results));
+    HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
+    uint32_t hc[26] = {0};
+    HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
+    const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
+    if (demand <= pool_cap || demand > 0xFFFF0000ull) break;  // level limit / beyond 32-bit offsets: report the flag
+    pool_cap = demand;
+    ctx->pool_hint = pool_cap;
+  }
   const uint64_t na = std::max<uint64_t>(NA, 1);
   DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
                   &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};

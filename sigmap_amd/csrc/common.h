@@ -98,6 +98,7 @@ struct smhip_ctx {
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
   uint64_t cap_queries = 0, cap_anchors = 0;
+  uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
   // sDTW refinement
   smhip::DevBuf ref_sig, ref_off, refine_dist, refine_end;
   uint32_t ref_n = 0;

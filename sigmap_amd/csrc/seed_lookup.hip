@@ -74,7 +74,7 @@ struct Sink {
   uint32_t *q_nodes;    // optional per-query stats
   uint32_t *q_points;
   smhip_chunk_result *results;  // unused (per-chunk sums are formed by AnchorCountKernel)
-  uint32_t *counters;   // [0] stack overflow flag, [1] #overflow queries, [2] pool top, [3] pool full
+  uint32_t *counters;   // [0] stack overflow flag, [1] #overflow queries, [3] pool full, [24..25] pool cursor (u64)
   Hit *pool;            // overflow pool: hits beyond the fast slots, in geometric segments
   uint32_t *ovf_tab;    // [n_queries][kOvfLevels] pool offset of each segment
   uint64_t pool_cap;
@@ -107,10 +107,13 @@ __device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint
   const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
   if (k == first) {  // first hit of this segment: allocate it
     const uint32_t size = sink.fast_cap << level;
-    const uint32_t base = atomicAdd(&sink.counters[2], size);
-    ovf_base = base;
+    // 64-bit cursor (counters[24..25]): it keeps counting past the end of the pool, so that the
+    // host learns the exact demand of a launch that ran out of room
+    const unsigned long long base =
+        atomicAdd(reinterpret_cast<unsigned long long *>(sink.counters + 24), (unsigned long long)size);
+    ovf_base = (uint32_t)base;
     if (level == 0) atomicAdd(&sink.counters[1], 1u);
-    if ((uint64_t)base + size > sink.pool_cap || level >= (uint32_t)kOvfLevels) {
+    if (base + size > sink.pool_cap || level >= (uint32_t)kOvfLevels) {
       atomicOr(&sink.counters[3], 1u);  // reported as SMHIP_ST_HIT_POOL_FULL
       ovf_base = 0xFFFFFFFFu;
     }

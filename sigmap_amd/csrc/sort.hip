@@ -24,6 +24,8 @@ constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
 constexpr uint32_t kMaxQueriesPerChunk = (kFeatStride - 5) / 1 + 1;  // step >= 1
 constexpr uint32_t kBuckets = 256;    // buckets of the two-level sort
 constexpr uint32_t kMaxBucket = 512;  // largest bucket one wave rank-sorts (8 keys per lane)
+constexpr uint32_t kBigBuckets = 1024;  // buckets of a chunk too large for LDS (== kSortThreads)
+constexpr uint32_t kWaveKeys = kLdsKeys / (kSortThreads / 64);  // 1024: a wave's slice of the LDS key array
 
 template <typename KeyPtr>
 __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t tid) {
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   while (npad < n) npad <<= 1;
   const bool in_lds = npad <= kLdsKeys;
   uint64_t *gkeys = a.keys + 2 * base;  // per-chunk scratch of 2n >= npad keys
+  const uint64_t *gsorted = gkeys;       // where the sorted keys end up when they are not in LDS
   uint32_t *u_qpos = a.a_qpos + base;  // (target and group travel in the key)
   float *u_dist = a.a_dist + base;
 
@@ -239,7 +242,80 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       __syncthreads();
     }
   } else {
-    __syncthreads();  // everyone is done with the offsets
+    // ---- large chunk (more keys than LDS holds; large references): the same two levels through
+    // the L2-resident scratch -- counting sort into 1024 buckets of the dense key (gkeys[0..n) ->
+    // gkeys[n..2n)), then every bucket is loaded into a wave's 8 KB slice of LDS, sorted there by
+    // a wave-level bitonic network (no workgroup barriers) and written back.
+    atomicMax(&s_maxt, local_maxt);
+    uint32_t *hist_l = reinterpret_cast<uint32_t *>(lds_keys);  // [kBigBuckets]: counts, then cursors
+    __syncthreads();  // everyone is done with the offsets; s_maxt ready
+    hist_l[tid] = 0;  // kBigBuckets == kSortThreads
+    const uint64_t span = (uint64_t)s_maxt + 1ull;
+    const uint64_t range = span << gbits;
+    const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
+    const uint32_t shift = rbits > 10u ? rbits - 10u : 0u;
+    auto bucket_of = [&](uint64_t key) {
+      return (uint32_t)(((key >> (32 + ibits)) * span + ((key >> ibits) & 0xFFFFFFFFull)) >> shift);
+    };
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&hist_l[bucket_of(gkeys[i])], 1u);
+    __syncthreads();
+    const uint32_t mycount = hist_l[tid];
+    atomicMax(&s_maxb, mycount);
+    part[tid] = mycount;
+    __syncthreads();
+    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+      const uint32_t v = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t excl = part[tid] - mycount;
+    __syncthreads();
+    part[tid] = excl;  // bucket starts
+    hist_l[tid] = 0;   // insertion cursors
+    __syncthreads();
+    if (s_maxb <= kWaveKeys) {
+      uint64_t *gk2 = gkeys + n;
+      for (uint32_t i = tid; i < n; i += kSortThreads) {
+        const uint64_t key = gkeys[i];
+        const uint32_t b = bucket_of(key);
+        gk2[part[b] + atomicAdd(&hist_l[b], 1u)] = key;
+      }
+      __syncthreads();
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      uint64_t *slice = lds_keys + (size_t)wave * kWaveKeys;
+      for (uint32_t b = wave; b < kBigBuckets; b += kSortThreads / 64) {
+        const uint32_t b0 = part[b], m = (b + 1 < kBigBuckets ? part[b + 1] : n) - b0;
+        if (m < 2) continue;
+        uint32_t mp = 64;
+        while (mp < m) mp <<= 1;
+        for (uint32_t j = lane; j < mp; j += 64) slice[j] = j < m ? gk2[b0 + j] : ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 2; k <= mp; k <<= 1) {
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < mp / 2; t += 64) {
+              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const uint32_t l = i | j;
+              const uint64_t x = slice[i], y = slice[l];
+              if ((x > y) == ((i & k) == 0)) {
+                slice[i] = y;
+                slice[l] = x;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        for (uint32_t j = lane; j < m; j += 64) gk2[b0 + j] = slice[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      gsorted = gk2;
+      bucketed = true;
+    }
   }
   if (!bucketed) {
     if (reg_keys) {
@@ -256,7 +332,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   uint32_t *s_tpos = a.s_tpos + base, *s_qpos = a.s_qpos + base, *s_grp = a.s_grp + base;
   float *s_dist = a.s_dist + base;
   for (uint32_t i = tid; i < n; i += kSortThreads) {
-    const uint64_t key = in_lds ? lds_keys[i] : gkeys[i];
+    const uint64_t key = in_lds ? lds_keys[i] : gsorted[i];
     const uint32_t u = (uint32_t)(key & idx_mask);
     s_tpos[i] = (uint32_t)(key >> ibits);
     s_grp[i] = (uint32_t)(key >> (32 + ibits));
@@ -268,11 +344,11 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   // thread that owns the run's first element
   // ((group, target) of sorted element i = key >> ibits; the sorted keys are still in LDS / scratch)
   for (uint32_t i = tid; i < n; i += kSortThreads) {
-    const uint64_t gt = (in_lds ? lds_keys[i] : gkeys[i]) >> ibits;
-    const bool run_start = i == 0 || ((in_lds ? lds_keys[i - 1] : gkeys[i - 1]) >> ibits) != gt;
+    const uint64_t gt = (in_lds ? lds_keys[i] : gsorted[i]) >> ibits;
+    const bool run_start = i == 0 || ((in_lds ? lds_keys[i - 1] : gsorted[i - 1]) >> ibits) != gt;
     if (!run_start) continue;
     uint32_t e = i + 1;
-    while (e < n && ((in_lds ? lds_keys[e] : gkeys[e]) >> ibits) == gt) ++e;
+    while (e < n && ((in_lds ? lds_keys[e] : gsorted[e]) >> ibits) == gt) ++e;
     for (uint32_t x = i + 1; x < e; ++x) {
       const uint32_t kq = s_qpos[x];
       const float kd = s_dist[x];
@@ -292,7 +368,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
     uint32_t cnt = 0;
     const uint32_t gsh = 32 + ibits;
-    auto grp_of = [&](uint32_t i) { return (uint32_t)((in_lds ? lds_keys[i] : gkeys[i]) >> gsh); };
+    auto grp_of = [&](uint32_t i) { return (uint32_t)((in_lds ? lds_keys[i] : gsorted[i]) >> gsh); };
     for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1 : 0;
     __syncthreads();
     part[tid] = cnt;
