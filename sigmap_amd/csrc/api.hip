@@ -4,6 +4,8 @@
 
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace smhip;
@@ -406,7 +408,9 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
   // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
   // the size is remembered for the following batches).
-  uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(nq_cap * 64 + (1u << 22), ctx->pool_hint), 0xFFFF0000ull);
+  const char *pool_env = getenv("SMHIP_POOL_MIN");  // test knob: makes the first size too small
+  const uint64_t pool_first = pool_env ? (uint64_t)strtoull(pool_env, nullptr, 10) : nq_cap * 64 + (1u << 22);
+  uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
   uint64_t NA = 0;
   for (int attempt = 0;; ++attempt) {

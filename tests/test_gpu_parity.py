@@ -234,6 +234,34 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     tree.close(); dev.close()
 
 
+def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tree):
+    """A wide search radius gives every chunk more anchors than the LDS sort holds (> 16384: the
+    L2-scratch two-level sort) and, with 32 fast slots per query, far more overflow hits than the
+    initial pool (the pool is grown to the measured demand and the search repeated).  Results must
+    still equal the oracle run with the same radius."""
+    pa, ix, ref_lens = small_world["pa"][:16], small_world["ix"], small_world["ref_lens"]
+    samples, offsets = _batch(pa)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    radius = 0.5
+    dev.params.search_radius = radius
+    dev.params.hits_per_query_fast = 32
+    os.environ["SMHIP_POOL_MIN"] = "4096"   # first pool far too small: forces the grow-and-repeat path
+    try:
+        res = dev.map_chunks(samples, offsets, n_refs=3)
+    finally:
+        del os.environ["SMHIP_POOL_MIN"]
+    assert (res["status"] == 0).all()
+    assert res["n_anchors"].min() > 16384 and dev.debug_counters()[1] > 1000
+    names = ["contig0", "contig1", "contig2"]
+    lines = _paf_lines(res, pa, names, ref_lens)
+    for i, x in enumerate(pa):
+        m = po.map_read(oracle_tree, ix.positions, x, 3, ref_lens, params={"search_radius": radius})
+        assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+        assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+    dev.close()
+
+
 def test_pipeline_empty_and_degenerate_batches(device):
     res = device.map_chunks(np.zeros(0, np.float32), np.array([0], np.uint32), n_refs=3)
     assert len(res) == 0
