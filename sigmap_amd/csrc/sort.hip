@@ -113,48 +113,98 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   uint64_t mykeys[kPerThread];
   const bool reg_keys = in_lds;  // LDS path: n <= kLdsKeys, so kPerThread registers suffice
   uint32_t local_maxt = 0;
-  for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) {
-    uint32_t tpos, qpos, grp;
-    float dist;
-    if (i < ncar) {
-      const smhip_carried_anchor ca = a.carried[a.carried_off[c] + i];
-      tpos = ca.target_position;
-      qpos = ca.query_position;
-      dist = ca.distance;
-      grp = ca.ref_strand;
-    } else {
-      const uint32_t h0 = i - ncar;
-      uint32_t lo = 0, hi = nq;  // largest k with qoff[k] <= h0
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (qoff[mid] <= h0) lo = mid; else hi = mid;
-      }
-      const uint32_t k = lo, h = h0 - qoff[k];
-      const uint32_t qi = q0 + k;
-      const uint32_t cnt = a.q_count[qi];
-      (void)cnt;
-      Hit hit;
-      if (h < a.fast_cap) {
-        hit = a.region[(size_t)qi * a.fast_cap + h];
-      } else {  // geometric overflow segments (seed_lookup.hip EmitHit)
-        const uint32_t kk = h - a.fast_cap;
-        const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
-        const uint32_t first = a.fast_cap * ((1u << level) - 1u);
-        const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-        if (seg != 0xFFFFFFFFu) hit = a.ovf_pool[(size_t)seg + (kk - first)];
-        else { hit.position = 0; hit.dist = 0; hit.slot = 0; }
-      }
-      const uint32_t ref = (uint32_t)(hit.position >> 33);
-      tpos = (uint32_t)(hit.position >> 1);
-      grp = (ref << 1) | (uint32_t)(hit.position & 1);
-      qpos = (k + 1) * a.step + qso;  // position + query_start_offset
-      dist = hit.dist;
+  uint32_t search_steps = 0;  // binary-search steps that cover nq + 1 offsets
+  while ((1u << search_steps) < nq + 1) ++search_steps;
+  const uint64_t car0 = a.carried_off ? a.carried_off[c] : 0;
+  // Four anchors per pass: their four query searches advance together, then the four 16-byte
+  // records (a hit, or a carried anchor: same size) are fetched with one wait, then the keys.
+  auto decode4 = [&](uint32_t i0, uint64_t (&keys4)[4]) {
+    uint32_t lo[4], kq[4];
+    const uint4 *src[4];
+    bool live[4], zero[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      lo[u] = 0;
+      live[u] = i0 + u * kSortThreads < n;
     }
-    local_maxt = max(local_maxt, tpos);
-    u_qpos[i] = qpos;
-    u_dist[i] = dist;
-    const uint64_t key = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
-    if (reg_keys) mykeys[it] = key; else gkeys[i] = key;
+    for (uint32_t st = search_steps; st-- > 0;) {  // largest k with qoff[k] <= h0 (qoff[0] = 0)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * kSortThreads;
+        const uint32_t h0 = i >= ncar ? i - ncar : 0;
+        const uint32_t mid = lo[u] + (1u << st);
+        if (mid < nq && qoff[mid] <= h0) lo[u] = mid;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u * kSortThreads;
+      zero[u] = false;
+      kq[u] = lo[u];
+      src[u] = reinterpret_cast<const uint4 *>(a.region);  // harmless default for lanes past the end
+      if (live[u]) {
+        if (i < ncar) {
+          src[u] = reinterpret_cast<const uint4 *>(a.carried + car0 + i);
+        } else {
+          const uint32_t h = i - ncar - qoff[lo[u]];
+          const uint32_t qi = q0 + lo[u];
+          if (h < a.fast_cap) {
+            src[u] = reinterpret_cast<const uint4 *>(a.region + (size_t)qi * a.fast_cap + h);
+          } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow)
+            const uint32_t kk = h - a.fast_cap;
+            const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+            const uint32_t first = a.fast_cap * ((1u << level) - 1u);
+            const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
+            if (seg != 0xFFFFFFFFu) src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
+            else zero[u] = true;
+          }
+        }
+      }
+    }
+    uint4 raw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[u] = *src[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u * kSortThreads;
+      if (!live[u]) continue;
+      uint32_t tpos, qpos, grp;
+      float dist;
+      if (i < ncar) {  // smhip_carried_anchor {ref_strand, target_position, query_position, distance}
+        grp = raw[u].x;
+        tpos = raw[u].y;
+        qpos = raw[u].z;
+        dist = __uint_as_float(raw[u].w);
+      } else {  // Hit {uint64 position, dist, slot}
+        const uint64_t position = zero[u] ? 0ull : ((uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32));
+        const uint32_t ref = (uint32_t)(position >> 33);
+        tpos = (uint32_t)(position >> 1);
+        grp = (ref << 1) | (uint32_t)(position & 1);
+        qpos = (kq[u] + 1) * a.step + qso;  // position + query_start_offset
+        dist = zero[u] ? 0.0f : __uint_as_float(raw[u].z);
+      }
+      local_maxt = max(local_maxt, tpos);
+      u_qpos[i] = qpos;
+      u_dist[i] = dist;
+      keys4[u] = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
+    }
+  };
+  if (reg_keys) {  // statically indexed registers (a run-time index would put the array in scratch)
+#pragma unroll
+    for (uint32_t bt = 0; bt < kPerThread / 4; ++bt) {
+      uint64_t k4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+      if (tid + bt * 4 * kSortThreads < n) decode4(tid + bt * 4 * kSortThreads, k4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mykeys[bt * 4 + u] = k4[u];
+    }
+  } else {
+    for (uint32_t i0 = tid; i0 < n; i0 += 4 * kSortThreads) {
+      uint64_t k4[4];
+      decode4(i0, k4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * kSortThreads < n) gkeys[i0 + u * kSortThreads] = k4[u];
+    }
   }
   // ---- two-level sort (LDS path): counting sort of the keys into <= 256 buckets of the dense
   // key grp * (max target + 1) + target (monotone in the key), then every bucket - a few dozen
@@ -170,7 +220,9 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
     const uint32_t shift = rbits > 8u ? rbits - 8u : 0u;
     uint32_t myb[kPerThread];
-    for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) {
+#pragma unroll
+    for (uint32_t it = 0; it < kPerThread; ++it) {
+      if (tid + it * kSortThreads >= n) continue;
       const uint64_t key = mykeys[it];
       const uint64_t dense = (key >> (32 + ibits)) * span + ((key >> ibits) & 0xFFFFFFFFull);
       myb[it] = (uint32_t)(dense >> shift);
@@ -197,8 +249,9 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     __syncthreads();
     bucketed = s_maxb <= kMaxBucket;
     if (bucketed) {
-      for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it)
-        lds_keys[bstart[myb[it]] + atomicAdd(&hist[myb[it]], 1u)] = mykeys[it];
+#pragma unroll
+      for (uint32_t it = 0; it < kPerThread; ++it)
+        if (tid + it * kSortThreads < n) lds_keys[bstart[myb[it]] + atomicAdd(&hist[myb[it]], 1u)] = mykeys[it];
       __syncthreads();
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       for (uint32_t b = wave; b < kBuckets; b += kSortThreads / 64) {
@@ -319,7 +372,9 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   }
   if (!bucketed) {
     if (reg_keys) {
-      for (uint32_t it = 0, i = tid; i < n; i += kSortThreads, ++it) lds_keys[i] = mykeys[it];
+#pragma unroll
+      for (uint32_t it = 0; it < kPerThread; ++it)
+        if (tid + it * kSortThreads < n) lds_keys[tid + it * kSortThreads] = mykeys[it];
     }
     for (uint32_t i = n + tid; i < npad; i += kSortThreads) {
       if (in_lds) lds_keys[i] = ~0ull; else gkeys[i] = ~0ull;
