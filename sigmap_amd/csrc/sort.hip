@@ -386,13 +386,30 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   // ---- scatter into sorted order
   uint32_t *s_tpos = a.s_tpos + base, *s_qpos = a.s_qpos + base, *s_grp = a.s_grp + base;
   float *s_dist = a.s_dist + base;
-  for (uint32_t i = tid; i < n; i += kSortThreads) {
-    const uint64_t key = in_lds ? lds_keys[i] : gsorted[i];
-    const uint32_t u = (uint32_t)(key & idx_mask);
-    s_tpos[i] = (uint32_t)(key >> ibits);
-    s_grp[i] = (uint32_t)(key >> (32 + ibits));
-    s_qpos[i] = u_qpos[u];
-    s_dist[i] = u_dist[u];
+  for (uint32_t i0 = tid; i0 < n; i0 += 4 * kSortThreads) {  // four elements per pass: one wait per gather level
+    uint64_t key[4];
+    uint32_t gq[4];
+    float gd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = min(i0 + u * kSortThreads, n - 1);
+      key[u] = in_lds ? lds_keys[i] : gsorted[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t from = (uint32_t)(key[u] & idx_mask);
+      gq[u] = u_qpos[from];
+      gd[u] = u_dist[from];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u * kSortThreads;
+      if (i >= n) continue;
+      s_tpos[i] = (uint32_t)(key[u] >> ibits);
+      s_grp[i] = (uint32_t)(key[u] >> (32 + ibits));
+      s_qpos[i] = gq[u];
+      s_dist[i] = gd[u];
+    }
   }
   __syncthreads();
   // ---- order runs of equal (group, target) by (query, distance): insertion sort by the
@@ -417,28 +434,54 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       s_dist[y] = kd;
     }
   }
-  // ---- group boundaries, in order
+  // ---- group boundaries, in order: every element that starts a group appends its index to the
+  // list (coalesced, order-free), then the list - one entry per (reference, strand) present - is
+  // rank-sorted.  Chunks with more groups than the rank sort handles count and write in index order.
   {
-    const uint32_t per_a = (n + kSortThreads - 1) / kSortThreads;
-    const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
-    uint32_t cnt = 0;
     const uint32_t gsh = 32 + ibits;
     auto grp_of = [&](uint32_t i) { return (uint32_t)((in_lds ? lds_keys[i] : gsorted[i]) >> gsh); };
-    for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1 : 0;
-    __syncthreads();
-    part[tid] = cnt;
-    __syncthreads();
-    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
-      const uint32_t v = tid >= d ? part[tid - d] : 0;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
-    }
-    uint32_t w = tid ? part[tid - 1] : 0;
     uint32_t *gs = a.group_start + base;
-    for (uint32_t i = ab; i < ae; ++i)
-      if (i == 0 || grp_of(i - 1) != grp_of(i)) gs[w++] = i;
-    if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
+    __syncthreads();
+    if (tid == 0) s_maxb = 0;  // reused as the list length
+    __syncthreads();
+    uint32_t mine_cnt = 0;
+    for (uint32_t i = tid; i < n; i += kSortThreads) mine_cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1u : 0u;
+    if (mine_cnt) atomicAdd(&s_maxb, mine_cnt);
+    __syncthreads();
+    const uint32_t G = s_maxb;
+    if (G <= kSortThreads) {
+      __syncthreads();
+      if (tid == 0) s_maxt = 0;  // reused as the append cursor
+      __syncthreads();
+      for (uint32_t i = tid; i < n; i += kSortThreads)
+        if (i == 0 || grp_of(i - 1) != grp_of(i)) part[atomicAdd(&s_maxt, 1u)] = i;
+      __syncthreads();
+      if (tid < G) {
+        const uint32_t v = part[tid];
+        uint32_t rank = 0;
+        for (uint32_t x = 0; x < G; ++x) rank += part[x] < v ? 1u : 0u;
+        gs[rank] = v;
+      }
+      if (tid == 0) a.n_groups[c] = G;
+    } else {
+      const uint32_t per_a = (n + kSortThreads - 1) / kSortThreads;
+      const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
+      uint32_t cnt = 0;
+      for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1 : 0;
+      __syncthreads();
+      part[tid] = cnt;
+      __syncthreads();
+      for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+      }
+      uint32_t w = tid ? part[tid - 1] : 0;
+      for (uint32_t i = ab; i < ae; ++i)
+        if (i == 0 || grp_of(i - 1) != grp_of(i)) gs[w++] = i;
+      if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
+    }
   }
 }
 
