@@ -234,6 +234,43 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     tree.close(); dev.close()
 
 
+def test_pipeline_heavy_ties_large_chunks(small_world):
+    """160 copies of contig 0's + strand point cloud at the SAME reference positions: a read from
+    that strand gets tens of thousands of anchors per chunk (the L2-scratch sort), every (group,
+    target) value repeated a hundred times (buckets beyond a wave's LDS slice: the global bitonic
+    fallback; tie runs of a hundred ordered by (query, distance)), and one bucket holding every
+    anchor of the chunk for the chaining kernels."""
+    base_ix, truth = small_world["ix"], small_world["truth"]
+    ref_of = np.asarray(base_ix.positions) >> np.uint64(33)
+    n0 = int(np.argmax(ref_of != 0))  # the cloud starts with contig 0's + strand
+    vals0 = np.ascontiguousarray(base_ix.values[:n0]).copy()
+    pos0 = np.ascontiguousarray(base_ix.positions[:n0]).copy()
+    assert n0 > 100000 and ((pos0 & np.uint64(1)) == 0).all()
+    copies = 160
+    values = np.concatenate([vals0 + np.float32(2e-5 * k) for k in range(copies)]).astype(np.float32)
+    positions = np.tile(pos0, copies)
+    ix = pipeline.HostIndex.from_points(positions, values, threads=4)
+    pick = [i for i in range(len(truth)) if truth["contig"][i] == 0 and truth["strand"][i] == 0][:3]
+    assert len(pick) >= 2
+    pa = [small_world["pa"][i] for i in pick]
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    samples, offsets = _batch(pa)
+    res = dev.map_chunks(samples, offsets, n_refs=1)
+    assert (res["status"] == 0).all() and res["n_anchors"].min() > 16384
+    tree = po.OracleTree(ix.values.copy())
+    for i, x in enumerate(pa):
+        f, _ = po.generate_events(x)
+        chains, st = po.generate_chains(tree, ix.positions, f, 1)
+        assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits
+        assert res[i]["n_chains"] == len(chains)
+        for k, c in enumerate(chains[:4]):
+            g = res[i]["chains"][k]
+            assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
+            assert g["n_anchors"] == c["n_anchors"]
+    tree.close(); dev.close()
+
+
 def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tree):
     """A wide search radius gives every chunk more anchors than the LDS sort holds (> 16384: the
     L2-scratch two-level sort) and, with 32 fast slots per query, far more overflow hits than the
