@@ -44,7 +44,7 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 
 constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
-constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit (else the wave reads them from L2)
+constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else through an LDS ring of that many anchors
 
 // ---- C0: which anchors can be settled without the sequential DP?  One thread per anchor.
 // The predecessor scan of anchor i (spatial_index.cc:461-540) only looks at predecessor SCORES
@@ -287,12 +287,33 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
                                             int max_gap_length, int max_target_gap_length, int chaining_band_length,
                                             int max_num_skips) {
   float gm = *gmax_slot;  // maximum over the anchors the classify kernel settled
+  // kLds: the whole bucket is staged (index = bucket-local anchor).  Otherwise the LDS arrays are a
+  // RING over the bucket (slot = anchor & (kBigGroupCap - 1)) that follows the unsettled anchors:
+  // before anchor ai is chained, the anchors up to ai that are not in the ring yet are staged, so
+  // the kBigGroupCap anchors ending at ai -- where a predecessor scan normally stays -- are read
+  // from LDS (with the scores of earlier unsettled anchors as they were computed); older
+  // predecessors come from memory.
+  constexpr uint32_t kMask = (uint32_t)kBigGroupCap - 1u;
+  uint32_t staged = 0;
   for (uint32_t pi = 0; pi < npend; ++pi) {
     const uint32_t ai = pend[pi] - s;  // bucket-local index of the next unsettled anchor
-    const float coef = (float)(1 - 0.2 * (double)(kLds ? l_d[ai] : dist[ai]) / (double)radius);
+    if (!kLds) {
+      const uint32_t from = max(staged, ai + 1 > (uint32_t)kBigGroupCap ? ai + 1 - (uint32_t)kBigGroupCap : 0u);
+      for (uint32_t i = from + lane; i <= ai; i += 64) {
+        l_t[i & kMask] = (int32_t)tpos[i];
+        l_q[i & kMask] = (int32_t)qpos[i];
+        l_d[i & kMask] = dist[i];
+        l_s[i & kMask] = score[i];
+      }
+      staged = ai + 1;
+      __syncthreads();
+    }
+    const uint32_t am = kLds ? ai : (ai & kMask);
+    const int32_t ring_lo = kLds ? 0 : (int32_t)ai - (int32_t)kBigGroupCap + 1;  // oldest anchor still in LDS
+    const float coef = (float)(1 - 0.2 * (double)l_d[am] / (double)radius);
     float best = coef * (float)dim;
     uint32_t best_pred = ai;
-    const int32_t ct = kLds ? l_t[ai] : (int32_t)tpos[ai], cq = kLds ? l_q[ai] : (int32_t)qpos[ai];
+    const int32_t ct = l_t[am], cq = l_q[am];
     int32_t start_idx = 0;
     if (ai > (uint32_t)chaining_band_length) start_idx = (int32_t)ai - chaining_band_length;
     int32_t num_skips = 0;
@@ -302,7 +323,9 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
       int cls = 0;  // 0 = end of range / target-gap exit, 1 = `continue`, 3 = evaluated
       float cur = 0.0f;
       if (in_range) {
-        const int32_t pt = kLds ? l_t[pj] : (int32_t)tpos[pj], pq = kLds ? l_q[pj] : (int32_t)qpos[pj];
+        const bool in_ring = kLds || pj >= ring_lo;
+        const uint32_t pm = kLds ? (uint32_t)pj : ((uint32_t)pj & kMask);
+        const int32_t pt = in_ring ? l_t[pm] : (int32_t)tpos[pj], pq = in_ring ? l_q[pm] : (int32_t)qpos[pj];
         if (pq == cq || pt == ct) {
           cls = 1;
         } else if (pt + max_target_gap_length < ct) {
@@ -318,7 +341,7 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
             const int gap_length = abs(td - qd);
             const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
             if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f)
-              cur = (kLds ? l_s[pj] : score[pj]) + matching;
+              cur = (in_ring ? l_s[pm] : score[pj]) + matching;
           }
         }
       }
@@ -355,7 +378,7 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
       num_skips = __shfl(ns_after, 63, 64);
     }
     if (lane == 0) {
-      if (kLds) l_s[ai] = best;
+      l_s[am] = best;
       score[ai] = best;
       pred[ai] = s + best_pred;  // chunk-local absolute index
     }
