@@ -59,10 +59,13 @@ def main(tag):
             "kernel": seed,
             "seed_lookup_hbm_bytes_per_launch": int((fetch_kb + write_kb) * 1024),
             "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+            "upper_bound_bytes_if_every_read_request_were_128B": int((2 * fetch_kb + write_kb) * 1024),
             "note": "rocprofv3 FETCH_SIZE/WRITE_SIZE (KB) per launch, separate --pmc passes; FETCH_SIZE = "
                     "TCC_EA0_RDREQ x 64 B.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a "
                     "wide coalesced stream; this kernel issues 16-byte gathers, for which the counter is "
-                    "uncalibrated, so the figure is the uncorrected count (true bytes are between 1x and 2x).",
+                    "uncalibrated: node records are fetched as single 64-byte sectors (counted exactly), point blocks "
+                    "as 128-byte requests (counted half), so the figure is the uncorrected count and the true "
+                    "bytes lie between it and the upper bound given here.",
         }
         json.dump(out, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_default.json", "kt_bench.json"):
