@@ -59,6 +59,27 @@ uint64_t smhost_level_means(const float *level_means, int kmer_size, const char 
 uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation, float range,
                           float offset, float *out);
 
+/* SignalBatch::LoadAllReadSignals, signal_batch.cc:24-67: every FAST5 file (single- or multi-read,
+ * signal_batch.cc:69-151) and every .sgr file under `path` (sub-directories included; or the one
+ * file), already converted to pA and filtered.  FAST5 needs a build with HDF5
+ * (smhost_have_fast5() == 1); without it a .fast5 file terminates the process like the reference's
+ * ExitWithMessage. */
+typedef struct smhost_signals smhost_signals;
+int smhost_have_fast5(void);
+smhost_signals *smhost_signals_load(const char *path);
+void smhost_signals_free(smhost_signals *s);
+uint64_t smhost_signals_count(const smhost_signals *s);
+/* read i: id (NUL terminated), pA values, their count, and the channel's conversion attributes */
+int smhost_signals_get(const smhost_signals *s, uint64_t i, const char **id, const float **pa, uint64_t *n,
+                       float *digitisation, float *range, float *offset);
+/* Test / generator support: one FAST5 file holding n_reads reads of raw ADC samples; multi_read = 0
+ * writes the single-read layout (/Raw/Reads/Read_k + /UniqueGlobalKey/channel_id), 1 the
+ * multi-read layout (/read_<id>/{Raw,channel_id}); attributes are written as doubles / strings
+ * like MinKNOW does.  Returns 0 on success. */
+int smhost_write_fast5(const char *path, int multi_read, uint32_t n_reads, const char *const *ids,
+                       const int16_t *const *raws, const uint32_t *raw_lens, float digitisation,
+                       float range, float offset);
+
 typedef struct {
   float search_radius;
   int32_t step_size, max_num_chunks, stop_min_anchors, output_min_anchors;

@@ -23,6 +23,8 @@ HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
     "smhost_index_free", "smhost_index_get", "smhost_reference_signal", "smhost_level_means",
     "smhost_raw_to_pa", "smhost_default_map_params", "smhost_should_stop", "smhost_format_paf",
+    "smhost_have_fast5", "smhost_signals_load", "smhost_signals_free", "smhost_signals_count",
+    "smhost_signals_get", "smhost_write_fast5",
 ]
 
 
@@ -132,6 +134,17 @@ def host_lib():
         L.smhost_level_means.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_void_p]
         L.smhost_raw_to_pa.restype = C.c_uint32
         L.smhost_raw_to_pa.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.smhost_signals_load.restype = C.c_void_p
+        L.smhost_signals_load.argtypes = [C.c_char_p]
+        L.smhost_signals_free.argtypes = [C.c_void_p]
+        L.smhost_signals_free.restype = None
+        L.smhost_signals_count.restype = C.c_uint64
+        L.smhost_signals_count.argtypes = [C.c_void_p]
+        L.smhost_signals_get.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float)]
+        L.smhost_write_fast5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
+                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.smhost_default_map_params.argtypes = [C.POINTER(MapParams)]
         L.smhost_should_stop.argtypes = [C.c_void_p, C.POINTER(MapParams)]
         L.smhost_format_paf.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,

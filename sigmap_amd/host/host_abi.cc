@@ -131,6 +131,51 @@ uint64_t smhost_reference_signal(const float *level_means, int kmer_size, const 
   return z.size();
 }
 
+struct smhost_signals {
+  SignalBatch batch;
+};
+
+int smhost_have_fast5(void) { return SignalBatch::HaveFAST5() ? 1 : 0; }
+
+smhost_signals *smhost_signals_load(const char *path) {
+  if (!path) return nullptr;
+  smhost_signals *s = new smhost_signals;
+  s->batch.InitializeLoading(path);
+  s->batch.LoadAllReadSignals();
+  s->batch.FinalizeLoading();
+  return s;
+}
+
+void smhost_signals_free(smhost_signals *s) { delete s; }
+
+uint64_t smhost_signals_count(const smhost_signals *s) { return s ? s->batch.GetNumSignals() : 0; }
+
+int smhost_signals_get(const smhost_signals *s, uint64_t i, const char **id, const float **pa, uint64_t *n,
+                       float *digitisation, float *range, float *offset) {
+  if (!s || i >= s->batch.GetNumSignals()) return -1;
+  const Signal &g = s->batch.GetSignalAt(i);
+  if (id) *id = g.id.c_str();
+  if (pa) *pa = g.signal_values.data();
+  if (n) *n = g.signal_values.size();
+  if (digitisation) *digitisation = g.digitisation;
+  if (range) *range = g.range;
+  if (offset) *offset = g.offset;
+  return 0;
+}
+
+int smhost_write_fast5(const char *path, int multi_read, uint32_t n_reads, const char *const *ids,
+                       const int16_t *const *raws, const uint32_t *raw_lens, float digitisation,
+                       float range, float offset) {
+  if (!path || !ids || !raws || !raw_lens) return -1;
+  std::vector<std::string> idv(n_reads);
+  std::vector<std::vector<int16_t>> rv(n_reads);
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    idv[r] = ids[r];
+    rv[r].assign(raws[r], raws[r] + raw_lens[r]);
+  }
+  return SignalBatch::WriteFAST5(path, multi_read != 0, idv, digitisation, range, offset, rv) ? 0 : -1;
+}
+
 uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation, float range,
                           float offset, float *out) {
   SignalBatch b;

@@ -70,26 +70,52 @@ bool SignalBatch::WriteSGR(const std::string &path, const std::vector<std::strin
   return fclose(f) == 0;
 }
 
+// signal_batch.cc:24-67: every file under the directory (sub-directories included) whose path
+// contains ".fast5" is read as FAST5; ".sgr" files are this build's own container.  Files are taken
+// in sorted path order (the reference follows readdir order).
+static void CollectSignalFiles(const std::string &dir_path, std::vector<std::string> *fast5,
+                               std::vector<std::string> *sgr, int depth) {
+  DIR *dir = opendir(dir_path.c_str());
+  if (!dir) return;
+  struct dirent *ent;
+  std::vector<std::string> subdirs;
+  while ((ent = readdir(dir)) != nullptr) {
+    const std::string name = ent->d_name;
+    if (name == "." || name == "..") continue;
+    const std::string path = dir_path + "/" + name;
+    DIR *sub = opendir(path.c_str());
+    if (sub) {
+      closedir(sub);
+      subdirs.push_back(path);
+    } else if (path.find(".fast5") != std::string::npos) {
+      fast5->push_back(path);
+    } else if (name.size() > 4 && name.compare(name.size() - 4, 4, ".sgr") == 0) {
+      sgr->push_back(path);
+    } else if (path.find(".blow5") != std::string::npos || path.find(".slow5") != std::string::npos) {
+      std::cerr << "Skipping " << path << ": BLOW5 ingestion needs slow5lib, which this build does not have.\n";
+    }
+  }
+  closedir(dir);
+  if (depth < 8)
+    for (const auto &p : subdirs) CollectSignalFiles(p, fast5, sgr, depth + 1);
+}
+
 size_t SignalBatch::LoadAllReadSignals() {
   const double t0 = GetRealTime();
-  std::vector<std::string> files;
+  std::vector<std::string> fast5, sgr;
   DIR *dir = opendir(signal_directory_.c_str());
   if (dir) {
-    struct dirent *ent;
-    while ((ent = readdir(dir)) != nullptr) {
-      const std::string name = ent->d_name;
-      if (name.size() > 4 && name.compare(name.size() - 4, 4, ".sgr") == 0)
-        files.push_back(signal_directory_ + "/" + name);
-      else if (name.find(".fast5") != std::string::npos || name.find(".blow5") != std::string::npos ||
-               name.find(".slow5") != std::string::npos)
-        std::cerr << "Skipping " << name << ": FAST5/BLOW5 ingestion is not built (use .sgr).\n";
-    }
     closedir(dir);
-    std::sort(files.begin(), files.end());
+    CollectSignalFiles(signal_directory_, &fast5, &sgr, 0);
+    std::sort(fast5.begin(), fast5.end());
+    std::sort(sgr.begin(), sgr.end());
+  } else if (signal_directory_.find(".fast5") != std::string::npos) {
+    fast5.push_back(signal_directory_);  // a single file
   } else {
-    files.push_back(signal_directory_);  // a single file
+    sgr.push_back(signal_directory_);
   }
-  for (const auto &p : files) AddSignalsFromSGR(p);
+  for (const auto &p : fast5) AddSignalsFromFAST5(p);
+  for (const auto &p : sgr) AddSignalsFromSGR(p);
   std::cerr << "Loaded " << signals_.size() << " reads in " << GetRealTime() - t0 << "s.\n";
   return signals_.size();
 }

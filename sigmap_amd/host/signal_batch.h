@@ -2,10 +2,10 @@
 // signal_batch.h:14-57: InitializeLoading, LoadAllReadSignals, GetSignalAt,
 // GetSignalNameAt, GetSignalLengthAt, FinalizeLoading, ConvertSequencesToSignals).
 //
-// On-disk read container: this build's own flat format (".sgr", below).  FAST5 / BLOW5
-// ingestion is the reference's third-party I/O layer (hdf5_tools.hpp, slow5lib) and is a
-// "next" row of the scope table; the pA conversion and (30,200) pA
-// filter that define what the hot path sees are implemented here.
+// On-disk read containers: FAST5 (single- and multi-read, fast5_reader.cc, when HDF5 is present
+// at build time) and this build's own flat format (".sgr", below).  BLOW5 needs slow5lib, which
+// is not vendored.  The pA conversion and (30,200) pA filter that define what
+// the hot path sees are implemented here.
 //
 //   .sgr : "SGR1" | u32 n_reads | n_reads x { u32 id_len | id bytes | f32 digitisation |
 //          f32 range | f32 offset | u32 n_raw | i16 raw[n_raw] }       (little endian)
@@ -36,6 +36,11 @@ class SignalBatch {
   void AddSignal(const std::string &id, float digitisation, float range, float offset,
                  const int16_t *raw, size_t n_raw);
   void AddSignalsFromSGR(const std::string &path);
+  void AddSignalsFromFAST5(const std::string &path);  // signal_batch.cc:69-151
+  static bool HaveFAST5();
+  static bool WriteFAST5(const std::string &path, bool multi_read, const std::vector<std::string> &ids,
+                         float digitisation, float range, float offset,
+                         const std::vector<std::vector<int16_t>> &raws);
   static bool WriteSGR(const std::string &path, const std::vector<std::string> &ids,
                        float digitisation, float range, float offset,
                        const std::vector<std::vector<int16_t>> &raws);

@@ -105,3 +105,39 @@ def write_sgr(path, raw, ids=None, digitisation=DIGITISATION, rng=RANGE, offset=
             f.write(struct.pack("<I", len(rid)) + rid)
             f.write(struct.pack("<fffI", digitisation, rng, offset, len(r)))
             f.write(r.tobytes())
+
+
+def write_fast5(path, raw, ids=None, multi_read=True, digitisation=DIGITISATION, rng=RANGE, offset=OFFSET):
+    """One FAST5 file (multi- or single-read layout) through the host library's HDF5 writer."""
+    import ctypes as C
+    from . import _abi
+    L = _abi.host_lib()
+    if not L.smhost_have_fast5():
+        raise RuntimeError("host library was built without HDF5")
+    raws = [np.ascontiguousarray(r, dtype=np.int16) for r in raw]
+    names = [(ids[i] if ids else "read%d" % i).encode() for i in range(len(raws))]
+    idp = (C.c_char_p * len(raws))(*names)
+    rp = (C.c_void_p * len(raws))(*[r.ctypes.data for r in raws])
+    lens = np.array([len(r) for r in raws], dtype=np.uint32)
+    if L.smhost_write_fast5(path.encode(), 1 if multi_read else 0, len(raws), idp, rp, _abi.ptr(lens),
+                            digitisation, rng, offset) != 0:
+        raise RuntimeError("smhost_write_fast5 failed for " + path)
+
+
+def load_signals(path):
+    """[(id, pA float32 array, digitisation, range, offset)] of every read under `path` (host loader)."""
+    import ctypes as C
+    from . import _abi
+    L = _abi.host_lib()
+    h = L.smhost_signals_load(path.encode())
+    out = []
+    try:
+        for i in range(L.smhost_signals_count(h)):
+            rid, pa, n = C.c_char_p(), C.POINTER(C.c_float)(), C.c_uint64()
+            dg, rg, of = C.c_float(), C.c_float(), C.c_float()
+            assert L.smhost_signals_get(h, i, C.byref(rid), C.byref(pa), C.byref(n), C.byref(dg), C.byref(rg), C.byref(of)) == 0
+            vals = np.ctypeslib.as_array(pa, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+            out.append((rid.value.decode(), vals, dg.value, rg.value, of.value))
+    finally:
+        L.smhost_signals_free(h)
+    return out

@@ -496,6 +496,17 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     assert [strip(l) for l in got] == exp
     assert sum(1 for l in exp if "\t*\t" not in l) >= 18
     tree.close()
+    # the same reads as one multi-read FAST5 file (signal_batch.cc:69-151): identical PAF
+    if _abi.host_lib().smhost_have_fast5():
+        os.makedirs(tmp_path / "reads5")
+        synth.write_fast5(str(tmp_path / "reads5" / "a.fast5"), raws, ["read%03d" % i for i in range(len(raws))])
+        r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                            "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads5"), "-o", str(tmp_path / "out5.paf")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got5 = [strip(l) for l in open(tmp_path / "out5.paf").read().splitlines()]
+        rename = lambda l: "\t".join(["read%d" % int(l.split("\t")[0][4:])] + l.split("\t")[1:])
+        assert [rename(l) for l in got5] == exp
     # --sdtw-band adds a dt:f: tag to rows that have a chain and changes nothing else
     r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
                         "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out2.paf"),
