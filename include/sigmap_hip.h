@@ -207,6 +207,19 @@ int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64
 
 /* ---- per-stage entry points (parity tests address each kernel in isolation) ---- */
 
+/* The reference's CWT feature path for a batch of chunks: Sigmap::GenerateFeatureSignalUsingCWT,
+ * sigmap.cc:1085-1098 = MAD normalisation (:1100-1129) -> one-scale DoG CWT (GenerateCWTSignal
+ * :1157-1174 -> cwt.cc) -> z-score (:1131-1155) -> GeneratePeaks (:1176-1196, hysteresis SD/4).
+ * scale0 is the CWT scale (the reference uses 8 for reads, sigmap.cc:947); 4 <= scale0 <= 64.
+ * feat / positions: n_chunks x feat_stride (peaks beyond feat_stride are counted, not stored);
+ * cwt_out (optional): n_chunks x 4096 floats, the CWT signal of every chunk.
+ * Dormant in the reference's CLI (CWTAlign is disabled, sigmap.cc:1499-1504): offered as a stage,
+ * not wired into smhip_map_run.  The CWT agrees with the reference's f32-FFT evaluation to that
+ * FFT's rounding (about 2e-7 of the signal's maximum), not bit for bit. */
+int smhip_cwt_features(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                       float scale0, uint32_t feat_stride, float *feat, uint32_t *positions, uint32_t *n_features,
+                       float *cwt_out);
+
 /* Sigmap::GenerateEvents, sigmap.cc:1048-1083 (DetectEvents event.h:226 + z-score
  * sigmap.cc:1131 + compression).  feat/stdv: n_chunks x feat_stride floats. */
 int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,

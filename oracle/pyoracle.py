@@ -276,3 +276,43 @@ def sdtw_banded(target, query, lo, hi):
     end = C.c_int64()
     d = lib().so_sdtw_banded(_p(t), len(t), _p(q), len(q), _p(lo), _p(hi), C.byref(end))
     return d, end.value
+
+
+# ---- CWT feature path (D1-D3)
+def mad_normalize(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(len(x), np.float32)
+    lib().so_mad_normalize.restype = C.c_float
+    mad = lib().so_mad_normalize(_p(x), C.c_size_t(len(x)), _p(out))
+    return out, mad
+
+
+def cwt_dog(x, scale0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(len(x), np.float32)
+    lib().so_cwt_dog(_p(x), C.c_size_t(len(x)), C.c_float(scale0), _p(out))
+    return out
+
+
+def ref_cwt_dog(x, scale0):
+    """The REAL reference cwt.cc (oracle/_ref), when it was built."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(len(x), np.float32)
+    ref().ref_cwt_dog(_p(x), C.c_size_t(len(x)), C.c_float(scale0), _p(out))
+    return out
+
+
+def generate_peaks(x, selective):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    pk, pos = np.zeros(len(x), np.float32), np.zeros(len(x), np.uint32)
+    lib().so_generate_peaks.restype = C.c_size_t
+    n = lib().so_generate_peaks(_p(x), C.c_size_t(len(x)), C.c_float(selective), _p(pk), _p(pos))
+    return pk[:n].copy(), pos[:n].copy()
+
+
+def cwt_features(x, scale0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    pk, pos, cw = np.zeros(len(x), np.float32), np.zeros(len(x), np.uint32), np.zeros(len(x), np.float32)
+    lib().so_cwt_features.restype = C.c_size_t
+    n = lib().so_cwt_features(_p(x), C.c_size_t(len(x)), C.c_float(scale0), _p(pk), _p(pos), _p(cw))
+    return pk[:n].copy(), pos[:n].copy(), cw

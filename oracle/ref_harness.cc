@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "cwt.h"
 #include "event.h"
 #include "nanoflann.hpp"
 #include "pore_model.h"
@@ -199,5 +200,17 @@ long ref_level_means(const char *model_path, const char *seq, uint32_t start, ui
   std::vector<float> v = pm.GetLevelMeansAt(seq, start, end);
   memcpy(out, v.data(), v.size() * 4);
   return (long)v.size();
+}
+
+// sigmap.cc:1157-1174 GenerateCWTSignal's calls into cwt.cc (cwt_init :1633, setCWTScales :1711,
+// cwt :1735, cwavelet :1762, DoG daughter :1595-1630): one-scale DoG (m = 2) CWT, real part.
+void ref_cwt_dog(const float *x, size_t n, float scale0, float *out) {
+  char wave[] = "dog";
+  char type[] = "pow";
+  sigmap::cwt_object wt = sigmap::cwt_init(wave, 2.0, (int)n, 1, 1);
+  sigmap::setCWTScales(wt, scale0, 1, type, 2.0);
+  sigmap::cwt(wt, x);
+  for (size_t i = 0; i < n; ++i) out[i] = wt->output[i].re;
+  sigmap::cwt_free(wt);
 }
 }

@@ -1381,3 +1381,107 @@ float so_sdtw_banded(const float *target, size_t tlen, const float *query, size_
   free(cur);
   return best;
 }
+
+
+/* ===================== CWT feature path (D1-D3) ===================== */
+static int so_cmp_float(const void *a, const void *b) {
+  const float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+
+/* sigmap.cc:1100-1129 (std::nth_element at n/2 == the value at index n/2 of the sorted array) */
+float so_mad_normalize(const float *x, size_t n, float *out) {
+  float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+  memcpy(tmp, x, n * sizeof(float));
+  qsort(tmp, n, sizeof(float), so_cmp_float);
+  const float median = tmp[n / 2];
+  for (size_t i = 0; i < n; ++i) tmp[i] = fabsf(x[i] - median); /* taken on the unsorted values: same multiset */
+  qsort(tmp, n, sizeof(float), so_cmp_float);
+  const float mad = tmp[n / 2];
+  for (size_t i = 0; i < n; ++i) out[i] = (x[i] - median) / mad;
+  free(tmp);
+  return mad;
+}
+
+/* cwt.cc:1633-1709 (npad), :1762-1841 (cwavelet), :1595-1630 (DoG daughter, m = 2: sign +1, real) */
+void so_cwt_dog(const float *x, size_t n, float scale0, float *out) {
+  if (n == 0) return;
+  const float t1 = 0.499999f + logf((float)n) / logf(2.0f);
+  const int ibase2 = 1 + (int)t1;
+  const size_t npad = (size_t)1 << ibase2;
+  const double pi = 4.0 * atan(1.0);
+  const double s = (double)scale0, dt = 1.0;
+  /* sqrt(2 pi s / dt) * sqrt(1 / Gamma(m + 1/2)), Gamma(2.5) = 3 sqrt(pi) / 4 */
+  const double norm = sqrt(2.0 * pi * s / dt) * sqrt(1.0 / (0.75 * sqrt(pi)));
+  /* daughter on the wavenumber grid kwave[k] = k * 2 pi / (npad dt) (symmetric in k) */
+  double *D = (double *)malloc((npad / 2 + 1) * sizeof(double));
+  for (size_t k = 0; k <= npad / 2; ++k) {
+    const double sk = s * ((double)k * 2.0 * pi / ((double)npad * dt));
+    D[k] = norm * sk * sk * exp(-0.5 * sk * sk);
+  }
+  /* impulse response.  For s >= 4 the spectrum is ~0 at the Nyquist wavenumber and h decays like
+   * exp(-(j/s)^2/2): beyond |j| = 9 s it is below 1e-17 of its peak.  For smaller scales the
+   * sampled spectrum is cut at Nyquist with a kink and h has 1/j^2 tails: keep every lag. */
+  size_t L = s >= 4.0 ? (size_t)(9.0 * s) + 4 : npad / 2 - 1;
+  if (L > npad / 2 - 1) L = npad / 2 - 1;
+  if (L > n - 1) L = n - 1;
+  double *h = (double *)malloc((L + 1) * sizeof(double));
+  for (size_t j = 0; j <= L; ++j) {
+    double acc = D[0] + ((npad / 2) * j % 2 ? -D[npad / 2] : D[npad / 2]);
+    for (size_t k = 1; k < npad / 2; ++k) acc += 2.0 * D[k] * cos(2.0 * pi * (double)((k * j) % npad) / (double)npad);
+    h[j] = acc / (double)npad;
+  }
+  float ymean = 0.0f; /* cwt_type is float: sequential f32 sum (cwt.cc:1786-1790) */
+  for (size_t i = 0; i < n; ++i) ymean += x[i];
+  ymean /= (float)n;
+  for (size_t i = 0; i < n; ++i) {
+    double acc = 0.0;
+    const size_t lo = i > L ? i - L : 0, hi = i + L < n ? i + L : n - 1;
+    for (size_t m = lo; m <= hi; ++m) acc += (double)(x[m] - ymean) * h[m > i ? m - i : i - m];
+    out[i] = (float)acc;
+  }
+  free(D);
+  free(h);
+}
+
+/* sigmap.cc:1176-1196 */
+size_t so_generate_peaks(const float *x, size_t n, float selective, float *peaks, uint32_t *positions) {
+  size_t np = 0;
+  if (n < 3) return 0;
+  float previous_valley = x[0], previous_peak = x[0];
+  for (size_t i = 1; i + 1 < n; ++i) {
+    if (x[i] > x[i - 1] && x[i] >= x[i + 1] && x[i] >= previous_valley + selective) {
+      peaks[np] = x[i];
+      positions[np++] = (uint32_t)i;
+      previous_peak = x[i];
+    } else if (x[i] < x[i - 1] && x[i] <= x[i + 1] && x[i] <= previous_peak - selective) {
+      peaks[np] = x[i];
+      positions[np++] = (uint32_t)i;
+      previous_valley = x[i];
+    }
+  }
+  return np;
+}
+
+/* sigmap.cc:1085-1098 */
+size_t so_cwt_features(const float *x, size_t n, float scale0, float *feat, uint32_t *positions, float *cwt_out) {
+  if (n < 3) return 0;
+  float *a = (float *)malloc(n * sizeof(float)), *b = (float *)malloc(n * sizeof(float));
+  so_mad_normalize(x, n, a);
+  so_cwt_dog(a, n, scale0, b);
+  if (cwt_out) memcpy(cwt_out, b, n * sizeof(float));
+  /* GenerateZscoreNormalizedSignal returns SD (sigmap.cc:1131-1155); selective = SD / 4 */
+  double mean = 0;
+  for (size_t i = 0; i < n; ++i) mean += b[i];
+  mean /= n;
+  double SD = 0;
+  for (size_t i = 0; i < n; ++i) SD += (b[i] - mean) * (b[i] - mean);
+  SD /= (n - 1);
+  SD = sqrt(SD);
+  for (size_t i = 0; i < n; ++i) a[i] = (float)((b[i] - mean) / SD);
+  const float sd_f = (float)SD;
+  const size_t np = so_generate_peaks(a, n, sd_f / 4, feat, positions);
+  free(a);
+  free(b);
+  return np;
+}

@@ -207,6 +207,23 @@ float so_sdtw(const float *target, size_t tlen, const float *query, size_t qlen,
 float so_sdtw_banded(const float *target, size_t tlen, const float *query, size_t qlen,
                      const uint32_t *lo, const uint32_t *hi, int64_t *end);
 
+/* ---- CWT feature path (dormant in the reference's CLI: CWTAlign, sigmap.cc:932) ---- */
+/* sigmap.cc:1100-1129 GenerateMADNormalizedSignal: the n/2-th order statistic as "median", same
+ * for the absolute deviations; out = (x - median) / MAD.  Returns MAD. */
+float so_mad_normalize(const float *x, size_t n, float *out);
+/* sigmap.cc:1157-1174 GenerateCWTSignal -> cwt.cc cwt_init/setCWTScales/cwt/cwavelet with the DoG
+ * (m = 2) daughter of cwt.cc:1595-1630, one scale.  The reference evaluates
+ *   out = IFFT( D .* FFT(x - mean(x), npad) / npad ),  D[k] = norm (s k)^2 exp(-(s k)^2 / 2)
+ * with an f32 mixed-radix FFT; this restatement evaluates the same linear map as the convolution
+ * with h[j] = (1/npad) sum_k D[k] cos(2 pi k j / npad) in double, so it agrees with the real cwt.cc
+ * (oracle/_ref ref_cwt_dog) to the f32 FFT's rounding, not bit for bit: "tolerance parity". */
+void so_cwt_dog(const float *x, size_t n, float scale0, float *out);
+/* sigmap.cc:1176-1196 GeneratePeaks.  Returns the number of peaks / valleys written. */
+size_t so_generate_peaks(const float *x, size_t n, float selective, float *peaks, uint32_t *positions);
+/* sigmap.cc:1085-1098 GenerateFeatureSignalUsingCWT: MAD -> CWT(scale0) -> z-score -> peaks with
+ * selective = SD / 4.  cwt_out (optional, n floats) receives the CWT signal. */
+size_t so_cwt_features(const float *x, size_t n, float scale0, float *feat, uint32_t *positions, float *cwt_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ HIP_SYMBOLS = [
     "smhip_index_upload", "smhip_index_export", "smhip_index_attach", "smhip_batch_upload",
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
     "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
-    "smhip_seed_lookup", "smhip_sdtw_banded",
+    "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -185,6 +185,7 @@ def hip_lib():
         L.smhip_refine_run.argtypes = [vp, u32, u32]
         L.smhip_refine_download.argtypes = [vp, vp, vp]
         L.smhip_debug_counters.argtypes = [vp, vp]
+        L.smhip_cwt_features.argtypes = [vp, vp, vp, u32, C.c_float, u32, vp, vp, vp, vp]
         L.smhip_timing_enable.argtypes = [vp, C.c_int]
         L.smhip_timing_reset.argtypes = [vp]
         L.smhip_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]

@@ -6,6 +6,8 @@
 
 #include <stdlib.h>
 
+#include <math.h>
+
 #include "common.h"
 
 using namespace smhip;
@@ -695,6 +697,64 @@ int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,
     if (n_events) n_events[c] = res[c].n_events;
     if (status) status[c] = res[c].status;
   }
+  ctx->run_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_cwt_features(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                       float scale0, uint32_t feat_stride, float *feat, uint32_t *positions, uint32_t *n_features,
+                       float *cwt_out) {
+  if (!ctx || !feat || !positions || !n_features) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!(scale0 >= 4.0f && scale0 <= 64.0f)) return Fail(ctx, SMHIP_EINVAL, "scale0 must be in [4, 64]");
+  if (feat_stride == 0) return Fail(ctx, SMHIP_EINVAL, "feat_stride must be positive");
+  int rc = smhip_batch_upload(ctx, samples_pa, sample_offsets, n_chunks, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (n_chunks == 0) return SMHIP_OK;
+  // impulse response of the reference's spectral filter (cwt.cc:1595-1630, 1762-1841) for the
+  // padded length every chunk of up to 4096 samples gets (cwt.cc:1698-1700: 8192), in double
+  const size_t npad = 8192;
+  const double pi = 4.0 * atan(1.0), s = (double)scale0;
+  const double norm = sqrt(2.0 * pi * s) * sqrt(1.0 / (0.75 * sqrt(pi)));  // Gamma(2.5) = 3 sqrt(pi) / 4
+  const uint32_t L = (uint32_t)(9.0 * s) + 4;
+  std::vector<double> D(npad / 2 + 1), h(L + 1);
+  for (size_t k = 0; k <= npad / 2; ++k) {
+    const double sk = s * ((double)k * 2.0 * pi / (double)npad);
+    D[k] = norm * sk * sk * exp(-0.5 * sk * sk);
+  }
+  for (size_t j = 0; j <= L; ++j) {
+    double acc = D[0] + ((npad / 2) * j % 2 ? -D[npad / 2] : D[npad / 2]);
+    for (size_t k = 1; k < npad / 2; ++k) acc += 2.0 * D[k] * cos(2.0 * pi * (double)((k * j) % npad) / (double)npad);
+    h[j] = acc / (double)npad;
+  }
+  DevBuf d_h, d_rows, d_feat, d_pos, d_n;
+  auto free_all = [&]() {
+    for (DevBuf *b : {&d_h, &d_rows, &d_feat, &d_pos, &d_n}) b->Free();
+  };
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  const uint64_t nf = (uint64_t)n_chunks * feat_stride;
+  step(d_h.Reserve((L + 1) * sizeof(double)));
+  step(d_rows.Reserve((uint64_t)n_chunks * 4096 * sizeof(float)));
+  step(d_feat.Reserve(nf * sizeof(float)));
+  step(d_pos.Reserve(nf * sizeof(uint32_t)));
+  step(d_n.Reserve((uint64_t)n_chunks * sizeof(uint32_t)));
+  if (e == hipSuccess) step(hipMemcpyAsync(d_h.p, h.data(), (L + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (e == hipSuccess) step(hipMemsetAsync(d_rows.p, 0, (uint64_t)n_chunks * 4096 * sizeof(float), ctx->stream));
+  if (e == hipSuccess)
+    step(LaunchCwtFeatures(ctx, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), n_chunks, d_h.as<double>(), L,
+                           d_rows.as<float>(), feat_stride, d_feat.as<float>(), d_pos.as<uint32_t>(),
+                           d_n.as<uint32_t>()));
+  if (e == hipSuccess) step(hipMemcpyAsync(feat, d_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipMemcpyAsync(positions, d_pos.p, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess)
+    step(hipMemcpyAsync(n_features, d_n.p, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess && cwt_out)
+    step(hipMemcpyAsync(cwt_out, d_rows.p, (uint64_t)n_chunks * 4096 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipStreamSynchronize(ctx->stream));
+  free_all();
+  if (e != hipSuccess) return HipFail(ctx, e, "smhip_cwt_features");
   ctx->run_done = false;
   return SMHIP_OK;
 }

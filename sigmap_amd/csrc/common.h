@@ -172,6 +172,9 @@ struct ChainArgs {
 };
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
                        uint64_t n_anchors_total);
+hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint32_t *off, uint32_t n_chunks,
+                             const double *h, uint32_t L, float *cwt_rows, uint32_t feat_stride, float *feat,
+                             uint32_t *pos, uint32_t *n_feat);
 hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, const float *feat,
                             uint32_t feat_stride, const uint32_t *qstart, uint32_t n_chunks, const float *ref_sig,
                             const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,

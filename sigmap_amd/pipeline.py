@@ -177,6 +177,20 @@ class DeviceMapper:
         self._check(self.L.smhip_refine_download(self._h, ptr(dist), ptr(end)), "smhip_refine_download")
         return dist, end
 
+    def cwt_features(self, samples, offsets, scale0=8.0, feat_stride=2736, want_cwt=False):
+        """The reference's CWT feature path (smhip_cwt_features): per chunk the peak / valley values,
+        their sample positions and count; optionally the CWT signal rows (n_chunks x 4096)."""
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        n = len(offsets) - 1
+        feat = np.zeros((n, feat_stride), np.float32)
+        pos = np.zeros((n, feat_stride), np.uint32)
+        cnt = np.zeros(n, np.uint32)
+        rows = np.zeros((n, 4096), np.float32) if want_cwt else None
+        self._check(self.L.smhip_cwt_features(self._h, ptr(samples), ptr(offsets), n, scale0, feat_stride, ptr(feat),
+                                              ptr(pos), ptr(cnt), ptr(rows) if want_cwt else None), "smhip_cwt_features")
+        return feat, pos, cnt, rows
+
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint32)
         self._check(self.L.smhip_debug_counters(self._h, ptr(out)), "smhip_debug_counters")

@@ -6,6 +6,7 @@ container only (needs /root/reference); the .npz files are committed, the refere
   kdtree.npz : 40 kb point cloud -> pre-order tree dump + vind + bbox       (nanoflann.hpp:858-1004)
                + 300 queries -> hit lists in traversal order                 (nanoflann.hpp:1278-1410)
   levels.npz : pore-model table + sequences -> level means                  (pore_model.cc:57-81)
+  cwt.npz    : 4 MAD-normalised signals x scales {8, 5, 2} -> DoG CWT signal (cwt.cc:1633-1841)
 """
 import ctypes as C
 import os
@@ -101,6 +102,17 @@ def main():
             lv[f"seq{i}"] = np.frombuffer(s, dtype=np.uint8); lv[f"lv{i}"] = out[:n].copy()
         lv["level_means"] = lm
     np.savez_compressed(os.path.join(OUT, "levels.npz"), **lv)
+    # ---- CWT (the real cwt.cc on MAD-normalised reads; one ragged)
+    cw = {}
+    for r in range(4):
+        pa = pipeline.raw_to_pa(raw[r], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        if r == 3:
+            pa = pa[:2501]
+        a, _ = po.mad_normalize(pa)
+        cw["in%d" % r] = a
+        for sc in (8, 5, 2):
+            cw["out%d_s%d" % (r, sc)] = po.ref_cwt_dog(a, float(sc))
+    np.savez_compressed(os.path.join(OUT, "cwt.npz"), **cw)
     print("golden written:", os.listdir(OUT))
 
 

@@ -417,6 +417,55 @@ def test_band_sweep_properties():
     dev.close()
 
 
+# ------------------------------------------------------------------ CWT feature path (D1-D3)
+
+@pytest.mark.parametrize("scale0", [8.0, 5.0])
+def test_cwt_features_match_oracle_and_reference(device, small_world, scale0):
+    """MAD normalisation and the peak picker are exact; the DoG CWT is the same linear map as the
+    reference's f32-FFT evaluation, so it is held to the FFT's rounding: 1e-5 of the signal's maximum
+    against the oracle restatement AND against the real cwt.cc (oracle/_ref) -- measured 2e-7.  A
+    peak that hinges on the last bit of a CWT value may move, so peak lists are compared through the
+    oracle's peak picker run on the DEVICE's CWT signal (exact), and against the oracle's own
+    end-to-end list with a small allowance."""
+    pa = small_world["pa"][:12] + [small_world["pa"][0][:1500], np.full(4000, 90.0, np.float32) + np.arange(4000, dtype=np.float32) % 7]
+    samples, offsets = _batch(pa)
+    feat, pos, cnt, rows = device.cwt_features(samples, offsets, scale0=scale0, want_cwt=True)
+    total = same = 0
+    for i, x in enumerate(pa):
+        n = len(x)
+        a, _ = po.mad_normalize(x)
+        ocw = po.cwt_dog(a, scale0)
+        tol = 1e-5 * float(np.abs(ocw).max())
+        assert np.abs(rows[i, :n] - ocw).max() <= tol
+        if po.have_ref():
+            assert np.abs(rows[i, :n] - po.ref_cwt_dog(a, scale0)).max() <= tol
+        # D3 exactly, given the device's own CWT signal
+        z = np.zeros(n, np.float32)
+        po.lib().so_zscore(po._p(np.ascontiguousarray(rows[i, :n])), C.c_size_t(n), po._p(z))
+        # (SD accumulated sequentially in f64 like the reference; numpy's pairwise sums can differ)
+        pk, pp = po.generate_peaks(z, _oracle_sd(rows[i, :n]) / np.float32(4))
+        assert cnt[i] == len(pk)
+        assert np.array_equal(pos[i, :cnt[i]], pp) and np.array_equal(bits(feat[i, :cnt[i]]), bits(pk))
+        # end to end against the oracle (its own CWT): the same peaks but for last-bit cases
+        opk, opp, _ = po.cwt_features(x, scale0)
+        total += len(opp)
+        same += len(np.intersect1d(opp, pos[i, :cnt[i]]))
+    assert total > 2000 and same >= 0.995 * total
+
+
+def _oracle_sd(x):
+    """SD exactly as GenerateZscoreNormalizedSignal accumulates it (sequential f64), narrowed to f32."""
+    mean = 0.0
+    for v in x:
+        mean += float(v)
+    mean /= len(x)
+    sd = 0.0
+    for v in x:
+        sd += (float(v) - mean) * (float(v) - mean)
+    sd /= (len(x) - 1)
+    return np.float32(np.sqrt(sd))
+
+
 # ------------------------------------------------------------------ banded sDTW (D4/D5)
 
 def test_sdtw_kernel_matches_oracle(device):

@@ -160,3 +160,35 @@ def test_sdtw_full_band_equals_unbanded():
     d2, end2 = po.sdtw_banded(t, q, lo, hi)
     assert d == d2 and end == end2
     assert 155 <= end <= 165
+
+
+# ------------------------------------------------------------------ CWT feature path (D1-D3)
+
+def test_cwt_against_reference_golden():
+    """The oracle's restatement of the one-scale DoG CWT vs the output of the REAL cwt.cc (golden):
+    same linear map, evaluated in double instead of with an f32 FFT -> agreement to the FFT's
+    rounding (2e-7 of the maximum measured; 1e-5 required)."""
+    g = np.load(os.path.join(GOLDEN, "cwt.npz"))
+    for r in range(4):
+        for sc in (8, 5, 2):
+            want = g["out%d_s%d" % (r, sc)]
+            got = po.cwt_dog(g["in%d" % r], float(sc))
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+            if po.have_ref():
+                assert np.array_equal(bits(po.ref_cwt_dog(g["in%d" % r], float(sc))), bits(want))
+
+
+def test_mad_and_peaks_known_answers():
+    x = np.array([5, 1, 9, 3, 7, 2, 8], np.float32)          # sorted: 1 2 3 5 7 8 9 -> [n/2] = 5
+    out, mad = po.mad_normalize(x)                           # |x-5| sorted: 0 2 2 3 3 4 4 -> [3] = 3
+    assert mad == 3.0 and np.array_equal(out, (x - 5) / np.float32(3))
+    even = np.array([4, 1, 3, 2], np.float32)                # "fake median": sorted[2] = 3 (upper of the two)
+    out, mad = po.mad_normalize(even)                        # |x-3| = 1 2 0 1 -> sorted 0 1 1 2 -> [2] = 1
+    assert mad == 1.0 and np.array_equal(out, even - 3)
+    sig = np.array([0, 1, 0, 2, 0, 0.1, 0, -2, 0, 3, 3, 0], np.float32)
+    pk, pos = po.generate_peaks(sig, 0.5)
+    # 1@1 peak (>= valley 0 + .5); 0@2 valley (<= peak 1 - .5); 2@3 peak; 0@4 valley; .1@5 no (too small);
+    # -2@7 valley; 3@9 peak (3 > 0, 3 >= 3); 3@10 is not > its left neighbour
+    assert pos.tolist() == [1, 2, 3, 4, 7, 9] and pk.tolist() == [1, 0, 2, 0, -2, 3]
+    f, p, cw = po.cwt_features(np.linspace(60, 120, 50).astype(np.float32) + np.float32(5) * np.sin(np.arange(50, dtype=np.float32)), 4.0)
+    assert len(f) == len(p) and (np.diff(p.astype(np.int64)) > 0).all()
