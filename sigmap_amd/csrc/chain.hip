@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
                                                     int max_num_skips, uint32_t *__restrict__ big_list,
                                                     uint32_t *__restrict__ big_count,
                                                     const uint32_t *__restrict__ n_pending) {
+  __shared__ uint32_t s_ids[kBigPendingMin][64];  // each lane's pending anchor ids
   const uint32_t total_groups = goff[n_chunks];
   // grid-stride over buckets (the bucket total is only known on the device)
   for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_groups; gi += gridDim.x * 64) {
@@ -203,54 +204,91 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     big_list[atomicAdd(big_count, 1u)] = gi;
     continue;
   }
+  // The anchors of the slice are chained in order (each may read the scores of the ones before),
+  // but everything an anchor needs EXCEPT those scores -- its id, its own record, the positions of
+  // its first kPf predecessors -- is fetched while the previous anchor is being chained, so an
+  // anchor costs one memory round trip (the scores) instead of four dependent ones.
+  const uint32_t npl = p1 - p0;  // <= kBigPendingMin
+#pragma unroll
+  for (int k = 0; k < kBigPendingMin; ++k) s_ids[k][threadIdx.x] = pending[min(p0 + (uint32_t)k, npend ? npend - 1 : 0u)];
+  struct Pre {
+    uint32_t ai;
+    float d;
+    int32_t ct, cq, pt[kPf], pq[kPf];
+  };
+  auto issue = [&](uint32_t k, Pre &P) {
+    const uint32_t ai = s_ids[k][threadIdx.x];
+    P.ai = ai;
+    P.d = dist[ai];
+    P.ct = (int32_t)tpos[ai];
+    P.cq = (int32_t)qpos[ai];
+    const int32_t aidx = (int32_t)(ai - s);
+    const int32_t sidx = aidx > chaining_band_length ? aidx - chaining_band_length : 0;
+#pragma unroll
+    for (int j = 0; j < kPf; ++j) {
+      const int32_t pj = max(max(aidx - 1 - j, sidx), 0);  // clamped: always a valid address
+      P.pt[j] = (int32_t)tpos[s + pj];
+      P.pq[j] = (int32_t)qpos[s + pj];
+    }
+  };
   float gm = 0.0f;
-  for (uint32_t pi = p0; pi < p1; ++pi) {
+  Pre cur{}, nxt{};
+  if (npl > 0) issue(0, cur);
+  for (uint32_t k = 0; k < npl; ++k) {
    {
-    const uint32_t ai = pending[pi];
+    if (k + 1 < npl) issue(k + 1, nxt);
+    const uint32_t ai = cur.ai;
     const uint32_t anchor_index = ai - s;
-    const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
+    const float coef = (float)(1 - 0.2 * (double)cur.d / (double)radius);
     float best = coef * (float)dim;
     uint32_t best_pred = anchor_index;
-    const int32_t ct = (int32_t)tpos[ai], cq = (int32_t)qpos[ai];
+    const int32_t ct = cur.ct, cq = cur.cq;
     int32_t start_idx = 0;
     if (anchor_index > (uint32_t)chaining_band_length) start_idx = (int32_t)anchor_index - chaining_band_length;
     int32_t num_skips = 0;
     bool done = false;
+    bool first = true;
     for (int32_t pj0 = (int32_t)anchor_index - 1; pj0 >= start_idx && !done; pj0 -= kPf) {
       int32_t pt[kPf], pq[kPf];
       float ps[kPf];
 #pragma unroll
-      for (int k = 0; k < kPf; ++k) {
+      for (int kk = 0; kk < kPf; ++kk) {
         // unconditional loads from a clamped index: a conditional load compiles to a branch with
         // its own s_waitcnt, i.e. one memory round trip per predecessor instead of one per block
-        const int32_t pj = max(pj0 - k, start_idx);
-        pt[k] = (int32_t)tpos[s + pj];
-        pq[k] = (int32_t)qpos[s + pj];
-        ps[k] = score[s + pj];
+        const int32_t pj = max(pj0 - kk, start_idx);
+        if (first) {
+          pt[kk] = cur.pt[kk];
+          pq[kk] = cur.pq[kk];
+        } else {
+          pt[kk] = (int32_t)tpos[s + pj];
+          pq[kk] = (int32_t)qpos[s + pj];
+        }
+        ps[kk] = score[s + pj];
       }
+      first = false;
 #pragma unroll
-      for (int k = 0; k < kPf; ++k) {
-        const int32_t pj = pj0 - k;
+      for (int kk = 0; kk < kPf; ++kk) {
+        const int32_t pj = pj0 - kk;
         if (done || pj < start_idx) break;
-        if (pq[k] == cq) continue;
-        if (pt[k] == ct) continue;
-        if (pt[k] + max_target_gap_length < ct) {
+        if (pq[kk] == cq) continue;
+        if (pt[kk] == ct) continue;
+        if (pt[kk] + max_target_gap_length < ct) {
           done = true;
           break;
         }
-        const int32_t td = ct - pt[k];
-        const int32_t qd = cq - pq[k];
-        float cur = 0;
+        const int32_t td = ct - pt[kk];
+        const int32_t qd = cq - pq[kk];
+        float curv = 0;
         if (qd < 0) continue;
         {
           const int32_t m = min(min(td, qd), dim);
           const float matching = (float)m * coef;
           const int gap_length = abs(td - qd);
           const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-          if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) cur = ps[k] + matching;
+          if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) curv = ps[kk] + matching;
         }
-        if (cur > best) {
-          best = cur;
+        if (curv > best) {
+          best = curv;
           best_pred = (uint32_t)pj;
           --num_skips;
         } else {
@@ -266,6 +304,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     pred[ai] = s + best_pred;  // chunk-local absolute index
     used[ai] = 0;
     gm = fmaxf(gm, best);
+    cur = nxt;
    }
   }
   if (gm > gmax[g]) gmax[g] = gm;  // the classify kernel stored the maximum over the settled anchors
