@@ -678,6 +678,29 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
     for (uint32_t i = lane; i < nch0; i += 64) ch[i] = gch[i];
   }
   __syncthreads();
+  // Descending by operator> (spatial_index.cc:569-570), keeping the order of equal chains: with up
+  // to 64 candidates every lane ranks its own chain against the others (LDS broadcasts) -- the
+  // one-lane insertion sort of a few dozen 32-byte records took 100 000+ cycles per chunk.
+  bool sorted = false;
+  {
+    const uint32_t nchp = min(n_chains_in[c], (uint32_t)kChainCap);
+    if (nchp <= 64) {
+      ChainTmp mine{};
+      if (lane < nchp) mine = ch[lane];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nchp; ++j) {
+        const ChainTmp o = ch[j];
+        if (lane < nchp && j != lane) {
+          if (ChainGreater(o, mine)) ++rank;
+          else if (!ChainGreater(mine, o) && j < lane) ++rank;
+        }
+      }
+      __syncthreads();
+      if (lane < nchp) ch[rank] = mine;
+      __syncthreads();
+      sorted = true;
+    }
+  }
   if (lane == 0) {
     uint32_t nch = n_chains_in[c];
     if (nch > (uint32_t)kChainCap) {
@@ -686,7 +709,7 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
     }
     uint32_t np = 0;
     if (nch > 0) {
-      for (uint32_t i = 1; i < nch; ++i) {  // insertion sort, descending by operator>
+      for (uint32_t i = 1; i < nch && !sorted; ++i) {  // more than 64 candidates: insertion sort
         const ChainTmp x = ch[i];
         uint32_t j = i;
         while (j > 0 && ChainGreater(x, ch[j - 1])) {
