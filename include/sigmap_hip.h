@@ -95,17 +95,20 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
  * These are the walker's own structures, derived from the smhip_node array at upload. */
 typedef struct {
   int32_t dim;
-  uint32_t pad;
-  uint64_t n_nodes, m_size;
-  void *nodes;      uint64_t nodes_bytes;      /* 64 B per tree node, pre-order (child1 = self+1):
-                                                  inner {divlow, divhigh, child2, feat}, leaf
-                                                  {left, n, boff, 0xFFFFFFFF}; then lo[6], hi[6] =
-                                                  tight box of the points below the node */
+  uint32_t root_ref;                           /* 0, or 0x80000000 when the tree is a single leaf */
+  uint64_t n_nodes, n_leaves, m_size;          /* n_nodes = INNER nodes (one record each) */
+  void *nodes;      uint64_t nodes_bytes;      /* 64 B per inner node, pre-order among the inner nodes:
+                                                  {divlow, divhigh, ref1 | feat << 28, ref2}, then the
+                                                  tight boxes of both children as 24 x u16 on the grid
+                                                  in bbox[12..23]; ref = inner index, or 0x80000000 |
+                                                  leaf ordinal */
+  void *leaf_tab;   uint64_t leaf_tab_bytes;   /* uint32 per leaf: (boff / 16) | n << 27 */
   void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks at slot `boff`:
                                                   n x {v0..v3}, then n x {v4, v5, uint64 position} */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[slots / 2]: original point index of the
                                                   point in first-half slot boff + t at (boff >> 1) + t */
-  void *bbox;       uint64_t bbox_bytes;       /* float[2*dim] */
+  void *bbox;       uint64_t bbox_bytes;       /* float[4*dim]: root box {low0, high0, ...}, then
+                                                  base[dim], step[dim] of the box grid */
 } smhip_index_dev;
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
 /* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */

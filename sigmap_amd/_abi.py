@@ -85,8 +85,10 @@ CARRIED_DTYPE = np.dtype([("ref_strand", "<u4"), ("target_position", "<u4"),
 
 
 class IndexDev(C.Structure):
-    _fields_ = [("dim", C.c_int32), ("pad", C.c_uint32), ("n_nodes", C.c_uint64), ("m_size", C.c_uint64),
+    _fields_ = [("dim", C.c_int32), ("root_ref", C.c_uint32),
+                ("n_nodes", C.c_uint64), ("n_leaves", C.c_uint64), ("m_size", C.c_uint64),
                 ("nodes", C.c_void_p), ("nodes_bytes", C.c_uint64),
+                ("leaf_tab", C.c_void_p), ("leaf_tab_bytes", C.c_uint64),
                 ("leaf_pts", C.c_void_p), ("leaf_pts_bytes", C.c_uint64),
                 ("leaf_vind", C.c_void_p), ("leaf_vind_bytes", C.c_uint64),
                 ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64)]

@@ -152,7 +152,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+  DevBuf *bufs[] = {&ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
@@ -182,34 +182,40 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
   // Walker structures (layouts: seed_lookup.hip header) from the pre-order node array: one
-  // 64-byte record per node and per-leaf point blocks of 2 * roundup(n, 8) 16-byte slots (whole
-  // 128-byte lines).  The boxes are filled on the device: leaves by the gather, inner nodes level
-  // by level from the deepest one up.
-  std::vector<uint32_t> h_nodes(n_nodes * 16, 0), depth(n_nodes, 0);
-  uint64_t n_inner = 0, n_slots = 0, leaf_points = 0;
+  // 64-byte record per INNER node, one table word and one point block of 2 * roundup(n, 8) 16-byte
+  // slots (whole 128-byte lines) per leaf.  The boxes are computed on the device: leaves by the
+  // gather, inner nodes level by level from the deepest one up, then quantised into the parents.
+  std::vector<uint32_t> ref_of(n_nodes), depth(n_nodes, 0);
+  uint64_t n_inner = 0, n_leaves = 0, n_slots = 0, leaf_points = 0;
   uint32_t max_depth = 0;
   for (uint64_t i = 0; i < n_nodes; ++i) {
+    if (nodes[i].feat >= 0) ref_of[i] = (uint32_t)n_inner++;
+    else ref_of[i] = kLeafTag | (uint32_t)n_leaves++;
+  }
+  if (n_inner >= (1ull << 27) || n_leaves >= (1ull << 27))
+    return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit node references");
+  std::vector<uint32_t> h_inner(std::max<uint64_t>(n_inner, 1) * 16, 0), leaf_left(n_leaves), leaf_tab(n_leaves);
+  for (uint64_t i = 0; i < n_nodes; ++i) {
     const smhip_node &nd = nodes[i];
-    uint32_t *o = &h_nodes[(size_t)i * 16];
     if (nd.feat >= 0) {
       if (nd.feat >= dim || i + 1 >= n_nodes || nd.child2 >= n_nodes || nd.child2 <= i + 1)
         return Fail(ctx, SMHIP_EINVAL, "malformed inner node (children must follow in pre-order)");
+      uint32_t *o = &h_inner[(size_t)ref_of[i] * 16];
       o[0] = nd.a;
       o[1] = nd.b;
-      o[2] = nd.child2;
-      o[3] = (uint32_t)nd.feat;
+      o[2] = ref_of[i + 1] | ((uint32_t)nd.feat << 28);
+      o[3] = ref_of[nd.child2];
       depth[i + 1] = depth[nd.child2] = depth[i] + 1;
       max_depth = std::max(max_depth, depth[i] + 1);
-      ++n_inner;
     } else {
       if (nd.b < nd.a || nd.b > m_size) return Fail(ctx, SMHIP_EINVAL, "leaf range outside the point list");
-      if (nd.b - nd.a > 255) return Fail(ctx, SMHIP_EINVAL, "leaf with more than 255 points");
-      if (n_slots > 0xFFFFFF00ull) return Fail(ctx, SMHIP_EINVAL, "index too large for 32-bit leaf block offsets");
-      const uint32_t n = nd.b - nd.a;
-      o[0] = nd.a;
-      o[1] = n;
-      o[2] = (uint32_t)n_slots;
-      o[3] = 0xFFFFFFFFu;
+      // the scan phase tests one point per lane, 21 lanes per leaf (the reference builds with
+      // max_leaf = 20, sigmap.cc:1426)
+      if (nd.b - nd.a > 21) return Fail(ctx, SMHIP_EINVAL, "leaf with more than 21 points");
+      if (n_slots >= (1ull << 31)) return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit leaf block numbers");
+      const uint32_t n = nd.b - nd.a, l = ref_of[i] & ~kLeafTag;
+      leaf_left[l] = nd.a;
+      leaf_tab[l] = (uint32_t)(n_slots >> 4) | (n << 27);
       n_slots += 2ull * ((n + 7u) & ~7u);
       leaf_points += n;
     }
@@ -224,27 +230,31 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   {
     std::vector<uint64_t> cur(level_start.begin(), level_start.end() - 1);
     for (uint64_t i = 0; i < n_nodes; ++i)
-      if (nodes[i].feat >= 0) level_nodes[cur[depth[i]]++] = (uint32_t)i;
+      if (nodes[i].feat >= 0) level_nodes[cur[depth[i]]++] = ref_of[i];
   }
+  const uint32_t root_ref = ref_of[0];
   ctx->leaf_pts_bytes = n_slots * 16 + 128;
-  HIPCHK(ctx->ix_nodes.Reserve(n_nodes * 64));
+  HIPCHK(ctx->ix_nodes.Reserve(std::max<uint64_t>(n_inner, 1) * 64));
+  HIPCHK(ctx->ix_tab.Reserve(n_leaves * sizeof(uint32_t)));
   HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
   ctx->leaf_vind_bytes = (n_slots / 2 + 32) * sizeof(uint32_t);
   HIPCHK(ctx->ix_vind.Reserve(ctx->leaf_vind_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_vind.p, 0, ctx->leaf_vind_bytes, ctx->stream));
-  HIPCHK(ctx->ix_bbox.Reserve(2 * dim * sizeof(float)));
-  // staging copies of the original-order point cloud, freed after the leaf-major gather
-  DevBuf d_values, d_positions, d_levels, d_vind;
+  HIPCHK(ctx->ix_bbox.Reserve(4 * dim * sizeof(float)));
+  // staging copies of the original-order point cloud and the exact boxes, freed after the build
+  DevBuf d_values, d_positions, d_levels, d_vind, d_left, d_leaf_box, d_inner_box, d_flag;
   HIPCHK(d_values.Reserve(n_points * sizeof(float)));
   hipError_t e = d_positions.Reserve(n_points * sizeof(uint64_t));
   if (e == hipSuccess) e = d_levels.Reserve(level_nodes.size() * sizeof(uint32_t));
   if (e == hipSuccess) e = d_vind.Reserve(m_size * sizeof(uint32_t));
+  if (e == hipSuccess) e = d_left.Reserve(n_leaves * sizeof(uint32_t));
+  if (e == hipSuccess) e = d_leaf_box.Reserve(n_leaves * 12 * sizeof(float));
+  if (e == hipSuccess) e = d_inner_box.Reserve(std::max<uint64_t>(n_inner, 1) * 12 * sizeof(float));
+  if (e == hipSuccess) e = d_flag.Reserve(sizeof(uint32_t));
   auto cleanup = [&]() {
-    d_values.Free();
-    d_positions.Free();
-    d_levels.Free();
-    d_vind.Free();
+    for (DevBuf *b : {&d_values, &d_positions, &d_levels, &d_vind, &d_left, &d_leaf_box, &d_inner_box, &d_flag})
+      b->Free();
   };
   if (e != hipSuccess) {
     cleanup();
@@ -261,21 +271,31 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   HIPCHK2(hipMemcpyAsync(d_values.p, values, n_points * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_positions.p, positions, n_points * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_vind.p, vind, m_size * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, h_nodes.data(), n_nodes * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_nodes.p, h_inner.data(), h_inner.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(ctx->ix_tab.p, leaf_tab.data(), n_leaves * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemcpyAsync(d_left.p, leaf_left.data(), n_leaves * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(d_levels.p, level_nodes.data(), level_nodes.size() * sizeof(uint32_t),
                          hipMemcpyHostToDevice, ctx->stream));
   HIPCHK2(hipMemcpyAsync(ctx->ix_bbox.p, root_bbox, 2 * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK2(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), ctx->stream));
   HIPCHK2(LaunchLeafGather(ctx, dim, d_values.as<float>(), d_positions.as<uint64_t>(), d_vind.as<uint32_t>(),
-                           ctx->ix_nodes.p, n_nodes, ctx->ix_pts.as<float>(), ctx->ix_vind.as<uint32_t>()));
+                           d_left.as<uint32_t>(), ctx->ix_tab.as<uint32_t>(), n_leaves, ctx->ix_pts.as<float>(),
+                           ctx->ix_vind.as<uint32_t>(), d_leaf_box.as<float>()));
   for (uint32_t d = max_depth + 1; d-- > 0;)
     HIPCHK2(LaunchInnerBoxes(ctx, ctx->ix_nodes.p, d_levels.as<uint32_t>() + level_start[d],
-                             (uint32_t)(level_start[d + 1] - level_start[d])));
+                             (uint32_t)(level_start[d + 1] - level_start[d]), d_leaf_box.as<float>(),
+                             d_inner_box.as<float>()));
+  HIPCHK2(LaunchPackBoxes(ctx, ctx->ix_nodes.p, n_inner, root_ref, d_leaf_box.as<float>(), d_inner_box.as<float>(),
+                          ctx->ix_bbox.as<float>() + 2 * dim, d_flag.as<uint32_t>()));
+  uint32_t pack_error = 0;
+  HIPCHK2(hipMemcpyAsync(&pack_error, d_flag.p, sizeof pack_error, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK2(hipStreamSynchronize(ctx->stream));
 #undef HIPCHK2
   cleanup();
+  if (pack_error) return Fail(ctx, SMHIP_EINVAL, "point coordinates cannot be boxed on the 16-bit grid (non-finite values?)");
   ctx->dim = dim;
-  ctx->index = IndexView{ctx->ix_nodes.as<uint4>(), ctx->ix_pts.as<float>(), ctx->ix_vind.as<uint32_t>(),
-                         ctx->ix_bbox.as<float>(), n_nodes, m_size};
+  ctx->index = IndexView{ctx->ix_nodes.as<uint4>(), ctx->ix_tab.as<uint32_t>(), ctx->ix_pts.as<float>(),
+                         ctx->ix_vind.as<uint32_t>(), ctx->ix_bbox.as<float>(), n_inner, n_leaves, m_size, root_ref};
   ctx->have_index = true;
   ctx->index_owned = true;
   return SMHIP_OK;
@@ -286,30 +306,38 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "no index resident");
   memset(out, 0, sizeof *out);
   out->dim = ctx->dim;
-  out->n_nodes = ctx->index.n_nodes;
+  out->root_ref = ctx->index.root_ref;
+  out->n_nodes = ctx->index.n_inner;
+  out->n_leaves = ctx->index.n_leaves;
   out->m_size = ctx->index.m_size;
-  out->nodes = (void *)ctx->index.nodes;
-  out->nodes_bytes = ctx->index.n_nodes * 64;
+  out->nodes = (void *)ctx->index.inner;
+  out->nodes_bytes = std::max<uint64_t>(ctx->index.n_inner, 1) * 64;
+  out->leaf_tab = (void *)ctx->index.leaf_tab;
+  out->leaf_tab_bytes = ctx->index.n_leaves * sizeof(uint32_t);
   out->leaf_pts = (void *)ctx->index.leaf_pts;
   out->leaf_pts_bytes = ctx->leaf_pts_bytes;
   out->leaf_vind = (void *)ctx->index.leaf_vind;
   out->leaf_vind_bytes = ctx->leaf_vind_bytes;
   out->bbox = (void *)ctx->index.bbox;
-  out->bbox_bytes = 2 * ctx->dim * sizeof(float);
+  out->bbox_bytes = 4 * ctx->dim * sizeof(float);
   return SMHIP_OK;
 }
 
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (!ctx || !in) return SMHIP_EINVAL;
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
-  if (!in->nodes || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_nodes == 0)
+  if (!in->nodes || !in->leaf_tab || !in->leaf_pts || !in->leaf_vind || !in->bbox || in->n_leaves == 0)
     return Fail(ctx, SMHIP_EINVAL, "null index array");
-  if (in->nodes_bytes < in->n_nodes * 64 || in->leaf_pts_bytes < in->m_size * 32 ||
-      in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 48)
+  if (in->nodes_bytes < in->n_nodes * 64 || in->leaf_tab_bytes < in->n_leaves * 4 ||
+      in->leaf_pts_bytes < in->m_size * 32 || in->leaf_vind_bytes < in->m_size * 4 || in->bbox_bytes < 96)
     return Fail(ctx, SMHIP_EINVAL, "index array smaller than its declared element count");
+  if (in->n_nodes + 1 != in->n_leaves || (in->n_nodes == 0) != (in->root_ref == kLeafTag) ||
+      (in->n_nodes != 0 && in->root_ref != 0))
+    return Fail(ctx, SMHIP_EINVAL, "inconsistent node counts / root reference");
   ctx->dim = in->dim;
-  ctx->index = IndexView{(const uint4 *)in->nodes, (const float *)in->leaf_pts, (const uint32_t *)in->leaf_vind,
-                         (const float *)in->bbox, in->n_nodes, in->m_size};
+  ctx->index = IndexView{(const uint4 *)in->nodes, (const uint32_t *)in->leaf_tab, (const float *)in->leaf_pts,
+                         (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->n_leaves,
+                         in->m_size, in->root_ref};
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->leaf_vind_bytes = in->leaf_vind_bytes;
   ctx->have_index = true;

@@ -35,13 +35,18 @@ struct ChainTmp {
 };
 
 // Device view of the index (all pointers device memory; layouts: seed_lookup.hip header).
+constexpr uint32_t kLeafTag = 0x80000000u;  // a node ref with this bit names a leaf (ordinal in the low 27 bits)
+
 struct IndexView {
-  const uint4 *nodes;         // 4 x uint4 per tree node (pre-order): {divlow, divhigh, child2, feat} or
-                              // {left, n, boff, 0xFFFFFFFF}, then lo[6], hi[6] of the node's tight box
+  const uint4 *inner;         // 4 x uint4 per INNER node: {divlow, divhigh, ref1 | feat << 28, ref2}, then the
+                              // children's tight boxes, 24 x u16 (layout: seed_lookup.hip header)
+  const uint32_t *leaf_tab;   // per leaf: (first slot of its point block / 16) | n << 27
   const float *leaf_pts;      // per-leaf 128-byte-aligned point blocks
   const uint32_t *leaf_vind;  // [n_slots / 2] Hit.slot -> original point index
-  const float *bbox;          // [12] low0, high0, ...
-  uint64_t n_nodes, m_size;
+  const float *bbox;          // [24] low0, high0, ... of nanoflann's root box; then base[6], step[6] of the
+                              // grid the children's boxes are quantised on
+  uint64_t n_inner, n_leaves, m_size;
+  uint32_t root_ref;          // 0 (inner record 0), or kLeafTag for a tree that is a single leaf
 };
 
 // Grow-only device buffer.
@@ -83,7 +88,7 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_nodes, ix_pts, ix_vind, ix_bbox, scan_tmp;
+  smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, scan_tmp;
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   // batch inputs
   uint32_t n_chunks = 0;
@@ -117,9 +122,13 @@ namespace smhip {
 // Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
 // launch status.
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts,
-                            uint32_t *slot_vind);
-hipError_t LaunchInnerBoxes(smhip_ctx *ctx, void *nodes, const uint32_t *level_nodes, uint32_t count);
+                            const uint32_t *vind, const uint32_t *leaf_left, const uint32_t *leaf_tab,
+                            uint64_t n_leaves, float *leaf_pts, uint32_t *slot_vind, float *leaf_box);
+hipError_t LaunchInnerBoxes(smhip_ctx *ctx, const void *inner, const uint32_t *level_nodes, uint32_t count,
+                            const float *leaf_box, float *inner_box);
+// grid = {base[6], step[6]} from the root's tight box; then the children's boxes of every inner record
+hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32_t root_ref, const float *leaf_box,
+                           const float *inner_box, float *grid, uint32_t *error_flag);
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);

@@ -6,10 +6,13 @@
 // from SpatialIndex::GenerateChains (spatial_index.cc:351-409).
 //
 // Data layout in HBM (built once per index from the pre-order smhip_node array + point cloud):
-//   nodes    : one 64-byte record (one sector) per tree node, in pre-order (child1 = self + 1):
-//                inner {divlow, divhigh, child2, feat}  lo[6] hi[6]
-//                leaf  {left, n, boff, 0xFFFFFFFF}      lo[6] hi[6]
-//              lo/hi is the TIGHT bounding box of the points below the node.
+//   inner    : one 64-byte record (one sector) per INNER node, numbered in pre-order among the inner
+//              nodes: {divlow, divhigh, ref1 | feat << 28, ref2} and the TIGHT bounding boxes of
+//              BOTH CHILDREN, 24 x u16: child1 lo[6], hi[6], child2 lo[6], hi[6], quantised on the
+//              root box per dimension (value = root_lo + q * (root_hi - root_lo) / 65534) and
+//              rounded OUTWARDS, so a quantised box contains the exact one.  A ref is an inner
+//              index, or kLeafTag | leaf ordinal (tree order): leaves have no record of their own.
+//   leaf_tab : uint32 per leaf: (first 16-byte slot of its point block / 16) | n << 27
 //   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf at slot offset `boff`: n "first
 //              halves" {v0,v1,v2,v3}, then (from slot boff + roundup(n, 8)) n "second halves"
 //              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte line.
@@ -27,14 +30,17 @@
 // the reference.
 //
 // What is NOT visited although nanoflann visits it (results are identical, argument in place):
-// a node whose tight box is at squared distance >= radius from the query.  The box distance is
+// a node whose (outward-rounded) tight box is at squared distance >= radius from the query; the
+// test is made at the PARENT, which holds both children's boxes, so such a node costs neither a
+// visit nor a stack entry, and a leaf costs no record read at all.  The box distance is
 // accumulated with nanoflann's own association order (evalMetric) and every f32 operation
 // involved is monotone, so it is a lower bound of the f32 distance nanoflann would compute for
 // any point below the node -- no point there can pass `dist < radius`, the subtree contributes no
 // hit, and skipping it changes neither the hit list nor its order.  nanoflann's own rule is still
 // applied with its own arithmetic on top (it must be: it is not implied bit-for-bit by the box rule).
-// On the 12 Mb index this visits 331 node records per query instead of nanoflann's 470 and tests
-// 205 points instead of 1196.  kStrict = true switches the box rule off for inner nodes and counts
+// On the 12 Mb index this reads about 250 node records per query where nanoflann visits 470 nodes
+// and tests 205 points instead of 1196 (what bounds the kernel is the number of 64-byte sectors it
+// touches: DESIGN.md 4.2).  kStrict = true switches the box rule off for inner nodes and counts
 // nanoflann's work (nodes visited, points it would test): that is the census the roofline's
 // algorithmic bytes are computed from, and what the per-stage tests compare with the oracle.
 //
@@ -60,6 +66,8 @@ namespace {
 
 constexpr int kSeedThreads = 256;
 constexpr int kFifo = 4;  // pending leaves per lane
+constexpr uint32_t kIdxMask = 0x07FFFFFFu;  // index part of a ref (inner index or leaf ordinal)
+constexpr uint32_t kPassTag = 0x40000000u;  // stack entry / current node: the box test at the parent was passed
 
 struct QueryRec {  // 32 B
   float q[6];
@@ -144,6 +152,12 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
 #pragma unroll
   for (int k = 0; k < 12; ++k)
     root_box[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[k])));
+  float box_base[6], box_step[6];  // grid of the children's quantised boxes (wave-uniform too)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    box_base[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[12 + k])));
+    box_step[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[18 + k])));
+  }
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, qi = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
-  // pending leaves of this lane's query, in the order they were reached: boff; n in fifo_n
+  // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
   __shared__ uint32_t fifo[kFifo][kSeedThreads];
   __shared__ uint32_t ovf_lds[kSeedThreads];  // scan phase: overflow segment base of each lane's query
   // staging of the cooperative node fetch: 64 records x 64 B per wave
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   const uint32_t lane = threadIdx.x & 63u;
   uint4 *stage_w = stage[threadIdx.x >> 6];
   uint32_t tcnt = 0, thead = 0;
-  uint32_t fifo_cnt = 0, fifo_n = 0;  // fifo_n: 8 bits of n per entry
+  uint32_t fifo_cnt = 0;
   uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
   uint32_t st_walk = 0, st_walk_lanes = 0, st_scan = 0, st_scan_lanes = 0;  // wave-uniform statistics
   // A load that would otherwise add a dependent round trip to an iteration is issued one
@@ -193,10 +207,18 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {boff, owner lane | n << 8}
       float4 *own_a = reinterpret_cast<float4 *>(stage_w + 128);  // [64] q0..q3 of the owning lane
       uint4 *own_b = stage_w + 192;                                // [64] q4, q5, query id, hits so far
+      {
+        uint32_t tab[kFifo];
 #pragma unroll
-      for (int e = 0; e < kFifo; ++e)
-        if ((uint32_t)e < c)
-          ents[my_first + e] = make_uint2(fifo[e][threadIdx.x], lane | (((fifo_n >> (8 * e)) & 0xFFu) << 8));
+        for (int e = 0; e < kFifo; ++e) tab[e] = (uint32_t)e < c ? ix.leaf_tab[fifo[e][threadIdx.x]] : 0u;
+#pragma unroll
+        for (int e = 0; e < kFifo; ++e)
+          if ((uint32_t)e < c) {
+            const uint32_t nleaf = tab[e] >> 27;
+            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 4, lane | (nleaf << 8));
+            if (!kStrict) np += nleaf;  // (strict: counted when the leaf was visited)
+          }
+      }
       if (c > 0) {
         own_a[lane] = make_float4(q0, q1, q2, q3);
         own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
@@ -279,7 +301,6 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         ovf_base = ovf_lds[threadIdx.x];
       }
       fifo_cnt = 0;
-      fifo_n = 0;
       if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
         sink.q_count[qi] = hits;
         if (sink.q_nodes) sink.q_nodes[qi] = nn;
@@ -327,14 +348,14 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         mind = 0.0f;
         SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
         SM_INIT_DIM(5, d5)
-        node = 0; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
+        node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
         mode = M_NODE;
       }
       pool_next += take;
       need = __ballot(active && mode == M_FETCH);
     }
     {
-      const uint32_t want = (active && mode == M_NODE) ? node : 0xFFFFFFFFu;
+      const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
       uint32_t nsrc[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       for (int r = 0; r < 4; ++r) {
         const uint32_t src = (uint32_t)r * 16u + (lane >> 2);
         if (nsrc[r] != 0xFFFFFFFFu) {
-          const uint4 *g = ix.nodes + (size_t)nsrc[r] * 4 + ((lane & 3u) ^ ((src >> 2) & 3u));
+          const uint4 *g = ix.inner + (size_t)nsrc[r] * 4 + ((lane & 3u) ^ ((src >> 2) & 3u));
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                            (__attribute__((address_space(3))) void *)(stage_w + r * 64), 16, 0, 0);
         }
@@ -358,53 +379,60 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       rf_pending = false;
     }
     if (active && mode == M_NODE) {
-      const uint32_t rot = (lane >> 2) & 3u;
-      const uint4 *mine = stage_w + lane * 4;
-      const uint4 r = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
-      // squared distance from the query to the node's tight box, accumulated like evalMetric
-      // (nanoflann.hpp:391-406): a lower bound of every point's f32 distance (monotone ops)
-#define SM_BOX(qq, ll, hh) fmaxf(fmaxf((qq) - __uint_as_float(hh), __uint_as_float(ll) - (qq)), 0.0f)
-      const float e0 = SM_BOX(q0, b0.x, b1.z), e1 = SM_BOX(q1, b0.y, b1.w), e2 = SM_BOX(q2, b0.z, b2.x);
-      const float e3 = SM_BOX(q3, b0.w, b2.y), e4 = SM_BOX(q4, b1.x, b2.z), e5 = SM_BOX(q5, b1.y, b2.w);
-#undef SM_BOX
-      float lb = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-      lb += e4 * e4;
-      lb += e5 * e5;
-      const bool is_leaf = r.w == 0xFFFFFFFFu;
-      const bool inside = lb < radius;
       bool pop = true;
-      if (kStrict || inside) ++nn;
-      if (is_leaf) {
-        // a leaf visit of searchLevel (nanoflann.hpp:1350-1369); r = {left, n, boff, -}
-        if (kStrict) np += r.y;  // the reference evaluates every point of a visited leaf
-        if (inside && r.y > 0) {
-          if (!kStrict) np += r.y;
-          fifo[fifo_cnt][threadIdx.x] = r.z;
-          fifo_n |= r.y << (8 * fifo_cnt);
-          ++fifo_cnt;
+      if (node & kLeafTag) {
+        // a leaf visit of searchLevel (nanoflann.hpp:1350-1369): the root of a one-leaf tree, or a far
+        // child popped from the stack; kPassTag = its box test (made at the parent) was passed
+        const uint32_t leaf = node & kIdxMask;
+        ++nn;
+        if (kStrict) np += ix.leaf_tab[leaf] >> 27;  // the reference evaluates every point of a visited leaf
+        if (node & kPassTag) fifo[fifo_cnt++][threadIdx.x] = leaf;
+      } else {
+        // an inner visit (nanoflann.hpp:1371-1408); hd = {divlow, divhigh, ref1 | feat << 28, ref2}
+        const uint32_t rot = (lane >> 2) & 3u;
+        const uint4 *mine = stage_w + lane * 4;
+        const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
+        ++nn;
+        // squared distances from the query to the children's boxes, accumulated like evalMetric
+        // (nanoflann.hpp:391-406): lower bounds of every point's f32 distance (monotone ops; the
+        // boxes are rounded outwards).  b0 = c1.lo[0..5], c1.hi[0..1]; b1 = c1.hi[2..5], c2.lo[0..3];
+        // b2 = c2.lo[4..5], c2.hi[0..5]
+#define SM_DQ(word, half, k) __fmaf_rn((float)(((word) >> (16 * (half))) & 0xFFFFu), box_step[k], box_base[k])
+#define SM_BOX(qq, lo, hi) fmaxf(fmaxf((qq) - (hi), (lo) - (qq)), 0.0f)
+        float lb1, lb2;
+        {
+          const float e0 = SM_BOX(q0, SM_DQ(b0.x, 0, 0), SM_DQ(b0.w, 0, 0)), e1 = SM_BOX(q1, SM_DQ(b0.x, 1, 1), SM_DQ(b0.w, 1, 1));
+          const float e2 = SM_BOX(q2, SM_DQ(b0.y, 0, 2), SM_DQ(b1.x, 0, 2)), e3 = SM_BOX(q3, SM_DQ(b0.y, 1, 3), SM_DQ(b1.x, 1, 3));
+          const float e4 = SM_BOX(q4, SM_DQ(b0.z, 0, 4), SM_DQ(b1.y, 0, 4)), e5 = SM_BOX(q5, SM_DQ(b0.z, 1, 5), SM_DQ(b1.y, 1, 5));
+          lb1 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+          lb1 += e4 * e4;
+          lb1 += e5 * e5;
         }
-      } else if (kStrict || inside) {  // nanoflann.hpp:1371-1408; r = {divlow, divhigh, child2, feat}
-        const uint32_t idx = r.w;
-        // q[idx], dists[idx]: a balanced tree of bit-selects (v_bfi_b32) on the bits of idx, 5 per
-        // value; written on integers so that the compiler keeps them branch-free
-        const uint32_t m0 = 0u - (idx & 1u), m1 = 0u - ((idx >> 1) & 1u), m2 = 0u - ((idx >> 2) & 1u);
-#define SM_SEL(m, a, b) (((m) & (a)) | (~(m) & (b))) /* m ? a : b */
-#define SM_PICK(x0, x1, x2, x3, x4, x5)                                                                  \
-  SM_SEL(m2, SM_SEL(m0, __float_as_uint(x5), __float_as_uint(x4)),                                       \
-         SM_SEL(m1, SM_SEL(m0, __float_as_uint(x3), __float_as_uint(x2)),                                \
-                SM_SEL(m0, __float_as_uint(x1), __float_as_uint(x0))))
-        const float val = __uint_as_float(SM_PICK(q0, q1, q2, q3, q4, q5));
-        const float dst = __uint_as_float(SM_PICK(d0, d1, d2, d3, d4, d5));
-#undef SM_PICK
-#undef SM_SEL
-        const float divlow = __uint_as_float(r.x), divhigh = __uint_as_float(r.y);
+        {
+          const float e0 = SM_BOX(q0, SM_DQ(b1.z, 0, 0), SM_DQ(b2.y, 0, 0)), e1 = SM_BOX(q1, SM_DQ(b1.z, 1, 1), SM_DQ(b2.y, 1, 1));
+          const float e2 = SM_BOX(q2, SM_DQ(b1.w, 0, 2), SM_DQ(b2.z, 0, 2)), e3 = SM_BOX(q3, SM_DQ(b1.w, 1, 3), SM_DQ(b2.z, 1, 3));
+          const float e4 = SM_BOX(q4, SM_DQ(b2.x, 0, 4), SM_DQ(b2.w, 0, 4)), e5 = SM_BOX(q5, SM_DQ(b2.x, 1, 5), SM_DQ(b2.w, 1, 5));
+          lb2 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+          lb2 += e4 * e4;
+          lb2 += e5 * e5;
+        }
+#undef SM_BOX
+#undef SM_DQ
+        const uint32_t idx = (hd.z >> 28) & 7u;
+        const uint32_t ref1 = hd.z & (kLeafTag | kIdxMask), ref2 = hd.w & (kLeafTag | kIdxMask);
+        // q[idx], dists[idx]: a balanced tree of selects on the bits of idx (5 per value)
+        const bool i0 = (idx & 1u) != 0, i1 = (idx & 2u) != 0, i2 = (idx & 4u) != 0;
+        const float val = i2 ? (i0 ? q5 : q4) : (i1 ? (i0 ? q3 : q2) : (i0 ? q1 : q0));
+        const float dst = i2 ? (i0 ? d5 : d4) : (i1 ? (i0 ? d3 : d2) : (i0 ? d1 : d0));
+        const float divlow = __uint_as_float(hd.x), divhigh = __uint_as_float(hd.y);
         const float diff1 = val - divlow, diff2 = val - divhigh;
         const bool low_side = (diff1 + diff2) < 0;
-        const uint32_t next = low_side ? node + 1 : r.z, other = low_side ? r.z : node + 1;
+        const uint32_t next = low_side ? ref1 : ref2, other = low_side ? ref2 : ref1;
+        const bool in_next = (low_side ? lb1 : lb2) < radius, in_other = (low_side ? lb2 : lb1) < radius;
         const float dcut = low_side ? diff2 : diff1;
         const float cut = dcut * dcut;
         const float nm = mind + cut - dst;
-        if (nm <= radius) {  // mindistsq * epsError <= worstDist(), epsError == 1
+        if (nm <= radius && (kStrict || in_other)) {  // mindistsq * epsError <= worstDist(), epsError == 1
           if (sp + tcnt < (uint32_t)kStackDepth) {
             const uint32_t slot = thead ^ 1u;
             if (tcnt == 2) {  // spill the older cached entry
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
             }
             // the entry is the current dists with dists[idx] = cut: written whole, then one word
             // replaced (words 2..7 of the entry are dists[0..5])
-            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other), nm, d0, d1);
+            tos[slot][0][threadIdx.x] = make_float4(__uint_as_float(other | (in_other ? kPassTag : 0u)), nm, d0, d1);
             tos[slot][1][threadIdx.x] = make_float4(d2, d3, d4, d5);
             const uint32_t word = idx + 2u;
             reinterpret_cast<float *>(&tos[slot][word >> 2][threadIdx.x])[word & 3u] = cut;
@@ -425,8 +453,16 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
             atomicOr(&sink.counters[0], 1u);
           }
         }
-        node = next;
-        pop = false;
+        if (next & kLeafTag) {  // the near child is a leaf: visited here, it has no record
+          if (kStrict || in_next) {
+            ++nn;
+            if (kStrict) np += ix.leaf_tab[next & kIdxMask] >> 27;
+            if (in_next) fifo[fifo_cnt++][threadIdx.x] = next & kIdxMask;
+          }
+        } else if (kStrict || in_next) {
+          node = next | kPassTag;
+          pop = false;
+        }
       }
       if (pop) {
         if (sp + tcnt == 0) {  // traversal of this query complete
@@ -503,18 +539,19 @@ __global__ void QueryExpandRawKernel(const float *__restrict__ queries, uint32_t
   }
 }
 
-// One thread per node, leaves only: writes the leaf's point block (layout in the file header) and
-// the tight bounding box into its record.  v[d] = values[vind[i] + d] (sigmap_adaptor.h:94-97: k-d
-// point i is the window values[i..i+dim)), position = Point.position of the window's first element.
+// One thread per leaf: writes the leaf's point block (layout in the file header) and its exact
+// tight box {lo[6], hi[6]}.  v[d] = values[vind[i] + d] (sigmap_adaptor.h:94-97: k-d point i is the
+// window values[i..i+dim)), position = Point.position of the window's first element.
 __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_t *__restrict__ positions,
-                                 const uint32_t *__restrict__ vind, uint4 *__restrict__ nodes,
-                                 uint64_t n_nodes, float *__restrict__ leaf_pts, uint32_t *__restrict__ slot_vind) {
+                                 const uint32_t *__restrict__ vind, const uint32_t *__restrict__ leaf_left,
+                                 const uint32_t *__restrict__ leaf_tab, uint64_t n_leaves,
+                                 float *__restrict__ leaf_pts, uint32_t *__restrict__ slot_vind,
+                                 float *__restrict__ leaf_box) {
   float4 *o = reinterpret_cast<float4 *>(leaf_pts);
-  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_nodes;
+  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_leaves;
        k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint4 hd = nodes[k * 4];
-    if (hd.w != 0xFFFFFFFFu) continue;
-    const uint32_t left = hd.x, n = hd.y, boff = hd.z, rn = (n + 7u) & ~7u;
+    const uint32_t tab = leaf_tab[k];
+    const uint32_t left = leaf_left[k], n = tab >> 27, boff = (tab & kIdxMask) << 4, rn = (n + 7u) & ~7u;
     float lo[6], hi[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
@@ -536,29 +573,82 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
       o[(size_t)boff + rn + t] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
                                              __uint_as_float((uint32_t)(pos >> 32)));
     }
-    float4 *rec = reinterpret_cast<float4 *>(nodes + k * 4);
-    rec[1] = make_float4(lo[0], lo[1], lo[2], lo[3]);
-    rec[2] = make_float4(lo[4], lo[5], hi[0], hi[1]);
-    rec[3] = make_float4(hi[2], hi[3], hi[4], hi[5]);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      leaf_box[k * 12 + d] = lo[d];
+      leaf_box[k * 12 + 6 + d] = hi[d];
+    }
   }
 }
 
-// Boxes of the inner nodes of one tree level (deepest level first): the union of the children's.
-__global__ void InnerBoxKernel(uint4 *__restrict__ nodes, const uint32_t *__restrict__ level_nodes, uint32_t count) {
+__device__ __forceinline__ const float *BoxOf(uint32_t ref, const float *leaf_box, const float *inner_box) {
+  return (ref & kLeafTag) ? leaf_box + (size_t)(ref & kIdxMask) * 12 : inner_box + (size_t)(ref & kIdxMask) * 12;
+}
+
+// Exact boxes of the inner nodes of one tree level (deepest level first): the union of the children's.
+__global__ void InnerBoxKernel(const uint4 *__restrict__ inner, const uint32_t *__restrict__ level_nodes,
+                               uint32_t count, const float *__restrict__ leaf_box, float *__restrict__ inner_box) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
     const uint64_t i = level_nodes[t];
-    float4 *rec = reinterpret_cast<float4 *>(nodes + i * 4);
-    const uint32_t c2 = nodes[i * 4].z;
-    const float4 *a = reinterpret_cast<const float4 *>(nodes + (i + 1) * 4);
-    const float4 *b = reinterpret_cast<const float4 *>(nodes + (uint64_t)c2 * 4);
-    const float4 a1 = a[1], a2 = a[2], a3 = a[3], b1 = b[1], b2 = b[2], b3 = b[3];
-    rec[1] = make_float4(fminf(a1.x, b1.x), fminf(a1.y, b1.y), fminf(a1.z, b1.z), fminf(a1.w, b1.w));
-    rec[2] = make_float4(fminf(a2.x, b2.x), fminf(a2.y, b2.y), fmaxf(a2.z, b2.z), fmaxf(a2.w, b2.w));
-    rec[3] = make_float4(fmaxf(a3.x, b3.x), fmaxf(a3.y, b3.y), fmaxf(a3.z, b3.z), fmaxf(a3.w, b3.w));
+    const uint4 hd = inner[i * 4];
+    const float *a = BoxOf(hd.z, leaf_box, inner_box), *b = BoxOf(hd.w, leaf_box, inner_box);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      inner_box[i * 12 + d] = fminf(a[d], b[d]);
+      inner_box[i * 12 + 6 + d] = fmaxf(a[6 + d], b[6 + d]);
+    }
   }
 }
 
-// ---- visiting order of the queries.  Bucket = pre-order index of the leaf that contains the
+// grid[0..5] = base, grid[6..11] = step: the root's tight box cut into 65534 steps per dimension.
+__global__ void BoxGridKernel(uint32_t root_ref, const float *__restrict__ leaf_box,
+                              const float *__restrict__ inner_box, float *__restrict__ grid) {
+  const int d = threadIdx.x;
+  if (d >= 6) return;
+  const float *r = BoxOf(root_ref, leaf_box, inner_box);
+  grid[d] = r[d];
+  grid[6 + d] = (r[6 + d] - r[d]) / 65534.0f;
+}
+
+// The children's boxes of every inner record, on the grid, rounded outwards: the quantised lo
+// dequantises (with the walker's own expression) to a value <= the exact lo, hi to one >= the exact hi.
+__global__ void PackBoxesKernel(uint4 *__restrict__ inner, uint64_t n_inner, const float *__restrict__ leaf_box,
+                                const float *__restrict__ inner_box, const float *__restrict__ grid,
+                                uint32_t *__restrict__ error_flag) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_inner;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 hd = inner[i * 4];
+    uint32_t q[24];  // child1 lo[6], hi[6], child2 lo[6], hi[6]
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float *bx = BoxOf(c ? hd.w : hd.z, leaf_box, inner_box);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const float base = grid[d], step = grid[6 + d], lo = bx[d], hi = bx[6 + d];
+        int ql = 0, qh = 0;
+        if (step > 0.0f) {
+          ql = (int)fminf(fmaxf(floorf((lo - base) / step), 0.0f), 65535.0f);
+          qh = (int)fminf(fmaxf(ceilf((hi - base) / step), 0.0f), 65535.0f);
+        }
+        while (ql > 0 && __fmaf_rn((float)ql, step, base) > lo) --ql;
+        while (qh < 65535 && __fmaf_rn((float)qh, step, base) < hi) ++qh;
+        if (!(__fmaf_rn((float)ql, step, base) <= lo) || !(__fmaf_rn((float)qh, step, base) >= hi)) bad = true;
+        q[c * 12 + d] = (uint32_t)ql;
+        q[c * 12 + 6 + d] = (uint32_t)qh;
+      }
+    }
+    if (bad) atomicOr(error_flag, 1u);
+    uint32_t w[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w[k] = q[2 * k] | (q[2 * k + 1] << 16);
+    inner[i * 4 + 1] = make_uint4(w[0], w[1], w[2], w[3]);
+    inner[i * 4 + 2] = make_uint4(w[4], w[5], w[6], w[7]);
+    inner[i * 4 + 3] = make_uint4(w[8], w[9], w[10], w[11]);
+  }
+}
+
+// ---- visiting order of the queries.  Bucket = ordinal (tree order) of the leaf that contains the
 // query point (a stackless best-child descent) >> shift; the buckets are cut into 8 equal ranges
 // (one per XCD), and inside a range the queries are visited in 4 cost classes, most expensive
 // first, each class in bucket order.  The class is |q|^2 (the windows are z-scored, so density -
@@ -573,15 +663,14 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
-    uint32_t node = 0;
-    for (;;) {
-      const uint4 rec = ix.nodes[(size_t)node * 4];
-      if (rec.w == 0xFFFFFFFFu) break;
-      const float val = r.q[rec.w];
+    uint32_t node = ix.root_ref;
+    while (!(node & kLeafTag)) {
+      const uint4 rec = ix.inner[(size_t)node * 4];
+      const float val = r.q[(rec.z >> 28) & 7u];
       const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
-      node = (diff1 + diff2) < 0 ? node + 1 : rec.z;
+      node = ((diff1 + diff2) < 0 ? rec.z : rec.w) & (kLeafTag | kIdxMask);
     }
-    const uint32_t lb = node >> shift, range = lb / per_range;
+    const uint32_t lb = (node & kIdxMask) >> shift, range = lb / per_range;
     const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
                      r.q[5] * r.q[5];
     const uint32_t cls = r2 < 2.2f ? 0u : (r2 < 3.8f ? 1u : (r2 < 6.2f ? 2u : 3u));
@@ -637,19 +726,29 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qre
 }  // namespace
 
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
-                            const uint32_t *vind, void *nodes, uint64_t n_nodes, float *leaf_pts,
-                            uint32_t *slot_vind) {
+                            const uint32_t *vind, const uint32_t *leaf_left, const uint32_t *leaf_tab,
+                            uint64_t n_leaves, float *leaf_pts, uint32_t *slot_vind, float *leaf_box) {
   if (dim != 6) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind,
-                     reinterpret_cast<uint4 *>(nodes), n_nodes, leaf_pts, slot_vind);
+  hipLaunchKernelGGL(LeafGatherKernel, dim3(4096), dim3(256), 0, ctx->stream, values, positions, vind, leaf_left,
+                     leaf_tab, n_leaves, leaf_pts, slot_vind, leaf_box);
   return hipGetLastError();
 }
 
-hipError_t LaunchInnerBoxes(smhip_ctx *ctx, void *nodes, const uint32_t *level_nodes, uint32_t count) {
+hipError_t LaunchInnerBoxes(smhip_ctx *ctx, const void *inner, const uint32_t *level_nodes, uint32_t count,
+                            const float *leaf_box, float *inner_box) {
   if (count == 0) return hipSuccess;
   const uint32_t blocks = std::min<uint32_t>((count + 255) / 256, 4096);
-  hipLaunchKernelGGL(InnerBoxKernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(nodes),
-                     level_nodes, count);
+  hipLaunchKernelGGL(InnerBoxKernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(inner),
+                     level_nodes, count, leaf_box, inner_box);
+  return hipGetLastError();
+}
+
+hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32_t root_ref, const float *leaf_box,
+                           const float *inner_box, float *grid, uint32_t *error_flag) {
+  hipLaunchKernelGGL(BoxGridKernel, dim3(1), dim3(64), 0, ctx->stream, root_ref, leaf_box, inner_box, grid);
+  if (n_inner)
+    hipLaunchKernelGGL(PackBoxesKernel, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(inner),
+                       n_inner, leaf_box, inner_box, grid, error_flag);
   return hipGetLastError();
 }
 
@@ -666,9 +765,9 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
                            uint32_t n_queries_host, uint64_t n_max, const uint32_t **order_out,
                            const uint32_t **range_end_out, uint32_t *range_stride_out) {
   uint32_t bits = 1;
-  while ((1ull << bits) < ctx->index.n_nodes) ++bits;
+  while ((1ull << bits) < ctx->index.n_leaves) ++bits;
   const uint32_t shift = bits > 17 ? bits - 17 : 0;
-  const uint32_t per_range = ((uint32_t)(ctx->index.n_nodes >> shift) + 8) / 8;  // leaf buckets per XCD range
+  const uint32_t per_range = ((uint32_t)(ctx->index.n_leaves >> shift) + 8) / 8;  // leaf buckets per XCD range
   const uint32_t n_buckets = 8 * kCostClasses * per_range + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;

@@ -9,7 +9,8 @@ import numpy as np
 
 from . import _abi
 
-_ARRAYS = ["nodes", "leaf_pts", "leaf_vind", "bbox"]
+_ARRAYS = ["nodes", "leaf_tab", "leaf_pts", "leaf_vind", "bbox"]
+_SCALARS = ["dim", "root_ref", "n_nodes", "n_leaves", "m_size"]
 
 
 def shard_range(n_items, rank, world):
@@ -65,22 +66,22 @@ def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
 
 def replicate_index(dev, ix, rank, world, local_rank, dist):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
-    uploads, then each of the four device arrays is sent with ONE RCCL broadcast and the peers
+    uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive."""
     if world == 1:
         dev.upload_index(ix)
         return None
     import torch
     device = torch.device("cuda", local_rank)
-    meta = [0] * (3 + len(_ARRAYS))
+    meta = [0] * (len(_SCALARS) + len(_ARRAYS))
     d = None
     if rank == 0:
         dev.upload_index(ix)
         d = dev.export_index()
-        meta = [d.dim, d.n_nodes, d.m_size] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
+        meta = [int(getattr(d, f)) for f in _SCALARS] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
     meta = broadcast_meta(meta, rank, dist, device)
     tensors = []
-    for a, nbytes in zip(_ARRAYS, meta[3:]):
+    for a, nbytes in zip(_ARRAYS, meta[len(_SCALARS):]):
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if rank == 0:
             _hip_memcpy_d2d(t.data_ptr(), getattr(d, a), nbytes)
@@ -89,8 +90,9 @@ def replicate_index(dev, ix, rank, world, local_rank, dist):
     torch.cuda.synchronize()
     if rank != 0:
         nd = _abi.IndexDev()
-        nd.dim, nd.n_nodes, nd.m_size = meta[0], meta[1], meta[2]
-        for a, t, nbytes in zip(_ARRAYS, tensors, meta[3:]):
+        for f, v in zip(_SCALARS, meta):
+            setattr(nd, f, v)
+        for a, t, nbytes in zip(_ARRAYS, tensors, meta[len(_SCALARS):]):
             setattr(nd, a, t.data_ptr())
             setattr(nd, a + "_bytes", nbytes)
         dev.attach_index(nd)

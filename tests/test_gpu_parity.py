@@ -195,6 +195,45 @@ def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
     assert np.array_equal(base.tobytes(), tiny.tobytes())
 
 
+def test_index_export_copy_attach_gives_identical_results(device, small_world):
+    """What the multi-GPU replication does on the device side (multigpu.replicate_index): the exported
+    walker arrays are copied byte for byte into fresh device buffers and a second context attaches the
+    copies."""
+    from sigmap_amd import multigpu
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    pa = small_world["pa"][:24]
+    samples, offsets = _batch(pa)
+    base = device.map_chunks(samples, offsets, n_refs=3)
+    d = device.export_index()
+    assert d.n_nodes + 1 == d.n_leaves and d.bbox_bytes == 96
+    nd = _abi.IndexDev()
+    for f in multigpu._SCALARS:
+        setattr(nd, f, getattr(d, f))
+    keep = []
+    for a in multigpu._ARRAYS:
+        nbytes = int(getattr(d, a + "_bytes"))
+        t = C.c_void_p()
+        assert hip.hipMalloc(C.byref(t), nbytes) == 0
+        multigpu._hip_memcpy_d2d(t.value, getattr(d, a), nbytes)  # hipMemcpy: synchronous
+        setattr(nd, a, t.value)
+        setattr(nd, a + "_bytes", nbytes)
+        keep.append(t)
+    peer = pipeline.DeviceMapper(0)
+    peer.attach_index(nd)
+    got = peer.map_chunks(samples, offsets, n_refs=3)
+    assert np.array_equal(base.tobytes(), got.tobytes())
+    bad = _abi.IndexDev()
+    C.memmove(C.byref(bad), C.byref(nd), C.sizeof(nd))
+    bad.n_leaves += 1
+    with pytest.raises(RuntimeError):
+        peer.attach_index(bad)
+    peer.close()
+    for t in keep:
+        hip.hipFree(t)
+
+
 def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     """spatial_index.cc:371-372: only the first num_nearest_points hits IN TRAVERSAL ORDER become
     anchors.  A point cloud that repeats one signal 12 times gives every seed >= 12 hits; with the
