@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 = auto, 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="batches in flight per GPU: steps alternate over this many contexts / HIP streams "
+                         "that share the resident index (1 = strictly serial steps)")
     return ap.parse_args()
 
 
@@ -104,11 +107,13 @@ def main():
     ref_lens = np.array(genome_lens, dtype=np.uint32)
     lm = synth.make_pore_model()
     genome = synth.make_genome(7, genome_lens)  # every rank: cheap, and reads are cut from it
-    dev = pipeline.DeviceMapper(local_rank)
-    if args.walk_blocks:
-        dev.params.walk_blocks_per_cu = args.walk_blocks
-    if args.fast_cap:
-        dev.params.hits_per_query_fast = args.fast_cap
+    pool = pipeline.MapperPool(local_rank, max(1, args.depth))
+    dev = pool.first
+    for dv in pool.devs:
+        if args.walk_blocks:
+            dv.params.walk_blocks_per_cu = args.walk_blocks
+        if args.fast_cap:
+            dv.params.hits_per_query_fast = args.fast_cap
     ix = None
     t_build = 0.0
     if rank == 0:
@@ -117,60 +122,80 @@ def main():
         ix = pipeline.HostIndex.build(genome, lm, threads=max(1, (os.cpu_count() or 1) // max(world, 1)))
         t_build = time.perf_counter() - t0
     keepalive = replicate_index(dev, ix, rank, world, local_rank, dist)  # RCCL broadcast when world > 1
+    pool.share_index()  # the other contexts of this GPU borrow the same arrays
 
     raw, _ = synth.simulate_reads(genome, lm, args.reads, seed=1000 + rank)
     pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
     samples = np.concatenate(pa)
-    dev.upload_batch(samples, offsets)  # inputs resident in HBM before the timed region
+    pool.for_each(lambda dv: dv.upload_batch(samples, offsets))  # inputs resident in HBM before the timed region
     if args.sdtw_band > 0:
         ref_sig, ref_off = pipeline.reference_signals(genome, lm)
-        dev.upload_reference(ref_sig, ref_off)
+        pool.for_each(lambda dv: dv.upload_reference(ref_sig, ref_off))
 
-    def step():
-        dev.run(n_refs)
+    def step(dv=dev, _i=0):
+        dv.run(n_refs)
         if args.sdtw_band > 0:
-            dev.refine(band=args.sdtw_band, pad=32)
-        dev.sync()
-        res = dev.download()
-        if args.sdtw_band > 0:
-            step.refined = dev.refine_download()
-        return res
+            dv.refine(band=args.sdtw_band, pad=32)
+        dv.sync()
+        res = dv.download()
+        refined = dv.refine_download() if args.sdtw_band > 0 else None
+        return res, refined
 
     # Census (untimed): one pass with the walker restricted to exactly nanoflann's node set, so
     # that nodes_visited / points_tested count the REFERENCE's work on these inputs (SURVEY 8d:
     # "counted on the actual inputs").  The timed passes skip subtrees whose tight box is out of
     # range (same hits, same order) and therefore touch fewer bytes than the algorithmic figure.
     dev.params.reference_walk = 1
-    census = step()
+    census, _ = step()
     dev.params.reference_walk = 0
-    for _ in range(args.warmup):
-        res = step()
-    dev.timing(True)
-    dev.timing_reset()
+    # warm-up: W steps, and at least one on every context (each sizes its own scratch and hit pool)
+    pool.run_steps(max(args.warmup, len(pool.devs)), step)
+    pool.for_each(lambda dv: (dv.timing(True), dv.timing_reset()))
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        dev.sync()
+        pool.for_each(lambda dv: dv.sync())
+
+    def kernel_times(devs):
+        # per-kernel device time (HIP events on each context's stream)
+        kern = {}
+        for name in ["events", "seed_lookup", "sort", "chain", "sdtw"]:
+            got = [dv.timing_get(name) for dv in devs]  # (mean ms, launches) per context
+            n = sum(int(g[1]) for g in got)
+            ms = sum(g[0] * g[1] for g in got) / max(n, 1)
+            kern[name] = {"mean_ms": round(ms, 4), "launches": n}
+        return kern
+
+    # Reference pass (not the reported value): the same K steps strictly one after the other on one
+    # context, so that every kernel has the GPU to itself -- the standalone kernel durations.
+    serial = None
+    if len(pool.devs) > 1:
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(dev, i)
+        fence()
+        serial = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "kernels": kernel_times([dev])}
+        pool.for_each(lambda dv: dv.timing_reset())
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    results = pool.run_steps(args.steps, step)  # EXACTLY K steps, step i on context i % depth
     fence()
     dt = time.perf_counter() - t0
+    res, refined = results[-1]
+    contexts_agree = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel device time (HIP events on the context stream, inside the timed region)
-    kern = {}
-    for name in ["events", "seed_lookup", "sort", "chain", "sdtw"]:
-        ms, n = dev.timing_get(name)
-        kern[name] = {"mean_ms": round(ms, 4), "launches": int(n)}
+    # inside the timed region kernels of different batches run concurrently, so a launch's duration
+    # includes the time it shares the GPU with the other context's kernels
+    kern = kernel_times(pool.devs)
 
     if rank == 0:
         R = args.reads
@@ -211,6 +236,8 @@ def main():
                             f"{args.contig_len} bp random reference (yeast-sized), event+seed+sort+chain"
                             f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU",
                 "chunks_per_gpu_per_step": R,
+                "batches_in_flight": len(pool.devs),
+                "contexts_agree": bool(contexts_agree),
                 "index_points": int(dev_index_points(ix)) if ix is not None else None,
                 "mapped_fraction": round(float((res["n_chains"] > 0).mean()), 4),
                 "queries_per_chunk": round(queries / R, 2),
@@ -224,7 +251,7 @@ def main():
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
                 "walker_phase_stats": walker_stats(dev),
-                "sdtw_refined_fraction": (round(float((step.refined[1] >= 0).mean()), 4)
+                "sdtw_refined_fraction": (round(float((refined[1] >= 0).mean()), 4)
                                           if args.sdtw_band > 0 else None),
                 "index_build_s": round(t_build, 2),
                 "kernels": kern,
@@ -239,6 +266,16 @@ def main():
                 "traffic": traffic,
             },
         }
+        if serial is not None:
+            s_ms = serial["kernels"]["seed_lookup"]["mean_ms"]
+            s_ach = bytes_per_launch / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+            out["serial_steps"] = {  # the reference pass above: one batch in flight, kernels run alone
+                "ms_per_step": round(serial["ms_per_step"], 3),
+                "value": round(R * world / (serial["ms_per_step"] * 1e-3), 1),
+                "kernels": serial["kernels"],
+                "roofline": {"kernel": "seed_lookup", "achieved": round(s_ach, 1),
+                             "frac": round(s_ach / HBM_PEAK_GBS, 4)},
+            }
         if world == 1 and not args.no_cpu and args.cpu_sample != 0:
             n_sample = args.cpu_sample if args.cpu_sample > 0 else 24 * min(os.cpu_count() or 1, 32)
             out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, n_sample)

@@ -650,16 +650,16 @@ __global__ void PackBoxesKernel(uint4 *__restrict__ inner, uint64_t n_inner, con
 
 // ---- visiting order of the queries.  Bucket = ordinal (tree order) of the leaf that contains the
 // query point (a stackless best-child descent) >> shift; the buckets are cut into 8 equal ranges
-// (one per XCD), and inside a range the queries are visited in 4 cost classes, most expensive
+// (one per XCD), and inside a range the queries are visited in 8 cost classes, most expensive
 // first, each class in bucket order.  The class is |q|^2 (the windows are z-scored, so density -
 // and with it the number of nodes a search visits - falls with the distance from the origin:
 // measured correlation -0.8); visiting the cheap queries last keeps the tail of the launch, when
 // lanes run out of work one by one, short.  Counting sort on (range, class, bucket in range).
-constexpr uint32_t kCostClasses = 4;
+constexpr uint32_t kCostClasses = 8;
 __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
-                               uint32_t shift, uint32_t per_range, uint32_t *__restrict__ keys,
-                               uint32_t *__restrict__ hist) {
+                               uint32_t shift, uint32_t per_range, uint32_t classes,
+                               uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
@@ -673,8 +673,11 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
     const uint32_t lb = (node & kIdxMask) >> shift, range = lb / per_range;
     const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
                      r.q[5] * r.q[5];
-    const uint32_t cls = r2 < 2.2f ? 0u : (r2 < 3.8f ? 1u : (r2 < 6.2f ? 2u : 3u));
-    const uint32_t key = (range * kCostClasses + cls) * per_range + (lb - range * per_range);
+    // quartiles of |q|^2 over the windows of simulated reads, each cut once more
+    uint32_t cls = r2 < 2.2f ? 0u : (r2 < 3.8f ? 1u : (r2 < 6.2f ? 2u : 3u));
+    cls = 2 * cls + (r2 >= (cls == 0 ? 1.5f : cls == 1 ? 3.0f : cls == 2 ? 4.9f : 8.5f) ? 1u : 0u);
+    cls = cls * classes / kCostClasses;  // (SMHIP_CLASSES = 1, 2, 4: coarser classes, for experiments)
+    const uint32_t key = (range * classes + cls) * per_range + (lb - range * per_range);
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
   }
@@ -768,7 +771,13 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
   while ((1ull << bits) < ctx->index.n_leaves) ++bits;
   const uint32_t shift = bits > 17 ? bits - 17 : 0;
   const uint32_t per_range = ((uint32_t)(ctx->index.n_leaves >> shift) + 8) / 8;  // leaf buckets per XCD range
-  const uint32_t n_buckets = 8 * kCostClasses * per_range + 1;
+  static int env_cls = -1;
+  if (env_cls < 0) {
+    const char *e0 = getenv("SMHIP_CLASSES");
+    env_cls = e0 ? atoi(e0) : 0;
+  }
+  const uint32_t classes = (env_cls > 0 && env_cls <= (int)kCostClasses) ? (uint32_t)env_cls : kCostClasses;
+  const uint32_t n_buckets = 8 * classes * per_range + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
   if ((e = ctx->q_order.Reserve(n_max * 32)) != hipSuccess) return e;
@@ -776,15 +785,15 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
   uint32_t *hist = ctx->q_hist.as<uint32_t>(), *cursor = hist + n_buckets + 1;
   if ((e = hipMemsetAsync(hist, 0, (size_t)n_buckets * 4, ctx->stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(QueryKeyKernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->index, qrec, n_queries_dev,
-                     n_queries_host, shift, per_range, ctx->q_keys.as<uint32_t>(), hist);
+                     n_queries_host, shift, per_range, classes, ctx->q_keys.as<uint32_t>(), hist);
   if ((e = LaunchScanU32(ctx, hist, n_buckets - 1, cursor)) != hipSuccess) return e;
   hipLaunchKernelGGL(QueryScatterKernel, dim3(2048), dim3(256), 0, ctx->stream, n_queries_dev, n_queries_host,
                      ctx->q_keys.as<uint32_t>(), cursor, qrec, ctx->q_order.as<QueryRec>());
   *order_out = ctx->q_order.as<uint32_t>();
   // after the scatter cursor[k] = end of bucket k, so range r of the order ends at
-  // cursor[(r + 1) * kCostClasses * per_range - 1]
+  // cursor[(r + 1) * classes * per_range - 1]
   *range_end_out = cursor;
-  *range_stride_out = kCostClasses * per_range;
+  *range_stride_out = classes * per_range;
   return hipGetLastError();
 }
 }  // namespace

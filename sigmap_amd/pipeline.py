@@ -257,3 +257,59 @@ class DeviceMapper:
             self.close()
         except Exception:
             pass
+
+
+class MapperPool:
+    """`depth` DeviceMapper contexts on ONE GPU (one HIP stream each) that share one resident index:
+    the first context owns the walker arrays, the others borrow them (smhip_index_export ->
+    smhip_index_attach, no copy).  The reads of a run are independent (one taskloop over all reads in
+    Sigmap::StreamingMap, sigmap.cc:618-666), so consecutive batches are mapped on alternating
+    contexts, each driven by its own host thread: the tail of one batch's tree walk and its sort /
+    chain / sDTW kernels overlap the next batch's walk.  Results do not depend on the context."""
+
+    def __init__(self, device=0, depth=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.devs = [DeviceMapper(device) for _ in range(depth)]
+
+    @property
+    def first(self):
+        return self.devs[0]
+
+    def share_index(self):
+        """Call after the first context has its index (upload_index or attach_index)."""
+        d = self.devs[0].export_index()
+        for dv in self.devs[1:]:
+            dv.attach_index(d)
+
+    def for_each(self, fn):
+        for dv in self.devs:
+            fn(dv)
+
+    def run_steps(self, n_steps, step_fn):
+        """step_fn(dev, step_index) is called for steps 0..n_steps-1, step i on context i % depth, the
+        steps of one context in order on that context's thread.  Returns the list of results."""
+        import threading
+        out = [None] * n_steps
+        err = []
+
+        def work(k):
+            try:
+                for i in range(k, n_steps, len(self.devs)):
+                    out[i] = step_fn(self.devs[k], i)
+            except BaseException as e:  # re-raised on the caller's thread
+                err.append(e)
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(min(len(self.devs), n_steps))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def close(self):
+        for dv in reversed(self.devs):  # borrowers first
+            dv.close()
+

@@ -234,6 +234,25 @@ def test_index_export_copy_attach_gives_identical_results(device, small_world):
         hip.hipFree(t)
 
 
+def test_mapper_pool_batches_in_flight_give_serial_results(device, small_world):
+    """Batches mapped concurrently on three contexts / streams that share one resident index
+    (pipeline.MapperPool) give byte for byte what one context gives one batch after the other."""
+    pa = small_world["pa"]
+    batches = [_batch(pa[i::5]) for i in range(5)] + [_batch(pa[:7])]
+    want = [device.map_chunks(s, o, n_refs=3).tobytes() for s, o in batches]
+    pool = pipeline.MapperPool(0, depth=3)
+    pool.first.upload_index(small_world["ix"])
+    pool.share_index()
+    for _ in range(2):  # second round: contexts reuse their scratch with other batch sizes
+        got = pool.run_steps(len(batches), lambda dv, i: dv.map_chunks(*batches[i], n_refs=3).tobytes())
+        assert got == want
+    def failing(dv, i):
+        raise ValueError("step %d" % i)
+    with pytest.raises(ValueError):  # an exception on a worker thread reaches the caller
+        pool.run_steps(2, failing)
+    pool.close()
+
+
 def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     """spatial_index.cc:371-372: only the first num_nearest_points hits IN TRAVERSAL ORDER become
     anchors.  A point cloud that repeats one signal 12 times gives every seed >= 12 hits; with the
