@@ -16,7 +16,9 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sigmap_hip.h"
@@ -57,7 +59,7 @@ class Sigmap {
     index.Save();
   }
 
-  void StreamingMap(int device, size_t max_batch_chunks, int sdtw_band) {
+  void StreamingMap(int device, size_t max_batch_chunks, int sdtw_band, int num_streams) {
     SignalBatch reads;
     reads.InitializeLoading(signal_directory_);
     const size_t num_reads = reads.LoadAllReadSignals();
@@ -69,13 +71,28 @@ class Sigmap {
     SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
     index.Load();
 
-    smhip_ctx *ctx = nullptr;
-    if (smhip_init(device, &ctx) != SMHIP_OK)
-      ExitWithMessage("No usable MI355X GPU (smhip_init failed): this build has no CPU mapping path.");
-    if (smhip_index_upload(ctx, index.dimension(), index.values().data(), index.positions().data(),
+    // `num_streams` device contexts (one HIP stream each) share the resident index: the first owns
+    // it, the others borrow its arrays.  Reads are independent (one taskloop over all reads,
+    // sigmap.cc:618-666), so every context maps its own batches, driven by its own host thread:
+    // one context's host work (batch assembly, downloads, stop rules) and the tail of its kernels
+    // overlap the other contexts' kernels.
+    num_streams = std::max(1, num_streams);
+    std::vector<smhip_ctx *> ctxs((size_t)num_streams, nullptr);
+    for (auto &c : ctxs)
+      if (smhip_init(device, &c) != SMHIP_OK)
+        ExitWithMessage("No usable MI355X GPU (smhip_init failed): this build has no CPU mapping path.");
+    if (smhip_index_upload(ctxs[0], index.dimension(), index.values().data(), index.positions().data(),
                            index.values().size(), index.tree().vind.data(), index.tree().m_size,
                            index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
-      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctx));
+      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0]));
+    {
+      smhip_index_dev shared;
+      if (smhip_index_export(ctxs[0], &shared) != SMHIP_OK)
+        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[0]));
+      for (size_t k = 1; k < ctxs.size(); ++k)
+        if (smhip_index_attach(ctxs[k], &shared) != SMHIP_OK)
+          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[k]));
+    }
     if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
       PoreModel pore_model;
       pore_model.Load(pore_model_file_path_);
@@ -91,8 +108,9 @@ class Sigmap {
         ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
         off.push_back(sig.size());
       }
-      if (smhip_reference_upload(ctx, sig.data(), off.data(), num_refs) != SMHIP_OK)
-        ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(ctx));
+      for (smhip_ctx *c : ctxs)
+        if (smhip_reference_upload(c, sig.data(), off.data(), num_refs) != SMHIP_OK)
+          ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
     }
     smhip_params dp;
     smhip_default_params(&dp);
@@ -118,87 +136,100 @@ class Sigmap {
       if (num_chunks[r] == 0 || params_.max_num_chunks <= 0) st[r].active = false;
     }
     const double t_map = GetRealTime();
-    std::vector<size_t> batch;
-    std::vector<float> samples;
-    std::vector<uint32_t> offsets, qstart, carried_off;
-    std::vector<smhip_carried_anchor> carried, out_anchors;
-    std::vector<smhip_chunk_result> results;
-    std::vector<uint64_t> out_off;
-    size_t cursor = 0;  // reads are admitted in order; a read stays in flight until it stops
-    std::vector<size_t> in_flight;
-    while (true) {
-      // admit new reads up to the batch budget
-      while (in_flight.size() < max_batch_chunks && cursor < num_reads) {
-        if (st[cursor].active) {
-          st[cursor].start_time = GetRealTime();
-          in_flight.push_back(cursor);
-        }
-        ++cursor;
-      }
-      if (in_flight.empty()) break;
-      batch = in_flight;
-      samples.clear();
-      offsets.assign(1, 0);
-      qstart.clear();
-      carried.clear();
-      carried_off.assign(1, 0);
-      for (size_t r : batch) {
-        const Signal &sig = reads.GetSignalAt(r);
-        const size_t b = (size_t)chunk_size * st[r].chunk_index;
-        samples.insert(samples.end(), sig.signal_values.begin() + b, sig.signal_values.begin() + b + chunk_size);
-        offsets.push_back((uint32_t)samples.size());
-        qstart.push_back(st[r].num_events);
-        carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
-        carried_off.push_back((uint32_t)carried.size());
-      }
-      results.resize(batch.size());
-      out_off.resize(batch.size() + 1);
-      int rc = smhip_batch_upload(ctx, samples.data(), offsets.data(), (uint32_t)batch.size(), qstart.data(),
-                                  carried.empty() ? nullptr : carried.data(),
-                                  carried.empty() ? nullptr : carried_off.data());
-      if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
-      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
-      if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
-      std::vector<float> dts(batch.size());
-      std::vector<int64_t> dte(batch.size());
-      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
-      uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
-      while (rc == SMHIP_OK) {
-        out_anchors.resize(cap);
-        rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
-        if (rc != SMHIP_ECAP) break;
-        cap *= 4;
-        rc = SMHIP_OK;
-      }
-      if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
-      in_flight.clear();
-      for (size_t bi = 0; bi < batch.size(); ++bi) {
-        const size_t r = batch[bi];
-        ReadState &s = st[r];
-        const smhip_chunk_result &res = results[bi];
-        if (res.status & ~SMHIP_ST_FEW_PEAKS)
-          std::cerr << "warning: read " << reads.GetSignalNameAt(r) << ": device capacity flag " << res.status << "\n";
-        bool stop = false;
-        if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
-          s.last = res;
-          s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
-          s.dt = dts[bi];
-          s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
-          s.num_events += res.n_features;
-          stop = ShouldStopMapping(res, params_);
-        }
-        if (!stop) {
-          ++s.chunk_index;
-          if (s.chunk_index < num_chunks[r] && s.chunk_index < (uint32_t)params_.max_num_chunks) {
-            in_flight.push_back(r);
-            continue;
+    size_t cursor = 0;  // reads are admitted in order; a read stays with the context that admitted it
+    std::mutex cursor_mutex;
+    // every context gets an equal share of the batch budget, so that `max_batch_chunks` bounds the
+    // chunks in flight on the GPU as it does with one context
+    const size_t lane_budget = std::max<size_t>(1, max_batch_chunks / ctxs.size());
+    auto lane = [&](smhip_ctx *ctx) {
+      std::vector<size_t> batch, in_flight;
+      std::vector<float> samples;
+      std::vector<uint32_t> offsets, qstart, carried_off;
+      std::vector<smhip_carried_anchor> carried, out_anchors;
+      std::vector<smhip_chunk_result> results;
+      std::vector<uint64_t> out_off;
+      while (true) {
+        {  // admit new reads up to this context's budget
+          std::lock_guard<std::mutex> lock(cursor_mutex);
+          while (in_flight.size() < lane_budget && cursor < num_reads) {
+            if (st[cursor].active) {
+              st[cursor].start_time = GetRealTime();
+              in_flight.push_back(cursor);
+            }
+            ++cursor;
           }
         }
-        s.active = false;
-        s.anchors.clear();
-        s.anchors.shrink_to_fit();
-        s.start_time = (GetRealTime() - s.start_time) * 1000;
+        if (in_flight.empty()) break;
+        batch = in_flight;
+        samples.clear();
+        offsets.assign(1, 0);
+        qstart.clear();
+        carried.clear();
+        carried_off.assign(1, 0);
+        for (size_t r : batch) {
+          const Signal &sig = reads.GetSignalAt(r);
+          const size_t b = (size_t)chunk_size * st[r].chunk_index;
+          samples.insert(samples.end(), sig.signal_values.begin() + b, sig.signal_values.begin() + b + chunk_size);
+          offsets.push_back((uint32_t)samples.size());
+          qstart.push_back(st[r].num_events);
+          carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
+          carried_off.push_back((uint32_t)carried.size());
+        }
+        results.resize(batch.size());
+        out_off.resize(batch.size() + 1);
+        int rc = smhip_batch_upload(ctx, samples.data(), offsets.data(), (uint32_t)batch.size(), qstart.data(),
+                                    carried.empty() ? nullptr : carried.data(),
+                                    carried.empty() ? nullptr : carried_off.data());
+        if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
+        if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
+        if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+        std::vector<float> dts(batch.size());
+        std::vector<int64_t> dte(batch.size());
+        if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
+        uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
+        while (rc == SMHIP_OK) {
+          out_anchors.resize(cap);
+          rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
+          if (rc != SMHIP_ECAP) break;
+          cap *= 4;
+          rc = SMHIP_OK;
+        }
+        if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+        in_flight.clear();
+        for (size_t bi = 0; bi < batch.size(); ++bi) {
+          const size_t r = batch[bi];
+          ReadState &s = st[r];
+          const smhip_chunk_result &res = results[bi];
+          if (res.status & ~SMHIP_ST_FEW_PEAKS)
+            std::cerr << "warning: read " << reads.GetSignalNameAt(r) << ": device capacity flag " << res.status << "\n";
+          bool stop = false;
+          if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
+            s.last = res;
+            s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
+            s.dt = dts[bi];
+            s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
+            s.num_events += res.n_features;
+            stop = ShouldStopMapping(res, params_);
+          }
+          if (!stop) {
+            ++s.chunk_index;
+            if (s.chunk_index < num_chunks[r] && s.chunk_index < (uint32_t)params_.max_num_chunks) {
+              in_flight.push_back(r);
+              continue;
+            }
+          }
+          s.active = false;
+          s.anchors.clear();
+          s.anchors.shrink_to_fit();
+          s.start_time = (GetRealTime() - s.start_time) * 1000;
+        }
       }
+    };
+    {
+      std::vector<std::thread> workers;
+      for (size_t k = 1; k < ctxs.size(); ++k) workers.emplace_back(lane, ctxs[k]);
+      lane(ctxs[0]);
+      for (auto &w : workers) w.join();
     }
     std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
 
@@ -221,7 +252,7 @@ class Sigmap {
     for (auto &g : rows)
       for (auto &line : g) fputs(line.c_str(), out);
     fclose(out);
-    smhip_destroy(ctx);
+    for (size_t k = ctxs.size(); k-- > 0;) smhip_destroy(ctxs[k]);  // borrowers first
   }
 
  protected:
@@ -255,7 +286,8 @@ const char *kHelp =
     "      --stop-mapping-mean FLOAT   best/mean chaining score ratio to stop mapping [5]\n"
     "      --stop-mapping-mean-output FLOAT  best/mean ratio to output mappings [5]\n"
     "      --sdtw-band INT             banded sDTW refinement of the best chain, adds dt:f: [0 = off]\n"
-    "      --device INT                GPU ordinal [0]\n      --batch-chunks INT          chunks per GPU batch [16384]\n"
+    "      --device INT                GPU ordinal [0]\n      --batch-chunks INT          chunks in flight on the GPU [16384]\n"
+    "      --streams INT               device contexts / HIP streams that share the index and the chunk budget [2]\n"
     "  -h, --help  Print help\n";
 }  // namespace
 
@@ -315,7 +347,8 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int device = a.Has("device") ? std::stoi(a.Str("device")) : 0;
     const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 16384;
     const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
-    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch, sdtw_band);
+    const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : 2;
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch, sdtw_band, streams);
   } else {
     std::cerr << kHelp;
   }

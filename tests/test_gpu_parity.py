@@ -623,6 +623,18 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     nodt = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith(("mt:f:", "dt:f:")))
     assert [nodt(l) for l in got2] == exp
     assert sum(1 for l in got2 if "\tdt:f:" in l) >= 18
+    # the number of device contexts / streams and the chunk budget never show in the output
+    # (default above: 2 streams; here one stream, and three streams with 3-chunk batches each)
+    for k, extra in enumerate((["--streams", "1"], ["--streams", "3", "--batch-chunks", "9", "--sdtw-band", "64"])):
+        r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                            "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"),
+                            "-o", str(tmp_path / ("out_s%d.paf" % k))] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        gots = open(tmp_path / ("out_s%d.paf" % k)).read().splitlines()
+        assert [nodt(l) for l in gots] == exp
+        if "--sdtw-band" in extra:
+            dt = lambda l: [f for f in l.split("\t") if f.startswith("dt:f:")]
+            assert [dt(l) for l in gots] == [dt(l) for l in got2]
 
 
 # ------------------------------------------------------------------ sDTW refinement of chain 0 (D4/D5)

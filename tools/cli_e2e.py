@@ -26,17 +26,21 @@ def main(reads=10000, n_chunks=1):
         t0 = time.perf_counter()
         r = subprocess.run([exe, "-i", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-o", d + "/idx"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
-        t1 = time.perf_counter()
-        r = subprocess.run([exe, "-m", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-x", d + "/idx", "-s", d + "/reads",
-                            "-o", d + "/out.paf"], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        t2 = time.perf_counter()
-        mapped = sum(1 for l in open(d + "/out.paf") if "\t*\t" not in l)
-        print("index %.2f s; map %d reads x %d chunk(s): %.2f s wall (process start, index load, upload, map, PAF) "
-              "= %.0f reads/s; mapped %d" % (t1 - t0, reads, n_chunks, t2 - t1, reads / (t2 - t1), mapped))
-        for line in r.stderr.splitlines()[-6:]:
-            print("   ", line)
-
+        print("index %.2f s" % (time.perf_counter() - t0))
+        ref_paf = None
+        for streams in (1, 2, 3):
+            t1 = time.perf_counter()
+            r = subprocess.run([exe, "-m", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-x", d + "/idx", "-s", d + "/reads",
+                                "-o", d + "/out.paf", "--streams", str(streams)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            t2 = time.perf_counter()
+            paf = ["\t".join(f for f in l.split("\t") if not f.startswith("mt:f:")) for l in open(d + "/out.paf")]
+            ref_paf = ref_paf or paf
+            mapped = sum(1 for l in paf if "\t*\t" not in l)
+            span = [l for l in r.stderr.splitlines() if l.startswith("Finished mapping in")]
+            print("--streams %d: map %d reads x %d chunk(s): %.2f s wall (process start, index load, upload, map, PAF) "
+                  "= %.0f reads/s; mapped %d; PAF identical to --streams 1: %s; %s"
+                  % (streams, reads, n_chunks, t2 - t1, reads / (t2 - t1), mapped, paf == ref_paf, span[-1] if span else ""))
 
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

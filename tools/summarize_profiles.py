@@ -21,13 +21,16 @@ def short(name):
 
 def main(tag):
     os.makedirs(DST, exist_ok=True)
-    ks = sorted(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)
-    rows = list(csv.DictReader(open(ks[-1])))  # newest run
-    with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    for sub, suffix in (("kt", ""), ("kt_serial", "_serial")):
+        ks = sorted(glob.glob(os.path.join(SRC, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
+        if not ks:
+            continue
+        rows = list(csv.DictReader(open(ks[-1])))  # newest run
+        with open(os.path.join(DST, f"{tag}_kernel_stats{suffix}.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     per = collections.defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
         if not os.path.isdir(d):
@@ -68,7 +71,7 @@ def main(tag):
                     "bytes lie between it and the upper bound given here.",
         }
         json.dump(out, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
-    for name in ("bench_default.json", "kt_bench.json"):
+    for name in ("bench_default.json", "kt_bench.json", "kt_serial_bench.json"):
         p = os.path.join(SRC, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(DST, f"{tag}_{name}"))
