@@ -650,12 +650,17 @@ __global__ void PackBoxesKernel(uint4 *__restrict__ inner, uint64_t n_inner, con
 
 // ---- visiting order of the queries.  Bucket = ordinal (tree order) of the leaf that contains the
 // query point (a stackless best-child descent) >> shift; the buckets are cut into 8 equal ranges
-// (one per XCD), and inside a range the queries are visited in 8 cost classes, most expensive
+// (one per XCD), and inside a range the queries are visited in 16 cost classes, most expensive
 // first, each class in bucket order.  The class is |q|^2 (the windows are z-scored, so density -
 // and with it the number of nodes a search visits - falls with the distance from the origin:
 // measured correlation -0.8); visiting the cheap queries last keeps the tail of the launch, when
 // lanes run out of work one by one, short.  Counting sort on (range, class, bucket in range).
-constexpr uint32_t kCostClasses = 8;
+constexpr uint32_t kCostClasses = 16;
+constexpr uint32_t kLeafBucketBits = 16;  // resolution of the leaf order inside a class
+// 1/16 ... 15/16 quantiles of |q|^2 over the query windows of simulated reads (speed only: a
+// different signal distribution changes the sizes of the classes, never a result)
+__constant__ float kClassThreshold[kCostClasses - 1] = {1.81f, 2.45f, 2.98f, 3.47f, 3.93f, 4.40f, 4.88f, 5.37f,
+                                                        5.90f, 6.46f, 7.10f, 7.85f, 8.76f, 9.98f, 11.95f};
 __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                const uint32_t *__restrict__ n_queries_dev, uint32_t n_queries_host,
                                uint32_t shift, uint32_t per_range, uint32_t classes,
@@ -673,10 +678,11 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
     const uint32_t lb = (node & kIdxMask) >> shift, range = lb / per_range;
     const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
                      r.q[5] * r.q[5];
-    // quartiles of |q|^2 over the windows of simulated reads, each cut once more
-    uint32_t cls = r2 < 2.2f ? 0u : (r2 < 3.8f ? 1u : (r2 < 6.2f ? 2u : 3u));
-    cls = 2 * cls + (r2 >= (cls == 0 ? 1.5f : cls == 1 ? 3.0f : cls == 2 ? 4.9f : 8.5f) ? 1u : 0u);
-    cls = cls * classes / kCostClasses;  // (SMHIP_CLASSES = 1, 2, 4: coarser classes, for experiments)
+    uint32_t cls = 0;  // number of thresholds <= r2 (binary search over 15 sorted values)
+#pragma unroll
+    for (uint32_t stepw = 8; stepw > 0; stepw >>= 1)
+      if (r2 >= kClassThreshold[cls + stepw - 1]) cls += stepw;
+    cls = cls * classes / kCostClasses;  // (SMHIP_CLASSES < 16: coarser classes, for experiments)
     const uint32_t key = (range * classes + cls) * per_range + (lb - range * per_range);
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
@@ -769,14 +775,16 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
                            const uint32_t **range_end_out, uint32_t *range_stride_out) {
   uint32_t bits = 1;
   while ((1ull << bits) < ctx->index.n_leaves) ++bits;
-  const uint32_t shift = bits > 17 ? bits - 17 : 0;
-  const uint32_t per_range = ((uint32_t)(ctx->index.n_leaves >> shift) + 8) / 8;  // leaf buckets per XCD range
-  static int env_cls = -1;
+  static int env_cls = -1, env_bits = 0;
   if (env_cls < 0) {
-    const char *e0 = getenv("SMHIP_CLASSES");
+    const char *e0 = getenv("SMHIP_CLASSES"), *e1 = getenv("SMHIP_BUCKET_BITS");
     env_cls = e0 ? atoi(e0) : 0;
+    if (e1) env_bits = atoi(e1);
   }
   const uint32_t classes = (env_cls > 0 && env_cls <= (int)kCostClasses) ? (uint32_t)env_cls : kCostClasses;
+  const uint32_t want_bits = env_bits > 0 ? (uint32_t)env_bits : kLeafBucketBits;
+  const uint32_t shift = bits > want_bits ? bits - want_bits : 0;
+  const uint32_t per_range = ((uint32_t)(ctx->index.n_leaves >> shift) + 8) / 8;  // leaf buckets per XCD range
   const uint32_t n_buckets = 8 * classes * per_range + 1;
   hipError_t e;
   if ((e = ctx->q_keys.Reserve(n_max * 4)) != hipSuccess) return e;
