@@ -114,6 +114,26 @@ def test_seed_lookup_tiny_trees(npts):
     dev.close(); tree.close()
 
 
+def test_upload_rejects_leaves_the_scan_cannot_hold():
+    """The scan phase tests one point per lane, 21 lanes per leaf: a tree built with a larger
+    max_leaf is refused at upload with a message, never searched wrongly."""
+    rng = np.random.default_rng(9)
+    vals = rng.normal(size=600).astype(np.float32)
+    ok = pipeline.HostIndex.from_points(np.arange(600, dtype=np.uint64) << 1, vals, max_leaf=21, threads=1)
+    big = pipeline.HostIndex.from_points(np.arange(600, dtype=np.uint64) << 1, vals, max_leaf=40, threads=1)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ok)
+    tree = po.OracleTree(ok.values.copy(), leaf_max=21)
+    qs = np.array([vals[i:i + 6] for i in range(0, 590, 7)], np.float32)
+    counts, idx, dist, _, _ = dev.seed_lookup(qs, cap=64)
+    for k in range(len(qs)):
+        n, oi, od, _ = tree.radius_search(qs[k], 0.08)
+        assert counts[k] == n and np.array_equal(idx[k, :n], oi) and np.array_equal(bits(dist[k, :n]), bits(od))
+    with pytest.raises(RuntimeError, match="more than 21 points"):
+        dev.upload_index(big)
+    dev.close(); tree.close()
+
+
 def test_seed_lookup_matches_reference_golden():
     g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
     ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=2)
