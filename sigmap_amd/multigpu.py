@@ -2,7 +2,11 @@
 xGMI on ROCm).  The path shards by reads with a full index replica per GPU:
 the only collective is the start-up broadcast of the device-resident index arrays; there is
 no data-path collective.  The same functions run on CPU tensors with the gloo backend, which
-is how the world_size-2 tests exercise them without GPUs."""
+is how the world_size-2 tests exercise them without GPUs.
+
+A process that uses torch on the GPU together with this package must `import torch` BEFORE the
+first DeviceMapper is created (bench.py does): torch brings its own HIP runtime, and the process has
+to end up with one runtime, the one loaded first."""
 import ctypes as C
 
 import numpy as np
