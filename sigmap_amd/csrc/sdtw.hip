@@ -198,32 +198,51 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
   // starts at tb = first t with g(t) + half >= d; tb only moves forward as d grows.  Each
   // diagonal writes that interval plus a margin of FLT_MAX cells, which is all the next two
   // diagonals can read.  Row 0 and column 0 are constants (FLT_MAX / 0) and are never stored.
-  uint32_t tb = 1;
+  // (all quantities below fit 32 bits: rows and columns are < 2^14)
+  // tb is found without a dependent LDS read per diagonal: lane l keeps g(tb_base + l) + half in a
+  // register (INT_MAX past the last row), the qualifying rows are a suffix of the wave (g grows),
+  // and the registers are re-based when tb has moved half a wave.
+  const int32_t half32 = (int32_t)half, Q32 = (int32_t)Q;
+  uint32_t tb = 1, tb_base = 1, te_hi = 0xFFFFFFFFu;
+  auto g_of = [&](uint32_t row) { return row <= T ? (int32_t)row + cen[row] + half32 : 0x7FFFFFFF; };
+  int32_t g_lane = g_of(tb_base + lane);
   for (uint32_t d = 2; d <= T + Q; ++d) {
-    while (tb <= T && (int64_t)tb + cen[tb] + half < (int64_t)d) ++tb;
+    for (;;) {
+      const uint64_t mk = __ballot(g_lane >= (int32_t)d);
+      const uint32_t adv = mk ? (uint32_t)__builtin_ctzll(mk) : 64u;
+      tb = tb_base + adv;
+      // rows whose band has begun on this diagonal (g - half <= d): a prefix of the wave; when it
+      // ends inside the wave its last row bounds the interval from above
+      const uint64_t bk = __ballot(g_lane <= (int32_t)d + 2 * half32);
+      te_hi = (bk >> 63) ? 0xFFFFFFFFu : tb_base + (uint32_t)__popcll(bk) + 2u;  // last begun row + 3
+      if (adv < 32u || tb > T) break;
+      tb_base = tb;
+      g_lane = g_of(tb_base + lane);
+    }
     const uint32_t t_min = d > Q ? d - Q : 1, t_max = d - 1 < T ? d - 1 : T;  // q in [1, Q], t in [1, T]
     const uint32_t w_lo = max(t_min, tb > 3 ? tb - 3 : 1u);
-    const uint32_t w_hi = min(t_max, tb + band + 6);
+    const uint32_t w_hi = min(t_max, min(te_hi, tb + band + 6));
     for (uint32_t t = w_lo + lane; t <= w_hi && w_lo <= w_hi; t += 64) {
-      const uint32_t q = d - t;
+      const int32_t q = (int32_t)(d - t);
       float v = FLT_MAX;
-      const int64_t centre = cen[t];
-      int64_t lo = centre - half, hi = centre + half;
-      if (lo < 1) lo = 1;
-      if (hi > (int64_t)Q) hi = Q;
-      if ((int64_t)q >= lo && (int64_t)q <= hi) {
+      const int32_t centre = cen[t];
+      // the three ring cells are read unconditionally (always addressable), so that they are issued
+      // together with the band centre instead of one after the other behind the boundary tests
+      const float ra = d0[(t - 1) & rmask], rb = d1[(t - 1) & rmask], rc = d1[t & rmask];
+      const int32_t lo = max(centre - half32, 1), hi = min(centre + half32, Q32);
+      if (q >= lo && q <= hi) {
         const float cost = fabsf(tg[t - 1] - qr[q - 1]);
         // (t-1, q-1), (t-1, q), (t, q-1) with the boundary constants of sigmap.cc:1263-1271
-        const float a = t == 1 ? (q == 1 ? 0.0f : FLT_MAX) : (q == 1 ? 0.0f : d0[(t - 1) & rmask]);
-        const float b = t == 1 ? FLT_MAX : d1[(t - 1) & rmask];
-        const float cc = q == 1 ? 0.0f : d1[t & rmask];
+        const float a = q == 1 ? 0.0f : (t == 1 ? FLT_MAX : ra);
+        const float b = t == 1 ? FLT_MAX : rb;
+        const float cc = q == 1 ? 0.0f : rc;
         float m = a;
         if (b < m) m = b;
         if (cc < m) m = cc;
         v = cost + m;
       }
       d2[t & rmask] = v;
-      if (q == Q) {
+      if (q == Q32) {
         if (v < best || (v == best && t < best_t)) {
           best = v;
           best_t = t;
