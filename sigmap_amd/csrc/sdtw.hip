@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
   uint32_t tb = 1, tb_base = 1, te_hi = 0xFFFFFFFFu;
   auto g_of = [&](uint32_t row) { return row <= T ? (int32_t)row + cen[row] + half32 : 0x7FFFFFFF; };
   int32_t g_lane = g_of(tb_base + lane);
-  for (uint32_t d = 2; d <= T + Q; ++d) {
+  // The interval of diagonal d + 1 is computed while diagonal d is swept, and the operands of its
+  // first-pass cell that do not depend on diagonal d (signal values, band centre) are loaded then:
+  // the sweep of a diagonal waits for LDS only.
+  auto interval = [&](uint32_t d, uint32_t &w_lo, uint32_t &w_hi) {
     for (;;) {
       const uint64_t mk = __ballot(g_lane >= (int32_t)d);
       const uint32_t adv = mk ? (uint32_t)__builtin_ctzll(mk) : 64u;
@@ -220,40 +223,68 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
       g_lane = g_of(tb_base + lane);
     }
     const uint32_t t_min = d > Q ? d - Q : 1, t_max = d - 1 < T ? d - 1 : T;  // q in [1, Q], t in [1, T]
-    const uint32_t w_lo = max(t_min, tb > 3 ? tb - 3 : 1u);
-    const uint32_t w_hi = min(t_max, min(te_hi, tb + band + 6));
-    for (uint32_t t = w_lo + lane; t <= w_hi && w_lo <= w_hi; t += 64) {
-      const int32_t q = (int32_t)(d - t);
-      float v = FLT_MAX;
-      const int32_t centre = cen[t];
-      // the three ring cells are read unconditionally (always addressable), so that they are issued
-      // together with the band centre instead of one after the other behind the boundary tests
-      const float ra = d0[(t - 1) & rmask], rb = d1[(t - 1) & rmask], rc = d1[t & rmask];
-      const int32_t lo = max(centre - half32, 1), hi = min(centre + half32, Q32);
-      if (q >= lo && q <= hi) {
-        const float cost = fabsf(tg[t - 1] - qr[q - 1]);
-        // (t-1, q-1), (t-1, q), (t, q-1) with the boundary constants of sigmap.cc:1263-1271
-        const float a = q == 1 ? 0.0f : (t == 1 ? FLT_MAX : ra);
-        const float b = t == 1 ? FLT_MAX : rb;
-        const float cc = q == 1 ? 0.0f : rc;
-        float m = a;
-        if (b < m) m = b;
-        if (cc < m) m = cc;
-        v = cost + m;
+    w_lo = max(t_min, tb > 3 ? tb - 3 : 1u);
+    w_hi = min(t_max, min(te_hi, tb + band + 6));
+  };
+  struct Ops {
+    float tv, qv;
+    int32_t centre;
+  };
+  auto fetch = [&](uint32_t d, uint32_t t) {  // clamped: always addressable
+    Ops o;
+    const uint32_t tc = min(t, T);
+    o.tv = tg[tc - 1];
+    o.qv = qr[min(max((int32_t)(d - t) - 1, 0), Q32 - 1)];
+    o.centre = cen[tc];
+    return o;
+  };
+  auto cell = [&](uint32_t d, uint32_t t, const Ops &o) {
+    const int32_t q = (int32_t)(d - t);
+    float v = FLT_MAX;
+    // the three ring cells are read unconditionally (always addressable), so that they are issued
+    // together instead of one after the other behind the boundary tests
+    const float ra = d0[(t - 1) & rmask], rb = d1[(t - 1) & rmask], rc = d1[t & rmask];
+    const int32_t lo = max(o.centre - half32, 1), hi = min(o.centre + half32, Q32);
+    if (q >= lo && q <= hi) {
+      const float cost = fabsf(o.tv - o.qv);
+      // (t-1, q-1), (t-1, q), (t, q-1) with the boundary constants of sigmap.cc:1263-1271
+      const float a = q == 1 ? 0.0f : (t == 1 ? FLT_MAX : ra);
+      const float b = t == 1 ? FLT_MAX : rb;
+      const float cc = q == 1 ? 0.0f : rc;
+      float m = a;
+      if (b < m) m = b;
+      if (cc < m) m = cc;
+      v = cost + m;
+    }
+    d2[t & rmask] = v;
+    if (q == Q32) {
+      if (v < best || (v == best && t < best_t)) {
+        best = v;
+        best_t = t;
       }
-      d2[t & rmask] = v;
-      if (q == Q32) {
-        if (v < best || (v == best && t < best_t)) {
-          best = v;
-          best_t = t;
-        }
-      }
+    }
+  };
+  uint32_t w_lo, w_hi, n_lo = 0, n_hi = 0;
+  interval(2, w_lo, w_hi);
+  Ops cur = fetch(2, w_lo + lane), nxt = cur;
+  for (uint32_t d = 2; d <= T + Q; ++d) {
+    if (d < T + Q) {
+      interval(d + 1, n_lo, n_hi);
+      nxt = fetch(d + 1, n_lo + lane);
+    }
+    if (w_lo <= w_hi) {
+      const uint32_t t = w_lo + lane;
+      if (t <= w_hi) cell(d, t, cur);
+      for (uint32_t t2 = t + 64; t2 <= w_hi; t2 += 64) cell(d, t2, fetch(d, t2));  // rare second pass
     }
     __syncthreads();
     float *tmp = d0;
     d0 = d1;
     d1 = d2;
     d2 = tmp;
+    w_lo = n_lo;
+    w_hi = n_hi;
+    cur = nxt;
   }
   for (int off = 32; off > 0; off >>= 1) {
     const float ob = __shfl_down(best, off, 64);
