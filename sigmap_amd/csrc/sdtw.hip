@@ -304,6 +304,156 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
     }
   }
 }
+
+// Register version of the same sweep for narrow bands: lane l owns the rows t = l (mod 64), one at a
+// time, keeps its row's two newest cells in registers and receives the neighbouring row's newest
+// cell with one wave rotate per diagonal -- no LDS traffic for the DP itself (the query and the band
+// centres are staged in LDS once).  It needs the rows that are live at the same time to span
+// fewer than 62 rows, which is checked up front on the band centres (g(t + 62) - g(t) > band + 3:
+// row t + 62 begins after row t has ended); problems that fail the check, have more than
+// `max_rows` rows or more than kSysQ query values are left to the ring kernel (end_pos = -2).
+// Same cells, same operations, same tie rule: results are bit-identical to the ring kernel's.
+constexpr uint32_t kSysQ = 1024;
+
+__global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_result *__restrict__ results,
+                                                              const float *__restrict__ feat, uint32_t feat_stride,
+                                                              const uint32_t *__restrict__ qstart,
+                                                              const float *__restrict__ ref_sig,
+                                                              const uint64_t *__restrict__ ref_off, uint32_t n_refs,
+                                                              uint32_t band, uint32_t pad, int dim,
+                                                              float *__restrict__ dist, int64_t *__restrict__ end_pos,
+                                                              uint32_t max_rows) {
+  extern __shared__ float sm[];
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  const smhip_chunk_result &res = results[c];
+  bool ok = res.n_chains >= 1 && res.chains[0].ref < n_refs;
+  uint32_t T = 0, Q = res.n_features;
+  int64_t t0 = 0, start = 0, den = 1, qa = 0, qb = 0;
+  const float *tg = nullptr;
+  bool defer = false;
+  if (ok) {
+    const smhip_chain ch = res.chains[0];
+    const uint32_t strand = ch.direction == 1 ? 0u : 1u;
+    const uint64_t so = ref_off[2 * ch.ref + strand], se = ref_off[2 * ch.ref + strand + 1];
+    const int64_t len = (int64_t)(se - so);
+    start = ch.start;
+    const int64_t endp = ch.end;
+    t0 = start - (int64_t)pad < 0 ? 0 : start - (int64_t)pad;
+    int64_t t1 = endp + dim + (int64_t)pad;
+    if (t1 > len) t1 = len;
+    const uint32_t qs0 = qstart ? qstart[c] : 0;
+    qa = (int64_t)res.c0_last_qpos - qs0;
+    qb = (int64_t)res.c0_first_qpos - qs0;
+    if (qa < 0) qa = 0;
+    if (qb < 0) qb = 0;
+    den = endp - start > 0 ? endp - start : 1;
+    if (t1 <= t0 || t1 - t0 > (int64_t)kSdtwMaxT || Q == 0) {
+      ok = false;
+    } else if (t1 - t0 > (int64_t)max_rows || Q > kSysQ) {
+      defer = true;
+    } else {
+      T = (uint32_t)(t1 - t0);
+      tg = ref_sig + so + t0;
+    }
+  }
+  if (!ok || defer) {
+    if (lane == 0) {
+      dist[c] = FLT_MAX;
+      end_pos[c] = ok ? -2 : -1;
+    }
+    return;
+  }
+  float *qs = sm;                                           // [kSysQ] the query
+  int32_t *cen = reinterpret_cast<int32_t *>(sm + kSysQ);   // [T + 2] band centre of every row
+  const float *qr = feat + (size_t)c * feat_stride;
+  for (uint32_t q = lane; q < Q; q += 64) qs[q] = qr[q];
+  for (uint32_t t = lane; t < T + 2; t += 64) {
+    const int64_t ta = t0 + (int64_t)t - 1;
+    cen[t] = (int32_t)(1 + qa + FloorDiv((ta - start) * (qb - qa), den));
+  }
+  __syncthreads();
+  const int32_t half32 = (int32_t)(band / 2), Q32 = (int32_t)Q;
+  {
+    bool wide = false;
+    for (uint32_t t = 1 + lane; t + 62 <= T; t += 64)
+      if ((int32_t)(t + 62) + cen[t + 62] - ((int32_t)t + cen[t]) <= 2 * half32 + 3) wide = true;
+    if (__ballot(wide)) {
+      if (lane == 0) {
+        dist[c] = FLT_MAX;
+        end_pos[c] = -2;
+      }
+      return;
+    }
+  }
+  // this lane's current row and its constants
+  uint32_t t = lane == 0 ? 64u : lane;
+  float tv = 0.0f;
+  int32_t lo = 1, hi = 0, gend = 0x7FFFFFFF;  // a row past T: never in the band, never left
+  auto load_row = [&]() {
+    if (t <= T) {
+      const int32_t centre = cen[t];
+      tv = tg[t - 1];
+      lo = max(centre - half32, 1);
+      hi = min(centre + half32, Q32);
+      gend = (int32_t)t + centre + half32;  // last diagonal with a cell of this row inside the band
+    } else {
+      lo = 1;
+      hi = 0;
+      gend = 0x7FFFFFFF;
+    }
+  };
+  load_row();
+  float v1 = FLT_MAX;      // this row's cell on the previous diagonal: (t, q - 1)
+  float a_prev = FLT_MAX;  // the row above on the diagonal before that: (t - 1, q - 1)
+  float best = FLT_MAX;
+  uint32_t best_t = 0xFFFFFFFFu;
+  for (uint32_t d = 2; d <= T + Q; ++d) {
+    // (t - 1, q): the row above on the previous diagonal, from the neighbouring lane (lane 0 <- 63)
+    const float b_in =
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
+    const int32_t q = (int32_t)d - (int32_t)t;
+    const float qv = qs[min(max(q - 1, 0), Q32 - 1)];
+    // boundary constants of sigmap.cc:1263-1271
+    const float a = q == 1 ? 0.0f : (t == 1 ? FLT_MAX : a_prev);
+    const float b = t == 1 ? FLT_MAX : b_in;
+    const float cc = q == 1 ? 0.0f : v1;
+    float m = a;
+    if (b < m) m = b;
+    if (cc < m) m = cc;
+    const float v = (q >= lo && q <= hi) ? fabsf(tv - qv) + m : FLT_MAX;
+    if (q == Q32 && t <= T) {
+      if (v < best || (v == best && t < best_t)) {
+        best = v;
+        best_t = t;
+      }
+    }
+    a_prev = b_in;
+    v1 = v;
+    // The row is left one diagonal after its last in-band cell, so that the row below has read that
+    // cell; the new row (64 further) has not begun, so FLT_MAX is its cell as well as the old row's.
+    if (gend < (int32_t)d) {
+      t += 64;
+      load_row();
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_down(best, off, 64);
+    const uint32_t ot = __shfl_down(best_t, off, 64);
+    if (ob < best || (ob == best && ot < best_t)) {
+      best = ob;
+      best_t = ot;
+    }
+  }
+  if (lane == 0) {
+    if (best < FLT_MAX) {
+      dist[c] = best;
+      end_pos[c] = t0 + (int64_t)best_t;
+    } else {
+      dist[c] = FLT_MAX;
+      end_pos[c] = -1;
+    }
+  }
+}
 }  // namespace
 
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
@@ -347,8 +497,20 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
-                     qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0, ring);
+  static int use_ring = -1;
+  if (use_ring < 0) use_ring = getenv("SMHIP_SDTW_RING") ? 1 : 0;  // (experiments: skip the register kernel)
+  if (use_ring) {
+    hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
+                       qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0, ring);
+  } else {
+    // pass 1: register sweep (narrow, short problems); what it defers (end_pos = -2) is swept by the
+    // ring kernel, first with room for 1021 rows (high occupancy), then, below, with room for 8192
+    const size_t lds_sys = ((size_t)kSysQ + fast_rows + 2) * sizeof(float);
+    hipLaunchKernelGGL(SdtwChainSystolicKernel, dim3(n_chunks), dim3(64), lds_sys, ctx->stream, results, feat,
+                       feat_stride, qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows);
+    hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
+                       qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 1, ring);
+  }
   hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_full, ctx->stream, results, feat, feat_stride,
                      qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, (uint32_t)kSdtwMaxT, 1, ring);
   return hipGetLastError();
