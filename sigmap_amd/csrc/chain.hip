@@ -107,10 +107,27 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
       bool isolated = true;
       int32_t skips = 0;
       uint32_t steps = 0;
+      // the predecessor's record (bucket, target, query) is read one step ahead of its use, all
+      // three words together, so that a step of the scan does not wait for LDS
+      auto rec = [&](uint32_t pj, uint32_t &rg, int32_t &rt, int32_t &rq) {
+        if (pj >= w0) {
+          rg = s_g[pj - w0];
+          rt = s_t[pj - w0];
+          rq = s_q[pj - w0];
+        } else {
+          rg = grp[pj];
+          rt = (int32_t)tpos[pj];
+          rq = (int32_t)qpos[pj];
+        }
+      };
+      uint32_t ng = ~g;
+      int32_t nt = 0, nq = 0;
+      if (ai > 0) rec(ai - 1, ng, nt, nq);
       for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-        const bool in_lds = pj >= w0;
-        if ((in_lds ? s_g[pj - w0] : grp[pj]) != g) break;  // bucket start
-        const int32_t pt = in_lds ? s_t[pj - w0] : (int32_t)tpos[pj], pq = in_lds ? s_q[pj - w0] : (int32_t)qpos[pj];
+        const uint32_t pg = ng;
+        const int32_t pt = nt, pq = nq;
+        if (pj > 0) rec(pj - 1, ng, nt, nq);
+        if (pg != g) break;  // bucket start
         if (pq == cq || pt == ct) continue;
         if (pt + max_target_gap_length < ct) break;
         const int32_t td = ct - pt, qd = cq - pq;
