@@ -672,16 +672,12 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
 }
 
 // ---- C3: GeneratePrimaryChains + ComputeMAPQ + chain statistics + carry-over anchors, one wave
-// per chunk (spatial_index.cc:222-274, sigmap.cc:702-729).  Lane 0 orders and filters the (few)
-// candidate chains; all lanes gather the chains' anchors through the recorded index lists; lane 0
-// then adds chain 0's statistics in the reference's order (f32 sums are order-sensitive).
-constexpr uint32_t kStatLds = 384;   // anchors of chain 0 staged in LDS for the sequential sums
+// per chunk (spatial_index.cc:222-274, sigmap.cc:702-729).  The candidate chains are ranked and
+// filtered by the whole wave; all lanes gather the chains' anchors through the recorded index lists;
+// chain 0's statistics are added up in the reference's order (f32 sums are order-sensitive).
 
 __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
                                                           const uint32_t *__restrict__ n_chains_in) {
-  __shared__ uint32_t s_np;
-  __shared__ uint32_t l_t[kStatLds], l_q[kStatLds];
-  __shared__ float l_d[kStatLds];
   const uint32_t c = blockIdx.x, lane = threadIdx.x;
   const uint64_t base = a.anchor_off[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
@@ -695,96 +691,110 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
     for (uint32_t i = lane; i < nch0; i += 64) ch[i] = gch[i];
   }
   __syncthreads();
-  // Descending by operator> (spatial_index.cc:569-570), keeping the order of equal chains: with up
-  // to 64 candidates every lane ranks its own chain against the others (LDS broadcasts) -- the
-  // one-lane insertion sort of a few dozen 32-byte records took 100 000+ cycles per chunk.
-  bool sorted = false;
+  // Descending by operator> (spatial_index.cc:569-570), keeping the order of equal chains: every
+  // lane ranks its own (up to two) chains against all the others (LDS broadcasts) -- a one-lane
+  // insertion sort of a few dozen 32-byte records took 100 000+ cycles per chunk.
   {
+    static_assert(kChainCap <= 128, "two chains per lane");
     const uint32_t nchp = min(n_chains_in[c], (uint32_t)kChainCap);
-    if (nchp <= 64) {
-      ChainTmp mine{};
-      if (lane < nchp) mine = ch[lane];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < nchp; ++j) {
-        const ChainTmp o = ch[j];
-        if (lane < nchp && j != lane) {
-          if (ChainGreater(o, mine)) ++rank;
-          else if (!ChainGreater(mine, o) && j < lane) ++rank;
+    ChainTmp mine[2] = {};
+    uint32_t rank[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (lane + 64u * h < nchp) mine[h] = ch[lane + 64u * h];
+    for (uint32_t j = 0; j < nchp; ++j) {
+      const ChainTmp o = ch[j];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t self = lane + 64u * h;
+        if (self < nchp && j != self) {
+          if (ChainGreater(o, mine[h])) ++rank[h];
+          else if (!ChainGreater(mine[h], o) && j < self) ++rank[h];
         }
       }
-      __syncthreads();
-      if (lane < nchp) ch[rank] = mine;
-      __syncthreads();
-      sorted = true;
     }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (lane + 64u * h < nchp) ch[rank[h]] = mine[h];
+    __syncthreads();
   }
-  if (lane == 0) {
-    uint32_t nch = n_chains_in[c];
-    if (nch > (uint32_t)kChainCap) {
-      res.status |= SMHIP_ST_CHAIN_CAP;
-      nch = kChainCap;
-    }
-    uint32_t np = 0;
-    if (nch > 0) {
-      for (uint32_t i = 1; i < nch && !sorted; ++i) {  // more than 64 candidates: insertion sort
-        const ChainTmp x = ch[i];
-        uint32_t j = i;
-        while (j > 0 && ChainGreater(x, ch[j - 1])) {
-          ch[j] = ch[j - 1];
-          --j;
-        }
-        ch[j] = x;
+  // spatial_index.cc:222-253: greedy, in rank order; primaries are compacted to the front of ch[].
+  // The candidates are taken one after the other, but each is tested against all kept primaries at
+  // once: lane l holds primaries l and l + 64 in registers.  (With one lane doing both loops a chunk
+  // whose candidates all score alike cost 16 000 dependent LDS round trips, and the launch waited.)
+  uint32_t nch = n_chains_in[c];
+  if (nch > (uint32_t)kChainCap) {
+    if (lane == 0) res.status |= SMHIP_ST_CHAIN_CAP;
+    nch = kChainCap;
+  }
+  uint32_t np = 0;
+  if (nch > 0) {
+    uint32_t p_ref[2] = {0, 0}, p_start[2] = {0, 0}, p_end[2] = {0, 0};
+    float last_score;
+    {
+      const ChainTmp x = ch[0];
+      if (lane == 0) {
+        p_ref[0] = x.ref;
+        p_start[0] = x.start;
+        p_end[0] = x.end;
       }
-      // spatial_index.cc:222-253: primaries are compacted to the front of ch[]
+      last_score = x.score;
       np = 1;
-      for (uint32_t ci = 1; ci < nch; ++ci) {
-        bool is_primary = true;
-        if (ch[ci].score < ch[np - 1].score / 3) break;
-        for (uint32_t pi = 0; pi < np; ++pi) {
-          if (ch[ci].ref == ch[pi].ref) {
-            if (max(ch[ci].start, ch[pi].start) > min(ch[ci].end, ch[pi].end)) {
-            } else {
-              is_primary = false;
-              break;
+    }
+    for (uint32_t ci = 1; ci < nch; ++ci) {
+      const ChainTmp x = ch[ci];
+      if (x.score < last_score / 3) break;
+      bool overlaps = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (lane + 64u * h < np && x.ref == p_ref[h] && !(max(x.start, p_start[h]) > min(x.end, p_end[h])))
+          overlaps = true;
+      if (__ballot(overlaps) == 0) {
+        if (lane == (np & 63u)) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if ((np >> 6) == (uint32_t)h) {
+              p_ref[h] = x.ref;
+              p_start[h] = x.start;
+              p_end[h] = x.end;
             }
-          }
         }
-        if (is_primary) {
-          const ChainTmp x = ch[ci];
-          ch[np++] = x;
-        }
-      }
-      // spatial_index.cc:255-274
-      uint32_t mapq;
-      if (np == 1) {
-        mapq = 60;
-      } else {
-        int m = (int)(40 * (1 - ch[1].score / ch[0].score));
-        if (m > 60) m = 60;
-        if (m < 0) m = 0;
-        mapq = (uint32_t)m;
-      }
-      res.n_chains = np;
-      float sum = 0;
-      for (uint32_t i = 0; i < np; ++i) sum += ch[i].score;  // sigmap.cc:702-705
-      res.sum_score = sum;
-      for (uint32_t i = 0; i < np && i < SMHIP_TOPK; ++i) {
-        smhip_chain o;
-        o.score = ch[i].score;
-        o.ref = ch[i].ref;
-        o.start = ch[i].start;
-        o.end = ch[i].end;
-        o.n_anchors = ch[i].n_anchors;
-        o.mapq = i == 0 ? mapq : 0;
-        o.direction = ch[i].direction;
-        o.pad = 0;
-        res.chains[i] = o;
+        if (lane == 0) ch[np] = x;  // np <= ci: nothing unread is overwritten
+        last_score = x.score;
+        ++np;
       }
     }
-    s_np = np;
   }
   __syncthreads();
-  const uint32_t np = s_np;
+  if (lane == 0 && np > 0) {
+    // spatial_index.cc:255-274
+    uint32_t mapq;
+    if (np == 1) {
+      mapq = 60;
+    } else {
+      int m = (int)(40 * (1 - ch[1].score / ch[0].score));
+      if (m > 60) m = 60;
+      if (m < 0) m = 0;
+      mapq = (uint32_t)m;
+    }
+    res.n_chains = np;
+    float sum = 0;
+    for (uint32_t i = 0; i < np; ++i) sum += ch[i].score;  // sigmap.cc:702-705
+    res.sum_score = sum;
+    for (uint32_t i = 0; i < np && i < SMHIP_TOPK; ++i) {
+      smhip_chain o;
+      o.score = ch[i].score;
+      o.ref = ch[i].ref;
+      o.start = ch[i].start;
+      o.end = ch[i].end;
+      o.n_anchors = ch[i].n_anchors;
+      o.mapq = i == 0 ? mapq : 0;
+      o.direction = ch[i].direction;
+      o.pad = 0;
+      res.chains[i] = o;
+    }
+  }
   if (np == 0) {
     if (lane == 0) a.out_anchor_cnt[c] = 0;
     return;
@@ -793,62 +803,69 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
   // next chunk's carry-over
   uint32_t w = 0;
   smhip_carried_anchor *out = a.out_anchors ? a.out_anchors + base : nullptr;
+  // chain 0's sums (sigmap.cc:714-729) are order-sensitive f32 additions.  The anchors stay in the
+  // registers of the lanes that gathered them, the gaps to the previous anchor are formed in
+  // parallel, and every lane adds the 64 values of a tile up in index order from broadcasts
+  // (v_readlane): the same additions in the same order, without a memory round trip per anchor.
+  float ad = 0, at = 0, aq = 0;
+  uint32_t carry_t = 0, carry_q = 0;  // last anchor of the previous tile
   for (uint32_t i = 0; i < np; ++i) {
     const ChainTmp ci = ch[i];
     const uint32_t g_id = grp[ci.end_anchor];
     const uint32_t *lst = lists + ci.list_off;
     const uint32_t na = ci.n_anchors;
-    for (uint32_t k = lane; k < na; k += 64) {
-      const uint32_t ai = lst[k];
-      const uint32_t t = tpos[ai], q = qpos[ai];
-      const float d = dist[ai];
-      if (out) {
-        smhip_carried_anchor o;
-        o.ref_strand = g_id;
-        o.target_position = t;
-        o.query_position = q;
-        o.distance = d;
-        out[w + k] = o;
+    for (uint32_t k0 = 0; k0 < na; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      uint32_t t = 0, q = 0;
+      float d = 0.0f;
+      if (k < na) {
+        const uint32_t ai = lst[k];
+        t = tpos[ai];
+        q = qpos[ai];
+        d = dist[ai];
+        if (out) {
+          smhip_carried_anchor o;
+          o.ref_strand = g_id;
+          o.target_position = t;
+          o.query_position = q;
+          o.distance = d;
+          out[w + k] = o;
+        }
       }
-      if (i == 0 && k < kStatLds) {
-        l_t[k] = t;
-        l_q[k] = q;
-        l_d[k] = d;
+      if (i != 0) continue;
+      uint32_t pt = (uint32_t)__shfl_up((int)t, 1), pq = (uint32_t)__shfl_up((int)q, 1);
+      if (lane == 0) {
+        pt = carry_t;
+        pq = carry_q;
+      }
+      const float gt = (float)(uint32_t)(pt - t), gq = (float)(uint32_t)(pq - q);
+      const uint32_t kn = min(na - k0, 64u);
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        if ((uint32_t)j < kn) {
+          ad += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+          if (k0 + (uint32_t)j > 0) {
+            at += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gt), j));
+            aq += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gq), j));
+          }
+        }
+      }
+      if (k0 == 0) {
+        const uint32_t q_first = (uint32_t)__builtin_amdgcn_readlane((int)q, 0);
+        if (lane == 0) res.c0_first_qpos = q_first;
+      }
+      carry_t = (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
+      carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+      if (k0 + 64 >= na) {
+        const uint32_t q_last = (uint32_t)__shfl((int)q, (int)(na - 1 - k0));
+        if (lane == 0) res.c0_last_qpos = q_last;
       }
     }
     w += na;
-    if (i == 0) {
-      __syncthreads();
-      if (lane == 0) {  // sigmap.cc:714-729 in the reference's accumulation order
-        float ad = 0, at = 0, aq = 0;
-        uint32_t pt_prev = 0, pq_prev = 0;
-        for (uint32_t k = 0; k < na; ++k) {
-          uint32_t t, q;
-          float d;
-          if (k < kStatLds) {
-            t = l_t[k];
-            q = l_q[k];
-            d = l_d[k];
-          } else {
-            const uint32_t ai = lst[k];
-            t = tpos[ai];
-            q = qpos[ai];
-            d = dist[ai];
-          }
-          ad += d;
-          if (k == 0) res.c0_first_qpos = q;
-          if (k + 1 == na) res.c0_last_qpos = q;
-          if (k > 0) {
-            at += (float)(uint32_t)(pt_prev - t);
-            aq += (float)(uint32_t)(pq_prev - q);
-          }
-          pt_prev = t;
-          pq_prev = q;
-        }
-        res.c0_sum_dist = ad;
-        res.c0_sum_tgap = at;
-        res.c0_sum_qgap = aq;
-      }
+    if (i == 0 && lane == 0) {
+      res.c0_sum_dist = ad;
+      res.c0_sum_tgap = at;
+      res.c0_sum_qgap = aq;
     }
   }
   if (lane == 0) a.out_anchor_cnt[c] = w;
