@@ -511,10 +511,15 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
 
 // ---- C2: one wave per chunk: running max_chaining_score across buckets (spatial_index.cc:420,
 // 542-549), chain ends, traceback (spatial_index.cc:165-220, 552-568)
+constexpr float kLongChainScore = 60.0f;  // buckets whose best candidate scores at least this are traced by the whole wave
+constexpr uint32_t kTraceWindow = 1024;  // (pred, used) entries staged in LDS below the anchor being traced
+
 __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_anchors, int num_best_chains,
                                                       float min_chaining_score, uint32_t *__restrict__ n_chains_out,
                                                       const uint32_t *__restrict__ n_pending, int dim) {
   __shared__ uint32_t s_nchains;
+  __shared__ uint32_t w_pred[kTraceWindow];
+  __shared__ uint8_t w_used[kTraceWindow];
   const uint32_t c = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   const uint64_t base = a.anchor_off[c];
@@ -556,10 +561,15 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
     }
   }
   __syncthreads();
-  for (uint32_t g = lane; g < G; g += 64) {
-    const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
+  for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+    const uint32_t g = g0 + lane;
+    uint32_t s = 0, lim = 0, grp_id = 0;
+    float max_after = 0.0f;
+    Cand top[3] = {};
+    if (g < G) {
+    s = gstart[g];
+    const uint32_t e = g + 1 < G ? gstart[g + 1] : n;
     float run_max = pmax[g];  // max_chaining_score on entry to this bucket
-    Cand top[3];
     uint32_t ntop = 0;
     auto consider = [&](uint32_t ai, float sc) {
       if (sc > run_max) run_max = sc;
@@ -615,56 +625,142 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
       }
     }
     run_max = fmaxf(run_max, gmax[g]);  // (the bucket maximum includes the settled anchors)
-    const float max_after = run_max;  // max_chaining_score after the bucket
-    const uint32_t grp_id = grp[s];
-    const uint32_t ref = grp_id >> 1;
-    const uint32_t direction = (grp_id & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
-    const uint32_t lim = min(ntop, (uint32_t)min(num_best_chains, 3));
-    uint32_t cursor = s;  // chain anchor lists are packed into this bucket's own slice of `lists`
-    for (uint32_t k = 0; k < lim; ++k) {
-      // TracebackChains, spatial_index.cc:165-220 (pred[] holds chunk-local absolute indices)
-      const uint32_t end_abs = s + top[k].idx;
-      if (!used[end_abs]) {
-        // (the loop below is the reference's, with pred[p] fetched beside used[p]: one memory
-        // round trip per chain anchor instead of two dependent ones)
-        bool stop_at_used = false;
-        uint32_t cur = end_abs;
-        const uint32_t list_off = cursor;
-        uint32_t num = 0;
-        uint32_t pc = pred[cur];
-        for (;;) {
-          lists[cursor++] = cur;
-          used[cur] = 1;
-          ++num;
-          if (pc == cur) break;
-          const uint8_t up = used[pc];
-          const uint32_t pp = pred[pc];
-          if (up) {
-            stop_at_used = true;
-            break;
+    max_after = run_max;  // max_chaining_score after the bucket
+    grp_id = grp[s];
+    lim = min(ntop, (uint32_t)min(num_best_chains, 3));
+    // A bucket whose best candidate scores below kLongChainScore has short chains (an anchor adds at
+    // most `dim` to a score): its lane traces them itself, all such buckets of the wave at once.
+    if (lim > 0 && top[0].score < kLongChainScore) {
+      const uint32_t ref = grp_id >> 1;
+      const uint32_t direction = (grp_id & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
+      uint32_t cursor = s;  // chain anchor lists are packed into this bucket's own slice of `lists`
+      for (uint32_t k = 0; k < lim; ++k) {
+        const uint32_t end_abs = s + top[k].idx;
+        if (!used[end_abs]) {
+          // (the reference's loop, with pred[p] fetched beside used[p]: one memory round trip per
+          // chain anchor instead of two dependent ones)
+          bool stop_at_used = false;
+          uint32_t cur = end_abs;
+          const uint32_t list_off = cursor;
+          uint32_t num = 0;
+          uint32_t pc = pred[cur];
+          for (;;) {
+            lists[cursor++] = cur;
+            used[cur] = 1;
+            ++num;
+            if (pc == cur) break;
+            const uint8_t up = used[pc];
+            const uint32_t pp = pred[pc];
+            if (up) {
+              stop_at_used = true;
+              break;
+            }
+            cur = pc;
+            pc = pp;
           }
-          cur = pc;
-          pc = pp;
-        }
-        if (num >= (uint32_t)min_num_anchors) {
-          float adjusted = score[end_abs];
-          if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
-          const uint32_t slot = atomicAdd(&s_nchains, 1u);
-          if (slot < (uint32_t)kChainCap) {
-            ChainTmp ch;
-            ch.score = adjusted;
-            ch.ref = ref;
-            ch.start = tpos[cur];
-            ch.end = tpos[end_abs];
-            ch.n_anchors = num;
-            ch.direction = direction;
-            ch.end_anchor = end_abs;
-            ch.list_off = list_off;
-            a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
+          if (num >= (uint32_t)min_num_anchors) {
+            float adjusted = score[end_abs];
+            if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
+            const uint32_t slot = atomicAdd(&s_nchains, 1u);
+            if (slot < (uint32_t)kChainCap) {
+              ChainTmp ch;
+              ch.score = adjusted;
+              ch.ref = ref;
+              ch.start = tpos[cur];
+              ch.end = tpos[end_abs];
+              ch.n_anchors = num;
+              ch.direction = direction;
+              ch.end_anchor = end_abs;
+              ch.list_off = list_off;
+              a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
+            }
           }
         }
+        if (score[end_abs] < max_after / 2) break;  // spatial_index.cc:563-567
       }
-      if (score[end_abs] < max_after / 2) break;  // spatial_index.cc:563-567
+      lim = 0;
+    }
+    }
+    // TracebackChains, spatial_index.cc:165-220 (pred[] holds chunk-local absolute indices).  A
+    // traceback is a pointer chase -- one memory round trip per chain anchor, ~250 of them for the
+    // true locus of a read -- so the buckets with a long candidate are taken one after the other by
+    // the WHOLE wave: their owner's state is broadcast, a window of 1024 (pred, used) entries
+    // below the current anchor is staged in LDS by all lanes, and the chase runs on LDS.
+    for (uint64_t todo = __ballot(lim > 0); todo; todo &= todo - 1) {
+      const int src = __builtin_ctzll(todo);
+      const uint32_t bs = (uint32_t)__shfl((int)s, src), blim = (uint32_t)__shfl((int)lim, src);
+      const float bmax_after = __shfl(max_after, src);
+      const uint32_t bgrp = (uint32_t)__shfl((int)grp_id, src);
+      uint32_t bidx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bidx[k] = (uint32_t)__shfl((int)top[k].idx, src);
+      const uint32_t ref = bgrp >> 1;
+      const uint32_t direction = (bgrp & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
+      uint32_t cursor = bs;  // chain anchor lists are packed into this bucket's own slice of `lists`
+      uint32_t w_lo = 1, w_hi = 0;  // window [w_lo, w_hi) of the bucket staged in LDS (empty)
+      auto ensure = [&](uint32_t p) {  // wave-uniform
+        if (p >= w_lo && p < w_hi) return;
+        __syncthreads();
+        w_hi = p + 1;
+        w_lo = w_hi - bs > kTraceWindow ? w_hi - kTraceWindow : bs;
+        for (uint32_t i = lane; i < w_hi - w_lo; i += 64) {
+          w_pred[i] = pred[w_lo + i];
+          w_used[i] = used[w_lo + i];
+        }
+        __syncthreads();
+      };
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if ((uint32_t)k >= blim) break;
+        const uint32_t end_abs = bs + bidx[k];
+        ensure(end_abs);
+        if (!w_used[end_abs - w_lo]) {
+          bool stop_at_used = false;
+          uint32_t cur = end_abs;
+          const uint32_t list_off = cursor;
+          uint32_t num = 0;
+          uint32_t pc = w_pred[cur - w_lo];
+          for (;;) {
+            if (lane == 0) {
+              lists[cursor] = cur;
+              used[cur] = 1;
+            }
+            w_used[cur - w_lo] = 1;  // (every lane writes the same value)
+            ++cursor;
+            ++num;
+            if (pc == cur) break;
+            ensure(pc);
+            const uint8_t up = w_used[pc - w_lo];
+            const uint32_t pp = w_pred[pc - w_lo];
+            if (up) {
+              stop_at_used = true;
+              break;
+            }
+            cur = pc;
+            pc = pp;
+          }
+          if (num >= (uint32_t)min_num_anchors) {
+            float adjusted = score[end_abs];
+            if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
+            if (lane == 0) {
+              const uint32_t slot = atomicAdd(&s_nchains, 1u);
+              if (slot < (uint32_t)kChainCap) {
+                ChainTmp ch;
+                ch.score = adjusted;
+                ch.ref = ref;
+                ch.start = tpos[cur];
+                ch.end = tpos[end_abs];
+                ch.n_anchors = num;
+                ch.direction = direction;
+                ch.end_anchor = end_abs;
+                ch.list_off = list_off;
+                a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
+              }
+            }
+          }
+        }
+        if (score[end_abs] < bmax_after / 2) break;  // spatial_index.cc:563-567
+      }
     }
   }
   __syncthreads();
