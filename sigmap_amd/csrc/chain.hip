@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
 
 // ---- C2: one wave per chunk: running max_chaining_score across buckets (spatial_index.cc:420,
 // 542-549), chain ends, traceback (spatial_index.cc:165-220, 552-568)
+constexpr uint32_t kCoopScanMin = 48;     // buckets with more DP-scored anchors than this are scanned by the whole wave
 constexpr float kLongChainScore = 60.0f;  // buckets whose best candidate scores at least this are traced by the whole wave
 constexpr uint32_t kTraceWindow = 1024;  // (pred, used) entries staged in LDS below the anchor being traced
 
@@ -563,8 +564,9 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
   __syncthreads();
   for (uint32_t g0 = 0; g0 < G; g0 += 64) {
     const uint32_t g = g0 + lane;
-    uint32_t s = 0, lim = 0, grp_id = 0;
-    float max_after = 0.0f;
+    uint32_t s = 0, lim = 0, grp_id = 0, p_lo = 0, p_hi = 0, ntop_l = 0;
+    float max_after = 0.0f, run_max_l = 0.0f;
+    bool coop = false;
     Cand top[3] = {};
     if (g < G) {
     s = gstart[g];
@@ -591,9 +593,15 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
       // DP kernels scored need to be looked at.
       uint32_t lo2 = 0, hi2 = npend;
       while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
+      uint32_t lo3 = lo2, hi3 = npend;
+      while (lo3 < hi3) { const uint32_t mid = (lo3 + hi3) >> 1; if (pending[mid] < e) lo3 = mid + 1; else hi3 = mid; }
+      p_lo = lo2;
+      p_hi = lo3;
+      // a bucket with many DP-scored anchors (the true locus) is scanned by the whole wave below
+      coop = p_hi - p_lo > kCoopScanMin;
       // kPf list entries, then their kPf scores, per pair of memory round trips (clamped
       // unconditional loads: a conditional one would wait on its own)
-      bool more = lo2 < npend;
+      bool more = lo2 < npend && !coop;
       for (uint32_t pi = lo2; more; pi += kPf) {
         uint32_t ids[kPf];
         float sc8[kPf];
@@ -624,6 +632,63 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
         }
       }
     }
+    run_max_l = run_max;
+    ntop_l = ntop;
+    }
+    // Whole-wave scan of the buckets flagged above: 64 of the bucket's DP-scored anchors at a time;
+    // the running maximum becomes an inclusive prefix maximum (shuffles) and the three best chain ends
+    // under (score desc, index desc) -- what the sequential insertion keeps -- are picked by wave
+    // maxima of the key score_bits << 32 | index (scores are positive: they order like their bits).
+    for (uint64_t todo = __ballot(coop); todo; todo &= todo - 1) {
+      const int src = __builtin_ctzll(todo);
+      const uint32_t b_lo = (uint32_t)__shfl((int)p_lo, src), b_hi = (uint32_t)__shfl((int)p_hi, src);
+      const uint32_t bs = (uint32_t)__shfl((int)s, src);
+      float carry = __shfl(run_max_l, src);
+      unsigned long long best3[3] = {0, 0, 0};  // descending; 0 = none (a candidate's key is > 0)
+      for (uint32_t t0 = b_lo; t0 < b_hi; t0 += 64) {
+        const uint32_t pi = t0 + lane;
+        const bool valid = pi < b_hi;
+        const uint32_t ai = valid ? pending[pi] : 0u;
+        const float sc = valid ? score[ai] : 0.0f;
+        float pm = sc;  // inclusive prefix maximum (scores are >= 0)
+        for (int d = 1; d < 64; d <<= 1) {
+          const float o = __shfl_up(pm, d, 64);
+          if ((int)lane >= d) pm = fmaxf(pm, o);
+        }
+        pm = fmaxf(pm, carry);
+        carry = __shfl(pm, 63, 64);
+        unsigned long long key = 0;
+        if (valid && sc >= min_chaining_score && sc > pm / 2)  // spatial_index.cc:545-549
+          key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(ai - bs);
+        for (int r = 0; r < 3 && __ballot(key != 0); ++r) {
+          unsigned long long m = key;
+          for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long o = __shfl_xor(m, d, 64);
+            if (o > m) m = o;
+          }
+          if (key == m) key = 0;  // keys are distinct (distinct indices): exactly one lane
+          // insert m into the descending best3
+          if (m > best3[0]) { best3[2] = best3[1]; best3[1] = best3[0]; best3[0] = m; }
+          else if (m > best3[1]) { best3[2] = best3[1]; best3[1] = m; }
+          else if (m > best3[2]) { best3[2] = m; }
+          else break;  // the tile's remaining candidates are smaller still
+        }
+      }
+      if ((int)lane == src) {
+        run_max_l = carry;
+        ntop_l = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (best3[k]) {
+            top[k].score = __uint_as_float((uint32_t)(best3[k] >> 32));
+            top[k].idx = (uint32_t)best3[k];
+            ntop_l = k + 1;
+          }
+      }
+    }
+    if (g < G) {
+    float run_max = run_max_l;
+    const uint32_t ntop = ntop_l;
     run_max = fmaxf(run_max, gmax[g]);  // (the bucket maximum includes the settled anchors)
     max_after = run_max;  // max_chaining_score after the bucket
     grp_id = grp[s];
