@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *
 // row t + 62 begins after row t has ended); problems that fail the check, have more than
 // `max_rows` rows or more than kSysQ query values are left to the ring kernel (end_pos = -2).
 // Same cells, same operations, same tie rule: results are bit-identical to the ring kernel's.
-constexpr uint32_t kSysQ = 1024;
+constexpr uint32_t kSysQ = 640;  // query values staged in LDS (a 4000-sample chunk has ~450 events)
 
 __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_result *__restrict__ results,
                                                               const float *__restrict__ feat, uint32_t feat_stride,
@@ -363,20 +363,24 @@ __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_
     }
     return;
   }
+  // 4.6 KB of LDS per wave: what this sweep lives on is the number of waves a SIMD can interleave
   float *qs = sm;                                           // [kSysQ] the query
-  int32_t *cen = reinterpret_cast<int32_t *>(sm + kSysQ);   // [T + 2] band centre of every row
+  int16_t *cen = reinterpret_cast<int16_t *>(sm + kSysQ);   // [T + 2] band centre of every row (< 2^15)
   const float *qr = feat + (size_t)c * feat_stride;
   for (uint32_t q = lane; q < Q; q += 64) qs[q] = qr[q];
+  bool out_of_range = false;
   for (uint32_t t = lane; t < T + 2; t += 64) {
     const int64_t ta = t0 + (int64_t)t - 1;
-    cen[t] = (int32_t)(1 + qa + FloorDiv((ta - start) * (qb - qa), den));
+    const int64_t cv = 1 + qa + FloorDiv((ta - start) * (qb - qa), den);
+    if (cv < -32768 || cv > 32767) out_of_range = true;
+    cen[t] = (int16_t)cv;
   }
   __syncthreads();
   const int32_t half32 = (int32_t)(band / 2), Q32 = (int32_t)Q;
   {
-    bool wide = false;
+    bool wide = out_of_range;  // (a centre that does not fit 16 bits: left to the ring kernel as well)
     for (uint32_t t = 1 + lane; t + 62 <= T; t += 64)
-      if ((int32_t)(t + 62) + cen[t + 62] - ((int32_t)t + cen[t]) <= 2 * half32 + 3) wide = true;
+      if ((int32_t)(t + 62) + (int32_t)cen[t + 62] - ((int32_t)t + (int32_t)cen[t]) <= 2 * half32 + 3) wide = true;
     if (__ballot(wide)) {
       if (lane == 0) {
         dist[c] = FLT_MAX;
@@ -505,7 +509,7 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
   } else {
     // pass 1: register sweep (narrow, short problems); what it defers (end_pos = -2) is swept by the
     // ring kernel, first with room for 1021 rows (high occupancy), then, below, with room for 8192
-    const size_t lds_sys = ((size_t)kSysQ + fast_rows + 2) * sizeof(float);
+    const size_t lds_sys = (size_t)kSysQ * sizeof(float) + ((size_t)fast_rows + 2) * sizeof(int16_t);
     hipLaunchKernelGGL(SdtwChainSystolicKernel, dim3(n_chunks), dim3(64), lds_sys, ctx->stream, results, feat,
                        feat_stride, qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows);
     hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
