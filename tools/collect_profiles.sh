@@ -20,5 +20,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum T
   i=$((i+1))
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu --depth 1 > /dev/null 2> $OUT/pmc_${i}_err.log
 done
-timeout 900 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default_err.log
+timeout 900 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default_err.log
 du -sh $OUT
