@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
     ap.add_argument("--depth", type=int, default=2,
-                    help="batches in flight per GPU: steps alternate over this many contexts / HIP streams "
+                    help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
     return ap.parse_args()
 
@@ -149,8 +149,10 @@ def main():
     dev.params.reference_walk = 1
     census, _ = step()
     dev.params.reference_walk = 0
-    # warm-up: W steps, and at least one on every context (each sizes its own scratch and hit pool)
-    pool.run_steps(max(args.warmup, len(pool.devs)), step)
+    # warm-up: W steps, and one on every context (each sizes its own scratch and hit pool)
+    pool.for_each(lambda dv: step(dv))
+    if args.warmup > len(pool.devs):
+        pool.run_steps(args.warmup - len(pool.devs), step)
     pool.for_each(lambda dv: (dv.timing(True), dv.timing_reset()))
 
     def fence():
@@ -183,7 +185,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    results = pool.run_steps(args.steps, step)  # EXACTLY K steps, step i on context i % depth
+    results = pool.run_steps(args.steps, step)  # EXACTLY K steps, each on the context that is free next
     fence()
     dt = time.perf_counter() - t0
     res, refined = results[-1]

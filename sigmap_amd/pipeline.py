@@ -263,8 +263,8 @@ class MapperPool:
     """`depth` DeviceMapper contexts on ONE GPU (one HIP stream each) that share one resident index:
     the first context owns the walker arrays, the others borrow them (smhip_index_export ->
     smhip_index_attach, no copy).  The reads of a run are independent (one taskloop over all reads in
-    Sigmap::StreamingMap, sigmap.cc:618-666), so consecutive batches are mapped on alternating
-    contexts, each driven by its own host thread: the tail of one batch's tree walk and its sort /
+    Sigmap::StreamingMap, sigmap.cc:618-666), so every batch is mapped on whichever context is
+    free next, each context driven by its own host thread: the tail of one batch's tree walk and its sort /
     chain / sDTW kernels overlap the next batch's walk.  Results do not depend on the context."""
 
     def __init__(self, device=0, depth=2):
@@ -287,15 +287,23 @@ class MapperPool:
             fn(dv)
 
     def run_steps(self, n_steps, step_fn):
-        """step_fn(dev, step_index) is called for steps 0..n_steps-1, step i on context i % depth, the
-        steps of one context in order on that context's thread.  Returns the list of results."""
+        """step_fn(dev, step_index) is called once for every step 0..n_steps-1: each context's thread
+        takes the next step not yet started when it has finished its previous one.  Returns the list
+        of results in step order."""
         import threading
         out = [None] * n_steps
         err = []
+        lock = threading.Lock()
+        nxt = [0]
 
         def work(k):
             try:
-                for i in range(k, n_steps, len(self.devs)):
+                while not err:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= n_steps:
+                        break
                     out[i] = step_fn(self.devs[k], i)
             except BaseException as e:  # re-raised on the caller's thread
                 err.append(e)
