@@ -67,16 +67,31 @@ __global__ __launch_bounds__(64) void PrefixKernel(const float *__restrict__ sam
   ps[0] = 0.0f;
   pss[0] = 0.0f;
   uint32_t i = 0;
-  for (; i + kBlk <= n; i += kBlk) {
-    float v[kBlk];
+  // blocks of kPre samples, the next block's loads in flight while the current one is added up
+  // (the additions are a dependent chain; a lane's loads are 4-byte reads 16 KB apart from its
+  // neighbours', so a block costs a full memory round trip)
+  constexpr int kPre = 16;
+  float cur[kPre], nxt[kPre];
+  if (kPre <= n) {
 #pragma unroll
-    for (int k = 0; k < kBlk; ++k) v[k] = x[i + k];
+    for (int k = 0; k < kPre; ++k) cur[k] = x[k];
+  }
+  for (; i + kPre <= n; i += kPre) {
+    const bool more = i + 2 * kPre <= n;
+    if (more) {
 #pragma unroll
-    for (int k = 0; k < kBlk; ++k) {
-      a = a + v[k];
-      b = b + v[k] * v[k];
+      for (int k = 0; k < kPre; ++k) nxt[k] = x[i + kPre + k];
+    }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      a = a + cur[k];
+      b = b + cur[k] * cur[k];
       ps[i + k + 1] = a;
       pss[i + k + 1] = b;
+    }
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) cur[k] = nxt[k];
     }
   }
   for (; i < n; ++i) {
