@@ -64,9 +64,9 @@ typedef struct {
   float min_chaining_score;       /* 10 */
   /* device-side capacities (not reference semantics; exceeding one is reported, never
    * silently truncated) */
-  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pass (512) */
+  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pool (512) */
   uint32_t walk_blocks_per_cu;    /* resident 256-thread workgroups per CU of the tree walker
-                                     (0 = default 6; speed only) */
+                                     (0 = default 4; speed only) */
   uint32_t reference_walk;        /* 0: skip subtrees whose tight box is out of range (same hits,
                                      same order).  1: visit exactly nanoflann's node set, so that
                                      nodes_visited / points_tested count the reference's work
