@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Randomised parity run (development aid, beyond the fixed seeds of tests/): for a range of seeds,
+genomes of random shapes (incl. repeats), noisy / truncated reads, and random device parameters,
+the GPU path's per-chunk records + refinement must equal the oracle's.  Usage:
+  python tools/fuzz_parity.py [n_rounds] [first_seed]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np  # noqa: E402
+
+from oracle import pyoracle as po  # noqa: E402
+from sigmap_amd import _abi, pipeline, synth  # noqa: E402
+from test_gpu_parity import _paf_lines  # noqa: E402
+
+
+def main(rounds, first):
+    bad = 0
+    for seed in range(first, first + rounds):
+        rng = np.random.default_rng(seed)
+        n_contigs = int(rng.integers(1, 5))
+        lens = [int(rng.integers(20000, 120000)) for _ in range(n_contigs)]
+        genome = synth.make_genome(seed, lens)
+        if rng.random() < 0.5:  # a repeat: the second half of contig 0 copies its first half
+            g0 = genome[0]
+            half = len(g0) // 2
+            genome[0] = g0[:half] + g0[:len(g0) - half]
+        lm = synth.make_pore_model()
+        n_reads = int(rng.integers(8, 40))
+        raw, _ = synth.simulate_reads(genome, lm, n_reads, seed + 1000)
+        pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+        kind = ["read"] * len(pa)
+        for i in range(len(pa)):  # pure-noise reads, flat reads (few events), reads with a stuck stretch
+            u = rng.random()
+            if u < 0.10:
+                pa[i] = rng.normal(90, 12, size=len(pa[i])).astype(np.float32)
+                kind[i] = "noise"
+            elif u < 0.15:
+                pa[i] = np.full(len(pa[i]), 85.0, np.float32) + rng.normal(0, 0.01, size=len(pa[i])).astype(np.float32)
+                kind[i] = "flat"
+            elif u < 0.25:
+                a = int(rng.integers(0, len(pa[i]) - 600))
+                pa[i] = pa[i].copy()
+                pa[i][a:a + 500] = pa[i][a]
+                kind[i] = "stuck"
+        ix = pipeline.HostIndex.build(genome, lm, threads=4)
+        tree = po.OracleTree(ix.values.copy())
+        ref_lens = np.array([len(g) for g in genome], dtype=np.uint32)
+        dev = pipeline.DeviceMapper(0)
+        dev.params.walk_blocks_per_cu = int(rng.choice([0, 1, 2, 8]))
+        dev.params.reference_walk = int(rng.integers(0, 2))
+        dev.params.hits_per_query_fast = int(rng.choice([512, 64, 4]))
+        dev.upload_index(ix)
+        samples = np.concatenate(pa)
+        offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
+        res = dev.map_chunks(samples, offsets, n_refs=n_contigs)
+        names = ["contig%d" % i for i in range(n_contigs)]
+        lines = _paf_lines(res, pa, names, ref_lens)
+        mism = 0
+        for i, x in enumerate(pa):
+            m = po.map_read(tree, ix.positions, x, n_contigs, ref_lens)
+            ok = lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+            ok = ok and res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+            if dev.params.reference_walk:
+                ok = ok and res[i]["nodes_visited"] == m.stats.search.nodes and res[i]["points_tested"] == m.stats.search.points
+            if not ok:
+                mism += 1
+                print("   MISMATCH read %d (%s): status %d\n     gpu: %s\n     ora: %s" % (
+                    i, kind[i], res[i]["status"], lines[i][:200], po.format_paf(m, "read%d" % i, names, ref_lens)[:200]))
+        # refinement (register sweep / ring sweep, whichever takes the problem) against the oracle's
+        # banded sDTW on the same window and band
+        band, pad = int(rng.choice([16, 32, 64, 128])), int(rng.choice([0, 32, 100]))
+        sig, offs = pipeline.reference_signals(genome, lm)
+        dev.upload_reference(sig, offs)
+        dev.refine(band=band, pad=pad); dev.sync()
+        dist, end = dev.refine_download()
+        feat, _, nf, _, _ = dev.events(samples, offsets)
+        rmis = 0
+        for i in range(len(pa)):
+            r = res[i]
+            if r["n_chains"] == 0:
+                rmis += end[i] != -1
+                continue
+            c0 = r["chains"][0]
+            strand = 0 if c0["direction"] == 1 else 1
+            so, se = int(offs[2 * c0["ref"] + strand]), int(offs[2 * c0["ref"] + strand + 1])
+            start, endp = int(c0["start"]), int(c0["end"])
+            t0 = max(0, start - pad); t1 = min(se - so, endp + 6 + pad)
+            q = feat[i, :nf[i]]
+            qa, qb = int(r["c0_last_qpos"]), int(r["c0_first_qpos"])
+            den = max(1, endp - start)
+            ta = np.arange(t0, t1, dtype=np.int64)
+            centre = 1 + qa + ((ta - start) * (qb - qa)) // den
+            lo = np.clip(centre - band // 2, 1, None).astype(np.int64)
+            hi = np.maximum(np.clip(centre + band // 2, None, len(q)).astype(np.int64), 0)
+            d, e = po.sdtw_banded(sig[so + t0:so + t1], q, lo.astype(np.uint32), hi.astype(np.uint32))
+            okr = (end[i] == -1) if e < 0 else (np.float32(dist[i]).tobytes() == np.float32(d).tobytes() and end[i] == t0 + e)
+            if not okr:
+                rmis += 1
+                print("   REFINE MISMATCH read %d (%s): band %d pad %d gpu (%r, %d) oracle (%r, %d)" % (
+                    i, kind[i], band, pad, dist[i], end[i], d, t0 + e if e >= 0 else -1))
+        mism += rmis
+        print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d cap=%d): %d mismatches, %d mapped"
+              % (seed, n_contigs, lens, n_reads, dev.params.walk_blocks_per_cu, dev.params.reference_walk,
+                 dev.params.hits_per_query_fast, mism, int((res["n_chains"] > 0).sum())), flush=True)
+        bad += mism
+        dev.close(); tree.close(); ix.close()
+    print("TOTAL mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
