@@ -201,6 +201,28 @@ def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, bloc
     assert good >= len(pa) - 3
 
 
+def test_pipeline_degenerate_signals_match_oracle(device, small_world, oracle_tree):
+    """Reads that are not clean copies of the reference -- pure noise, an almost flat signal, reads
+    with a stuck stretch, wide noise -- give the oracle's records and PAF rows too (the kinds of input
+    tools/fuzz_parity.py draws)."""
+    rng = np.random.default_rng(77)
+    ix, ref_lens = small_world["ix"], small_world["ref_lens"]
+    base = small_world["pa"]
+    pa = [rng.normal(90, 12, size=4000).astype(np.float32),
+          np.full(4000, 85.0, np.float32) + rng.normal(0, 0.01, size=4000).astype(np.float32),
+          base[0].copy(), base[1].copy(), rng.normal(120, 30, size=4000).astype(np.float32).clip(31, 199)]
+    pa[2][1000:1500] = pa[2][1000]
+    pa[3][:700] = pa[3][700]
+    samples, offsets = _batch(pa)
+    res = device.map_chunks(samples, offsets, n_refs=3)
+    names = ["contig0", "contig1", "contig2"]
+    lines = _paf_lines(res, pa, names, ref_lens)
+    for i, x in enumerate(pa):
+        m = po.map_read(oracle_tree, ix.positions, x, 3, ref_lens)
+        assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+        assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+
+
 def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
     """Queries with more hits than the fast slots are re-walked into exact-size segments:
     results must not depend on the capacity."""
