@@ -173,7 +173,7 @@ __device__ __forceinline__ void DetectorStep(Detector *d, int k, float cur, uint
 // the state it started from is re-run from the true state, round after round until nothing
 // changes (at most kPeakSegs - 1 rounds = the sequential order), so the peak list is the one the
 // reference's loop produces whatever the signal looks like.
-constexpr int kPeakSegs = 8;
+constexpr int kPeakSegs = 16;
 constexpr uint32_t kPeakWarm = 96;
 
 struct PeakState {  // the varying part of the two detectors (det 0 is never masked)
