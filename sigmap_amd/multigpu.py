@@ -68,15 +68,20 @@ def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
         raise RuntimeError(f"hipMemcpy D2D failed: {rc}")
 
 
-def replicate_index(dev, ix, rank, world, local_rank, dist):
+def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
     uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
-    attach the received buffers (smhip_index_attach).  Returns objects to keep alive."""
+    attach the received buffers (smhip_index_attach).  Returns objects to keep alive.
+    `device` / `copy_fn(dst_ptr, src_ptr, nbytes)` default to this rank's GPU and a device-to-device
+    hipMemcpy; the world_size-2 gloo test passes "cpu" and a host copy to run this very function."""
     if world == 1:
         dev.upload_index(ix)
         return None
     import torch
-    device = torch.device("cuda", local_rank)
+    on_gpu = device is None
+    if on_gpu:
+        device = torch.device("cuda", local_rank)
+    copy_fn = copy_fn or _hip_memcpy_d2d
     meta = [0] * (len(_SCALARS) + len(_ARRAYS))
     d = None
     if rank == 0:
@@ -88,10 +93,11 @@ def replicate_index(dev, ix, rank, world, local_rank, dist):
     for a, nbytes in zip(_ARRAYS, meta[len(_SCALARS):]):
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if rank == 0:
-            _hip_memcpy_d2d(t.data_ptr(), getattr(d, a), nbytes)
+            copy_fn(t.data_ptr(), getattr(d, a), nbytes)
         dist.broadcast(t, src=0)  # RCCL broadcast over xGMI
         tensors.append(t)
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     if rank != 0:
         nd = _abi.IndexDev()
         for f, v in zip(_SCALARS, meta):

@@ -79,3 +79,79 @@ def test_shard_range_partitions_everything():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+class _FakeContext:
+    """Stands in for pipeline.DeviceMapper on a machine without a GPU: "device" arrays are host
+    buffers, export hands out their addresses, attach records what it was given."""
+
+    def __init__(self):
+        self.exported = None
+        self.attached = None
+        self._keep = []
+
+    def upload_index(self, ix):
+        import ctypes as C
+        from sigmap_amd import _abi
+        rng = np.random.default_rng(5)
+        d = _abi.IndexDev()
+        d.dim, d.root_ref, d.n_nodes, d.n_leaves, d.m_size = 6, 0, 1000, 1001, 12345
+        for name, nbytes in (("nodes", 64000), ("leaf_tab", 4004), ("leaf_pts", 70000), ("leaf_vind", 9000), ("bbox", 96)):
+            buf = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+            self._keep.append(buf)
+            setattr(d, name, buf.ctypes.data)
+            setattr(d, name + "_bytes", nbytes)
+        self.exported = d
+
+    def export_index(self):
+        return self.exported
+
+    def attach_index(self, nd):
+        import ctypes as C
+        from sigmap_amd import multigpu
+        self.attached = {f: int(getattr(nd, f)) for f in multigpu._SCALARS}
+        for a in multigpu._ARRAYS:
+            n = int(getattr(nd, a + "_bytes"))
+            self.attached[a] = bytes((C.c_uint8 * n).from_address(getattr(nd, a)))
+
+
+def _replicate_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes as C
+    import torch.distributed as dist
+    from sigmap_amd import multigpu
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = _FakeContext()
+        keep = multigpu.replicate_index(dev, None, rank, world, rank, dist, device="cpu",
+                                        copy_fn=lambda dst, src, n: C.memmove(dst, src, n))
+        if rank == 0:
+            d = dev.exported
+            want = {f: int(getattr(d, f)) for f in multigpu._SCALARS}
+            for a in multigpu._ARRAYS:
+                n = int(getattr(d, a + "_bytes"))
+                want[a] = bytes((C.c_uint8 * n).from_address(getattr(d, a)))
+            q.put((0, want))
+        else:
+            q.put((rank, dev.attached if keep is not None else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_replicate_index_hands_the_peer_identical_arrays():
+    """multigpu.replicate_index itself (the function bench.py calls for N > 1), with host buffers in
+    place of device memory: the peer attaches the scalars and byte-identical copies of all five arrays."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is not None and got[1] == got[0]
+
