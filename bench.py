@@ -212,9 +212,10 @@ def main():
         bytes_per_launch = 2 * CHUNK * R + 16 * nodes + 28 * points + 24 * anchors + 64 * R
         # Launch duration of the dominant kernel: HIP events around the seed-lookup stage.  With one
         # batch in flight that bracket is the stage's kernels (rocprofv3's kernel trace of the same
-        # command agrees: profiles/).  With several in flight it also spans the time the stage's
-        # kernels queue behind the other stream's, while the kernel itself runs exactly as long
-        # (the trace again), so the roofline uses the serial pass of this same run.
+        # command with --depth 1 agrees: profiles/).  With several in flight a launch has no single
+        # duration -- the bracket also spans the time the stage's kernels queue behind the other
+        # stream's, and two walkers that meet share the chip -- so the roofline uses the serial pass
+        # of this same run.
         seed_ms_overlapped = kern["seed_lookup"]["mean_ms"]
         seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"] if serial is not None else seed_ms_overlapped
         achieved = bytes_per_launch / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
