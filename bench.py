@@ -185,7 +185,10 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    results = pool.run_steps(args.steps, step)  # EXACTLY K steps, each on the context that is free next
+    # EXACTLY K steps, each on the context that is free next; the contexts start a fraction of a step
+    # apart (inside the timed region), so that their tree walks alternate from the first step on
+    stagger = (serial["ms_per_step"] * 1e-3 / len(pool.devs)) if serial is not None else 0.0
+    results = pool.run_steps(args.steps, step, stagger_s=stagger)
     fence()
     dt = time.perf_counter() - t0
     res, refined = results[-1]

@@ -286,11 +286,13 @@ class MapperPool:
         for dv in self.devs:
             fn(dv)
 
-    def run_steps(self, n_steps, step_fn):
+    def run_steps(self, n_steps, step_fn, stagger_s=0.0):
         """step_fn(dev, step_index) is called once for every step 0..n_steps-1: each context's thread
         takes the next step not yet started when it has finished its previous one.  Returns the list
-        of results in step order."""
+        of results in step order.  `stagger_s`: context k starts k * stagger_s late, so that the contexts
+        do not all begin with the same (longest) kernel and then share the GPU for it."""
         import threading
+        import time
         out = [None] * n_steps
         err = []
         lock = threading.Lock()
@@ -298,6 +300,8 @@ class MapperPool:
 
         def work(k):
             try:
+                if stagger_s > 0 and k > 0:
+                    time.sleep(k * stagger_s)
                 while not err:
                     with lock:
                         i = nxt[0]
