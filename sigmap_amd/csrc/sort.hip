@@ -19,10 +19,12 @@
 
 namespace smhip {
 namespace {
+
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
 constexpr uint32_t kMaxQueriesPerChunk = (kFeatStride - 5) / 1 + 1;  // step >= 1
-constexpr uint32_t kBuckets = 256;    // buckets of the two-level sort
+constexpr uint32_t kBucketBits = 10;
+constexpr uint32_t kBuckets = 1u << kBucketBits;  // buckets of the two-level sort (~9 keys each: four per wave pass)
 constexpr uint32_t kMaxBucket = 512;  // largest bucket one wave rank-sorts (8 keys per lane)
 constexpr uint32_t kBigBuckets = 1024;  // buckets of a chunk too large for LDS (== kSortThreads)
 constexpr uint32_t kWaveKeys = kLdsKeys / (kSortThreads / 64);  // 1024: a wave's slice of the LDS key array
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   extern __shared__ __align__(16) uint64_t lds_keys[];
   __shared__ uint32_t part[kSortThreads];
   __shared__ uint32_t hist[kBuckets + 1], bstart[kBuckets + 1];
-  __shared__ uint32_t s_maxt, s_maxb;
+  __shared__ uint32_t s_maxt, s_maxb, n_big;
+  __shared__ uint32_t big_list[kBuckets];
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const uint64_t base = a.anchor_off[c];
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     a.n_groups[c] = 0;
     s_maxt = 0;
     s_maxb = 0;
+    n_big = 0;
   }
   if (n == 0) return;
   if (n > (1u << ibits) || nq > kMaxQueriesPerChunk) {  // the key cannot index this many anchors
@@ -79,7 +83,6 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   const uint64_t *gsorted = gkeys;       // where the sorted keys end up when they are not in LDS
   uint32_t *u_qpos = a.a_qpos + base;  // (target and group travel in the key)
   float *u_dist = a.a_dist + base;
-
   // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts) into LDS
   // (the key array is not in use yet: its tail holds the nq+1 offsets during the decode)
   uint32_t *qoff = reinterpret_cast<uint32_t *>(lds_keys) + 2 * kLdsKeys - (kMaxQueriesPerChunk + 2);
@@ -116,20 +119,21 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   uint32_t search_steps = 0;  // binary-search steps that cover nq + 1 offsets
   while ((1u << search_steps) < nq + 1) ++search_steps;
   const uint64_t car0 = a.carried_off ? a.carried_off[c] : 0;
-  // Four anchors per pass: their four query searches advance together, then the four 16-byte
-  // records (a hit, or a carried anchor: same size) are fetched with one wait, then the keys.
-  auto decode4 = [&](uint32_t i0, uint64_t (&keys4)[4]) {
-    uint32_t lo[4], kq[4];
-    const uint4 *src[4];
-    bool live[4], zero[4];
+  // kDec anchors per pass: their query searches advance together, then the 16-byte records (a hit,
+  // or a carried anchor: same size) are fetched with one wait, then the keys.
+  constexpr int kDec = 4;
+  auto decode4 = [&](uint32_t i0, uint64_t (&keys4)[kDec]) {
+    uint32_t lo[kDec], kq[kDec];
+    const uint4 *src[kDec];
+    bool live[kDec], zero[kDec];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kDec; ++u) {
       lo[u] = 0;
       live[u] = i0 + u * kSortThreads < n;
     }
     for (uint32_t st = search_steps; st-- > 0;) {  // largest k with qoff[k] <= h0 (qoff[0] = 0)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kDec; ++u) {
         const uint32_t i = i0 + u * kSortThreads;
         const uint32_t h0 = i >= ncar ? i - ncar : 0;
         const uint32_t mid = lo[u] + (1u << st);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kDec; ++u) {
       const uint32_t i = i0 + u * kSortThreads;
       zero[u] = false;
       kq[u] = lo[u];
@@ -161,11 +165,11 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
         }
       }
     }
-    uint4 raw[4];
+    uint4 raw[kDec];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) raw[u] = *src[u];
+    for (int u = 0; u < kDec; ++u) raw[u] = *src[u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kDec; ++u) {
       const uint32_t i = i0 + u * kSortThreads;
       if (!live[u]) continue;
       uint32_t tpos, qpos, grp;
@@ -191,18 +195,20 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   };
   if (reg_keys) {  // statically indexed registers (a run-time index would put the array in scratch)
 #pragma unroll
-    for (uint32_t bt = 0; bt < kPerThread / 4; ++bt) {
-      uint64_t k4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-      if (tid + bt * 4 * kSortThreads < n) decode4(tid + bt * 4 * kSortThreads, k4);
+    for (uint32_t bt = 0; bt < kPerThread / kDec; ++bt) {
+      uint64_t k4[kDec];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) mykeys[bt * 4 + u] = k4[u];
+      for (int u = 0; u < kDec; ++u) k4[u] = ~0ull;
+      if (tid + bt * kDec * kSortThreads < n) decode4(tid + bt * kDec * kSortThreads, k4);
+#pragma unroll
+      for (int u = 0; u < kDec; ++u) mykeys[bt * kDec + u] = k4[u];
     }
   } else {
-    for (uint32_t i0 = tid; i0 < n; i0 += 4 * kSortThreads) {
-      uint64_t k4[4];
+    for (uint32_t i0 = tid; i0 < n; i0 += kDec * kSortThreads) {
+      uint64_t k4[kDec];
       decode4(i0, k4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < kDec; ++u)
         if (i0 + u * kSortThreads < n) gkeys[i0 + u * kSortThreads] = k4[u];
     }
   }
@@ -213,12 +219,12 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
   bool bucketed = false;
   if (in_lds) {
     atomicMax(&s_maxt, local_maxt);
-    if (tid < kBuckets + 1) hist[tid] = 0;
+    for (uint32_t i = tid; i < kBuckets + 1; i += kSortThreads) hist[i] = 0;
     __syncthreads();  // everyone is done with the offsets; s_maxt, hist ready
     const uint64_t span = (uint64_t)s_maxt + 1ull;
     const uint64_t range = span << gbits;  // dense keys are < range
     const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
-    const uint32_t shift = rbits > 8u ? rbits - 8u : 0u;
+    const uint32_t shift = rbits > kBucketBits ? rbits - kBucketBits : 0u;
     uint32_t myb[kPerThread];
 #pragma unroll
     for (uint32_t it = 0; it < kPerThread; ++it) {
@@ -229,23 +235,35 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       atomicAdd(&hist[myb[it]], 1u);
     }
     __syncthreads();
-    // exclusive scan of the 256 bucket sizes (first 256 threads, Hillis-Steele in `part`)
-    if (tid < kBuckets) {
-      part[tid] = hist[tid];
-      atomicMax(&s_maxb, hist[tid]);
+    // exclusive scan of the bucket sizes by one wave (16 buckets per lane, shuffles): two workgroup
+    // barriers instead of the twenty-two of a Hillis-Steele scan over 1024 threads
+    if (tid < 64) {
+      constexpr uint32_t kPer = kBuckets / 64;
+      uint32_t h[kPer], sum = 0, mx = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        h[k] = hist[kPer * tid + k];
+        sum += h[k];
+        mx = max(mx, h[k]);
+      }
+      uint32_t incl = sum;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        bstart[kPer * tid + k] = run;
+        run += h[k];
+        hist[kPer * tid + k] = 0;  // becomes the insertion cursor
+      }
+      if (tid == 0) {
+        s_maxb = mx;
+        bstart[kBuckets] = n;
+      }
     }
-    __syncthreads();
-    for (uint32_t d = 1; d < kBuckets; d <<= 1) {
-      const uint32_t v = (tid < kBuckets && tid >= d) ? part[tid - d] : 0;
-      __syncthreads();
-      if (tid < kBuckets) part[tid] += v;
-      __syncthreads();
-    }
-    if (tid < kBuckets) {
-      bstart[tid] = part[tid] - hist[tid];
-      hist[tid] = 0;  // becomes the insertion cursor
-    }
-    if (tid == 0) bstart[kBuckets] = n;
     __syncthreads();
     bucketed = s_maxb <= kMaxBucket;
     if (bucketed) {
@@ -254,12 +272,67 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
         if (tid + it * kSortThreads < n) lds_keys[bstart[myb[it]] + atomicAdd(&hist[myb[it]], 1u)] = mykeys[it];
       __syncthreads();
       const uint32_t lane = tid & 63u, wave = tid >> 6;
-      for (uint32_t b = wave; b < kBuckets; b += kSortThreads / 64) {
+      // Four buckets per pass of a wave, sixteen lanes each: a rank sort reads every key of a bucket
+      // once as an LDS broadcast, and a 64-lane 8-byte read occupies the LDS for four clocks however
+      // many lanes use it -- with one small bucket per wave the phase was bound by exactly that.
+      const uint32_t grp16 = lane >> 4, gl = lane & 15u;
+      for (uint32_t b4 = wave * 4; b4 < kBuckets; b4 += (kSortThreads / 64) * 4) {
+        const uint32_t b = b4 + grp16;
         const uint32_t b0 = bstart[b], m = bstart[b + 1] - b0;
-        if (m < 2) continue;
-        if (m <= 64) {  // the common case: one key per lane
-          const uint64_t mine = lane < m ? lds_keys[b0 + lane] : ~0ull;
+        const bool small = m <= 16;
+        const int msm = (int)(small ? m : 0u);  // (uniform per 16 lanes: four scalar reads, no LDS shuffle)
+        const uint32_t mmax = (uint32_t)max(max(__builtin_amdgcn_readlane(msm, 0), __builtin_amdgcn_readlane(msm, 16)),
+                                            max(__builtin_amdgcn_readlane(msm, 32), __builtin_amdgcn_readlane(msm, 48)));
+        if (mmax >= 2) {
+          const uint32_t ms = small ? m : 0u;  // groups with a larger bucket sit this pass out
+          const uint64_t mine = gl < ms ? lds_keys[b0 + gl] : ~0ull;
           uint32_t rank = 0;
+          for (uint32_t x = 0; x < mmax; x += 4) {
+            uint64_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = lds_keys[b0 + min(x + k, ms ? ms - 1 : 0u)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rank += (x + k < ms && o[k] < mine) ? 1u : 0u;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // all reads of the buckets precede the permuting writes
+          if (gl < ms) lds_keys[b0 + rank] = mine;
+        }
+        // buckets of 17..64 keys: one at a time by the whole wave, one key per lane
+        const uint64_t medium = __ballot(m > 16 && m <= 64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (!((medium >> (16 * g)) & 1ull)) continue;
+          const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, 16 * g);
+          const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * g);
+          const uint64_t mine = lane < cm ? lds_keys[c0 + lane] : ~0ull;
+          uint32_t rank = 0;
+          uint32_t x = 0;
+          for (; x + 8 <= cm; x += 8) {  // LDS broadcasts, eight in flight
+            uint64_t o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = lds_keys[c0 + x + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rank += o[k] < mine ? 1u : 0u;
+          }
+          for (; x < cm; ++x) rank += lds_keys[c0 + x] < mine ? 1u : 0u;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < cm) lds_keys[c0 + rank] = mine;
+        }
+        // (a heavy bucket -- the true locus of a read: hundreds of keys -- would keep one wave busy
+        // for tens of microseconds while the other fifteen wait at the barrier: left to the whole
+        // workgroup below)
+      }
+      if (tid < kBuckets && bstart[tid + 1] - bstart[tid] > 64) big_list[atomicAdd(&n_big, 1u)] = tid;
+      __syncthreads();
+      static_assert(kMaxBucket <= kSortThreads, "one key per thread in a heavy bucket");
+      for (uint32_t bi = 0; bi < n_big; ++bi) {
+        const uint32_t bb = big_list[bi];
+        const uint32_t b0 = bstart[bb], m = bstart[bb + 1] - b0;
+        const uint64_t mine = tid < m ? lds_keys[b0 + tid] : ~0ull;
+        uint32_t rank = 0;
+        if (tid < ((m + 63u) & ~63u)) {  // the waves that hold keys
           uint32_t x = 0;
           for (; x + 8 <= m; x += 8) {  // LDS broadcasts, eight in flight
             uint64_t o[8];
@@ -269,28 +342,10 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
             for (int k = 0; k < 8; ++k) rank += o[k] < mine ? 1u : 0u;
           }
           for (; x < m; ++x) rank += lds_keys[b0 + x] < mine ? 1u : 0u;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();  // all reads of the bucket precede the permuting writes
-          if (lane < m) lds_keys[b0 + rank] = mine;
-          continue;
         }
-        uint64_t mine[kMaxBucket / 64];
-        uint32_t rank[kMaxBucket / 64];
-#pragma unroll
-        for (uint32_t r = 0; r < kMaxBucket / 64; ++r) {
-          mine[r] = lane + 64 * r < m ? lds_keys[b0 + lane + 64 * r] : ~0ull;
-          rank[r] = 0;
-        }
-        for (uint32_t x = 0; x < m; ++x) {
-          const uint64_t other = lds_keys[b0 + x];
-#pragma unroll
-          for (uint32_t r = 0; r < kMaxBucket / 64; ++r) rank[r] += other < mine[r] ? 1u : 0u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (uint32_t r = 0; r < kMaxBucket / 64; ++r)
-          if (lane + 64 * r < m) lds_keys[b0 + rank[r]] = mine[r];
+        __syncthreads();  // all reads of the bucket precede the permuting writes
+        if (tid < m) lds_keys[b0 + rank] = mine;
+        __syncthreads();
       }
       __syncthreads();
     }
@@ -382,27 +437,27 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     __syncthreads();
     if (in_lds) BitonicSort(lds_keys, npad, tid); else BitonicSort(gkeys, npad, tid);
   }
-
   // ---- scatter into sorted order
   uint32_t *s_tpos = a.s_tpos + base, *s_qpos = a.s_qpos + base, *s_grp = a.s_grp + base;
   float *s_dist = a.s_dist + base;
-  for (uint32_t i0 = tid; i0 < n; i0 += 4 * kSortThreads) {  // four elements per pass: one wait per gather level
-    uint64_t key[4];
-    uint32_t gq[4];
-    float gd[4];
+  constexpr int kSc = 4;  // elements per pass: one wait per gather level
+  for (uint32_t i0 = tid; i0 < n; i0 += kSc * kSortThreads) {
+    uint64_t key[kSc];
+    uint32_t gq[kSc];
+    float gd[kSc];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kSc; ++u) {
       const uint32_t i = min(i0 + u * kSortThreads, n - 1);
       key[u] = in_lds ? lds_keys[i] : gsorted[i];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kSc; ++u) {
       const uint32_t from = (uint32_t)(key[u] & idx_mask);
       gq[u] = u_qpos[from];
       gd[u] = u_dist[from];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kSc; ++u) {
       const uint32_t i = i0 + u * kSortThreads;
       if (i >= n) continue;
       s_tpos[i] = (uint32_t)(key[u] >> ibits);
