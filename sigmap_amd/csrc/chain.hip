@@ -86,24 +86,41 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
   }
   if (tid == 0) s_run = 0;
   __syncthreads();
+  // The tile and the 256 anchors before it live in an LDS ring of 512 entries (anchor p in slot
+  // p & 511): the backward scans rarely leave that window, a tile overwrites the older half, and
+  // its records (and distances) were fetched into registers while the previous tile was processed.
+  uint32_t nx_t = 0, nx_q = 0, nx_g = 0;
+  float nx_d = 0.0f;
+  if (tid < n) {
+    nx_t = tpos[tid];
+    nx_q = qpos[tid];
+    nx_g = grp[tid];
+    nx_d = dist[tid];
+  }
   for (uint32_t t0 = 0; t0 < n; t0 += 256) {
-    // the tile and the 256 anchors before it in LDS: the backward scans rarely leave that window
     const uint32_t w0 = t0 >= 256 ? t0 - 256 : 0;
-    __syncthreads();
-    for (uint32_t k = tid; k < 512; k += 256) {
-      const uint32_t gi = w0 + k;
-      if (gi < n && gi < t0 + 256) {
-        s_t[k] = (int32_t)tpos[gi];
-        s_q[k] = (int32_t)qpos[gi];
-        s_g[k] = grp[gi];
+    __syncthreads();  // the scans of the previous tile are done with the half that is overwritten
+    const float my_dist = nx_d;
+    if (t0 + tid < n) {
+      s_t[(t0 + tid) & 511u] = (int32_t)nx_t;
+      s_q[(t0 + tid) & 511u] = (int32_t)nx_q;
+      s_g[(t0 + tid) & 511u] = nx_g;
+    }
+    {
+      const uint32_t gi = t0 + 256 + tid;  // next tile
+      if (gi < n) {
+        nx_t = tpos[gi];
+        nx_q = qpos[gi];
+        nx_g = grp[gi];
+        nx_d = dist[gi];
       }
     }
     __syncthreads();
     const uint32_t ai = t0 + tid;
     bool pend = false;
     if (ai < n) {
-      const uint32_t g = s_g[ai - w0];
-      const int32_t ct = s_t[ai - w0], cq = s_q[ai - w0];
+      const uint32_t g = s_g[ai & 511u];
+      const int32_t ct = s_t[ai & 511u], cq = s_q[ai & 511u];
       bool isolated = true;
       int32_t skips = 0;
       uint32_t steps = 0;
@@ -111,9 +128,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
       // three words together, so that a step of the scan does not wait for LDS
       auto rec = [&](uint32_t pj, uint32_t &rg, int32_t &rt, int32_t &rq) {
         if (pj >= w0) {
-          rg = s_g[pj - w0];
-          rt = s_t[pj - w0];
-          rq = s_q[pj - w0];
+          rg = s_g[pj & 511u];
+          rt = s_t[pj & 511u];
+          rq = s_q[pj & 511u];
         } else {
           rg = grp[pj];
           rt = (int32_t)tpos[pj];
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
         if (++skips > max_num_skips) break;
       }
       if (isolated) {
-        const float coef = (float)(1 - 0.2 * (double)dist[ai] / (double)radius);
+        const float coef = (float)(1 - 0.2 * (double)my_dist / (double)radius);
         const float sc = coef * (float)dim;
         score[ai] = sc;
         pred[ai] = ai;
