@@ -56,7 +56,7 @@ constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else thro
 // any other anchor.  Those anchors ("isolated", ~94 % of a noise bucket) are finished here in
 // parallel (score, predecessor, bucket maximum); the rest are flagged (used = 2) and listed in
 // index order for the sequential kernels.
-constexpr uint32_t kLdsGroups = 4096;  // bucket maxima kept in LDS by the classify kernel
+constexpr uint32_t kLdsGroups = 1024;  // bucket maxima kept in LDS by the classify kernel (LDS per workgroup decides its occupancy)
 
 __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float radius, int dim, int max_gap_length,
                                                            int max_target_gap_length, int chaining_band_length,
