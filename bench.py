@@ -280,6 +280,10 @@ def main():
                 "measured": ("HIP events, serial pass of this run (one batch in flight)" if serial is not None
                              else "HIP events, timed region"),
                 "launch_ms_bracket_in_timed_region": round(seed_ms_overlapped, 4),
+                "note": ("achieved = algorithmic bytes of the REFERENCE algorithm (census of nanoflann's node "
+                         "visits and point tests on these inputs, SURVEY 8d) / launch duration; the kernel "
+                         "returns the same hits while pruning exactly and moves `traffic` bytes, so the "
+                         "ratio to the HBM peak can exceed 1 (DESIGN.md 4.2 says what bounds the kernel)"),
             },
         }
         if serial is not None:
