@@ -165,7 +165,10 @@ typedef struct {
 int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets,
                        uint32_t n_chunks, const uint32_t *query_start_offsets,
                        const smhip_carried_anchor *carried, const uint32_t *carried_offsets);
-/* Launch events -> seeds -> radius search -> sort -> chain on the context stream (async). */
+/* Launch events -> seeds -> radius search -> sort -> chain on the context stream.  The kernels are
+ * enqueued; the call itself waits twice for a scalar it sizes the next stage's buffers with (the
+ * number of queries after event detection, the number of anchors after the search), so it returns
+ * when the search has finished and sort + chain are still running.  smhip_map_sync waits for the rest. */
 int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs);
 int smhip_map_sync(smhip_ctx *ctx);
 /* results: n_chunks records. chain_anchors (nullable): anchors of ALL primary chains,
@@ -229,6 +232,15 @@ int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,
                  const uint32_t *sample_offsets, uint32_t n_chunks, uint32_t feat_stride,
                  float *feat, float *stdv, uint32_t *n_features, uint32_t *n_events,
                  uint32_t *status);
+/* The intermediates of the last smhip_events (or smhip_map_run) launch, for comparison with the
+ * reference's DetectEvents stage by stage (event.h:58-68 prefix sums, :70-115 t-statistics of both
+ * windows, :117-182 peaks, :184-224 events).  Every output pointer is optional.  n_peaks: per chunk;
+ * peaks / ev_start / ev_length / ev_mean / ev_stdv: n_chunks x feat_stride (Event{start, length,
+ * mean, stdv}, event.h:16-21; a chunk with < 2 peaks has no events); ps / pss / t1 / t2: n_chunks x
+ * row_stride floats, entries [0, n] of each row valid (row_stride >= 4097). */
+int smhip_events_raw(smhip_ctx *ctx, uint32_t n_chunks, uint32_t feat_stride, uint32_t row_stride,
+                     uint32_t *n_peaks, uint32_t *peaks, uint32_t *ev_start, uint32_t *ev_length,
+                     float *ev_mean, float *ev_stdv, float *ps, float *pss, float *t1, float *t2);
 /* nanoflann radiusSearch, nanoflann.hpp:1278-1301, for n_queries windows of `dim` floats.
  * Hits of query i in traversal order at point_idx/dist[i*cap ..], counts[i] = total hits
  * (may exceed cap).  point_idx = original point-cloud index (the pair.first nanoflann

@@ -16,7 +16,7 @@ HIP_SYMBOLS = [
     "smhip_default_params", "smhip_init", "smhip_destroy", "smhip_last_error", "smhip_stream",
     "smhip_index_upload", "smhip_index_export", "smhip_index_attach", "smhip_batch_upload",
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
-    "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events",
+    "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
 ]
 HOST_SYMBOLS = [
@@ -192,6 +192,7 @@ def hip_lib():
         L.smhip_timing_reset.argtypes = [vp]
         L.smhip_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
         L.smhip_events.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, vp, vp, vp, vp, vp]
+        L.smhip_events_raw.argtypes = [vp, u32, u32, u32] + [vp] * 10
         L.smhip_seed_lookup.argtypes = [vp, C.POINTER(Params), vp, u32, u32, vp, vp, vp, vp, vp]
         L.smhip_sdtw_banded.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp]
         _hip = L

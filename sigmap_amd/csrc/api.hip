@@ -8,9 +8,31 @@
 
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 
 using namespace smhip;
+
+namespace smhip {
+const EnvKnobs &Knobs() {
+  static EnvKnobs k;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto geti = [](const char *name, int dflt) {
+      const char *e = getenv(name);
+      return e ? atoi(e) : dflt;
+    };
+    k.lane_blocks_per_cu = geti("SMHIP_LANE_BLOCKS_PER_CU", 0);
+    k.xcd_ranges = geti("SMHIP_XCD_RANGES", 1);
+    k.scan_threshold = geti("SMHIP_SCAN_THRESHOLD", 0);
+    k.classes = geti("SMHIP_CLASSES", 0);
+    k.bucket_bits = geti("SMHIP_BUCKET_BITS", 0);
+    k.sdtw_ring = getenv("SMHIP_SDTW_RING") ? 1 : 0;
+  });
+  return k;
+}
+}  // namespace smhip
 
 namespace {
 const char *kTimerNames[] = {"events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw"};
@@ -136,6 +158,8 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SMHIP_EHIP;
   if (device_ordinal < 0 || device_ordinal >= n) return SMHIP_EINVAL;
   if (hipSetDevice(device_ordinal) != hipSuccess) return SMHIP_EHIP;
+  // dynamic-LDS opt-ins are per device: set them for this context's device (idempotent)
+  if (InitSortAttributes() != hipSuccess || InitSdtwAttributes() != hipSuccess) return SMHIP_EHIP;
   smhip_ctx *ctx = new smhip_ctx;
   ctx->device = device_ordinal;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -412,7 +436,6 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->chunk_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
   HIPCHK(ctx->anchor_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t)));
   HIPCHK(ctx->n_groups.Reserve((uint64_t)R * sizeof(uint32_t)));
-  HIPCHK(ctx->chain_tmp.Reserve((uint64_t)R * kChainCap * sizeof(ChainTmp)));
   HIPCHK(ctx->out_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
   HIPCHK(ctx->counters.Reserve(32 * sizeof(uint32_t)));
   smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
@@ -438,7 +461,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
   // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
   // the size is remembered for the following batches).
-  const char *pool_env = getenv("SMHIP_POOL_MIN");  // test knob: makes the first size too small
+  // (SMHIP_POOL_MIN: test knob that makes the first size too small; read per call, nothing cached)
+  const char *pool_env = getenv("SMHIP_POOL_MIN");
   const uint64_t pool_first = pool_env ? (uint64_t)strtoull(pool_env, nullptr, 10) : nq_cap * 64 + (1u << 22);
   uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
@@ -515,7 +539,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   ca.score = ctx->score.as<float>();
   ca.pred = ctx->pred.as<uint32_t>();
   ca.used = ctx->used.as<uint8_t>();
-  ca.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
+  ca.chain_tmp = ca.chain_sorted = nullptr;  // sized and set by LaunchChain
+  ca.chain_off = nullptr;
   ca.scratch = ctx->keys.as<uint64_t>();
   ca.pending = ctx->a_tpos.as<uint32_t>();  // the unsorted SoA is dead after the sort
   ca.lists = ctx->a_qpos.as<uint32_t>();
@@ -524,7 +549,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();
   {
     ScopedTimer t(ctx, T_CHAIN);
-    HIPCHK(LaunchChain(ctx, *p, ca, R, NA));
+    HIPCHK(LaunchChain(ctx, *p, ca, R, NA, n_refs));
   }
   hipLaunchKernelGGL(OrStatusKernel, dim3(64), dim3(256), 0, ctx->stream, results, R, ctx->counters.as<uint32_t>());
   HIPCHK(hipGetLastError());
@@ -726,6 +751,57 @@ int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,
     if (status) status[c] = res[c].status;
   }
   ctx->run_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_events_raw(smhip_ctx *ctx, uint32_t n_chunks, uint32_t feat_stride, uint32_t row_stride, uint32_t *n_peaks,
+                     uint32_t *peaks, uint32_t *ev_start, uint32_t *ev_length, float *ev_mean, float *ev_stdv,
+                     float *ps, float *pss, float *t1, float *t2) {
+  if (!ctx) return SMHIP_EINVAL;
+  const auto &r = ctx->ev_rows;
+  if (r.n_chunks == 0 || !ctx->batch_ready) return Fail(ctx, SMHIP_ESTATE, "smhip_events_raw before smhip_events / smhip_map_run");
+  if (n_chunks != r.n_chunks || feat_stride != r.feat_stride)
+    return Fail(ctx, SMHIP_EINVAL, "n_chunks / feat_stride differ from the last event-detection launch");
+  if ((ps || pss || t1 || t2) && row_stride < (uint32_t)kMaxSamples + 1)
+    return Fail(ctx, SMHIP_EINVAL, "row_stride must be >= 4097");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t evn = (uint64_t)n_chunks * feat_stride;
+  DevBuf d_start, d_len;
+  std::vector<uint16_t> h_peaks;
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t x) {
+    if (e == hipSuccess) e = x;
+  };
+  if (ev_start || ev_length) {
+    step(d_start.Reserve(evn * 4));
+    step(d_len.Reserve(evn * 4));
+    if (e == hipSuccess) step(hipMemsetAsync(d_start.p, 0, evn * 4, ctx->stream));
+    if (e == hipSuccess) step(hipMemsetAsync(d_len.p, 0, evn * 4, ctx->stream));
+    if (e == hipSuccess) step(LaunchEventSpans(ctx, ctx->sample_off.as<uint32_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>()));
+    if (e == hipSuccess && ev_start) step(hipMemcpyAsync(ev_start, d_start.p, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (e == hipSuccess && ev_length) step(hipMemcpyAsync(ev_length, d_len.p, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (e == hipSuccess && n_peaks) step(hipMemcpyAsync(n_peaks, r.n_peaks, (uint64_t)n_chunks * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess && ev_mean) step(hipMemcpyAsync(ev_mean, r.ev_mean, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess && ev_stdv) step(hipMemcpyAsync(ev_stdv, r.ev_stdv, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess && peaks) {
+    h_peaks.resize((size_t)n_chunks * r.row_stride);
+    step(hipMemcpyAsync(h_peaks.data(), r.peaks, h_peaks.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  const float *rows[4] = {r.ps, r.pss, r.t1, r.t2};
+  float *outs[4] = {ps, pss, t1, t2};
+  for (int k = 0; k < 4; ++k)
+    if (e == hipSuccess && outs[k])
+      step(hipMemcpy2DAsync(outs[k], (size_t)row_stride * 4, rows[k], (size_t)r.row_stride * 4,
+                            (size_t)(kMaxSamples + 1) * 4, n_chunks, hipMemcpyDeviceToHost, ctx->stream));
+  if (e == hipSuccess) step(hipStreamSynchronize(ctx->stream));
+  d_start.Free();
+  d_len.Free();
+  if (e != hipSuccess) return HipFail(ctx, e, "smhip_events_raw");
+  if (peaks)  // rows of u16 sample indices -> n_chunks x feat_stride u32 (a chunk has at most feat_stride peaks)
+    for (uint32_t c = 0; c < n_chunks; ++c)
+      for (uint32_t k = 0; k < feat_stride; ++k)
+        peaks[(size_t)c * feat_stride + k] = k < r.row_stride ? h_peaks[(size_t)c * r.row_stride + k] : 0;
   return SMHIP_OK;
 }
 

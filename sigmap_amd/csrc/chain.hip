@@ -561,6 +561,10 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
   const uint32_t *pending = a.pending + base;
   const uint32_t npend = n_pending[c];
   const bool pending_only = min_chaining_score > (float)dim;
+  // the chunk's candidate chains: a slice of 3 per bucket (spatial_index.cc:555-568 keeps at most
+  // num_best_chains <= 3 per (strand, contig) bucket), so no candidate is ever dropped
+  ChainTmp *chain_out = a.chain_tmp + 3 * (size_t)a.chain_off[c];
+  const uint32_t chain_cap = 3 * G;
   // max_chaining_score on entry to each bucket = max over all earlier buckets (order ref0+,
   // ref0-, ref1+, ...; initial value 0): exclusive prefix max by wave shuffles, 64 at a time.
   {
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
             float adjusted = score[end_abs];
             if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
             const uint32_t slot = atomicAdd(&s_nchains, 1u);
-            if (slot < (uint32_t)kChainCap) {
+            if (slot < chain_cap) {  // (always: at most 3 candidates per bucket)
               ChainTmp ch;
               ch.score = adjusted;
               ch.ref = ref;
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
               ch.direction = direction;
               ch.end_anchor = end_abs;
               ch.list_off = list_off;
-              a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
+              chain_out[slot] = ch;
             }
           }
         }
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
             if (stop_at_used) adjusted -= score[pc];  // pc == pred[cur]
             if (lane == 0) {
               const uint32_t slot = atomicAdd(&s_nchains, 1u);
-              if (slot < (uint32_t)kChainCap) {
+              if (slot < chain_cap) {  // (always: at most 3 candidates per bucket)
                 ChainTmp ch;
                 ch.score = adjusted;
                 ch.ref = ref;
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
                 ch.direction = direction;
                 ch.end_anchor = end_abs;
                 ch.list_off = list_off;
-                a.chain_tmp[(size_t)c * kChainCap + slot] = ch;
+                chain_out[slot] = ch;
               }
             }
           }
@@ -854,38 +858,36 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
 // filtered by the whole wave; all lanes gather the chains' anchors through the recorded index lists;
 // chain 0's statistics are added up in the reference's order (f32 sums are order-sensitive).
 
-__global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
-                                                          const uint32_t *__restrict__ n_chains_in) {
-  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+// kBig = false: up to kChainCap candidates staged, ranked and filtered in LDS (every chunk of a
+// reference with up to 21 contigs, and almost every chunk otherwise).  kBig = true: any number of
+// candidates (3 per bucket, 2 buckets per contig), the same steps on the chunk's global slices.
+template <bool kBig>
+__device__ __forceinline__ void FinalizeBody(const ChainArgs &a, uint32_t c, uint32_t lane, uint32_t nch,
+                                             ChainTmp *ch /* LDS[kChainCap], or the global sorted slice */,
+                                             const ChainTmp *gch) {
   const uint64_t base = a.anchor_off[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
   const float *dist = a.s_dist + base;
   const uint32_t *lists = a.lists + base;
   smhip_chunk_result &res = a.results[c];
-  __shared__ ChainTmp ch[kChainCap];  // the chunk's candidate chains, staged for lane 0's ordering
-  {
-    const ChainTmp *gch = a.chain_tmp + (size_t)c * kChainCap;
-    const uint32_t nch0 = min(n_chains_in[c], (uint32_t)kChainCap);
-    for (uint32_t i = lane; i < nch0; i += 64) ch[i] = gch[i];
-  }
-  __syncthreads();
   // Descending by operator> (spatial_index.cc:569-570), keeping the order of equal chains: every
-  // lane ranks its own (up to two) chains against all the others (LDS broadcasts) -- a one-lane
-  // insertion sort of a few dozen 32-byte records took 100 000+ cycles per chunk.
-  {
+  // lane ranks its own chains against all the others (broadcast reads) -- a one-lane insertion sort
+  // of a few dozen 32-byte records took 100 000+ cycles per chunk.
+  if (!kBig) {
+    for (uint32_t i = lane; i < nch; i += 64) ch[i] = gch[i];
+    __syncthreads();
     static_assert(kChainCap <= 128, "two chains per lane");
-    const uint32_t nchp = min(n_chains_in[c], (uint32_t)kChainCap);
     ChainTmp mine[2] = {};
     uint32_t rank[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      if (lane + 64u * h < nchp) mine[h] = ch[lane + 64u * h];
-    for (uint32_t j = 0; j < nchp; ++j) {
+      if (lane + 64u * h < nch) mine[h] = ch[lane + 64u * h];
+    for (uint32_t j = 0; j < nch; ++j) {
       const ChainTmp o = ch[j];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const uint32_t self = lane + 64u * h;
-        if (self < nchp && j != self) {
+        if (self < nch && j != self) {
           if (ChainGreater(o, mine[h])) ++rank[h];
           else if (!ChainGreater(mine[h], o) && j < self) ++rank[h];
         }
@@ -894,53 +896,83 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      if (lane + 64u * h < nchp) ch[rank[h]] = mine[h];
+      if (lane + 64u * h < nch) ch[rank[h]] = mine[h];
+    __syncthreads();
+  } else {
+    for (uint32_t self = lane; self < nch; self += 64) {
+      const ChainTmp mine = gch[self];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nch; ++j) {
+        if (j == self) continue;
+        const ChainTmp o = gch[j];
+        if (ChainGreater(o, mine)) ++rank;
+        else if (!ChainGreater(mine, o) && j < self) ++rank;
+      }
+      ch[rank] = mine;
+    }
+    __threadfence_block();
     __syncthreads();
   }
   // spatial_index.cc:222-253: greedy, in rank order; primaries are compacted to the front of ch[].
   // The candidates are taken one after the other, but each is tested against all kept primaries at
-  // once: lane l holds primaries l and l + 64 in registers.  (With one lane doing both loops a chunk
-  // whose candidates all score alike cost 16 000 dependent LDS round trips, and the launch waited.)
-  uint32_t nch = n_chains_in[c];
-  if (nch > (uint32_t)kChainCap) {
-    if (lane == 0) res.status |= SMHIP_ST_CHAIN_CAP;
-    nch = kChainCap;
-  }
+  // once.  (With one lane doing both loops a chunk whose candidates all score alike cost 16 000
+  // dependent LDS round trips, and the launch waited.)
   uint32_t np = 0;
   if (nch > 0) {
-    uint32_t p_ref[2] = {0, 0}, p_start[2] = {0, 0}, p_end[2] = {0, 0};
-    float last_score;
-    {
-      const ChainTmp x = ch[0];
-      if (lane == 0) {
-        p_ref[0] = x.ref;
-        p_start[0] = x.start;
-        p_end[0] = x.end;
-      }
-      last_score = x.score;
-      np = 1;
-    }
-    for (uint32_t ci = 1; ci < nch; ++ci) {
-      const ChainTmp x = ch[ci];
-      if (x.score < last_score / 3) break;
-      bool overlaps = false;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (lane + 64u * h < np && x.ref == p_ref[h] && !(max(x.start, p_start[h]) > min(x.end, p_end[h])))
-          overlaps = true;
-      if (__ballot(overlaps) == 0) {
-        if (lane == (np & 63u)) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if ((np >> 6) == (uint32_t)h) {
-              p_ref[h] = x.ref;
-              p_start[h] = x.start;
-              p_end[h] = x.end;
-            }
+    if (!kBig) {  // lane l holds primaries l and l + 64 in registers
+      uint32_t p_ref[2] = {0, 0}, p_start[2] = {0, 0}, p_end[2] = {0, 0};
+      float last_score;
+      {
+        const ChainTmp x = ch[0];
+        if (lane == 0) {
+          p_ref[0] = x.ref;
+          p_start[0] = x.start;
+          p_end[0] = x.end;
         }
-        if (lane == 0) ch[np] = x;  // np <= ci: nothing unread is overwritten
         last_score = x.score;
-        ++np;
+        np = 1;
+      }
+      for (uint32_t ci = 1; ci < nch; ++ci) {
+        const ChainTmp x = ch[ci];
+        if (x.score < last_score / 3) break;
+        bool overlaps = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (lane + 64u * h < np && x.ref == p_ref[h] && !(max(x.start, p_start[h]) > min(x.end, p_end[h])))
+            overlaps = true;
+        if (__ballot(overlaps) == 0) {
+          if (lane == (np & 63u)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              if ((np >> 6) == (uint32_t)h) {
+                p_ref[h] = x.ref;
+                p_start[h] = x.start;
+                p_end[h] = x.end;
+              }
+          }
+          if (lane == 0) ch[np] = x;  // np <= ci: nothing unread is overwritten
+          last_score = x.score;
+          ++np;
+        }
+      }
+    } else {  // the kept primaries are read back from the front of the slice, 64 at a time
+      float last_score = ch[0].score;
+      np = 1;
+      for (uint32_t ci = 1; ci < nch; ++ci) {
+        const ChainTmp x = ch[ci];
+        if (x.score < last_score / 3) break;
+        bool overlaps = false;
+        for (uint32_t pi = lane; pi < np; pi += 64) {
+          const ChainTmp pk = ch[pi];
+          if (x.ref == pk.ref && !(max(x.start, pk.start) > min(x.end, pk.end))) overlaps = true;
+        }
+        if (__ballot(overlaps) == 0) {
+          if (lane == 0) ch[np] = x;  // np <= ci: nothing unread is overwritten
+          __threadfence_block();
+          __builtin_amdgcn_wave_barrier();
+          last_score = x.score;
+          ++np;
+        }
       }
     }
   }
@@ -1048,11 +1080,28 @@ __global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t 
   }
   if (lane == 0) a.out_anchor_cnt[c] = w;
 }
+
+__global__ __launch_bounds__(64) void ChainFinalizeKernel(ChainArgs a, uint32_t n_chunks,
+                                                          const uint32_t *__restrict__ n_chains_in) {
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  __shared__ ChainTmp ch[kChainCap];  // the chunk's candidate chains
+  const size_t slice = 3 * (size_t)a.chain_off[c];
+  const ChainTmp *gch = a.chain_tmp + slice;
+  uint32_t nch = n_chains_in[c];
+  const uint32_t cap = 3 * a.n_groups[c];
+  if (nch > cap) {  // cannot happen (3 candidates per bucket); reported, never silent
+    if (lane == 0) a.results[c].status |= SMHIP_ST_CHAIN_CAP;
+    nch = cap;
+  }
+  if (nch <= (uint32_t)kChainCap) FinalizeBody<false>(a, c, lane, nch, ch, gch);
+  else FinalizeBody<true>(a, c, lane, nch, a.chain_sorted + slice, gch);
+}
 }  // namespace
 
-hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
-                       uint64_t n_anchors_total) {
+hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a_in, uint32_t n_chunks,
+                       uint64_t n_anchors_total, uint32_t n_refs) {
   if (n_chunks == 0) return hipSuccess;
+  ChainArgs a = a_in;
   // every bucket holds at least one anchor, so the anchor total bounds the bucket total; buckets
   // sent to the wave-parallel kernel hold > kBigPendingMin anchors each
   const uint64_t max_big = n_anchors_total / kBigPendingMin + 1;
@@ -1063,6 +1112,13 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   uint32_t *big_count = n_pending + n_chunks, *big_list = big_count + 1;
   if ((e = hipMemsetAsync(big_count, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   if ((e = LaunchScanU32(ctx, a.n_groups, n_chunks, goff)) != hipSuccess) return e;
+  // candidate chains: 3 per bucket, a bucket holds >= 1 anchor and there are <= 2 per contig; second
+  // half = the ranked copy of the chunks with more than kChainCap candidates
+  const uint64_t max_cand = 3 * std::min<uint64_t>((uint64_t)n_chunks * 2 * n_refs, std::max<uint64_t>(n_anchors_total, 1));
+  if ((e = ctx->chain_tmp.Reserve(2 * max_cand * sizeof(ChainTmp))) != hipSuccess) return e;
+  a.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
+  a.chain_sorted = a.chain_tmp + max_cand;
+  a.chain_off = goff;
   const uint64_t max_groups = n_anchors_total;
   const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((max_groups + 63) / 64, 16384);
   hipLaunchKernelGGL(ChainClassifyKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.search_radius, kMaxDim,

@@ -19,7 +19,7 @@ constexpr int kMaxSamples = 4096;    // samples per chunk held in LDS (reference
 constexpr int kFeatStride = 2736;    // >= 2/3 * kMaxSamples + 2: upper bound on events per chunk
 constexpr int kStackDepth = 64;      // pending "other child" entries per tree walk
 constexpr int kOvfLevels = 16;       // overflow segments per query (sizes fast_cap << level)
-constexpr int kChainCap = 128;       // candidate chains per chunk before the primary filter
+constexpr int kChainCap = 128;       // candidate chains per chunk that ChainFinalize ranks in LDS (more: global path)
 
 struct Hit {  // 16 B: one radius-search result
   uint64_t position;  // Point.position of the matched reference window
@@ -95,7 +95,14 @@ struct smhip_ctx {
   uint64_t n_samples = 0, n_carried = 0;
   bool batch_ready = false, run_done = false;
   smhip::DevBuf samples, sample_off, qstart, carried, carried_off;
-  // per-chunk intermediates
+  // per-chunk intermediates.  ev_rows: where the last LaunchEvents put its scratch rows inside
+  // ev_scratch (smhip_events_raw reads them back for the per-stage tests)
+  struct EvRows {
+    const float *ps = nullptr, *pss = nullptr, *t1 = nullptr, *t2 = nullptr, *ev_mean = nullptr, *ev_stdv = nullptr;
+    const uint32_t *n_peaks = nullptr;
+    const uint16_t *peaks = nullptr;
+    uint32_t n_chunks = 0, feat_stride = 0, row_stride = 0;
+  } ev_rows;
   smhip::DevBuf ev_scratch, feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
   // per-query
   smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
@@ -119,6 +126,20 @@ struct smhip_ctx {
 };
 
 namespace smhip {
+// Experiment knobs from the environment (speed only, never results), read once per process under
+// std::call_once (api.hip) -- contexts are driven by concurrent host threads.
+struct EnvKnobs {
+  int lane_blocks_per_cu = 0;  // SMHIP_LANE_BLOCKS_PER_CU
+  int xcd_ranges = 1;          // SMHIP_XCD_RANGES
+  int scan_threshold = 0;      // SMHIP_SCAN_THRESHOLD
+  int classes = 0;             // SMHIP_CLASSES
+  int bucket_bits = 0;         // SMHIP_BUCKET_BITS
+  int sdtw_ring = 0;           // SMHIP_SDTW_RING
+};
+const EnvKnobs &Knobs();
+// Per-device kernel attributes (dynamic LDS opt-ins): called by smhip_init for the context's device.
+hipError_t InitSortAttributes();
+hipError_t InitSdtwAttributes();
 // Launchers implemented in the .hip files.  All enqueue on ctx->stream and return the
 // launch status.
 hipError_t LaunchLeafGather(smhip_ctx *ctx, int dim, const float *values, const uint64_t *positions,
@@ -132,6 +153,8 @@ hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
                         uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);
+// event spans (start, length) of the last LaunchEvents' raw events, event.h:200-224
+hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *off, uint32_t *ev_start, uint32_t *ev_length);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
@@ -171,7 +194,9 @@ struct ChainArgs {
   float *score;
   uint32_t *pred;
   uint8_t *used;
-  ChainTmp *chain_tmp;
+  ChainTmp *chain_tmp;           // candidate chains, chunk c at 3 * chain_off[c] (3 per bucket); set by LaunchChain
+  ChainTmp *chain_sorted;        // same layout: ranked copy for chunks with > kChainCap candidates
+  const uint32_t *chain_off;     // buckets before chunk c
   uint64_t *scratch;  // the sort's key buffer (2 keys per anchor), dead by now
   uint32_t *pending;  // per chunk: anchors that need the sequential DP, in index order (dead a_tpos)
   uint32_t *lists;    // per chunk: anchor index lists of the traced chains (dead a_qpos)
@@ -180,7 +205,7 @@ struct ChainArgs {
   uint32_t *out_anchor_cnt;
 };
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
-                       uint64_t n_anchors_total);
+                       uint64_t n_anchors_total, uint32_t n_refs);
 hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint32_t *off, uint32_t n_chunks,
                              const double *h, uint32_t L, float *cwt_rows, uint32_t feat_stride, float *feat,
                              uint32_t *pos, uint32_t *n_feat);

@@ -325,6 +325,25 @@ __global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restric
   }
 }
 
+// The spans EventMeanKernel averages over, written out for the per-stage tests (event.h:200-224:
+// Event.start, Event.length).
+__global__ __launch_bounds__(256) void EventSpanKernel(const uint32_t *__restrict__ off,
+                                                       const uint16_t *__restrict__ peaks_all,
+                                                       const uint32_t *__restrict__ n_peaks, uint32_t feat_stride,
+                                                       uint32_t *__restrict__ ev_start, uint32_t *__restrict__ ev_length) {
+  const uint32_t c = blockIdx.x;
+  uint32_t n = off[c + 1] - off[c];
+  if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
+  const uint32_t E = n_peaks[c] >= 2 ? n_peaks[c] : 0;
+  const uint16_t *peaks = peaks_all + (size_t)c * kRowStride;
+  for (uint32_t e = threadIdx.x; e < E && e < feat_stride; e += 256) {
+    const uint32_t start = e > 0 ? peaks[e - 1] : 0;
+    const uint32_t end = e < E - 1 ? peaks[e] : n;
+    ev_start[(size_t)c * feat_stride + e] = start;
+    ev_length[(size_t)c * feat_stride + e] = end - start;
+  }
+}
+
 // E5 -- sigmap.cc:1131-1155 (z-score: sequential f64 sums) + sigmap.cc:1073-1079 (keep i iff
 // i == 0 or |z[i] - last kept| > 0.1, float abs against the double constant).  Also derives the
 // number of seeds of the chunk and initialises its result record.
@@ -477,6 +496,8 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
   float *ev_mean = t2 + row, *ev_stdv = ev_mean + evn;
   uint32_t *n_peaks = reinterpret_cast<uint32_t *>(ev_stdv + evn);
   uint16_t *peaks = reinterpret_cast<uint16_t *>(n_peaks + n_chunks), *seg_peaks = peaks + row;
+  ctx->ev_rows = smhip_ctx::EvRows{ps, pss, t1, t2, ev_mean, ev_stdv, n_peaks, peaks, n_chunks, feat_stride,
+                                   (uint32_t)kRowStride};
   const uint32_t lane_blocks = (n_chunks + 63) / 64;
   hipLaunchKernelGGL(PrefixKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, samples, off, n_chunks, ps, pss);
   hipLaunchKernelGGL(TStatKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, t1, t2,
@@ -488,6 +509,14 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
                      ev_mean, ev_stdv, feat_stride);
   hipLaunchKernelGGL(FeatureKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, n_chunks, n_peaks, ev_mean, ev_stdv,
                      feat_stride, feat, stdv, results, nq, p.compress_delta, p.min_num_events, kMaxDim, p.step_size);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *off, uint32_t *ev_start, uint32_t *ev_length) {
+  const auto &r = ctx->ev_rows;
+  if (r.n_chunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(EventSpanKernel, dim3(r.n_chunks), dim3(256), 0, ctx->stream, off, r.peaks, r.n_peaks,
+                     r.feat_stride, ev_start, ev_length);
   return hipGetLastError();
 }
 

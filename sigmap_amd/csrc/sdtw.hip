@@ -460,20 +460,21 @@ __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_
 }
 }  // namespace
 
+hipError_t InitSdtwAttributes() {  // per device (smhip_init)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwKernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
                       const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n, float *dist,
                       int64_t *end, uint32_t max_t) {
   if (n == 0) return hipSuccess;
   if (max_t > (uint32_t)kSdtwMaxT) max_t = kSdtwMaxT;  // longer problems report FLT_MAX / -1
   const size_t lds = 3 * (size_t)(max_t + 1) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwKernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
   hipLaunchKernelGGL(SdtwKernel, dim3(n), dim3(64), lds, ctx->stream, target, t_off, query, q_off, lo, hi,
                      dist, end);
   return hipGetLastError();
@@ -494,16 +495,7 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
   const size_t lds_fast = (3 * (size_t)ring + fast_rows + 2) * sizeof(float);
   const size_t lds_full = (3 * (size_t)ring + kSdtwMaxT + 2) * sizeof(float);
   if (lds_full > 160 * 1024) return hipErrorInvalidValue;  // band beyond what the LDS rings hold
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  static int use_ring = -1;
-  if (use_ring < 0) use_ring = getenv("SMHIP_SDTW_RING") ? 1 : 0;  // (experiments: skip the register kernel)
-  if (use_ring) {
+  if (Knobs().sdtw_ring) {  // (experiments: skip the register kernel)
     hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
                        qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0, ring);
   } else {

@@ -705,14 +705,8 @@ constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a s
 
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qrec, const uint32_t *n_queries_dev,
                       uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride) {
-  static int env_blocks = -1, xcd_ranges = 1, env_thr = 0;
-  if (env_blocks < 0) {
-    const char *e1 = getenv("SMHIP_LANE_BLOCKS_PER_CU"), *e2 = getenv("SMHIP_XCD_RANGES"),
-               *e3 = getenv("SMHIP_SCAN_THRESHOLD");
-    env_blocks = e1 ? atoi(e1) : 0;
-    if (e2) xcd_ranges = atoi(e2);
-    if (e3) env_thr = atoi(e3);
-  }
+  const int env_blocks = Knobs().lane_blocks_per_cu, xcd_ranges = Knobs().xcd_ranges,
+            env_thr = Knobs().scan_threshold;
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
@@ -775,12 +769,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
                            const uint32_t **range_end_out, uint32_t *range_stride_out) {
   uint32_t bits = 1;
   while ((1ull << bits) < ctx->index.n_leaves) ++bits;
-  static int env_cls = -1, env_bits = 0;
-  if (env_cls < 0) {
-    const char *e0 = getenv("SMHIP_CLASSES"), *e1 = getenv("SMHIP_BUCKET_BITS");
-    env_cls = e0 ? atoi(e0) : 0;
-    if (e1) env_bits = atoi(e1);
-  }
+  const int env_cls = Knobs().classes, env_bits = Knobs().bucket_bits;
   const uint32_t classes = (env_cls > 0 && env_cls <= (int)kCostClasses) ? (uint32_t)env_cls : kCostClasses;
   const uint32_t want_bits = env_bits > 0 ? (uint32_t)env_bits : kLeafBucketBits;
   const uint32_t shift = bits > want_bits ? bits - want_bits : 0;

@@ -590,19 +590,17 @@ hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32
   return hipGetLastError();
 }
 
+hipError_t InitSortAttributes() {  // per device (smhip_init): the sort keeps up to kLdsKeys keys in LDS
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(SortKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)((size_t)kLdsKeys * sizeof(uint64_t)));
+}
+
 hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks) {
   uint32_t gbits = 1;
   while ((1ull << gbits) < 2ull * a.n_refs) ++gbits;
   if (gbits > 24) return hipErrorInvalidValue;
   const uint32_t ibits = 64 - 32 - gbits;
   const size_t lds = (size_t)kLdsKeys * sizeof(uint64_t);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortKernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
   hipLaunchKernelGGL(SortKernel, dim3(n_chunks), dim3(kSortThreads), lds, ctx->stream, a, gbits, ibits);
   return hipGetLastError();
 }

@@ -1,3 +1,14 @@
+// kdtree.cc -- parallel construction of the reference's k-d tree (divideTree / middleSplit_ /
+// planeSplit), producing the SAME tree as nanoflann 1.3.2 does: node boxes, split values, the
+// permutation `vind` and therefore the bytes of the .si file are the parity surface, and they depend
+// on the exact order of the swaps of nanoflann's Hoare-style partition.  PlaneSplit and MiddleSplit
+// below therefore follow nanoflann's planeSplit / middleSplit_ step for step
+// (reference: src/nanoflann.hpp:858-1004).
+//
+// nanoflann is Copyright 2008-2009 Marius Muja, 2008-2009 David G. Lowe, 2011-2016 Jose Luis Blanco,
+// distributed under the BSD license (the licence text is in the header of nanoflann.hpp); the two
+// routines named above are restatements of that algorithm, everything else here (the task-parallel
+// build, the flat pre-order node array) is this project's own.
 #include "kdtree.h"
 
 #include <omp.h>

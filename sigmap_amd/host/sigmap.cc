@@ -7,8 +7,9 @@
 // -i is Sigmap::ConstructIndex (sigmap.cc:999-1046).  -m is Sigmap::StreamingMap
 // (sigmap.cc:549-880) with the per-read taskloop turned into chunk rounds: round c sends chunk c
 // of every still-active read to the GPU in one batch (include/sigmap_hip.h), then the unchanged
-// early-stop / output rules run on the host (mapping_logic.cc).  Reads come from this build's
-// .sgr container (signal_batch.h); FAST5/BLOW5 ingestion is not built.
+// early-stop / output rules run on the host (mapping_logic.cc).  Reads come from FAST5 files (single-
+// and multi-read, through the HDF5 C API, fast5_reader.cc) or from this build's .sgr container
+// (signal_batch.h); BLOW5 needs slow5lib, which is not vendored, and is rejected loudly.
 #include <omp.h>
 
 #include <algorithm>
@@ -332,6 +333,14 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int dimension = a.Has("dimension") ? std::stoi(a.Str("dimension")) : 6;
     const int max_leaf = a.Has("max-leaf") ? std::stoi(a.Str("max-leaf")) : 20;
     std::cerr << "Dimension: " << dimension << ", max leaf: " << max_leaf << "\n";
+    // The device kernels are specialised (include/sigmap_hip.h, smhip_index_upload): refuse here,
+    // not after an hour of index construction, what `-m` could not load.
+    if (dimension != 6)
+      ExitWithMessage("This build maps with index dimension 6 only (-d " + std::to_string(dimension) +
+                      " would build an index that -m cannot use).");
+    if (max_leaf < 1 || max_leaf > 21)
+      ExitWithMessage("This build maps with at most 21 points per leaf (-l " + std::to_string(max_leaf) +
+                      " would build an index that -m cannot use).");
     const std::string ref = need("ref", "No reference file specified!");
     const std::string pm = need("pore-model", "No pore model file specified!");
     const std::string out = need("output", "No output file specified!");

@@ -221,6 +221,22 @@ class DeviceMapper:
                     "smhip_events")
         return feat, stdv, nf, ne, st
 
+    def events_raw(self, n_chunks, feat_stride=2736, row_stride=4097):
+        """Stage outputs of the last events() / run(): dict of n_peaks, peaks, start, length, mean, stdv
+        (n_chunks x feat_stride) and ps, pss, t1, t2 rows (n_chunks x row_stride)."""
+        o = {"n_peaks": np.zeros(n_chunks, np.uint32)}
+        for k in ("peaks", "start", "length"):
+            o[k] = np.zeros((n_chunks, feat_stride), np.uint32)
+        for k in ("mean", "stdv"):
+            o[k] = np.zeros((n_chunks, feat_stride), np.float32)
+        for k in ("ps", "pss", "t1", "t2"):
+            o[k] = np.zeros((n_chunks, row_stride), np.float32)
+        self._check(self.L.smhip_events_raw(self._h, n_chunks, feat_stride, row_stride, ptr(o["n_peaks"]),
+                                            ptr(o["peaks"]), ptr(o["start"]), ptr(o["length"]), ptr(o["mean"]),
+                                            ptr(o["stdv"]), ptr(o["ps"]), ptr(o["pss"]), ptr(o["t1"]), ptr(o["t2"])),
+                    "smhip_events_raw")
+        return o
+
     def seed_lookup(self, queries, cap=512):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         n = q.shape[0]

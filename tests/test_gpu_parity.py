@@ -38,8 +38,21 @@ def test_events_kernel_matches_reference_golden(device):
     pa = [g[f"x{r}"] for r in range(6)]  # includes a ragged 1777-sample chunk
     samples, offsets = _batch(pa)
     feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    raw = device.events_raw(6)
     for r in range(6):
-        assert ne[r] == len(g[f"mean{r}"])
+        n, E = len(pa[r]), len(g[f"mean{r}"])
+        assert ne[r] == E
+        # every stage of DetectEvents, bit for bit against the REAL event.h (tests/golden/make_golden.py)
+        for k in ("ps", "pss"):
+            assert np.array_equal(bits(raw[k][r, :n + 1]), bits(g[f"{k}{r}"])), (k, r)
+        assert np.array_equal(bits(raw["t1"][r, :n + 1]), bits(g[f"t1_{r}"]))
+        assert np.array_equal(bits(raw["t2"][r, :n + 1]), bits(g[f"t2_{r}"]))
+        assert raw["n_peaks"][r] == len(g[f"peaks{r}"])
+        assert np.array_equal(raw["peaks"][r, :raw["n_peaks"][r]], g[f"peaks{r}"].astype(np.uint32))
+        assert np.array_equal(raw["start"][r, :E], g[f"start{r}"].astype(np.uint32))
+        assert np.array_equal(raw["length"][r, :E], g[f"length{r}"].astype(np.uint32))
+        assert np.array_equal(bits(raw["mean"][r, :E]), bits(g[f"mean{r}"]))
+        assert np.array_equal(bits(raw["stdv"][r, :E]), bits(g[f"stdv{r}"]))
         # features are the z-scored, compressed event means: recompute from the golden events
         f, s = po.generate_events(pa[r])
         assert np.array_equal(bits(feat[r, :nf[r]]), bits(f))
@@ -221,6 +234,39 @@ def test_pipeline_degenerate_signals_match_oracle(device, small_world, oracle_tr
         m = po.map_read(oracle_tree, ix.positions, x, 3, ref_lens)
         assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
         assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+
+
+def test_many_contigs_more_than_128_candidate_chains():
+    """The reference keeps up to 3 chains per (strand, contig) bucket with no bound on their number
+    (spatial_index.cc:555-568).  140 contigs that share a 6 kb segment: a read from the segment chains
+    in every contig, so a chunk has > 128 candidate (and primary) chains -- beyond what the finalize
+    kernel ranks in LDS.  Records and PAF rows must still be the oracle's."""
+    NC = 140
+    shared = synth.make_genome(101, [6000])[0]
+    uniq = synth.make_genome(102, [2000] * (2 * NC))
+    genome = [uniq[2 * i] + shared + uniq[2 * i + 1] for i in range(NC)]
+    lm = synth.make_pore_model()
+    raw, _ = synth.simulate_reads([shared], lm, 12, seed=5)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    ix = pipeline.HostIndex.build(genome, lm, threads=4)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    tree = po.OracleTree(ix.values.copy())
+    ref_lens = np.array([len(g) for g in genome], np.uint32)
+    names = ["contig%d" % i for i in range(NC)]
+    samples, offsets = _batch(pa)
+    res = dev.map_chunks(samples, offsets, n_refs=NC)
+    lines = _paf_lines(res, pa, names, ref_lens)
+    most = 0
+    for i, x in enumerate(pa):
+        m = po.map_read(tree, ix.positions, x, NC, ref_lens)
+        most = max(most, m.n_chains)
+        assert res[i]["status"] == 0
+        assert res[i]["n_chains"] == m.n_chains and res[i]["n_anchors"] == m.stats.anchors
+        assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+    assert most > 128, most   # the case this test exists for
+    tree.close()
+    dev.close()
 
 
 def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
