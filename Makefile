@@ -8,7 +8,7 @@ HOSTFLAGS = -std=c++17 -O2 -ffp-contract=off -fopenmp -fPIC -Wall
 LIBDIR = sigmap_amd/lib
 CSRC = sigmap_amd/csrc
 HOST = sigmap_amd/host
-HIP_SRCS = $(CSRC)/api.hip $(CSRC)/events.hip $(CSRC)/seed_lookup.hip $(CSRC)/sort.hip $(CSRC)/chain.hip $(CSRC)/sdtw.hip $(CSRC)/cwt.hip
+HIP_SRCS = $(CSRC)/api.hip $(CSRC)/signal.hip $(CSRC)/events.hip $(CSRC)/seed_lookup.hip $(CSRC)/sort.hip $(CSRC)/chain.hip $(CSRC)/sdtw.hip $(CSRC)/cwt.hip
 HIP_OBJS = $(HIP_SRCS:$(CSRC)/%.hip=build/%.o)
 HOST_SRCS = $(HOST)/kdtree.cc $(HOST)/pore_model.cc $(HOST)/sequence_batch.cc $(HOST)/signal_batch.cc \
             $(HOST)/fast5_reader.cc $(HOST)/spatial_index.cc $(HOST)/mapping_logic.cc $(HOST)/host_abi.cc

@@ -165,6 +165,38 @@ typedef struct {
 int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets,
                        uint32_t n_chunks, const uint32_t *query_start_offsets,
                        const smhip_carried_anchor *carried, const uint32_t *carried_offsets);
+/* ---- resident reads: SignalBatch::AddSignal's conversion on the device (signal_batch.cc:139-151;
+ * the same loop for BLOW5 records at :195-207) ----
+ * The host keeps a read as its raw ADC counts + (digitisation, range, offset); a read crosses PCIe
+ * once, as int16.  The device converts pa = ((float)raw + offset) * (range / digitisation), drops
+ * samples outside (30, 200) pA and compacts the survivors in order into the read's SLOT, from which
+ * the batches then cut their chunks (the reference cuts its 4000-sample chunks from the FILTERED
+ * array, sigmap.cc:637-652).  The context holds n_slots slots of keep_samples floats each (e.g.
+ * max_num_chunks * 4000); the caller decides which read lives in which slot and when a slot is reused. */
+int smhip_reads_configure(smhip_ctx *ctx, uint32_t n_slots, uint32_t keep_samples);
+/* Read r = raw[raw_offsets[r] .. raw_offsets[r+1]) goes to slot slots[r] (slots == NULL: slot r).
+ * pa_len[r] (optional) = filtered length of the WHOLE read -- what Signal::signal_values.size() is in
+ * the reference (PAF column 2, and num_chunks = length / 4000, sigmap.cc:643) -- even when only the
+ * first keep_samples of them are kept.  The raw samples are copied by DMA on a separate stream, overlapped
+ * with the kernels of the previous batch, when `raw` is pinned memory (smhip_host_alloc).  With
+ * pa_len == NULL the call only enqueues work: `raw` must then stay untouched until the next
+ * smhip_map_sync (or any later call that returns results). */
+int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *raw_offsets,
+                           const float *digitisation, const float *range, const float *offset,
+                           const uint32_t *slots, uint32_t n_reads, uint32_t *pa_len);
+/* The next batch: chunk c = filtered samples [chunk_index[c] * chunk_size, + chunk_size) of slot
+ * slots[c], clipped to the slot's length (sigmap.cc:647-652).  Other arguments as smhip_batch_upload. */
+int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t chunk_size,
+                       uint32_t n_chunks, const uint32_t *query_start_offsets,
+                       const smhip_carried_anchor *carried, const uint32_t *carried_offsets);
+/* The filtered pA samples a slot holds (for parity tests against SignalBatch::AddSignal): up to cap
+ * floats; n_kept = samples held (<= keep_samples), n_total = filtered length of the whole read. */
+int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t cap, uint32_t *n_kept,
+                            uint32_t *n_total);
+/* Pinned (page-locked) host memory for the raw reads: DMA at link rate, truly asynchronous copies. */
+int smhip_host_alloc(void **out, size_t bytes);
+void smhip_host_free(void *p);
+
 /* Launch events -> seeds -> radius search -> sort -> chain on the context stream.  The kernels are
  * enqueued; the call itself waits twice for a scalar it sizes the next stage's buffers with (the
  * number of queries after event detection, the number of anchors after the search), so it returns
@@ -183,7 +215,7 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
                      const uint32_t *carried_offsets, smhip_chunk_result *results);
 /* Mean device time (ms) of the named kernel over the launches since the last
  * smhip_timing_reset(), measured with HIP events on the context stream.
- * names: "events", "seed_lookup", "sort", "chain", "sdtw". */
+ * names: "convert", "events", "seed_lookup", "sort", "chain", "sdtw". */
 /* ---- banded sDTW refinement of the best chain ----
  * The reference computes the z-scored expected signal of every contig strand at map time
  * (sigmap.cc:566-591) and aligns against it with Sigmap::sDTW (sigmap.cc:1259-1291) in its

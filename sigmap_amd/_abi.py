@@ -18,6 +18,8 @@ HIP_SYMBOLS = [
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
     "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
+    "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
+    "smhip_host_alloc", "smhip_host_free",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -193,6 +195,13 @@ def hip_lib():
         L.smhip_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
         L.smhip_events.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, vp, vp, vp, vp, vp]
         L.smhip_events_raw.argtypes = [vp, u32, u32, u32] + [vp] * 10
+        L.smhip_reads_configure.argtypes = [vp, u32, u32]
+        L.smhip_reads_upload_raw.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
+        L.smhip_batch_select.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+        L.smhip_reads_download_pa.argtypes = [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.smhip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        L.smhip_host_free.argtypes = [vp]
+        L.smhip_host_free.restype = None
         L.smhip_seed_lookup.argtypes = [vp, C.POINTER(Params), vp, u32, u32, vp, vp, vp, vp, vp]
         L.smhip_sdtw_banded.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp]
         _hip = L

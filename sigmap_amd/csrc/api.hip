@@ -35,8 +35,8 @@ const EnvKnobs &Knobs() {
 }  // namespace smhip
 
 namespace {
-const char *kTimerNames[] = {"events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw"};
-enum { T_EVENTS = 0, T_SEED, T_OVF, T_SORT, T_CHAIN, T_SDTW, T_COUNT };
+const char *kTimerNames[] = {"events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw", "convert"};
+enum { T_EVENTS = 0, T_SEED, T_OVF, T_SORT, T_CHAIN, T_SDTW, T_CONVERT, T_COUNT };
 
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
@@ -124,6 +124,29 @@ __global__ void OrStatusKernel(smhip_chunk_result *results, uint32_t n, const ui
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     results[i].status |= bits;
 }
+
+// query start offsets + carried anchors of a batch (shared by smhip_batch_upload / smhip_batch_select)
+int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *query_start_offsets,
+                          const smhip_carried_anchor *carried, const uint32_t *carried_offsets) {
+  const uint64_t n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
+  HIPCHK(ctx->qstart.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->carried_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx->carried.Reserve(std::max<uint64_t>(n_carried, 1) * sizeof(smhip_carried_anchor)));
+  if (query_start_offsets)
+    HIPCHK(hipMemcpyAsync(ctx->qstart.p, query_start_offsets, (uint64_t)n_chunks * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, ctx->stream));
+  else
+    HIPCHK(hipMemsetAsync(ctx->qstart.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  if (carried) {
+    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, carried_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->carried.p, carried, n_carried * sizeof(smhip_carried_anchor), hipMemcpyHostToDevice,
+                          ctx->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->carried_off.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  }
+  return SMHIP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -166,6 +189,12 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
     delete ctx;
     return SMHIP_EHIP;
   }
+  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->convert_done, hipEventDisableTiming) != hipSuccess) {
+    smhip_destroy(ctx);
+    return SMHIP_EHIP;
+  }
   ctx->timers.resize(T_COUNT);
   for (int i = 0; i < T_COUNT; ++i) ctx->timers[i].name = kTimerNames[i];
   *out = ctx;
@@ -175,9 +204,18 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
 void smhip_destroy(smhip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  DevBuf *bufs[] = {&ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
-                    &ctx->sample_off, &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
+  if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
+  if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+  DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->reads_pa,
+                    &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
+                    &ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+                    &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
                     &ctx->ovf_pool, &ctx->counters, &ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp,
@@ -190,7 +228,7 @@ void smhip_destroy(smhip_ctx *ctx) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -384,26 +422,22 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   const uint64_t n_samples = n_chunks ? sample_offsets[n_chunks] : 0;
   const uint64_t n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
   HIPCHK(ctx->samples.Reserve(std::max<uint64_t>(n_samples, 1) * sizeof(float)));
-  HIPCHK(ctx->sample_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
-  HIPCHK(ctx->qstart.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
-  HIPCHK(ctx->carried_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
-  HIPCHK(ctx->carried.Reserve(std::max<uint64_t>(n_carried, 1) * sizeof(smhip_carried_anchor)));
   HIPCHK(hipMemcpyAsync(ctx->samples.p, samples_pa, n_samples * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->sample_off.p, sample_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
-                        hipMemcpyHostToDevice, ctx->stream));
-  if (query_start_offsets)
-    HIPCHK(hipMemcpyAsync(ctx->qstart.p, query_start_offsets, (uint64_t)n_chunks * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
-  else
-    HIPCHK(hipMemsetAsync(ctx->qstart.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
-  if (carried) {
-    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, carried_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->carried.p, carried, n_carried * sizeof(smhip_carried_anchor), hipMemcpyHostToDevice,
-                          ctx->stream));
-  } else {
-    HIPCHK(hipMemsetAsync(ctx->carried_off.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  ctx->h_chunk_begin.resize((size_t)n_chunks + 1);
+  ctx->h_chunk_len.resize((size_t)n_chunks + 1);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    ctx->h_chunk_begin[c] = sample_offsets[c];
+    ctx->h_chunk_len[c] = sample_offsets[c + 1] - sample_offsets[c];
   }
+  HIPCHK(ctx->chunk_begin.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint64_t)));
+  HIPCHK(ctx->chunk_len.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  HIPCHK(hipMemcpyAsync(ctx->chunk_begin.p, ctx->h_chunk_begin.data(), (uint64_t)n_chunks * sizeof(uint64_t),
+                        hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->chunk_len.p, ctx->h_chunk_len.data(), (uint64_t)n_chunks * sizeof(uint32_t),
+                        hipMemcpyHostToDevice, ctx->stream));
+  ctx->chunk_src = ctx->samples.as<float>();
+  int rc = UploadBatchSideInputs(ctx, n_chunks, query_start_offsets, carried, carried_offsets);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host buffers are caller-owned: safe to reuse on return
   ctx->n_chunks = n_chunks;
   ctx->n_samples = n_samples;
@@ -411,6 +445,152 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   ctx->batch_ready = true;
   ctx->run_done = false;
   ctx->refine_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_host_alloc(void **out, size_t bytes) {
+  if (!out) return SMHIP_EINVAL;
+  *out = nullptr;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) return SMHIP_ENOMEM;
+  *out = p;
+  return SMHIP_OK;
+}
+
+void smhip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int smhip_reads_configure(smhip_ctx *ctx, uint32_t n_slots, uint32_t keep_samples) {
+  if (!ctx) return SMHIP_EINVAL;
+  if (n_slots == 0 || keep_samples == 0) return Fail(ctx, SMHIP_EINVAL, "n_slots and keep_samples must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx->reads_pa.Reserve((uint64_t)n_slots * keep_samples * sizeof(float)));
+  HIPCHK(ctx->slot_len.Reserve((uint64_t)n_slots * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(ctx->slot_len.p, 0, (uint64_t)n_slots * sizeof(uint32_t), ctx->stream));
+  ctx->n_slots = n_slots;
+  ctx->reads_keep = keep_samples;
+  return SMHIP_OK;
+}
+
+int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *raw_offsets, const float *digitisation,
+                           const float *range, const float *offset, const uint32_t *slots, uint32_t n_reads,
+                           uint32_t *pa_len) {
+  if (!ctx || !raw || !raw_offsets || !digitisation || !range || !offset) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->n_slots == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_reads_upload_raw before smhip_reads_configure");
+  if (n_reads == 0) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  // per-read records + segment starts, staged in pinned host memory owned by the context
+  const size_t meta_bytes = (size_t)n_reads * sizeof(RawReadMeta), seg_bytes = ((size_t)n_reads + 1) * sizeof(uint32_t);
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));  // the previous upload's staging is free again
+  if (meta_bytes + seg_bytes > ctx->h_meta_cap) {
+    if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+    ctx->h_meta = nullptr;
+    ctx->h_meta_cap = 0;
+    const size_t want = (meta_bytes + seg_bytes) * 2;
+    HIPCHK(hipHostMalloc(&ctx->h_meta, want, hipHostMallocDefault));
+    ctx->h_meta_cap = want;
+  }
+  RawReadMeta *meta = reinterpret_cast<RawReadMeta *>(ctx->h_meta);
+  uint32_t *seg_start = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->h_meta) + meta_bytes);
+  const uint64_t base = raw_offsets[0];
+  uint64_t n_segs = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    if (raw_offsets[r + 1] < raw_offsets[r]) return Fail(ctx, SMHIP_EINVAL, "raw offsets must be non-decreasing");
+    const uint64_t n = raw_offsets[r + 1] - raw_offsets[r];
+    if (n > 0xFFFFFFFFull) return Fail(ctx, SMHIP_EINVAL, "a read exceeds 2^32 samples");
+    const uint32_t slot = slots ? slots[r] : r;
+    if (slot >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
+    if (!(digitisation[r] != 0.0f)) return Fail(ctx, SMHIP_EINVAL, "digitisation must be non-zero");
+    meta[r] = RawReadMeta{raw_offsets[r] - base, (uint32_t)n, slot, digitisation[r], range[r], offset[r], 0u};
+    seg_start[r] = (uint32_t)n_segs;
+    n_segs += RawSegments((uint32_t)n);
+    if (n_segs > 0x7FFFFFFFull) return Fail(ctx, SMHIP_EINVAL, "too many samples in one upload");
+  }
+  seg_start[n_reads] = (uint32_t)n_segs;
+  const uint64_t n_raw = raw_offsets[n_reads] - base;
+  HIPCHK(ctx->reads_raw.Reserve(std::max<uint64_t>(n_raw, 1) * sizeof(int16_t)));
+  HIPCHK(ctx->reads_meta.Reserve(meta_bytes));
+  HIPCHK(ctx->reads_segstart.Reserve(seg_bytes));
+  HIPCHK(ctx->reads_seg.Reserve(n_segs * 2 * sizeof(uint32_t)));
+  HIPCHK(ctx->reads_len.Reserve((uint64_t)n_reads * sizeof(uint32_t)));
+  // H2D on the copy stream (overlaps whatever the compute stream is running: with pinned host memory,
+  // smhip_host_alloc, the copy is a DMA at link rate), after the previous conversion has consumed
+  // the staging buffer; the conversion on the compute stream waits for the copy.
+  HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->convert_done, 0));
+  HIPCHK(hipMemcpyAsync(ctx->reads_raw.p, raw + base, n_raw * sizeof(int16_t), hipMemcpyHostToDevice, ctx->copy_stream));
+  HIPCHK(hipMemcpyAsync(ctx->reads_meta.p, meta, meta_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  HIPCHK(hipMemcpyAsync(ctx->reads_segstart.p, seg_start, seg_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  HIPCHK(hipEventRecord(ctx->copy_done, ctx->copy_stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
+  {
+    ScopedTimer t(ctx, T_CONVERT);
+    HIPCHK(LaunchRawConvert(ctx, ctx->reads_raw.as<int16_t>(), ctx->reads_meta.as<RawReadMeta>(),
+                            ctx->reads_segstart.as<uint32_t>(), n_reads, (uint32_t)n_segs, ctx->reads_seg.as<uint32_t>(),
+                            ctx->reads_seg.as<uint32_t>() + n_segs, ctx->reads_pa.as<float>(), ctx->reads_keep,
+                            ctx->slot_len.as<uint32_t>(), ctx->reads_len.as<uint32_t>()));
+  }
+  HIPCHK(hipEventRecord(ctx->convert_done, ctx->stream));
+  if (pa_len) {
+    HIPCHK(hipMemcpyAsync(pa_len, ctx->reads_len.p, (uint64_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return SMHIP_OK;
+}
+
+int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t chunk_size,
+                       uint32_t n_chunks, const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                       const uint32_t *carried_offsets) {
+  if (!ctx || (n_chunks && (!slots || !chunk_index))) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->n_slots == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_batch_select before smhip_reads_configure");
+  if ((carried == nullptr) != (carried_offsets == nullptr))
+    return Fail(ctx, SMHIP_EINVAL, "carried and carried_offsets must be given together");
+  if (chunk_size == 0 || chunk_size > (uint32_t)kMaxSamples)
+    return Fail(ctx, SMHIP_EINVAL, "chunk_size must be 1..4096 (reference chunk size is 4000, sigmap.cc:639)");
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    if (slots[c] >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
+    if (((uint64_t)chunk_index[c] + 1) * chunk_size > ctx->reads_keep)
+      return Fail(ctx, SMHIP_EINVAL, "chunk beyond the samples a slot keeps (keep_samples of smhip_reads_configure)");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t nb = std::max<uint64_t>(n_chunks, 1);
+  HIPCHK(ctx->sel_slots.Reserve(nb * sizeof(uint32_t)));
+  HIPCHK(ctx->sel_chunk.Reserve(nb * sizeof(uint32_t)));
+  HIPCHK(ctx->chunk_begin.Reserve((nb + 1) * sizeof(uint64_t)));
+  HIPCHK(ctx->chunk_len.Reserve((nb + 1) * sizeof(uint32_t)));
+  HIPCHK(hipMemcpyAsync(ctx->sel_slots.p, slots, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->sel_chunk.p, chunk_index, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice,
+                        ctx->stream));
+  HIPCHK(LaunchSelectChunks(ctx, ctx->sel_slots.as<uint32_t>(), ctx->sel_chunk.as<uint32_t>(), n_chunks, chunk_size,
+                            ctx->reads_keep, ctx->slot_len.as<uint32_t>(), ctx->chunk_begin.as<uint64_t>(),
+                            ctx->chunk_len.as<uint32_t>()));
+  ctx->chunk_src = ctx->reads_pa.as<float>();
+  int rc = UploadBatchSideInputs(ctx, n_chunks, query_start_offsets, carried, carried_offsets);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned: safe to reuse on return
+  ctx->n_chunks = n_chunks;
+  ctx->n_samples = (uint64_t)n_chunks * chunk_size;
+  ctx->n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
+  ctx->batch_ready = true;
+  ctx->run_done = false;
+  ctx->refine_done = false;
+  return SMHIP_OK;
+}
+
+int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t cap, uint32_t *n_kept, uint32_t *n_total) {
+  if (!ctx || !pa) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (slot >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
+  HIPCHK(hipSetDevice(ctx->device));
+  uint32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, ctx->slot_len.as<uint32_t>() + slot, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint32_t kept = std::min(total, ctx->reads_keep), n = std::min(kept, cap);
+  HIPCHK(hipMemcpyAsync(pa, ctx->reads_pa.as<float>() + (size_t)slot * ctx->reads_keep, (size_t)n * sizeof(float),
+                        hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n_kept) *n_kept = kept;
+  if (n_total) *n_total = total;
   return SMHIP_OK;
 }
 
@@ -441,7 +621,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
   {
     ScopedTimer t(ctx, T_EVENTS);
-    HIPCHK(LaunchEvents(ctx, *p, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), R, kFeatStride,
+    HIPCHK(LaunchEvents(ctx, *p, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), R, kFeatStride,
                         ctx->feat.as<float>(), nullptr, results, ctx->nq.as<uint32_t>()));
   }
   HIPCHK(LaunchScanU32(ctx, ctx->nq.as<uint32_t>(), R, ctx->q_off.as<uint32_t>()));
@@ -734,7 +914,7 @@ int smhip_events(smhip_ctx *ctx, const smhip_params *p, const float *samples_pa,
   HIPCHK(ctx->nq.Reserve((uint64_t)n_chunks * sizeof(uint32_t)));
   {
     ScopedTimer t(ctx, T_EVENTS);
-    HIPCHK(LaunchEvents(ctx, *p, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), n_chunks, feat_stride,
+    HIPCHK(LaunchEvents(ctx, *p, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), n_chunks, feat_stride,
                         ctx->feat.as<float>(), ctx->stdv.as<float>(), ctx->results.as<smhip_chunk_result>(),
                         ctx->nq.as<uint32_t>()));
   }
@@ -777,7 +957,7 @@ int smhip_events_raw(smhip_ctx *ctx, uint32_t n_chunks, uint32_t feat_stride, ui
     step(d_len.Reserve(evn * 4));
     if (e == hipSuccess) step(hipMemsetAsync(d_start.p, 0, evn * 4, ctx->stream));
     if (e == hipSuccess) step(hipMemsetAsync(d_len.p, 0, evn * 4, ctx->stream));
-    if (e == hipSuccess) step(LaunchEventSpans(ctx, ctx->sample_off.as<uint32_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>()));
+    if (e == hipSuccess) step(LaunchEventSpans(ctx, ctx->chunk_len.as<uint32_t>(), d_start.as<uint32_t>(), d_len.as<uint32_t>()));
     if (e == hipSuccess && ev_start) step(hipMemcpyAsync(ev_start, d_start.p, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (e == hipSuccess && ev_length) step(hipMemcpyAsync(ev_length, d_len.p, evn * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
@@ -847,7 +1027,7 @@ int smhip_cwt_features(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   if (e == hipSuccess) step(hipMemcpyAsync(d_h.p, h.data(), (L + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   if (e == hipSuccess) step(hipMemsetAsync(d_rows.p, 0, (uint64_t)n_chunks * 4096 * sizeof(float), ctx->stream));
   if (e == hipSuccess)
-    step(LaunchCwtFeatures(ctx, ctx->samples.as<float>(), ctx->sample_off.as<uint32_t>(), n_chunks, d_h.as<double>(), L,
+    step(LaunchCwtFeatures(ctx, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), n_chunks, d_h.as<double>(), L,
                            d_rows.as<float>(), feat_stride, d_feat.as<float>(), d_pos.as<uint32_t>(),
                            d_n.as<uint32_t>()));
   if (e == hipSuccess) step(hipMemcpyAsync(feat, d_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

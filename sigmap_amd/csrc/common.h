@@ -27,6 +27,14 @@ struct Hit {  // 16 B: one radius-search result
   uint32_t slot;      // index in tree (leaf-major) order
 };
 
+struct RawReadMeta {  // one read of smhip_reads_upload_raw (32 B)
+  uint64_t raw_off;   // first ADC sample in the staged raw buffer
+  uint32_t n_raw;     // ADC samples
+  uint32_t slot;      // resident slot the filtered pA samples go to
+  float digitisation, range, offset;  // Signal{digitisation, range, offset}, signal_batch.h:14-25
+  uint32_t pad;
+};
+
 struct ChainTmp {
   float score;
   uint32_t ref, start, end, n_anchors, direction;
@@ -94,7 +102,20 @@ struct smhip_ctx {
   uint32_t n_chunks = 0;
   uint64_t n_samples = 0, n_carried = 0;
   bool batch_ready = false, run_done = false;
-  smhip::DevBuf samples, sample_off, qstart, carried, carried_off;
+  // chunk c of the batch = chunk_src[chunk_begin[c] .. + chunk_len[c]): chunk_src is `samples` (pA uploaded
+  // with the batch, smhip_batch_upload) or `reads_pa` (resident reads, smhip_reads_upload_raw + smhip_batch_select)
+  smhip::DevBuf samples, chunk_begin, chunk_len, qstart, carried, carried_off;
+  const float *chunk_src = nullptr;
+  // resident reads (SignalBatch::AddSignal on the device): raw ADC staging, per-read records, segment
+  // counts / bases, the slots' filtered pA samples (n_slots x reads_keep floats) and their lengths
+  smhip::DevBuf reads_raw, reads_meta, reads_segstart, reads_seg, reads_pa, slot_len, reads_len, sel_slots, sel_chunk;
+  hipStream_t copy_stream = nullptr;   // H2D of raw reads, overlapped with the kernels on `stream`
+  hipEvent_t copy_done = nullptr, convert_done = nullptr;
+  uint32_t n_slots = 0, reads_keep = 0;
+  void *h_meta = nullptr;              // pinned host staging of the per-read records + segment starts
+  size_t h_meta_cap = 0;
+  std::vector<uint64_t> h_chunk_begin; // scratch of smhip_batch_upload
+  std::vector<uint32_t> h_chunk_len;
   // per-chunk intermediates.  ev_rows: where the last LaunchEvents put its scratch rows inside
   // ev_scratch (smhip_events_raw reads them back for the per-stage tests)
   struct EvRows {
@@ -150,11 +171,19 @@ hipError_t LaunchInnerBoxes(smhip_ctx *ctx, const void *inner, const uint32_t *l
 // grid = {base[6], step[6]} from the root's tight box; then the children's boxes of every inner record
 hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32_t root_ref, const float *leaf_box,
                            const float *inner_box, float *grid, uint32_t *error_flag);
-hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
-                        uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
+hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint64_t *cbegin,
+                        const uint32_t *clen, uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);
 // event spans (start, length) of the last LaunchEvents' raw events, event.h:200-224
-hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *off, uint32_t *ev_start, uint32_t *ev_length);
+hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *clen, uint32_t *ev_start, uint32_t *ev_length);
+// signal.hip: raw ADC -> filtered pA of n_reads reads (n_segs segments in all) into their slots
+uint32_t RawSegments(uint32_t n_raw);
+hipError_t LaunchRawConvert(smhip_ctx *ctx, const int16_t *raw, const RawReadMeta *meta, const uint32_t *seg_start,
+                            uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, float *pa,
+                            uint32_t keep, uint32_t *slot_len, uint32_t *read_len);
+hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t n_chunks,
+                              uint32_t chunk_size, uint32_t keep, const uint32_t *slot_len, uint64_t *cbegin,
+                              uint32_t *clen);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
@@ -206,7 +235,8 @@ struct ChainArgs {
 };
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
                        uint64_t n_anchors_total, uint32_t n_refs);
-hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint32_t *off, uint32_t n_chunks,
+hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint64_t *cbegin, const uint32_t *clen,
+                             uint32_t n_chunks,
                              const double *h, uint32_t L, float *cwt_rows, uint32_t feat_stride, float *feat,
                              uint32_t *pos, uint32_t *n_feat);
 hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, const float *feat,

@@ -43,16 +43,17 @@ __device__ __forceinline__ void BitonicLds(float *v, uint32_t tid) {  // ascendi
 
 // D1 + D2: one workgroup per chunk.  cwt_out row stride kCwtPad.
 __global__ __launch_bounds__(kCwtThreads) void CwtKernel(const float *__restrict__ samples,
-                                                         const uint32_t *__restrict__ off, const double *__restrict__ h,
+                                                         const uint64_t *__restrict__ cbegin,
+                                                         const uint32_t *__restrict__ clen, const double *__restrict__ h,
                                                          uint32_t L, float *__restrict__ cwt_out) {
   __shared__ float s_sort[kCwtPad];
   __shared__ float s_x[kCwtPad];
   __shared__ float s_stat[2];
   extern __shared__ double s_h[];  // [L + 1]
   const uint32_t c = blockIdx.x, tid = threadIdx.x;
-  uint32_t n = off[c + 1] - off[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
-  const float *x = samples + off[c];
+  const float *x = samples + cbegin[c];
   float *out = cwt_out + (size_t)c * kCwtPad;
   if (n < 3) return;
   for (uint32_t i = tid; i < kCwtPad; i += kCwtThreads) {
@@ -89,13 +90,13 @@ __global__ __launch_bounds__(kCwtThreads) void CwtKernel(const float *__restrict
 
 // D3: one lane per chunk: z-score (sequential f64 sums, sigmap.cc:1131-1155: returns SD), then the
 // alternating peak / valley picker with hysteresis SD / 4 (sigmap.cc:1176-1196).
-__global__ __launch_bounds__(64) void CwtPeaksKernel(const uint32_t *__restrict__ off, uint32_t n_chunks,
+__global__ __launch_bounds__(64) void CwtPeaksKernel(const uint32_t *__restrict__ clen, uint32_t n_chunks,
                                                      const float *__restrict__ cwt, uint32_t feat_stride,
                                                      float *__restrict__ feat, uint32_t *__restrict__ pos,
                                                      uint32_t *__restrict__ n_feat) {
   const uint32_t c = blockIdx.x * 64 + threadIdx.x;
   if (c >= n_chunks) return;
-  uint32_t n = off[c + 1] - off[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   if (n < 3) {
     n_feat[c] = 0;
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(64) void CwtPeaksKernel(const uint32_t *__restrict_
 }
 }  // namespace
 
-hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint32_t *off, uint32_t n_chunks,
+hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint64_t *cbegin, const uint32_t *clen,
+                             uint32_t n_chunks,
                              const double *h, uint32_t L, float *cwt_rows, uint32_t feat_stride, float *feat,
                              uint32_t *pos, uint32_t *n_feat) {
   if (n_chunks == 0) return hipSuccess;
   hipLaunchKernelGGL(CwtKernel, dim3(n_chunks), dim3(kCwtThreads), (L + 1) * sizeof(double), ctx->stream, samples,
-                     off, h, L, cwt_rows);
-  hipLaunchKernelGGL(CwtPeaksKernel, dim3((n_chunks + 63) / 64), dim3(64), 0, ctx->stream, off, n_chunks, cwt_rows,
+                     cbegin, clen, h, L, cwt_rows);
+  hipLaunchKernelGGL(CwtPeaksKernel, dim3((n_chunks + 63) / 64), dim3(64), 0, ctx->stream, clen, n_chunks, cwt_rows,
                      feat_stride, feat, pos, n_feat);
   return hipGetLastError();
 }

@@ -54,12 +54,13 @@ struct Detector {  // event.h:45-56
 
 // E1 -- event.h:58-68.  ps[i+1] = ps[i] + x[i]; pss[i+1] = pss[i] + x[i]*x[i].
 __global__ __launch_bounds__(64) void PrefixKernel(const float *__restrict__ samples,
-                                                   const uint32_t *__restrict__ off, uint32_t n_chunks,
+                                                   const uint64_t *__restrict__ cbegin,
+                                                   const uint32_t *__restrict__ clen, uint32_t n_chunks,
                                                    float *__restrict__ ps_all, float *__restrict__ pss_all) {
   const uint32_t c = blockIdx.x * 64 + threadIdx.x;
   if (c >= n_chunks) return;
-  const uint32_t begin = off[c];
-  uint32_t n = off[c + 1] - begin;
+  const uint64_t begin = cbegin[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   const float *x = samples + begin;
   float *ps = ps_all + (size_t)c * kRowStride, *pss = pss_all + (size_t)c * kRowStride;
@@ -105,13 +106,13 @@ __global__ __launch_bounds__(64) void PrefixKernel(const float *__restrict__ sam
 
 // E2 -- event.h:70-115 for both windows, one thread per sample index (entries [0,w) and
 // (n-w, n] are zero).  The chunk's prefix sums are staged in LDS.
-__global__ __launch_bounds__(256) void TStatKernel(const uint32_t *__restrict__ off,
+__global__ __launch_bounds__(256) void TStatKernel(const uint32_t *__restrict__ clen,
                                                    const float *__restrict__ ps_all,
                                                    const float *__restrict__ pss_all, float *__restrict__ t1_all,
                                                    float *__restrict__ t2_all, uint32_t w1, uint32_t w2) {
   __shared__ float ps[kRowStride], pss[kRowStride];
   const uint32_t c = blockIdx.x, tid = threadIdx.x;
-  uint32_t n = off[c + 1] - off[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   const float *gps = ps_all + (size_t)c * kRowStride, *gpss = pss_all + (size_t)c * kRowStride;
   for (uint32_t i = tid; i <= n; i += 256) {
@@ -244,7 +245,7 @@ __device__ __forceinline__ void RunSteps(Detector *d, const float *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ off, uint32_t n_chunks,
+__global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ clen, uint32_t n_chunks,
                                                  const float *__restrict__ t1_all, const float *__restrict__ t2_all,
                                                  uint16_t *__restrict__ peaks_all, uint32_t *__restrict__ n_peaks,
                                                  uint16_t *__restrict__ seg_peaks_all, uint32_t w1, uint32_t w2,
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ of
   const bool live = c < n_chunks;
   uint32_t n = 0;
   if (live) {
-    n = off[c + 1] - off[c];
+    n = clen[c];
     if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   }
   const size_t row = (size_t)(live ? c : 0) * kRowStride;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ of
 // last peak is dropped).  num_events = 1 + #{i>=1 : 0 < peaks[i] < n}; every emitted peak is a
 // sample index in [1, n-1] (index 0 is never examined: masked_to >= 0), so that is n_peaks.
 // With fewer than 2 peaks the reference reads out of bounds: the chunk yields no events.
-__global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restrict__ off,
+__global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restrict__ clen,
                                                        const float *__restrict__ ps_all,
                                                        const float *__restrict__ pss_all,
                                                        const uint16_t *__restrict__ peaks_all,
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restric
                                                        float *__restrict__ ev_mean, float *__restrict__ ev_stdv,
                                                        uint32_t feat_stride) {
   const uint32_t c = blockIdx.x;
-  uint32_t n = off[c + 1] - off[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   const uint32_t E = n_peaks[c] >= 2 ? n_peaks[c] : 0;
   const float *ps = ps_all + (size_t)c * kRowStride, *pss = pss_all + (size_t)c * kRowStride;
@@ -327,12 +328,12 @@ __global__ __launch_bounds__(256) void EventMeanKernel(const uint32_t *__restric
 
 // The spans EventMeanKernel averages over, written out for the per-stage tests (event.h:200-224:
 // Event.start, Event.length).
-__global__ __launch_bounds__(256) void EventSpanKernel(const uint32_t *__restrict__ off,
+__global__ __launch_bounds__(256) void EventSpanKernel(const uint32_t *__restrict__ clen,
                                                        const uint16_t *__restrict__ peaks_all,
                                                        const uint32_t *__restrict__ n_peaks, uint32_t feat_stride,
                                                        uint32_t *__restrict__ ev_start, uint32_t *__restrict__ ev_length) {
   const uint32_t c = blockIdx.x;
-  uint32_t n = off[c + 1] - off[c];
+  uint32_t n = clen[c];
   if (n > (uint32_t)kMaxSamples) n = kMaxSamples;
   const uint32_t E = n_peaks[c] >= 2 ? n_peaks[c] : 0;
   const uint16_t *peaks = peaks_all + (size_t)c * kRowStride;
@@ -482,8 +483,8 @@ __global__ __launch_bounds__(256) void ScanApplyKernel(const uint32_t *__restric
 }
 }  // namespace
 
-hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint32_t *off,
-                        uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
+hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint64_t *cbegin,
+                        const uint32_t *clen, uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq) {
   if (n_chunks == 0) return hipSuccess;
   const size_t row = (size_t)n_chunks * kRowStride;
@@ -499,23 +500,23 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
   ctx->ev_rows = smhip_ctx::EvRows{ps, pss, t1, t2, ev_mean, ev_stdv, n_peaks, peaks, n_chunks, feat_stride,
                                    (uint32_t)kRowStride};
   const uint32_t lane_blocks = (n_chunks + 63) / 64;
-  hipLaunchKernelGGL(PrefixKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, samples, off, n_chunks, ps, pss);
-  hipLaunchKernelGGL(TStatKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, t1, t2,
+  hipLaunchKernelGGL(PrefixKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, samples, cbegin, clen, n_chunks, ps, pss);
+  hipLaunchKernelGGL(TStatKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, clen, ps, pss, t1, t2,
                      p.window_length1, p.window_length2);
-  hipLaunchKernelGGL(PeakKernel, dim3((n_chunks * kPeakSegs + 63) / 64), dim3(64), 0, ctx->stream, off, n_chunks, t1,
+  hipLaunchKernelGGL(PeakKernel, dim3((n_chunks * kPeakSegs + 63) / 64), dim3(64), 0, ctx->stream, clen, n_chunks, t1,
                      t2, peaks, n_peaks, seg_peaks,
                      p.window_length1, p.window_length2, p.threshold1, p.threshold2, p.peak_height);
-  hipLaunchKernelGGL(EventMeanKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, off, ps, pss, peaks, n_peaks,
+  hipLaunchKernelGGL(EventMeanKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, clen, ps, pss, peaks, n_peaks,
                      ev_mean, ev_stdv, feat_stride);
   hipLaunchKernelGGL(FeatureKernel, dim3(lane_blocks), dim3(64), 0, ctx->stream, n_chunks, n_peaks, ev_mean, ev_stdv,
                      feat_stride, feat, stdv, results, nq, p.compress_delta, p.min_num_events, kMaxDim, p.step_size);
   return hipGetLastError();
 }
 
-hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *off, uint32_t *ev_start, uint32_t *ev_length) {
+hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *clen, uint32_t *ev_start, uint32_t *ev_length) {
   const auto &r = ctx->ev_rows;
   if (r.n_chunks == 0) return hipSuccess;
-  hipLaunchKernelGGL(EventSpanKernel, dim3(r.n_chunks), dim3(256), 0, ctx->stream, off, r.peaks, r.n_peaks,
+  hipLaunchKernelGGL(EventSpanKernel, dim3(r.n_chunks), dim3(256), 0, ctx->stream, clen, r.peaks, r.n_peaks,
                      r.feat_stride, ev_start, ev_length);
   return hipGetLastError();
 }

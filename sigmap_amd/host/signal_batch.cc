@@ -10,6 +10,18 @@
 #include "utils.h"
 
 namespace sigmap {
+void SignalBatch::KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes) {
+  raw_mode_ = true;
+  alloc_ = alloc;
+  free_ = free_fn;
+  block_bytes_ = block_bytes;
+}
+
+SignalBatch::~SignalBatch() {
+  for (auto &b : blocks_)
+    if (b.base && free_) free_(b.base);
+}
+
 void SignalBatch::AddSignal(const std::string &id, float digitisation, float range, float offset,
                             const int16_t *raw, size_t n_raw) {
   Signal s;
@@ -17,6 +29,22 @@ void SignalBatch::AddSignal(const std::string &id, float digitisation, float ran
   s.digitisation = digitisation;
   s.range = range;
   s.offset = offset;
+  if (raw_mode_) {  // keep the ADC counts; the device converts (smhip_reads_upload_raw)
+    if (blocks_.empty() || blocks_.back().used + n_raw > blocks_.back().cap) {
+      const size_t cap = std::max(block_bytes_ / sizeof(int16_t), n_raw);
+      int16_t *base = static_cast<int16_t *>(alloc_(std::max<size_t>(cap, 1) * sizeof(int16_t)));
+      if (!base) ExitWithMessage("Cannot allocate the raw-signal arena.");
+      blocks_.push_back(Block{base, cap, 0});
+    }
+    Block &b = blocks_.back();
+    memcpy(b.base + b.used, raw, n_raw * sizeof(int16_t));
+    s.raw = b.base + b.used;
+    s.n_raw = n_raw;
+    s.raw_block = (uint32_t)(blocks_.size() - 1);
+    b.used += n_raw;
+    signals_.push_back(std::move(s));
+    return;
+  }
   s.signal_values.reserve(n_raw);
   const float scale = range / digitisation;
   for (size_t i = 0; i < n_raw; ++i) {

@@ -24,7 +24,14 @@ struct Signal {
   float digitisation = 0, range = 0, offset = 0;
   std::vector<float> signal_values;           // pA, filtered
   std::vector<float> negative_signal_values;  // reference minus strand only
-  size_t GetSignalLength() const { return signal_values.size(); }
+  // Raw mode (SignalBatch::KeepRaw): the read stays as its ADC counts in the batch's arena and the
+  // conversion above runs on the GPU (smhip_reads_upload_raw); signal_values stays empty and the
+  // filtered length is filled in by the mapper when the device has counted it.
+  const int16_t *raw = nullptr;
+  size_t n_raw = 0;
+  uint32_t raw_block = 0;        // arena block holding the samples
+  size_t filtered_length = 0;
+  size_t GetSignalLength() const { return raw ? filtered_length : signal_values.size(); }
 };
 
 class SignalBatch {
@@ -49,11 +56,33 @@ class SignalBatch {
   size_t GetNumSignals() const { return signals_.size(); }
   const Signal &GetSignalAt(size_t i) const { return signals_[i]; }
   const char *GetSignalNameAt(size_t i) const { return signals_[i].id.data(); }
-  size_t GetSignalLengthAt(size_t i) const { return signals_[i].signal_values.size(); }
+  size_t GetSignalLengthAt(size_t i) const { return signals_[i].GetSignalLength(); }
+
+  // Raw mode: AddSignal keeps the ADC counts (2 bytes per sample) instead of converting on the host.
+  // The samples of consecutive reads are packed into large arena blocks obtained from `alloc` (the
+  // CLI passes the device library's pinned allocator, so a run of reads is one DMA); a read never
+  // straddles two blocks.  Call before loading.
+  typedef void *(*ArenaAlloc)(size_t bytes);
+  typedef void (*ArenaFree)(void *p);
+  void KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes = (size_t)256 << 20);
+  bool raw_mode() const { return raw_mode_; }
+  void SetFilteredLengthAt(size_t i, size_t n) { signals_[i].filtered_length = n; }
+  // arena block b: base pointer (int16) and samples used
+  const int16_t *RawBlockBase(uint32_t b) const { return blocks_[b].base; }
+  ~SignalBatch();
 
  protected:
   std::string signal_directory_;
   std::vector<Signal> signals_;
+  struct Block {
+    int16_t *base;
+    size_t cap, used;
+  };
+  bool raw_mode_ = false;
+  ArenaAlloc alloc_ = nullptr;
+  ArenaFree free_ = nullptr;
+  size_t block_bytes_ = 0;
+  std::vector<Block> blocks_;
 };
 
 // (x - mean) / SD with mean and SD = sqrt(sum((x-mean)^2)/(n-1)) accumulated in double in

@@ -86,6 +86,34 @@ def reference_signals(genome, level_means, k=6):
     return np.concatenate(parts), np.array(offs, dtype=np.uint64)
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory (smhip_host_alloc): H2D copies from it are DMA at link
+    rate and asynchronous.  Keep the object alive while a copy may be in flight."""
+
+    def __init__(self, shape, dtype):
+        self.L = _abi.hip_lib()
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        if self.L.smhip_host_alloc(C.byref(p), max(n, 1)) != 0 or not p.value:
+            raise MemoryError("smhip_host_alloc failed")
+        self._p = p
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p is not None:
+            self.array = None
+            self.L.smhip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def default_params():
     p = _abi.Params()
     _abi.hip_lib().smhip_default_params(C.byref(p))
@@ -132,6 +160,44 @@ class DeviceMapper:
         co = None if carried_offsets is None else np.ascontiguousarray(carried_offsets, dtype=np.uint32)
         self._check(self.L.smhip_batch_upload(self._h, ptr(samples), ptr(offsets), self.n_chunks,
                                               ptr(qs), ptr(ca), ptr(co)), "smhip_batch_upload")
+
+    def configure_reads(self, n_slots, keep_samples):
+        """Resident read slots (SignalBatch::AddSignal on the device)."""
+        self._check(self.L.smhip_reads_configure(self._h, n_slots, keep_samples), "smhip_reads_configure")
+
+    def upload_raw(self, raw, raw_offsets, digitisation, rng, offset, slots=None, want_len=True):
+        """raw: int16 ADC samples of all reads, concatenated (numpy array, ideally a PinnedArray's);
+        per-read digitisation / range / offset arrays.  Returns the filtered length of every read
+        (None with want_len=False: the call then only enqueues work)."""
+        assert raw.dtype == np.int16 and raw.flags["C_CONTIGUOUS"]
+        ro = np.ascontiguousarray(raw_offsets, dtype=np.uint64)
+        n = len(ro) - 1
+        dg = np.ascontiguousarray(np.broadcast_to(np.float32(digitisation), (n,)), dtype=np.float32)
+        rg = np.ascontiguousarray(np.broadcast_to(np.float32(rng), (n,)), dtype=np.float32)
+        of = np.ascontiguousarray(np.broadcast_to(np.float32(offset), (n,)), dtype=np.float32)
+        sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.zeros(n, np.uint32) if want_len else None
+        self._check(self.L.smhip_reads_upload_raw(self._h, ptr(raw), ptr(ro), ptr(dg), ptr(rg), ptr(of), ptr(sl), n,
+                                                  ptr(out)), "smhip_reads_upload_raw")
+        return out
+
+    def select(self, slots, chunk_index, chunk_size=4000, query_start_offsets=None, carried=None,
+               carried_offsets=None):
+        sl = np.ascontiguousarray(slots, dtype=np.uint32)
+        ci = np.ascontiguousarray(chunk_index, dtype=np.uint32)
+        self.n_chunks = len(sl)
+        qs = None if query_start_offsets is None else np.ascontiguousarray(query_start_offsets, dtype=np.uint32)
+        ca = None if carried is None else np.ascontiguousarray(carried, dtype=_abi.CARRIED_DTYPE)
+        co = None if carried_offsets is None else np.ascontiguousarray(carried_offsets, dtype=np.uint32)
+        self._check(self.L.smhip_batch_select(self._h, ptr(sl), ptr(ci), chunk_size, self.n_chunks, ptr(qs), ptr(ca),
+                                              ptr(co)), "smhip_batch_select")
+
+    def download_pa(self, slot, cap):
+        pa = np.zeros(cap, np.float32)
+        kept, total = C.c_uint32(), C.c_uint32()
+        self._check(self.L.smhip_reads_download_pa(self._h, slot, ptr(pa), cap, C.byref(kept), C.byref(total)),
+                    "smhip_reads_download_pa")
+        return pa[:min(kept.value, cap)], kept.value, total.value
 
     def run(self, n_refs):
         self._check(self.L.smhip_map_run(self._h, C.byref(self.params), n_refs), "smhip_map_run")

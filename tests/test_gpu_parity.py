@@ -74,6 +74,76 @@ def test_events_edge_cases(device):
         device.events(np.zeros(5000, np.float32), np.array([0, 5000], np.uint32))
 
 
+# ------------------------------------------------------------------ ADC -> pA on the device (A1)
+
+def test_raw_conversion_matches_host_addsignal(device):
+    """SignalBatch::AddSignal (signal_batch.cc:139-151): scale, (30, 200) pA filter, in-order
+    compaction -- the device's resident-read path against the host conversion, bit for bit: reads with
+    samples below 30 and above 200 pA, ragged lengths (0, 1, a segment boundary, several segments), a
+    read longer than its slot keeps, per-read calibration constants."""
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 4000, 4095, 4096, 4097, 12000, 30011]
+    dg = np.array([8192, 8192, 8192, 2048, 8192, 8192, 4096, 8192], np.float32)
+    rg = np.array([1467.61, 1400.5, 1467.61, 748.58, 1467.61, 1211.3, 1467.61, 1467.61], np.float32)
+    of = np.array([10, -3, 10, 6, 10, 21, 10, 10], np.float32)
+    raws = []
+    for k, n in enumerate(lens):
+        r = rng.integers(-200, 1400, size=n).astype(np.int16)   # pA from about -30 to 250: both cuts are hit
+        if n >= 4000:
+            r[100:140] = 32767
+            r[-50:] = -32768
+        raws.append(r)
+    ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    pin = pipeline.PinnedArray((int(ro[-1]),), np.int16)
+    pin.array[:] = np.concatenate(raws)
+    keep = 12000
+    device.configure_reads(16, keep)
+    slots = np.array([3, 0, 5, 7, 1, 2, 9, 15], np.uint32)
+    got_len = device.upload_raw(pin.array, ro, dg, rg, of, slots=slots)
+    some_dropped = False
+    for k, r in enumerate(raws):
+        want = pipeline.raw_to_pa(r, dg[k], rg[k], of[k])
+        some_dropped |= 0 < len(want) < len(r)
+        assert got_len[k] == len(want), (k, got_len[k], len(want))
+        pa, kept, total = device.download_pa(int(slots[k]), keep)
+        assert total == len(want) and kept == min(len(want), keep)
+        assert np.array_equal(bits(pa), bits(want[:keep])), k
+    assert some_dropped
+    pin.close()
+
+
+def test_resident_reads_give_the_same_records_as_uploaded_pa(device, small_world):
+    """The two ways of feeding a batch -- pA chunks uploaded with the batch, or chunks cut on the device
+    out of resident reads converted from raw ADC counts -- give identical result records, for one-chunk
+    reads and for chunk 0 / chunk 1 of two-chunk reads."""
+    raw = small_world["raw"]
+    pa = small_world["pa"]
+    samples, offsets = _batch(pa)
+    base = device.map_chunks(samples, offsets, n_refs=3)
+    n = len(raw)
+    flat = np.ascontiguousarray(np.concatenate(raw).astype(np.int16))
+    ro = (np.arange(n + 1) * raw.shape[1]).astype(np.uint64)
+    device.configure_reads(n, 8000)
+    lens = device.upload_raw(flat, ro, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+    assert np.array_equal(lens, [len(x) for x in pa])
+    device.select(np.arange(n), np.zeros(n))
+    device.run(3); device.sync()
+    assert device.download().tobytes() == base.tobytes()
+    # two-chunk reads: slot k holds read 2k followed by read 2k+1
+    m = n // 2
+    ro2 = (np.arange(m + 1) * 2 * raw.shape[1]).astype(np.uint64)
+    lens2 = device.upload_raw(flat[:int(ro2[-1])], ro2, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+    assert np.array_equal(lens2, [len(pa[2 * k]) + len(pa[2 * k + 1]) for k in range(m)])
+    assert all(len(x) == 4000 for x in pa)   # (the generator's reads lose nothing to the filter)
+    sl = np.repeat(np.arange(m), 2)
+    ci = np.tile([0, 1], m)
+    device.select(sl, ci)
+    device.run(3); device.sync()
+    assert device.download().tobytes() == base[:2 * m].tobytes()
+    with pytest.raises(RuntimeError):   # a chunk beyond what a slot keeps is refused, not clipped silently
+        device.select([0], [2])
+
+
 # ------------------------------------------------------------------ seed lookup (A10)
 
 @pytest.mark.parametrize("blocks,strict", [(0, 0), (0, 1), (1, 0), (8, 1), (8, 0)])
