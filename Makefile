@@ -34,7 +34,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sigmap_hip.h
 
 $(LIBDIR)/libsigmap_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 cli: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so
 	@mkdir -p sigmap_amd/bin

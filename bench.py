@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- signal chunks/sec (4k-sample reads) mapped to a yeast-sized (12 Mb) reference.
 
-One "step" = one pass of the hot path (event detection -> k-d radius seed lookup -> anchor
-sort -> chaining) over one batch of synthetic 4000-sample chunks that is already resident in
-HBM.  At N=1 the workload is BASELINE.json configs[1]: 10 000 reads x 1 chunk vs 16 x 750 kb.
-For N>1 (launched by torch.distributed.run, one rank per GPU) rank 0 builds the index, the
-device-resident index arrays are replicated by one RCCL broadcast each, every rank maps its
-own 10 000-chunk shard (weak scaling, no data-path collective), and the reported value is
-(chunks processed by all ranks) / (max over ranks of the timed region).
+One "step" = one pass of the hot path (event detection -> k-d radius seed lookup -> anchor sort ->
+chaining -> banded sDTW refinement) over one batch of synthetic 4000-sample chunks.  At N=1 the
+workload is BASELINE.json configs[1]: 10 000 reads x 1 chunk vs 16 x 750 kb.  For N>1 (launched by
+torch.distributed.run, one rank per GPU) rank 0 builds the index, the device-resident index arrays
+are replicated by one RCCL broadcast each, every rank maps its own 10 000-chunk shard (weak scaling,
+no data-path collective), and the reported value is (chunks of all ranks) / (max over ranks of the
+timed region).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : algorithmic bytes of the dominant kernel (seed_lookup) / its HIP-event launch time
-  cpu_baseline : the CPU restatement (oracle/, "port") timed on a bounded sample, rank 0, N=1
+Two timed regions of EXACTLY K steps each, both fenced by barrier + synchronize:
+  value          : inputs resident in HBM when the region starts (the reads were converted from their
+                   ADC counts into the contexts' slots beforehand) -- the contract's definition;
+  pcie_inclusive : every step first copies its reads' int16 ADC counts from pinned host memory
+                   (DMA on a copy stream) and converts them on the device ("reads
+                   resident in host RAM").
+
+Prints ONE JSON line on rank 0, including
+  roofline     : HBM traffic of the dominant kernel (seed_lookup) from calibrated counters / its launch
+                 duration, next to the kernel's own algorithmic bytes and the reference algorithm's
+  cpu_baseline : the CPU restatement (oracle/, "port") timed on bounded samples, rank 0, N=1
 """
 import argparse
-import ctypes as C
+import datetime
 import json
 import os
 import sys
@@ -26,8 +34,10 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_STREAM_GBS = 6290.0    # same guide: measured streaming ceiling (float4 copy)
 CHUNK = 4000
+REF_CHUNKS_PER_S_PER_CORE = 19.6  # unmodified reference, -t 1, 12 Mb (survey probe)
 
 
 def parse():
@@ -40,8 +50,9 @@ def parse():
     ap.add_argument("--contig-len", type=int, default=750000)
     ap.add_argument("--walk-blocks", type=int, default=0, help="tree-walker workgroups per CU (0 = default)")
     ap.add_argument("--fast-cap", type=int, default=0, help="fast hit slots per query (0 = default)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 = auto, 0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU-baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive timed region")
     ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
@@ -49,37 +60,42 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ix, pa_list, n_refs, ref_lens, n_sample):
-    """Times the oracle (CPU restatement of the reference path) on a bounded sample with one
-    thread per host core (the reference parallelises over reads the same way, sigmap.cc:618-630).
-    This is the only place bench.py touches oracle/: as the measured CPU baseline."""
+def cpu_baseline(ix, pa_list, n_refs, ref_lens, seconds):
+    """The oracle (CPU restatement of the reference path) on bounded samples of the same reads: one
+    thread (BASELINE configs[0] is `-t 1`), then one thread per host core (the reference parallelises
+    over reads the same way, sigmap.cc:618-630).  This is the only place bench.py touches oracle/: as
+    the measured CPU baseline."""
     from oracle import pyoracle as po
-    cores = min(os.cpu_count() or 1, 32)
-    n_sample = min(n_sample, len(pa_list))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     tree = po.OracleTree(ix.values.copy())
     positions = np.ascontiguousarray(ix.positions)
-    idx = list(range(n_sample))
-    lock = threading.Lock()
 
-    def work():
-        while True:
-            with lock:
-                if not idx:
-                    return
-                i = idx.pop()
-            po.map_read(tree, positions, pa_list[i], n_refs, ref_lens)
+    def run(n_threads, n_sample):
+        sample = [pa_list[i % len(pa_list)] for i in range(n_sample)]
+        t0 = time.perf_counter()
+        po.map_reads(tree, positions, sample, n_refs, ref_lens, n_threads)   # OpenMP loop in the C oracle
+        dt = time.perf_counter() - t0
+        return n_sample / dt, dt
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work) for _ in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    probe, _ = run(1, 8)                                   # sizes the samples (about `seconds` per leg)
+    n1 = max(16, int(probe * seconds))
+    r1, s1 = run(1, n1)
+    pilot, _ = run(cores, cores * 2)                       # the parallel rate is not cores x the serial one
+    nall = max(cores * 4, int(pilot * seconds))
+    rall, sall = run(cores, nall)
     tree.close()
-    return {"value": round(n_sample / dt, 2), "unit": "chunks/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} of the same synthetic 4000-sample reads, same 12 Mb index, "
-                      f"oracle/sigmap_oracle.c so_map_read on {cores} threads, {dt:.1f} s"}
+    return {"value": round(rall, 2), "unit": "chunks/s", "cores": cores, "kind": "port",
+            "sample": f"{nall} chunks (the same synthetic 4000-sample reads, same 12 Mb index) through "
+                      f"oracle/sigmap_oracle.c so_map_reads (OpenMP) on {cores} threads in {sall:.1f} s; "
+                      f"-t 1 leg: {n1} chunks in {s1:.1f} s",
+            "t1_value": round(r1, 2), "per_core": round(rall / cores, 2),
+            "reference_t1_chunks_per_s": REF_CHUNKS_PER_S_PER_CORE,
+            "t1_vs_reference_t1": round(r1 / REF_CHUNKS_PER_S_PER_CORE, 3),
+            "note": "reference_t1 = the unmodified reference with -t 1 on the survey container's Xeon 2.1 GHz "
+                    "(BASELINE.md section 2); the port does the same work per read (same node visits, same hits)"}
 
 
 def main():
@@ -89,15 +105,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    import torch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything initialises HIP
+    import torch   # first: the process ends up with ONE HIP runtime, the one torch brings (multigpu.py)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs visible")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=600))
 
     from sigmap_amd import pipeline, synth
     from sigmap_amd.multigpu import replicate_index
@@ -124,16 +143,29 @@ def main():
     keepalive = replicate_index(dev, ix, rank, world, local_rank, dist)  # RCCL broadcast when world > 1
     pool.share_index()  # the other contexts of this GPU borrow the same arrays
 
-    raw, _ = synth.simulate_reads(genome, lm, args.reads, seed=1000 + rank)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
-    offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
-    samples = np.concatenate(pa)
-    pool.for_each(lambda dv: dv.upload_batch(samples, offsets))  # inputs resident in HBM before the timed region
+    R = args.reads
+    raw, _ = synth.simulate_reads(genome, lm, R, seed=1000 + rank)
+    # the rank's reads as they sit in host RAM: int16 ADC counts in pinned memory (one DMA per batch)
+    pinned = pipeline.PinnedArray((R * CHUNK,), np.int16)
+    pinned.array[:] = raw.reshape(-1)
+    raw_off = (np.arange(R + 1, dtype=np.uint64) * CHUNK)
+    slots = np.arange(R, dtype=np.uint32)
+    chunk0 = np.zeros(R, dtype=np.uint32)
+
+    def upload(dv, want_len=False):
+        return dv.upload_raw(pinned.array, raw_off, synth.DIGITISATION, synth.RANGE, synth.OFFSET, want_len=want_len)
+
+    pool.for_each(lambda dv: dv.configure_reads(R, CHUNK))
+    lens = [upload(dv, want_len=True) for dv in pool.devs]   # inputs resident in HBM from here on
+    assert all(int(l.min()) == CHUNK for l in lens), "the generator's reads lose no sample to the (30,200) pA filter"
     if args.sdtw_band > 0:
         ref_sig, ref_off = pipeline.reference_signals(genome, lm)
         pool.for_each(lambda dv: dv.upload_reference(ref_sig, ref_off))
 
-    def step(dv=dev, _i=0):
+    def step(dv=dev, _i=0, with_upload=False):
+        if with_upload:
+            upload(dv)                       # async: H2D on the copy stream, conversion waits for it
+        dv.select(slots, chunk0, CHUNK)
         dv.run(n_refs)
         if args.sdtw_band > 0:
             dv.refine(band=args.sdtw_band, pad=32)
@@ -145,12 +177,12 @@ def main():
     # Census (untimed): one pass with the walker restricted to exactly nanoflann's node set, so
     # that nodes_visited / points_tested count the REFERENCE's work on these inputs (SURVEY 8d:
     # "counted on the actual inputs").  The timed passes skip subtrees whose tight box is out of
-    # range (same hits, same order) and therefore touch fewer bytes than the algorithmic figure.
+    # range (same hits, same order) and therefore touch fewer bytes than that figure.
     dev.params.reference_walk = 1
     census, _ = step()
     dev.params.reference_walk = 0
     # warm-up: W steps, and one on every context (each sizes its own scratch and hit pool)
-    pool.for_each(lambda dv: step(dv))
+    pool.for_each(lambda dv: step(dv, with_upload=True))
     if args.warmup > len(pool.devs):
         pool.run_steps(args.warmup - len(pool.devs), step)
     pool.for_each(lambda dv: (dv.timing(True), dv.timing_reset()))
@@ -164,46 +196,62 @@ def main():
     def kernel_times(devs):
         # per-kernel device time (HIP events on each context's stream)
         kern = {}
-        for name in ["events", "seed_lookup", "sort", "chain", "sdtw"]:
+        for name in ["convert", "events", "seed_lookup", "sort", "chain", "sdtw"]:
             got = [dv.timing_get(name) for dv in devs]  # (mean ms, launches) per context
             n = sum(int(g[1]) for g in got)
             ms = sum(g[0] * g[1] for g in got) / max(n, 1)
             kern[name] = {"mean_ms": round(ms, 4), "launches": n}
         return kern
 
-    # Reference pass (not the reported value): the same K steps strictly one after the other on one
-    # context, so that every kernel has the GPU to itself -- the standalone kernel durations.
-    serial = None
-    if len(pool.devs) > 1:
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(dev, i)
-        fence()
-        serial = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "kernels": kernel_times([dev])}
-        pool.for_each(lambda dv: dv.timing_reset())
-
-    fence()
-    t0 = time.perf_counter()
-    # EXACTLY K steps, each on the context that is free next; the contexts start a fraction of a step
-    # apart (inside the timed region), so that their tree walks alternate from the first step on
-    stagger = (serial["ms_per_step"] * 1e-3 / len(pool.devs)) if serial is not None else 0.0
-    results = pool.run_steps(args.steps, step, stagger_s=stagger)
-    fence()
-    dt = time.perf_counter() - t0
-    res, refined = results[-1]
-    contexts_agree = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results)
-    if dist is not None:
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
-    # inside the timed region kernels of different batches run concurrently, so a launch's duration
-    # includes the time it shares the GPU with the other context's kernels
-    kern = kernel_times(pool.devs)
+    # Reference pass (not the reported value): the same K steps strictly one after the other on one
+    # context, so that every kernel has the GPU to itself -- the standalone kernel durations.
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(dev, i)
+    fence()
+    serial = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "kernels": kernel_times([dev])}
+    pool.for_each(lambda dv: dv.timing_reset())
+
+    # ---- timed region 1 (value): EXACTLY K steps, inputs resident in HBM, each on the context that is
+    # free next; the contexts start a fraction of a step apart (inside the timed region), so that their
+    # tree walks alternate from the first step on
+    stagger = (serial["ms_per_step"] * 1e-3 / len(pool.devs)) if len(pool.devs) > 1 else 0.0
+    fence()
+    t0 = time.perf_counter()
+    results = pool.run_steps(args.steps, step, stagger_s=stagger)
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    res, refined = results[-1]
+    contexts_agree = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results)
+    kern = kernel_times(pool.devs)  # (with batches in flight: brackets include queueing behind the other stream)
+
+    # ---- timed region 2 (pcie_inclusive): the same K steps, each starting with the DMA of its reads'
+    # ADC counts from pinned host memory and their conversion on the device
+    pcie = None
+    if not args.no_pcie:
+        pool.for_each(lambda dv: dv.timing_reset())
+        fence()
+        t0 = time.perf_counter()
+        results2 = pool.run_steps(args.steps, lambda dv, i: step(dv, i, with_upload=True), stagger_s=stagger)
+        fence()
+        dt2 = max_over_ranks(time.perf_counter() - t0)
+        same2 = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results2)
+        pcie = {"value": round(R * world * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                "h2d_bytes_per_step": int(R * CHUNK * 2), "results_identical": bool(same2),
+                "convert_kernel_ms": kernel_times(pool.devs)["convert"]["mean_ms"],
+                "vs_resident": round(dt / dt2, 4),
+                "what": "every step copies its reads' int16 ADC counts from pinned host memory (hipMemcpyAsync on a "
+                        "copy stream) and converts them on the device before mapping"}
 
     if rank == 0:
-        R = args.reads
         status_bad = int((res["status"] & ~np.uint32(1)).astype(bool).sum())
         nodes = int(census["nodes_visited"].sum())
         points = int(census["points_tested"].sum())
@@ -211,24 +259,27 @@ def main():
                    if k not in ("nodes_visited", "points_tested"))
         anchors = int(res["n_anchors"].sum())
         queries = int(res["n_queries"].sum())
-        # B_chunk = 2*S + Q*(Nn*16 + Np*28) + 24*A + 64, counted on the actual inputs
-        bytes_per_launch = 2 * CHUNK * R + 16 * nodes + 28 * points + 24 * anchors + 64 * R
-        # Launch duration of the dominant kernel: HIP events around the seed-lookup stage.  With one
-        # batch in flight that bracket is the stage's kernels (rocprofv3's kernel trace of the same
-        # command with --depth 1 agrees: profiles/).  With several in flight a launch has no single
-        # duration -- the bracket also spans the time the stage's kernels queue behind the other
-        # stream's, and two walkers that meet share the chip -- so the roofline uses the serial pass
-        # of this same run.
-        seed_ms_overlapped = kern["seed_lookup"]["mean_ms"]
-        seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"] if serial is not None else seed_ms_overlapped
-        achieved = bytes_per_launch / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        w_nodes = int(res["nodes_visited"].sum())
+        w_points = int(res["points_tested"].sum())
+        # B_chunk = 2*S + Q*(Nn*16 + Np*28) + 24*A + 64 with the REFERENCE's node visits and
+        # point tests, counted on the actual inputs (census pass)
+        ref_bytes = 2 * CHUNK * R + 16 * nodes + 28 * points + 24 * anchors + 64 * R
+        # the walker's own bytes: what it reads by its own layout -- one 64-byte record per node visit
+        # (leaf visits read no record: an upper bound), 32 bytes per point tested, 16 bytes per hit
+        # written, the query records -- i.e. what a perfect memory system would have to move for it
+        own_bytes = 64 * w_nodes + 32 * w_points + 16 * int(res["hits_total"].sum()) + 64 * queries
+        seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"]
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("seed_lookup_hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
+                traffic_src = j.get("source")
             except Exception:
                 traffic = None
+        basis = traffic if traffic else own_bytes
+        achieved = basis / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         total_chunks = R * world * args.steps
         out = {
             "metric": "signal chunks/sec (4k-sample reads) mapped to yeast ref",
@@ -246,20 +297,20 @@ def main():
             "config": {
                 "workload": f"{R} synthetic 4000-sample reads (1 chunk each) per GPU vs {n_refs} x "
                             f"{args.contig_len} bp random reference (yeast-sized), event+seed+sort+chain"
-                            f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU",
+                            f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU; "
+                            "inputs resident in HBM (pcie_inclusive: copied from pinned host RAM every step)",
                 "chunks_per_gpu_per_step": R,
                 "batches_in_flight": len(pool.devs),
                 "contexts_agree": bool(contexts_agree),
-                "index_points": int(dev_index_points(ix)) if ix is not None else None,
+                "index_points": int(ix.n_points) if ix is not None else None,
                 "mapped_fraction": round(float((res["n_chains"] > 0).mean()), 4),
                 "queries_per_chunk": round(queries / R, 2),
                 "nodes_per_query": round(nodes / max(queries, 1), 1),
                 "points_per_query": round(points / max(queries, 1), 1),
-                "walker_nodes_per_query": round(int(res["nodes_visited"].sum()) / max(queries, 1), 1),
-                "walker_points_per_query": round(int(res["points_tested"].sum()) / max(queries, 1), 1),
+                "walker_nodes_per_query": round(w_nodes / max(queries, 1), 1),
+                "walker_points_per_query": round(w_points / max(queries, 1), 1),
                 "census_results_identical": bool(same),
                 "anchors_per_chunk": round(anchors / R, 1),
-                "algorithmic_bytes_per_chunk": round(bytes_per_launch / R),
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
                 "walker_phase_stats": walker_stats(dev),
@@ -268,6 +319,7 @@ def main():
                 "index_build_s": round(t_build, 2),
                 "kernels": kern,  # event brackets in the timed region (with batches in flight: incl. queueing)
             },
+            "pcie_inclusive": pcie,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "seed_lookup",
@@ -276,30 +328,39 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
+                "basis": ("calibrated memory-side counters (profiles/r2_calibration.json: every L2 read miss is a "
+                          "128-byte request, writes by WRITE_SIZE), per launch, from the profile run named in "
+                          "traffic_source" if traffic else
+                          "the walker's own algorithmic bytes (no counter profile found under profiles/)"),
+                "frac_of_measured_streaming_ceiling": round(achieved / HBM_STREAM_GBS, 4),
                 "launch_ms": round(seed_ms, 4),
-                "measured": ("HIP events, serial pass of this run (one batch in flight)" if serial is not None
-                             else "HIP events, timed region"),
-                "launch_ms_bracket_in_timed_region": round(seed_ms_overlapped, 4),
-                "note": ("achieved = algorithmic bytes of the REFERENCE algorithm (census of nanoflann's node "
-                         "visits and point tests on these inputs, SURVEY 8d) / launch duration; the kernel "
-                         "returns the same hits while pruning exactly and moves `traffic` bytes, so the "
-                         "ratio to the HBM peak can exceed 1 (DESIGN.md 4.2 says what bounds the kernel)"),
+                "measured": "HIP events on the context stream, serial pass of this run (one batch in flight)",
+                "launch_ms_bracket_in_timed_region": round(kern["seed_lookup"]["mean_ms"], 4),
+                "own_algorithmic_bytes_per_launch": own_bytes,
+                "own_algorithmic_gbs": round(own_bytes / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,
+                "reference_algorithm_bytes_per_launch": ref_bytes,
+                "reference_algorithm_equiv_gbs": round(ref_bytes / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,
+                "note": ("frac = HBM-side bytes the kernel really moves / launch duration / 8 TB/s.  "
+                         "reference_algorithm_equiv_gbs prices the REFERENCE's node visits and point tests "
+                         "(SURVEY 8d formula, census pass) at this kernel's speed -- the kernel returns the same "
+                         "hits while pruning exactly, so that figure is not a utilisation and may exceed the peak"),
             },
-        }
-        if serial is not None:
-            out["serial_steps"] = {  # the reference pass above: one batch in flight, kernels run alone
+            "serial_steps": {  # the reference pass above: one batch in flight, kernels run alone
                 "ms_per_step": round(serial["ms_per_step"], 3),
                 "value": round(R * world / (serial["ms_per_step"] * 1e-3), 1),
                 "kernels": serial["kernels"],
-            }
-        if world == 1 and not args.no_cpu and args.cpu_sample != 0:
-            n_sample = args.cpu_sample if args.cpu_sample > 0 else 24 * min(os.cpu_count() or 1, 32)
-            out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, n_sample)
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw[:4096]]
+            out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     del keepalive
+    pinned.close()
 
 
 def walker_stats(dev):
@@ -307,10 +368,6 @@ def walker_stats(dev):
     c = dev.debug_counters()[8:16].view(np.uint64)
     return {"walk_iters": int(c[0]), "walk_lanes": round(float(c[1]) / max(int(c[0]), 1), 1),
             "scan_iters": int(c[2]), "scan_lanes": round(float(c[3]) / max(int(c[2]), 1), 1)}
-
-
-def dev_index_points(ix):
-    return ix.n_points
 
 
 if __name__ == "__main__":

@@ -113,6 +113,18 @@ typedef struct {
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
 /* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in);
+/* Copy exported array `array_id` (0 nodes, 1 leaf_tab, 2 leaf_pts, 3 leaf_vind, 4 bbox) into device
+ * memory the caller owns on the same GPU -- e.g. a torch tensor that torch.distributed then broadcasts
+ * (the copy runs on this library's HIP runtime and stream, not through a second runtime handle). */
+int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint64_t dst_bytes);
+/* Replicate the index of ctxs[root] onto the other contexts, ONE context per GPU of this process:
+ * one RCCL broadcast per walker array over xGMI (RCCL is used directly,
+ * ncclCommInitAll + ncclBroadcast inside one group call).  The reference has no counterpart (it is
+ * a single-process OpenMP program, sigmap.cc:618-632); reads then shard over the GPUs with no
+ * further communication.  n_gpus == 1 is a no-op.  Errors are reported on ctxs[root]. */
+int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root);
+/* GPUs visible to this process (0 when there is none / no HIP runtime). */
+int smhip_device_count(void);
 
 /* ---- one batch of signal chunks: replaces the body of the taskloop in
  * Sigmap::StreamingMap (sigmap.cc:647-666): GenerateEvents + GenerateChains per chunk ---- */
@@ -236,6 +248,17 @@ int smhip_reference_upload(smhip_ctx *ctx, const float *signals, const uint64_t 
 int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad);
 int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos);
 
+/* The same refinement with fast_dtw.cc::DTW()'s recurrence and its path (smhip_dtw_path below, D5):
+ * window and band exactly as smhip_refine_run.  Download: dist / end_pos as above but end_pos and
+ * start_pos are 0-based absolute target indices of the path's last / first cell (-1: no alignment);
+ * path_codes[path_off[c] .. + path_len[c]) = the path's codes from its first to its last cell
+ * (smhost_print_alignment gives the reference's per-base CIGAR).  path_codes may be NULL (lengths
+ * only); path_cap >= path_off[n_chunks] otherwise (SMHIP_ECAP tells that it was too small; the
+ * offsets are valid then). */
+int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad);
+int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, int64_t *start_pos,
+                               uint32_t *path_len, uint64_t *path_off, uint8_t *path_codes, uint64_t path_cap);
+
 /* Diagnostic counters of the last smhip_map_run: [0] stack-overflow flag, [1] queries that needed
  * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag. */
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
@@ -287,6 +310,22 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
 int smhip_sdtw_banded(smhip_ctx *ctx, const float *target, const uint64_t *t_off,
                       const float *query, const uint64_t *q_off, const uint32_t *lo,
                       const uint32_t *hi, uint32_t n_problems, float *dist, int64_t *end);
+
+/* fast_dtw.cc::DTW() (fast_dtw.cc:74-140) over per-row column windows, with its path: the same
+ * problem layout as smhip_sdtw_banded, but the recurrence has four candidates
+ *   { D[t-1][q-1] + c, D[t][q-1] + c, D[t][q-1] + 2, D[t-1][q] + 2 },  c = |target - query|
+ * (the "skip" moves cost a flat 2, fast_dtw.cc:76-77,113), the first minimum's index 0..3 is the
+ * cell's path code (0 one-to-one, 1 one base to several signals, 2 skip one signal, 3 skip one base),
+ * and a row can end the alignment only if its window reaches the last query column.  dist[i] /
+ * end[i]: distance and 0-based target coordinate of the end row (fast_dtw.cc:138; FLT_MAX / -1 when
+ * no row ends with a finite value).  path_codes[path_off[i] .. + path_len[i]): the codes along
+ * generate_path's path (fast_dtw.cc:51-72) from its first cell (query column 0, target coordinate
+ * start_target[i]) to the end cell; capacity path_off[i+1] - path_off[i] >= T_i + Q_i.
+ * smhost_print_alignment (sigmap_host.h) turns the codes into the reference's per-base CIGAR. */
+int smhip_dtw_path(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
+                   const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n_problems,
+                   float *dist, int64_t *end, uint8_t *path_codes, const uint64_t *path_off,
+                   uint32_t *path_len, int64_t *start_target);
 
 #ifdef __cplusplus
 }

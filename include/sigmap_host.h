@@ -87,6 +87,15 @@ typedef struct {
 } smhost_map_params; /* CLI defaults, sigmap.cc:1380-1419 */
 void smhost_default_map_params(smhost_map_params *p);
 
+/* print_alignment, fast_dtw.cc:160-209: the per-base CIGAR "(..)(..)" of a DTW path given as its
+ * codes (smhip_dtw_path).  Returns the length of the CIGAR (written NUL-terminated, truncated to cap). */
+int64_t smhost_print_alignment(const uint8_t *codes, uint64_t n, char *out, uint64_t cap);
+
+/* Read sharding of `sigmap -m --gpus N`: part `rank` of `world` maps the
+ * contiguous block [*lo, *hi) of n_items reads (read i -> part i * world / n_items); rows are merged by
+ * (reference index, read index), the reference's -t 1 order (sigmap.cc:201-213,223-238). */
+void smhost_shard_range(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t *hi);
+
 /* sigmap.cc:667-687: 1 = stop feeding chunks of this read */
 int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p);
 /* sigmap.cc:690-865 + output_tools.h:200-210,336-354: PAF line (without the wall-clock

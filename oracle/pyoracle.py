@@ -111,11 +111,17 @@ def lib():
         L.so_seed_positions.argtypes = [sz, C.c_int, C.c_int, vp]
         L.so_default_params.argtypes = [C.POINTER(MapParams)]
         L.so_map_read.argtypes = [vp, vp, vp, sz, sz, vp, C.POINTER(MapParams), C.POINTER(Mapping)]
+        L.so_map_reads.argtypes = [vp, vp, vp, vp, sz, sz, vp, C.POINTER(MapParams), vp, C.c_int]
         L.so_format_paf.argtypes = [C.POINTER(Mapping), C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, sz]
         L.so_sdtw.restype = C.c_float
         L.so_sdtw.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_int64)]
         L.so_sdtw_banded.restype = C.c_float
         L.so_sdtw_banded.argtypes = [vp, sz, vp, sz, vp, vp, C.POINTER(C.c_int64)]
+        L.so_dtw_window.restype = C.c_float
+        L.so_dtw_window.argtypes = [vp, sz, vp, sz, vp, vp, C.POINTER(C.c_int64), vp, C.POINTER(sz),
+                                    C.POINTER(C.c_int64)]
+        L.so_print_alignment.restype = sz
+        L.so_print_alignment.argtypes = [vp, sz, C.c_char_p, sz]
         _lib = L
     return _lib
 
@@ -254,6 +260,20 @@ def map_read(tree, positions, signal_pa, n_refs, ref_lens, params=None):
     return m
 
 
+def map_reads(tree, positions, pa_list, n_refs, ref_lens, n_threads):
+    """so_map_reads: the reads of pa_list on n_threads OpenMP threads; returns the Mapping array."""
+    flat = np.ascontiguousarray(np.concatenate(pa_list), dtype=np.float32)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in pa_list])]).astype(np.uint64)
+    positions = np.ascontiguousarray(positions, dtype=np.uint64)
+    ref_lens = np.ascontiguousarray(ref_lens, dtype=np.uint32)
+    p = MapParams()
+    lib().so_default_params(C.byref(p))
+    out = (Mapping * len(pa_list))()
+    lib().so_map_reads(tree.h, _p(positions), _p(flat), _p(offs), len(pa_list), n_refs, _p(ref_lens), C.byref(p),
+                       C.cast(out, C.c_void_p), n_threads)
+    return out
+
+
 def format_paf(m, read_name, ref_names, ref_lens):
     buf = C.create_string_buffer(2048)
     lib().so_format_paf(C.byref(m), read_name.encode(), ref_names[m.ref].encode(), int(ref_lens[m.ref]), buf, 2048)
@@ -276,6 +296,28 @@ def sdtw_banded(target, query, lo, hi):
     end = C.c_int64()
     d = lib().so_sdtw_banded(_p(t), len(t), _p(q), len(q), _p(lo), _p(hi), C.byref(end))
     return d, end.value
+
+
+def dtw_window(target, query, lo, hi):
+    """fast_dtw.cc::DTW over per-row windows + generate_path: (dist, end target 0-based, path codes
+    start -> end, start target 0-based)."""
+    t = np.ascontiguousarray(target, dtype=np.float32)
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    lo = np.ascontiguousarray(lo, dtype=np.uint32)
+    hi = np.ascontiguousarray(hi, dtype=np.uint32)
+    end, st, n = C.c_int64(), C.c_int64(), C.c_size_t()
+    codes = np.zeros(len(t) + len(q) + 1, np.uint8)
+    d = lib().so_dtw_window(_p(t), len(t), _p(q), len(q), _p(lo), _p(hi), C.byref(end), _p(codes), C.byref(n),
+                            C.byref(st))
+    return d, end.value, codes[:n.value].copy(), st.value
+
+
+def print_alignment(codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n = lib().so_print_alignment(_p(codes), len(codes), None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    lib().so_print_alignment(_p(codes), len(codes), buf, int(n) + 1)
+    return buf.value.decode()
 
 
 # ---- CWT feature path (D1-D3)

@@ -1383,6 +1383,174 @@ float so_sdtw_banded(const float *target, size_t tlen, const float *query, size_
 }
 
 
+/* The reference's read loop (sigmap.cc:618-632: one OpenMP task per read over a shared read-only index):
+ * n reads, read i = signal_pa[offsets[i] .. offsets[i+1]), on n_threads threads.  Used by bench.py's
+ * cpu_baseline leg and nothing else.  Compiled with -fopenmp; without it the loop runs serially. */
+void so_map_reads(const so_kdtree *t, const uint64_t *positions, const float *signal_pa, const uint64_t *offsets,
+                  size_t n, size_t n_refs, const uint32_t *ref_lens, const so_map_params *p, so_mapping *out,
+                  int n_threads) {
+  long i;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (i = 0; i < (long)n; ++i)
+    so_map_read(t, positions, signal_pa + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), n_refs, ref_lens, p,
+                &out[i]);
+}
+
+/* ===================== windowed DTW with path (D5) =====================
+ * fast_dtw.cc::DTW(), fast_dtw.cc:74-140, over a window whose row i holds the query columns
+ * lo[i]..hi[i] (1-based, inclusive, clipped to [1, qlen]) -- the shape of the rows expand_window()
+ * produces (fast_dtw.cc:11-49: sorted by target, then query) when the window is a band.
+ * Rows: previous_row = {0, FLT_MAX, ...} before row 0 and current_row[0] = 0 in every row (free start
+ * on the target, :94-99); four candidates in this order (:113)
+ *     { prev[q-1] + cost, cur[q-1] + cost, cur[q-1] + skip_query_cost(2), prev[q] + skip_target_cost(2) }
+ * with std::min_element's FIRST minimum, whose index 0..3 is the cell's path code (:127-129); a row
+ * is a candidate end iff its LAST cell is the last query column and its value is < the best so far
+ * (:131-134).  Cells outside the window stay FLT_MAX (the row buffers are re-filled with it, :136).
+ * generate_path (:51-72) walks back from the end row's last cell until it reaches query column 0
+ * (shifts by code: {-1,-1},{0,-1},{0,-1},{-1,0} in (target, query)), includes that cell, and reverses.
+ * Returns the distance; *end_target = 0-based target coordinate of the end row (:138), -1 if no row
+ * ends in the last column with a finite value (the reference would index window[-1] there);
+ * path_codes[0..*path_len) = the codes from the path's first cell to its last (cap tlen + qlen);
+ * *start_target = 0-based target coordinate of the first cell.
+ * PARITY UNPINNED: fast_dtw.cc includes signal_batch.h -> <slow5/slow5.h>, absent from this image. */
+float so_dtw_window(const float *target, size_t tlen, const float *query, size_t qlen, const uint32_t *lo,
+                    const uint32_t *hi, int64_t *end_target, uint8_t *path_codes, size_t *path_len,
+                    int64_t *start_target) {
+  float best = FLT_MAX;
+  int64_t end_row = -1;
+  *end_target = -1;
+  if (path_len) *path_len = 0;
+  if (start_target) *start_target = -1;
+  if (tlen == 0 || qlen == 0) return best;
+  size_t *row_off = (size_t *)malloc((tlen + 1) * sizeof(size_t));
+  uint32_t *ra = (uint32_t *)malloc(tlen * sizeof(uint32_t)), *rb = (uint32_t *)malloc(tlen * sizeof(uint32_t));
+  size_t cells = 0;
+  for (size_t i = 0; i < tlen; ++i) {
+    ra[i] = lo[i] < 1 ? 1 : lo[i];
+    rb[i] = hi[i] > qlen ? (uint32_t)qlen : hi[i];
+    row_off[i] = cells;
+    if (rb[i] >= ra[i]) cells += rb[i] - ra[i] + 1;
+  }
+  row_off[tlen] = cells;
+  uint8_t *code = (uint8_t *)malloc(cells ? cells : 1);
+  float *prev = (float *)malloc((qlen + 1) * sizeof(float));
+  float *cur = (float *)malloc((qlen + 1) * sizeof(float));
+  for (size_t q = 0; q <= qlen; ++q) prev[q] = cur[q] = FLT_MAX;
+  prev[0] = 0;
+  for (size_t i = 0; i < tlen; ++i) {
+    cur[0] = 0;
+    if (rb[i] >= ra[i]) {
+      for (size_t qp = ra[i]; qp <= rb[i]; ++qp) {
+        const float cost = fabsf(target[i] - query[qp - 1]);
+        const float cand[4] = {prev[qp - 1] + cost, cur[qp - 1] + cost, cur[qp - 1] + 2.0f, prev[qp] + 2.0f};
+        int arg = 0;
+        for (int k = 1; k < 4; ++k)
+          if (cand[k] < cand[arg]) arg = k; /* std::min_element: first of the smallest */
+        cur[qp] = cand[arg];
+        code[row_off[i] + (qp - ra[i])] = (uint8_t)arg;
+      }
+      if (rb[i] == qlen && cur[qlen] < best) { /* query_position of the row's last cell == query_length */
+        best = cur[qlen];
+        end_row = (int64_t)i;
+      }
+    }
+    float *tmp = cur;
+    cur = prev;
+    prev = tmp;
+    for (size_t q = 0; q <= qlen; ++q) cur[q] = FLT_MAX;
+  }
+  if (end_row >= 0) {
+    /* generate_path, fast_dtw.cc:51-72 */
+    size_t n = 0, t = (size_t)end_row, q = qlen; /* q 1-based: query_coord = q - 1 */
+    int ok = 1;
+    while (q != 1) {
+      const uint8_t c = code[row_off[t] + (q - ra[t])];
+      if (path_codes) path_codes[n] = c;
+      ++n;
+      if (c == 0) {
+        if (t == 0) { ok = 0; break; }
+        --t; --q;
+      } else if (c == 3) {
+        if (t == 0) { ok = 0; break; }
+        --t;
+      } else {
+        --q;
+      }
+      if (!(rb[t] >= ra[t] && q >= ra[t] && q <= rb[t])) { ok = 0; break; } /* the reference's map lookup would miss */
+    }
+    if (ok) {
+      if (path_codes) path_codes[n] = code[row_off[t] + (q - ra[t])];
+      ++n;
+      if (path_codes) /* std::reverse */
+        for (size_t a = 0, b = n - 1; a < b; ++a, --b) {
+          const uint8_t x = path_codes[a];
+          path_codes[a] = path_codes[b];
+          path_codes[b] = x;
+        }
+      if (path_len) *path_len = n;
+      if (start_target) *start_target = (int64_t)t;
+    }
+    *end_target = end_row; /* window[end][0].target_coord */
+  }
+  free(row_off); free(ra); free(rb); free(code); free(prev); free(cur);
+  return best;
+}
+
+/* print_alignment, fast_dtw.cc:160-209: per-base CIGAR "(..)(..)" from the path codes (0 one-to-one,
+ * 1 one base to several signals, 2 skip one signal, 3 skip one base; letters "MMID" indexed by the
+ * running flag).  Quirks kept: the run in progress when the path ends is never written, and a final
+ * code 0 / 3 closes the previous base without opening its own.  Returns the length written (without
+ * NUL), or the length needed when it exceeds cap. */
+size_t so_print_alignment(const uint8_t *codes, size_t n, char *out, size_t cap) {
+  static const char flags[] = "MMID";
+  size_t len = 0;
+#define SO_PUT(ch) do { if (len + 1 < cap) out[len] = (ch); ++len; } while (0)
+  if (n == 0) {
+    if (cap) out[0] = 0;
+    return 0;
+  }
+  size_t same = 1;
+  int last;
+  SO_PUT('(');
+  if (codes[0] == 3) {
+    SO_PUT('1'); SO_PUT('D'); SO_PUT(')'); SO_PUT('(');
+    last = 3;
+  } else {
+    last = codes[0] == 0 ? 1 : 2;
+  }
+  char num[24];
+  for (size_t i = 1; i < n; ++i) {
+    const int flag = codes[i];
+    if (flag == 1 || flag == 2) {
+      if (last == flag) {
+        ++same;
+      } else {
+        const int k = snprintf(num, sizeof num, "%zu", same);
+        for (int j = 0; j < k; ++j) SO_PUT(num[j]);
+        SO_PUT(flags[last]);
+        same = 1;
+        last = flag;
+      }
+    } else {
+      const int k = snprintf(num, sizeof num, "%zu", same);
+      for (int j = 0; j < k; ++j) SO_PUT(num[j]);
+      SO_PUT(flags[last]);
+      if (flag == 0) last = 1;
+      else if (flag == 3) last = 3;
+      if (i != n - 1) {
+        SO_PUT(')'); SO_PUT('(');
+        same = 1;
+      }
+    }
+  }
+  SO_PUT(')');
+#undef SO_PUT
+  if (cap) out[len < cap ? len : cap - 1] = 0;
+  return len;
+}
+
 /* ===================== CWT feature path (D1-D3) ===================== */
 static int so_cmp_float(const void *a, const void *b) {
   const float x = *(const float *)a, y = *(const float *)b;

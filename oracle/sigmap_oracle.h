@@ -192,6 +192,10 @@ typedef struct {
 void so_map_read(const so_kdtree *t, const uint64_t *positions, const float *signal_pa,
                  size_t signal_length, size_t n_refs, const uint32_t *ref_lens,
                  const so_map_params *p, so_mapping *out);
+/* n reads on n_threads OpenMP threads (the reference's taskloop, sigmap.cc:618-632); bench.py's CPU baseline */
+void so_map_reads(const so_kdtree *t, const uint64_t *positions, const float *signal_pa, const uint64_t *offsets,
+                  size_t n, size_t n_refs, const uint32_t *ref_lens, const so_map_params *p, so_mapping *out,
+                  int n_threads);
 /* PAF text without the leading "mt:f:" tag.  Returns bytes written (excluding NUL). */
 int so_format_paf(const so_mapping *m, const char *read_name, const char *ref_name,
                   uint32_t ref_len, char *buf, size_t cap);
@@ -206,6 +210,12 @@ float so_sdtw(const float *target, size_t tlen, const float *query, size_t qlen,
  * Cells outside are FLT_MAX.  With lo=1,hi=qlen for all rows this equals so_sdtw. */
 float so_sdtw_banded(const float *target, size_t tlen, const float *query, size_t qlen,
                      const uint32_t *lo, const uint32_t *hi, int64_t *end);
+/* D5: fast_dtw.cc::DTW() (fast_dtw.cc:74-140) over per-row column windows + generate_path (:51-72);
+ * print_alignment (:160-209).  See sigmap_oracle.c. */
+float so_dtw_window(const float *target, size_t tlen, const float *query, size_t qlen, const uint32_t *lo,
+                    const uint32_t *hi, int64_t *end_target, uint8_t *path_codes, size_t *path_len,
+                    int64_t *start_target);
+size_t so_print_alignment(const uint8_t *codes, size_t n, char *out, size_t cap);
 
 /* ---- CWT feature path (dormant in the reference's CLI: CWTAlign, sigmap.cc:932) ---- */
 /* sigmap.cc:1100-1129 GenerateMADNormalizedSignal: the n/2-th order statistic as "median", same

@@ -19,14 +19,14 @@ HIP_SYMBOLS = [
     "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
-    "smhip_host_alloc", "smhip_host_free",
+    "smhip_host_alloc", "smhip_host_free", "smhip_index_export_copy", "smhip_index_bcast", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
     "smhost_index_free", "smhost_index_get", "smhost_reference_signal", "smhost_level_means",
     "smhost_raw_to_pa", "smhost_default_map_params", "smhost_should_stop", "smhost_format_paf",
     "smhost_have_fast5", "smhost_signals_load", "smhost_signals_free", "smhost_signals_count",
-    "smhost_signals_get", "smhost_write_fast5",
+    "smhost_signals_get", "smhost_write_fast5", "smhost_shard_range", "smhost_print_alignment",
 ]
 
 
@@ -149,6 +149,10 @@ def host_lib():
                                          C.POINTER(C.c_float)]
         L.smhost_write_fast5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_void_p), C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.smhost_print_alignment.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        L.smhost_print_alignment.restype = C.c_int64
+        L.smhost_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.smhost_shard_range.restype = None
         L.smhost_default_map_params.argtypes = [C.POINTER(MapParams)]
         L.smhost_should_stop.argtypes = [C.c_void_p, C.POINTER(MapParams)]
         L.smhost_format_paf.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -202,6 +206,12 @@ def hip_lib():
         L.smhip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
         L.smhip_host_free.argtypes = [vp]
         L.smhip_host_free.restype = None
+        L.smhip_index_export_copy.argtypes = [vp, C.c_int, vp, u64]
+        L.smhip_index_bcast.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.smhip_device_count.argtypes = []
+        L.smhip_refine_path_run.argtypes = [vp, u32, u32]
+        L.smhip_refine_path_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64]
+        L.smhip_dtw_path.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]
         L.smhip_seed_lookup.argtypes = [vp, C.POINTER(Params), vp, u32, u32, vp, vp, vp, vp, vp]
         L.smhip_sdtw_banded.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp]
         _hip = L

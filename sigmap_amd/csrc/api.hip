@@ -8,6 +8,8 @@
 
 #include <math.h>
 
+#include <dlfcn.h>
+
 #include <mutex>
 
 #include "common.h"
@@ -214,6 +216,9 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->reads_pa,
                     &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
+                    &ctx->dl_off, &ctx->dl_compact, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
+                    &ctx->rp_qoff, &ctx->rp_qlen, &ctx->rp_lo, &ctx->rp_hi, &ctx->rp_width, &ctx->rp_celloff, &ctx->rp_codes,
+                    &ctx->rp_dist, &ctx->rp_end, &ctx->rp_path, &ctx->rp_plen, &ctx->rp_start,
                     &ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
@@ -385,6 +390,139 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   return SMHIP_OK;
 }
 
+int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint64_t dst_bytes) {
+  if (!ctx || !dst_device) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  smhip_index_dev d;
+  int rc = smhip_index_export(ctx, &d);
+  if (rc) return rc;
+  const void *src[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
+  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
+  if (array_id < 0 || array_id > 4) return Fail(ctx, SMHIP_EINVAL, "array_id must be 0..4");
+  if (dst_bytes < bytes[array_id]) return Fail(ctx, SMHIP_EINVAL, "destination smaller than the array");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(dst_device, src[array_id], bytes[array_id], hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SMHIP_OK;
+}
+
+// RCCL is loaded on first use: single-GPU runs never touch it.  (librccl.so.1; a process that has
+// torch loaded gets torch's copy, the same way it gets torch's HIP runtime.)
+}  // extern "C"
+namespace {
+struct Rccl {
+  typedef void *comm_t;
+  int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*Broadcast)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+const Rccl &LoadRccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      r.why = std::string("cannot load librccl: ") + dlerror();
+      return;
+    }
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.ok = r.CommInitAll && r.CommDestroy && r.Broadcast && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    if (!r.ok) r.why = "librccl lacks an expected symbol";
+  });
+  return r;
+}
+}  // namespace
+extern "C" {
+
+int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
+  if (!ctxs || n_gpus < 1 || root < 0 || root >= n_gpus) return SMHIP_EINVAL;
+  for (int i = 0; i < n_gpus; ++i)
+    if (!ctxs[i]) return SMHIP_EINVAL;
+  smhip_ctx *ctx = ctxs[root];  // errors are reported on the root context
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_index_bcast: the root context has no index");
+  for (int i = 0; i < n_gpus; ++i)
+    for (int j = i + 1; j < n_gpus; ++j)
+      if (ctxs[i]->device == ctxs[j]->device)
+        return Fail(ctx, SMHIP_EINVAL, "smhip_index_bcast needs one context per GPU (contexts of one GPU share the index "
+                                       "with smhip_index_export / smhip_index_attach)");
+  if (n_gpus == 1) return SMHIP_OK;
+  const Rccl &nc = LoadRccl();
+  if (!nc.ok) return Fail(ctx, SMHIP_EHIP, nc.why);
+  smhip_index_dev d;
+  int rc = smhip_index_export(ctx, &d);
+  if (rc) return rc;
+  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
+  void *root_ptr[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
+  // peers: their own buffers for the five walker arrays
+  for (int i = 0; i < n_gpus; ++i) {
+    if (i == root) continue;
+    smhip_ctx *p = ctxs[i];
+    if (hipSetDevice(p->device) != hipSuccess) return Fail(ctx, SMHIP_EHIP, "hipSetDevice(peer)");
+    DevBuf *b[5] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox};
+    for (int a = 0; a < 5; ++a) {
+      hipError_t e = b[a]->Reserve(bytes[a]);
+      if (e != hipSuccess) return HipFail(ctx, e, "peer index allocation");
+    }
+  }
+  std::vector<Rccl::comm_t> comms((size_t)n_gpus, nullptr);
+  std::vector<int> devs((size_t)n_gpus);
+  for (int i = 0; i < n_gpus; ++i) devs[i] = ctxs[i]->device;
+  int nr = nc.CommInitAll(comms.data(), n_gpus, devs.data());
+  if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(nr));
+  // ONE broadcast per array, all ranks of this process inside one group call
+  for (int a = 0; a < 5 && nr == 0; ++a) {
+    nr = nc.GroupStart();
+    for (int i = 0; i < n_gpus && nr == 0; ++i) {
+      smhip_ctx *p = ctxs[i];
+      DevBuf *b[5] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox};
+      void *recv = i == root ? root_ptr[a] : b[a]->p;
+      if (hipSetDevice(p->device) != hipSuccess) nr = 1;
+      if (nr == 0) nr = nc.Broadcast(root_ptr[a], recv, bytes[a], /*ncclUint8*/ 1, root, comms[i], p->stream);
+    }
+    const int ge = nc.GroupEnd();
+    if (nr == 0) nr = ge;
+  }
+  hipError_t he = hipSuccess;
+  for (int i = 0; i < n_gpus; ++i) {
+    if (hipSetDevice(ctxs[i]->device) != hipSuccess) he = hipErrorInvalidDevice;
+    const hipError_t e = hipStreamSynchronize(ctxs[i]->stream);
+    if (he == hipSuccess) he = e;
+  }
+  for (auto c : comms)
+    if (c) (void)nc.CommDestroy(c);
+  if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("RCCL broadcast: ") + nc.GetErrorString(nr));
+  if (he != hipSuccess) return HipFail(ctx, he, "index broadcast");
+  for (int i = 0; i < n_gpus; ++i) {
+    if (i == root) continue;
+    smhip_ctx *p = ctxs[i];
+    p->dim = ctx->dim;
+    p->index = IndexView{p->ix_nodes.as<uint4>(), p->ix_tab.as<uint32_t>(), p->ix_pts.as<float>(),
+                         p->ix_vind.as<uint32_t>(), p->ix_bbox.as<float>(), ctx->index.n_inner, ctx->index.n_leaves,
+                         ctx->index.m_size, ctx->index.root_ref};
+    p->leaf_pts_bytes = ctx->leaf_pts_bytes;
+    p->leaf_vind_bytes = ctx->leaf_vind_bytes;
+    p->have_index = true;
+    p->index_owned = true;
+  }
+  return SMHIP_OK;
+}
+
+int smhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (!ctx || !in) return SMHIP_EINVAL;
   if (in->dim != kMaxDim) return Fail(ctx, SMHIP_EINVAL, "device kernels are built for index dimension 6");
@@ -445,6 +583,7 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   ctx->batch_ready = true;
   ctx->run_done = false;
   ctx->refine_done = false;
+  ctx->refine_path_done = false;
   return SMHIP_OK;
 }
 
@@ -575,6 +714,7 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   ctx->batch_ready = true;
   ctx->run_done = false;
   ctx->refine_done = false;
+  ctx->refine_path_done = false;
   return SMHIP_OK;
 }
 
@@ -760,38 +900,26 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ResolveTimers(ctx);
   if (chain_anchors && chain_anchor_offsets) {
-    DevBuf out_off, compact;
+    // (context-owned scratch: a hipFree here would synchronise the whole device, i.e. stall the other
+    // contexts' streams)
+    DevBuf &out_off = ctx->dl_off, &compact = ctx->dl_compact;
     HIPCHK(out_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t)));
-    hipError_t e = LaunchScanU32ToU64(ctx, ctx->out_anchor_cnt.as<uint32_t>(), R, out_off.as<uint64_t>());
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(chain_anchor_offsets, out_off.p, ((uint64_t)R + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                         ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-      out_off.Free();
-      return HipFail(ctx, e, "chain anchor offsets");
-    }
+    HIPCHK(LaunchScanU32ToU64(ctx, ctx->out_anchor_cnt.as<uint32_t>(), R, out_off.as<uint64_t>()));
+    HIPCHK(hipMemcpyAsync(chain_anchor_offsets, out_off.p, ((uint64_t)R + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     const uint64_t total = chain_anchor_offsets[R];
-    if (total > chain_anchor_cap) {
-      out_off.Free();
-      return Fail(ctx, SMHIP_ECAP, "chain_anchor_cap too small");
-    }
+    if (total > chain_anchor_cap) return Fail(ctx, SMHIP_ECAP, "chain_anchor_cap too small");
     if (total > 0) {
-      e = compact.Reserve(total * sizeof(smhip_carried_anchor));
-      if (e == hipSuccess) {
-        hipLaunchKernelGGL(CompactAnchorsKernel, dim3(R), dim3(64), 0, ctx->stream,
-                           ctx->out_anchors.as<smhip_carried_anchor>(), ctx->anchor_off.as<uint64_t>(),
-                           out_off.as<uint64_t>(), compact.as<smhip_carried_anchor>());
-        e = hipGetLastError();
-      }
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(chain_anchors, compact.p, total * sizeof(smhip_carried_anchor), hipMemcpyDeviceToHost,
-                           ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      HIPCHK(compact.Reserve(total * sizeof(smhip_carried_anchor)));
+      hipLaunchKernelGGL(CompactAnchorsKernel, dim3(R), dim3(64), 0, ctx->stream,
+                         ctx->out_anchors.as<smhip_carried_anchor>(), ctx->anchor_off.as<uint64_t>(),
+                         out_off.as<uint64_t>(), compact.as<smhip_carried_anchor>());
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(chain_anchors, compact.p, total * sizeof(smhip_carried_anchor), hipMemcpyDeviceToHost,
+                            ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    out_off.Free();
-    compact.Free();
-    if (e != hipSuccess) return HipFail(ctx, e, "chain anchor download");
   }
   return SMHIP_OK;
 }
@@ -859,6 +987,114 @@ int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos) {
   HIPCHK(hipMemcpyAsync(end_pos, ctx->refine_end.p, (uint64_t)R * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ResolveTimers(ctx);
+  return SMHIP_OK;
+}
+
+int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
+  if (!ctx) return SMHIP_EINVAL;
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_path_run before smhip_map_run");
+  if (ctx->ref_n == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_path_run before smhip_reference_upload");
+  if (band == 0) return Fail(ctx, SMHIP_EINVAL, "band must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  ctx->refine_path_done = false;
+  ctx->rp_path_total = 0;
+  if (R == 0) {
+    ctx->refine_path_done = true;
+    return SMHIP_OK;
+  }
+  const smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+  const uint64_t r1 = (uint64_t)R + 1;
+  HIPCHK(ctx->rp_rows.Reserve(r1 * 4));
+  HIPCHK(ctx->rp_cap.Reserve(r1 * 4));
+  HIPCHK(ctx->rp_toff.Reserve(r1 * 8));
+  HIPCHK(ctx->rp_poff.Reserve(r1 * 8));
+  HIPCHK(ctx->rp_tgt.Reserve(r1 * 8));
+  HIPCHK(ctx->rp_qoff.Reserve(r1 * 8));
+  HIPCHK(ctx->rp_qlen.Reserve(r1 * 4));
+  HIPCHK(ctx->rp_dist.Reserve(r1 * 4));
+  HIPCHK(ctx->rp_end.Reserve(r1 * 8));
+  HIPCHK(ctx->rp_plen.Reserve(r1 * 4));
+  HIPCHK(ctx->rp_start.Reserve(r1 * 8));
+  ScopedTimer t(ctx, T_SDTW);
+  // rows and path capacity (T + Q) of every chunk's window, their prefix sums, the totals
+  HIPCHK(LaunchChainWindowRows(ctx, results, ctx->qstart.as<uint32_t>(), R, ctx->ref_off.as<uint64_t>(), ctx->ref_n, pad,
+                               ctx->rp_rows.as<uint32_t>(), ctx->rp_cap.as<uint32_t>()));
+  HIPCHK(LaunchScanU32ToU64(ctx, ctx->rp_rows.as<uint32_t>(), R, ctx->rp_toff.as<uint64_t>()));
+  HIPCHK(LaunchScanU32ToU64(ctx, ctx->rp_cap.as<uint32_t>(), R, ctx->rp_poff.as<uint64_t>()));
+  uint64_t totals[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(&totals[0], ctx->rp_toff.as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&totals[1], ctx->rp_poff.as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t n_rows = totals[0], n_path = totals[1];
+  if (n_rows > 0x7FFFFFFFull) return Fail(ctx, SMHIP_ECAP, "too many window rows in one batch");
+  const uint64_t nr = std::max<uint64_t>(n_rows, 1);
+  HIPCHK(ctx->rp_lo.Reserve(nr * 4));
+  HIPCHK(ctx->rp_hi.Reserve(nr * 4));
+  HIPCHK(ctx->rp_width.Reserve((nr + 1) * 4));
+  HIPCHK(ctx->rp_celloff.Reserve((nr + 1) * 4));
+  HIPCHK(ctx->rp_path.Reserve(std::max<uint64_t>(n_path, 1)));
+  HIPCHK(LaunchChainWindowFill(ctx, results, ctx->qstart.as<uint32_t>(), kFeatStride, R, ctx->ref_off.as<uint64_t>(),
+                               ctx->ref_n, band, pad, ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
+                               ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(), ctx->rp_lo.as<uint32_t>(),
+                               ctx->rp_hi.as<uint32_t>(), ctx->rp_width.as<uint32_t>()));
+  uint32_t n_cells = 0;
+  if (n_rows > 0) {
+    HIPCHK(LaunchScanU32(ctx, ctx->rp_width.as<uint32_t>(), (uint32_t)n_rows, ctx->rp_celloff.as<uint32_t>()));
+    HIPCHK(hipMemcpyAsync(&n_cells, ctx->rp_celloff.as<uint32_t>() + n_rows, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // (a 32-bit scan: more than 4 G cells in one batch would have wrapped)
+    if ((uint64_t)n_cells + band > 0xFFFFFFFFull) return Fail(ctx, SMHIP_ECAP, "too many window cells in one batch");
+  }
+  HIPCHK(ctx->rp_codes.Reserve(std::max<uint64_t>(n_cells, 1)));
+  HIPCHK(LaunchDtwPathChains(ctx, ctx->ref_sig.as<float>(), ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
+                             ctx->feat.as<float>(), ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(),
+                             ctx->rp_lo.as<uint32_t>(), ctx->rp_hi.as<uint32_t>(), ctx->rp_celloff.as<uint32_t>(),
+                             ctx->rp_codes.as<uint8_t>(), R, ctx->rp_dist.as<float>(), ctx->rp_end.as<int64_t>(),
+                             ctx->rp_path.as<uint8_t>(), ctx->rp_poff.as<uint64_t>(), ctx->rp_plen.as<uint32_t>(),
+                             ctx->rp_start.as<int64_t>()));
+  ctx->rp_path_total = n_path;
+  ctx->refine_path_done = true;
+  return SMHIP_OK;
+}
+
+int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, int64_t *start_pos, uint32_t *path_len,
+                               uint64_t *path_off, uint8_t *path_codes, uint64_t path_cap) {
+  if (!ctx || !dist || !end_pos || !start_pos || !path_len || !path_off) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->refine_path_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_path_download before smhip_refine_path_run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  path_off[0] = 0;
+  if (R == 0) return SMHIP_OK;
+  if (path_codes && path_cap < ctx->rp_path_total) return Fail(ctx, SMHIP_ECAP, "path_cap too small");
+  std::vector<uint64_t> tgt((size_t)R), toff((size_t)R + 1);
+  HIPCHK(hipMemcpyAsync(dist, ctx->rp_dist.p, (uint64_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(end_pos, ctx->rp_end.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(start_pos, ctx->rp_start.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(path_len, ctx->rp_plen.p, (uint64_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(path_off, ctx->rp_poff.p, ((uint64_t)R + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (path_codes && ctx->rp_path_total)
+    HIPCHK(hipMemcpyAsync(path_codes, ctx->rp_path.p, ctx->rp_path_total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ResolveTimers(ctx);
+  // window-relative rows -> absolute positions on the strand's signal, like smhip_refine_download:
+  // row r of chunk c is target index t0 + r, t0 = max(0, start - pad) = (window offset) - (strand offset)
+  std::vector<uint64_t> ref_off((size_t)2 * ctx->ref_n + 1);
+  HIPCHK(hipMemcpyAsync(ref_off.data(), ctx->ref_off.p, ref_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(tgt.data(), ctx->rp_tgt.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<smhip_chunk_result> res((size_t)R);
+  HIPCHK(hipMemcpyAsync(res.data(), ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (uint32_t c = 0; c < R; ++c) {
+    if (end_pos[c] < 0) continue;
+    const smhip_chain &ch = res[c].chains[0];
+    const uint64_t so = ref_off[2 * ch.ref + (ch.direction == 1 ? 0 : 1)];
+    const int64_t t0 = (int64_t)(tgt[c] - so);
+    end_pos[c] += t0;
+    if (start_pos[c] >= 0) start_pos[c] += t0;
+    if (path_codes) std::reverse(path_codes + path_off[c], path_codes + path_off[c] + path_len[c]);
+  }
   return SMHIP_OK;
 }
 
@@ -1149,6 +1385,88 @@ int smhip_sdtw_banded(smhip_ctx *ctx, const float *target, const uint64_t *t_off
   free_all();
   if (e != hipSuccess) return HipFail(ctx, e, "smhip_sdtw_banded");
   ResolveTimers(ctx);
+  return SMHIP_OK;
+}
+
+int smhip_dtw_path(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query, const uint64_t *q_off,
+                   const uint32_t *lo, const uint32_t *hi, uint32_t n_problems, float *dist, int64_t *end,
+                   uint8_t *path_codes, const uint64_t *path_off, uint32_t *path_len, int64_t *start_target) {
+  if (!ctx || !target || !t_off || !query || !q_off || !lo || !hi || !dist || !end || !path_codes || !path_off ||
+      !path_len || !start_target)
+    return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (n_problems == 0) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint64_t nt = t_off[n_problems], nqv = q_off[n_problems], np_total = path_off[n_problems];
+  uint32_t max_t = 0;
+  std::vector<uint64_t> cell_off(std::max<uint64_t>(nt, 1) + 1);
+  uint64_t cells = 0;
+  for (uint32_t i = 0; i < n_problems; ++i) {
+    if (t_off[i + 1] < t_off[i] || q_off[i + 1] < q_off[i] || path_off[i + 1] < path_off[i])
+      return Fail(ctx, SMHIP_EINVAL, "offsets must be non-decreasing");
+    const uint64_t T = t_off[i + 1] - t_off[i], Q = q_off[i + 1] - q_off[i];
+    if (path_off[i + 1] - path_off[i] < T + Q) return Fail(ctx, SMHIP_EINVAL, "path capacity must be >= T + Q per problem");
+    max_t = std::max<uint32_t>(max_t, (uint32_t)std::min<uint64_t>(T, 0xFFFFFFFFull));
+    for (uint64_t r = t_off[i]; r < t_off[i + 1]; ++r) {
+      const uint64_t a = std::max<uint32_t>(lo[r], 1u), b = std::min<uint64_t>(hi[r], Q);
+      cell_off[r] = cells;
+      if (b >= a) cells += b - a + 1;
+    }
+  }
+  DevBuf d_t, d_q, d_to, d_qo, d_lo, d_hi, d_co, d_codes, d_d, d_e, d_path, d_po, d_pl, d_st;
+  auto free_all = [&]() {
+    for (DevBuf *b : {&d_t, &d_q, &d_to, &d_qo, &d_lo, &d_hi, &d_co, &d_codes, &d_d, &d_e, &d_path, &d_po, &d_pl, &d_st}) b->Free();
+  };
+  hipError_t e = hipSuccess;
+  auto step = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  const uint64_t n1 = (uint64_t)n_problems + 1;
+  step(d_t.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_q.Reserve(std::max<uint64_t>(nqv, 1) * 4));
+  step(d_to.Reserve(n1 * 8));
+  step(d_qo.Reserve(n1 * 8));
+  step(d_lo.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_hi.Reserve(std::max<uint64_t>(nt, 1) * 4));
+  step(d_co.Reserve(std::max<uint64_t>(nt, 1) * 8));
+  step(d_codes.Reserve(std::max<uint64_t>(cells, 1)));
+  step(d_d.Reserve((uint64_t)n_problems * 4));
+  step(d_e.Reserve((uint64_t)n_problems * 8));
+  step(d_path.Reserve(std::max<uint64_t>(np_total, 1)));
+  step(d_po.Reserve(n1 * 8));
+  step(d_pl.Reserve((uint64_t)n_problems * 4));
+  step(d_st.Reserve((uint64_t)n_problems * 8));
+  auto h2d = [&](DevBuf &b, const void *src, uint64_t bytes) {
+    if (e == hipSuccess && bytes) step(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  };
+  h2d(d_t, target, nt * 4);
+  h2d(d_q, query, nqv * 4);
+  h2d(d_to, t_off, n1 * 8);
+  h2d(d_qo, q_off, n1 * 8);
+  h2d(d_lo, lo, nt * 4);
+  h2d(d_hi, hi, nt * 4);
+  h2d(d_co, cell_off.data(), nt * 8);
+  h2d(d_po, path_off, n1 * 8);
+  if (e == hipSuccess) {
+    ScopedTimer t(ctx, T_SDTW);
+    step(LaunchDtwPath(ctx, d_t.as<float>(), d_to.as<uint64_t>(), d_q.as<float>(), d_qo.as<uint64_t>(), d_lo.as<uint32_t>(),
+                       d_hi.as<uint32_t>(), d_co.as<uint64_t>(), d_codes.as<uint8_t>(), n_problems, d_d.as<float>(),
+                       d_e.as<int64_t>(), d_path.as<uint8_t>(), d_po.as<uint64_t>(), d_pl.as<uint32_t>(),
+                       d_st.as<int64_t>(), max_t));
+  }
+  auto d2h = [&](void *dst, DevBuf &b, uint64_t bytes) {
+    if (e == hipSuccess && bytes) step(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  };
+  d2h(dist, d_d, (uint64_t)n_problems * 4);
+  d2h(end, d_e, (uint64_t)n_problems * 8);
+  d2h(path_codes, d_path, np_total);
+  d2h(path_len, d_pl, (uint64_t)n_problems * 4);
+  d2h(start_target, d_st, (uint64_t)n_problems * 8);
+  if (e == hipSuccess) step(hipStreamSynchronize(ctx->stream));
+  free_all();
+  if (e != hipSuccess) return HipFail(ctx, e, "smhip_dtw_path");
+  ResolveTimers(ctx);
+  for (uint32_t i = 0; i < n_problems; ++i)  // the device walked end -> start: std::reverse (fast_dtw.cc:71)
+    std::reverse(path_codes + path_off[i], path_codes + path_off[i] + path_len[i]);
   return SMHIP_OK;
 }
 }  // extern "C"

@@ -129,11 +129,16 @@ struct smhip_ctx {
   smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
-      group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt;
+      group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact;
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
   // sDTW refinement
   smhip::DevBuf ref_sig, ref_off, refine_dist, refine_end;
+  // DTW-with-path refinement (smhip_refine_path_run): per-chunk / per-row window arrays and results
+  smhip::DevBuf rp_rows, rp_cap, rp_toff, rp_poff, rp_tgt, rp_qoff, rp_qlen, rp_lo, rp_hi, rp_width, rp_celloff, rp_codes,
+      rp_dist, rp_end, rp_path, rp_plen, rp_start;
+  uint64_t rp_path_total = 0;
+  bool refine_path_done = false;
   uint32_t ref_n = 0;
   bool refine_done = false;
   // host staging
@@ -243,6 +248,22 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
                             uint32_t feat_stride, const uint32_t *qstart, uint32_t n_chunks, const float *ref_sig,
                             const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,
                             int64_t *end_pos);
+hipError_t LaunchDtwPath(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
+                         const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, const uint64_t *cell_off,
+                         uint8_t *codes, uint32_t n, float *dist, int64_t *end, uint8_t *path, const uint64_t *path_off,
+                         uint32_t *path_len, int64_t *start_t, uint32_t max_t);
+hipError_t LaunchChainWindowRows(smhip_ctx *ctx, const smhip_chunk_result *results, const uint32_t *qstart,
+                                 uint32_t n_chunks, const uint64_t *ref_off, uint32_t n_refs, uint32_t pad, uint32_t *rows,
+                                 uint32_t *path_cap);
+hipError_t LaunchChainWindowFill(smhip_ctx *ctx, const smhip_chunk_result *results, const uint32_t *qstart,
+                                 uint32_t feat_stride, uint32_t n_chunks, const uint64_t *ref_off, uint32_t n_refs,
+                                 uint32_t band, uint32_t pad, const uint64_t *t_off, uint64_t *tgt_off, uint64_t *q_off,
+                                 uint32_t *q_len, uint32_t *lo, uint32_t *hi, uint32_t *width);
+hipError_t LaunchDtwPathChains(smhip_ctx *ctx, const float *ref_sig, const uint64_t *t_off, const uint64_t *tgt_off,
+                               const float *feat, const uint64_t *q_off, const uint32_t *q_len, const uint32_t *lo,
+                               const uint32_t *hi, const uint32_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
+                               int64_t *end, uint8_t *path, const uint64_t *path_off, uint32_t *path_len,
+                               int64_t *start_t);
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
                       const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, uint32_t n,
                       float *dist, int64_t *end, uint32_t max_t);

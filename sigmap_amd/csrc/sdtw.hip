@@ -115,6 +115,129 @@ __device__ __forceinline__ int64_t FloorDiv(int64_t a, int64_t b) {  // b > 0
   return q;
 }
 
+// ---- D5: fast_dtw.cc::DTW() (fast_dtw.cc:74-140) over per-row column windows, with the path.
+// Same boundary as above (previous_row = {0, FLT_MAX...}, current_row[0] = 0: fast_dtw.cc:94-99) but
+// FOUR candidates per cell, in this order (fast_dtw.cc:113):
+//   { D[t-1][q-1] + cost, D[t][q-1] + cost, D[t][q-1] + 2, D[t-1][q] + 2 }     (skip costs 2, :76-77)
+// the FIRST minimum wins (std::min_element) and its index 0..3 is the cell's path code (:127-129).
+// A row can end the alignment iff its last window cell is the last query column; first row with the
+// smallest value (strict <, :131-134).  The codes of the in-window cells go to global memory (one byte
+// per cell, row r at cell_off[r]); after the sweep lane 0 walks back like generate_path (:51-72) and
+// writes the codes from the end cell to the first cell that lies in query column 0.
+// t_off[p] = first ROW of problem p in lo / hi / cell_off; the target samples start at tgt_off[p]
+// (nullptr: at t_off[p]); the query at q_off[p] with q_len[p] values (nullptr: q_off[p+1] - q_off[p]).
+template <typename CellOffT>
+__global__ __launch_bounds__(64) void DtwPathKernel(const float *__restrict__ target, const uint64_t *__restrict__ t_off,
+                                                    const uint64_t *__restrict__ tgt_off,
+                                                    const float *__restrict__ query, const uint64_t *__restrict__ q_off,
+                                                    const uint32_t *__restrict__ q_len,
+                                                    const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                    const CellOffT *__restrict__ cell_off, uint8_t *__restrict__ codes,
+                                                    float *__restrict__ dist, int64_t *__restrict__ end,
+                                                    uint8_t *__restrict__ path, const uint64_t *__restrict__ path_off,
+                                                    uint32_t *__restrict__ path_len, int64_t *__restrict__ start_t) {
+  extern __shared__ float sm[];
+  const uint32_t p = blockIdx.x, lane = threadIdx.x;
+  const uint64_t tb = t_off[p], qb = q_off[p];
+  const uint32_t T = (uint32_t)(t_off[p + 1] - tb), Q = q_len ? q_len[p] : (uint32_t)(q_off[p + 1] - qb);
+  const uint32_t stride = T + 1;
+  float *d0 = sm, *d1 = sm + stride, *d2 = sm + 2 * stride;  // diagonals d-2, d-1, d (indexed by row t)
+  const float *tg = target + (tgt_off ? tgt_off[p] : tb), *qr = query + qb;
+  const uint32_t *plo = lo + tb, *phi = hi + tb;
+  const CellOffT *coff = cell_off + tb;
+  float best = FLT_MAX;
+  uint32_t best_t = 0xFFFFFFFFu;
+  if (lane == 0) {
+    dist[p] = FLT_MAX;
+    end[p] = -1;
+    path_len[p] = 0;
+    start_t[p] = -1;
+  }
+  if (T == 0 || Q == 0 || T > (uint32_t)kSdtwMaxT) return;
+  for (uint32_t t = lane; t <= T; t += 64) {
+    d0[t] = t == 0 ? 0.0f : FLT_MAX;
+    d1[t] = t == 1 ? 0.0f : FLT_MAX;
+    d2[t] = FLT_MAX;
+  }
+  __syncthreads();
+  for (uint32_t d = 2; d <= T + Q; ++d) {
+    const uint32_t t_lo = d > Q ? d - Q : 0, t_hi = d < T ? d : T;
+    for (uint32_t t = t_lo + lane; t <= t_hi; t += 64) {
+      const uint32_t q = d - t;
+      float v;
+      if (q == 0) {
+        v = 0.0f;  // current_row[0] = 0
+      } else if (t == 0) {
+        v = FLT_MAX;  // previous_row initial state
+      } else {
+        const uint32_t a = max(plo[t - 1], 1u), b = min(phi[t - 1], Q);
+        if (q < a || q > b) {
+          v = FLT_MAX;
+        } else {
+          const float cost = fabsf(tg[t - 1] - qr[q - 1]);
+          const float diag = d0[t - 1], up = d1[t - 1], left = d1[t];
+          const float c0 = diag + cost, c1 = left + cost, c2 = left + 2.0f, c3 = up + 2.0f;
+          v = c0;
+          uint32_t arg = 0;
+          if (c1 < v) { v = c1; arg = 1; }
+          if (c2 < v) { v = c2; arg = 2; }
+          if (c3 < v) { v = c3; arg = 3; }
+          codes[coff[t - 1] + (q - a)] = (uint8_t)arg;
+          if (q == Q && (v < best || (v == best && t < best_t))) {  // b == Q: the row's last cell
+            best = v;
+            best_t = t;
+          }
+        }
+      }
+      d2[t] = v;
+    }
+    __syncthreads();
+    float *tmp = d0;
+    d0 = d1;
+    d1 = d2;
+    d2 = tmp;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_down(best, off, 64);
+    const uint32_t ot = __shfl_down(best_t, off, 64);
+    if (ob < best || (ob == best && ot < best_t)) {
+      best = ob;
+      best_t = ot;
+    }
+  }
+  __threadfence_block();  // the codes written by the other lanes
+  __syncthreads();
+  if (lane != 0 || !(best < FLT_MAX)) return;
+  dist[p] = best;
+  end[p] = (int64_t)best_t - 1;  // window[end][0].target_coord: 0-based (fast_dtw.cc:138)
+  // generate_path
+  uint8_t *out = path + path_off[p];
+  const uint64_t cap = path_off[p + 1] - path_off[p];
+  uint32_t t = best_t, q = Q, n = 0;
+  bool ok = true;
+  while (q != 1) {
+    const uint32_t a = max(plo[t - 1], 1u);
+    const uint8_t c = codes[coff[t - 1] + (q - a)];
+    if (n < cap) out[n] = c;
+    ++n;
+    if (c == 0) { --t; --q; }
+    else if (c == 3) { --t; }
+    else { --q; }
+    if (t == 0) { ok = false; break; }
+    const uint32_t na = max(plo[t - 1], 1u), nb = min(phi[t - 1], Q);
+    if (q < na || q > nb) { ok = false; break; }  // (a finite cell's predecessor is always in the window)
+  }
+  if (ok) {
+    const uint32_t a = max(plo[t - 1], 1u);
+    if (n < cap) out[n] = codes[coff[t - 1] + (q - a)];
+    ++n;
+    if (n <= cap) {
+      path_len[p] = n;  // end -> start order; the host reverses (std::reverse, fast_dtw.cc:71)
+      start_t[p] = (int64_t)t - 1;
+    }
+  }
+}
+
 // Refinement of chain 0 of every chunk (contract: include/sigmap_hip.h smhip_refine_run).
 // Same sweep as SdtwKernel; the band is the linear diagonal through the chain's end anchors.
 __global__ __launch_bounds__(64) void SdtwChainKernel(const smhip_chunk_result *__restrict__ results,
@@ -465,6 +588,12 @@ hipError_t InitSdtwAttributes() {  // per device (smhip_init)
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(DtwPathKernel<uint64_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(DtwPathKernel<uint32_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -479,6 +608,124 @@ hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off
                      dist, end);
   return hipGetLastError();
 }
+hipError_t LaunchDtwPath(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,
+                         const uint64_t *q_off, const uint32_t *lo, const uint32_t *hi, const uint64_t *cell_off,
+                         uint8_t *codes, uint32_t n, float *dist, int64_t *end, uint8_t *path, const uint64_t *path_off,
+                         uint32_t *path_len, int64_t *start_t, uint32_t max_t) {
+  if (n == 0) return hipSuccess;
+  if (max_t > (uint32_t)kSdtwMaxT) max_t = kSdtwMaxT;  // longer problems report FLT_MAX / -1
+  const size_t lds = 3 * (size_t)(max_t + 1) * sizeof(float);
+  hipLaunchKernelGGL(DtwPathKernel<uint64_t>, dim3(n), dim3(64), lds, ctx->stream, target, t_off, nullptr, query, q_off,
+                     nullptr, lo, hi, cell_off, codes, dist, end, path, path_off, path_len, start_t);
+  return hipGetLastError();
+}
+
+// ---- the same for chain 0 of every chunk of the last smhip_map_run: window and band exactly as
+// smhip_refine_run defines them (include/sigmap_hip.h).  Pass 1 counts the rows of every chunk's
+// window, pass 2 writes the per-row column intervals and their widths.
+__device__ __forceinline__ bool ChainWindow(const smhip_chunk_result &res, const uint32_t *qstart, uint32_t c,
+                                            const uint64_t *ref_off, uint32_t n_refs, uint32_t pad, int dim,
+                                            int64_t &t0, int64_t &start, int64_t &den, int64_t &qa, int64_t &qb,
+                                            uint32_t &T, uint64_t &sig_off) {
+  T = 0;
+  if (!(res.n_chains >= 1 && res.chains[0].ref < n_refs) || res.n_features == 0) return false;
+  const smhip_chain ch = res.chains[0];
+  const uint32_t strand = ch.direction == 1 ? 0u : 1u;
+  const uint64_t so = ref_off[2 * ch.ref + strand], se = ref_off[2 * ch.ref + strand + 1];
+  const int64_t len = (int64_t)(se - so);
+  start = ch.start;
+  const int64_t endp = ch.end;
+  t0 = start - (int64_t)pad < 0 ? 0 : start - (int64_t)pad;
+  int64_t t1 = endp + dim + (int64_t)pad;
+  if (t1 > len) t1 = len;
+  const uint32_t qs = qstart ? qstart[c] : 0;
+  qa = (int64_t)res.c0_last_qpos - qs;
+  qb = (int64_t)res.c0_first_qpos - qs;
+  if (qa < 0) qa = 0;
+  if (qb < 0) qb = 0;
+  den = endp - start > 0 ? endp - start : 1;
+  if (t1 <= t0 || t1 - t0 > (int64_t)kSdtwMaxT) return false;
+  T = (uint32_t)(t1 - t0);
+  sig_off = so + (uint64_t)t0;
+  return true;
+}
+
+__global__ void ChainWindowRowsKernel(const smhip_chunk_result *__restrict__ results, const uint32_t *__restrict__ qstart,
+                                      uint32_t n_chunks, const uint64_t *__restrict__ ref_off, uint32_t n_refs,
+                                      uint32_t pad, int dim, uint32_t *__restrict__ rows, uint32_t *__restrict__ path_cap) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  int64_t t0, start, den, qa, qb;
+  uint32_t T;
+  uint64_t so;
+  const bool ok = ChainWindow(results[c], qstart, c, ref_off, n_refs, pad, dim, t0, start, den, qa, qb, T, so);
+  rows[c] = ok ? T : 0u;
+  path_cap[c] = ok ? T + results[c].n_features : 0u;
+}
+
+__global__ __launch_bounds__(64) void ChainWindowFillKernel(const smhip_chunk_result *__restrict__ results,
+                                                            const uint32_t *__restrict__ qstart, uint32_t feat_stride,
+                                                            const uint64_t *__restrict__ ref_off, uint32_t n_refs,
+                                                            uint32_t band, uint32_t pad, int dim,
+                                                            const uint64_t *__restrict__ t_off, uint64_t *__restrict__ tgt_off,
+                                                            uint64_t *__restrict__ q_off, uint32_t *__restrict__ q_len,
+                                                            uint32_t *__restrict__ lo, uint32_t *__restrict__ hi,
+                                                            uint32_t *__restrict__ width) {
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  int64_t t0, start, den, qa, qb;
+  uint32_t T;
+  uint64_t so = 0;
+  const bool ok = ChainWindow(results[c], qstart, c, ref_off, n_refs, pad, dim, t0, start, den, qa, qb, T, so);
+  const uint32_t Q = results[c].n_features;
+  if (lane == 0) {
+    tgt_off[c] = so;
+    q_off[c] = (uint64_t)c * feat_stride;
+    q_len[c] = ok ? Q : 0u;
+  }
+  if (!ok) return;
+  const int64_t half = band / 2;
+  const uint64_t rb = t_off[c];
+  for (uint32_t t = 1 + lane; t <= T; t += 64) {  // row t (1-based): absolute target index ta
+    const int64_t ta = t0 + (int64_t)t - 1;
+    const int64_t cen = 1 + qa + FloorDiv((ta - start) * (qb - qa), den);
+    int64_t a = cen - half, b = cen + half;
+    if (a < 1) a = 1;
+    if (b > (int64_t)Q) b = Q;
+    lo[rb + t - 1] = (uint32_t)a;
+    hi[rb + t - 1] = b < a ? (uint32_t)(a - 1) : (uint32_t)b;  // (empty row: hi = lo - 1)
+    width[rb + t - 1] = b < a ? 0u : (uint32_t)(b - a + 1);
+  }
+}
+
+hipError_t LaunchChainWindowRows(smhip_ctx *ctx, const smhip_chunk_result *results, const uint32_t *qstart,
+                                 uint32_t n_chunks, const uint64_t *ref_off, uint32_t n_refs, uint32_t pad, uint32_t *rows,
+                                 uint32_t *path_cap) {
+  hipLaunchKernelGGL(ChainWindowRowsKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, results, qstart,
+                     n_chunks, ref_off, n_refs, pad, kMaxDim, rows, path_cap);
+  return hipGetLastError();
+}
+
+hipError_t LaunchChainWindowFill(smhip_ctx *ctx, const smhip_chunk_result *results, const uint32_t *qstart,
+                                 uint32_t feat_stride, uint32_t n_chunks, const uint64_t *ref_off, uint32_t n_refs,
+                                 uint32_t band, uint32_t pad, const uint64_t *t_off, uint64_t *tgt_off, uint64_t *q_off,
+                                 uint32_t *q_len, uint32_t *lo, uint32_t *hi, uint32_t *width) {
+  hipLaunchKernelGGL(ChainWindowFillKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, results, qstart, feat_stride,
+                     ref_off, n_refs, band, pad, kMaxDim, t_off, tgt_off, q_off, q_len, lo, hi, width);
+  return hipGetLastError();
+}
+
+hipError_t LaunchDtwPathChains(smhip_ctx *ctx, const float *ref_sig, const uint64_t *t_off, const uint64_t *tgt_off,
+                               const float *feat, const uint64_t *q_off, const uint32_t *q_len, const uint32_t *lo,
+                               const uint32_t *hi, const uint32_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
+                               int64_t *end, uint8_t *path, const uint64_t *path_off, uint32_t *path_len,
+                               int64_t *start_t) {
+  if (n == 0) return hipSuccess;
+  const size_t lds = 3 * (size_t)(kSdtwMaxT + 1) * sizeof(float);
+  hipLaunchKernelGGL(DtwPathKernel<uint32_t>, dim3(n), dim3(64), lds, ctx->stream, ref_sig, t_off, tgt_off, feat, q_off,
+                     q_len, lo, hi, cell_off, codes, dist, end, path, path_off, path_len, start_t);
+  return hipGetLastError();
+}
+
 hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, const float *feat,
                             uint32_t feat_stride, const uint32_t *qstart, uint32_t n_chunks, const float *ref_sig,
                             const uint64_t *ref_off, uint32_t n_refs, uint32_t band, uint32_t pad, float *dist,

@@ -155,6 +155,22 @@ void SignalBatch::AddSignalsFromFAST5(const std::string &path) {
     if (d < 0) ExitWithMessage("FAST5 read without " + sig_path + " in " + path);
     hid_t sp = H5Dget_space(d);
     const hssize_t npts = H5Sget_simple_extent_npoints(sp);
+    if (raw_mode_) {
+      // the ADC counts stay 16-bit integers and the device converts them (SignalBatch::KeepRaw); MinKNOW
+      // writes the Signal dataset as int16, anything wider cannot be kept exactly
+      hid_t ft = H5Dget_type(d);
+      const bool int16_ok = H5Tget_class(ft) == H5T_INTEGER &&
+                            (H5Tget_size(ft) < 2 || (H5Tget_size(ft) == 2 && H5Tget_sign(ft) == H5T_SGN_2));
+      H5Tclose(ft);
+      if (!int16_ok) ExitWithMessage(sig_path + " in " + path + " is not a 16-bit signed integer dataset");
+      std::vector<int16_t> raw(npts > 0 ? (size_t)npts : 0);
+      if (npts > 0 && H5Dread(d, H5T_NATIVE_SHORT, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw.data()) < 0)
+        ExitWithMessage("Cannot read " + sig_path + " in " + path);
+      H5Sclose(sp);
+      H5Dclose(d);
+      AddSignal(id, digitisation, range, offset, raw.data(), raw.size());
+      return;
+    }
     std::vector<float> values(npts > 0 ? (size_t)npts : 0);
     if (npts > 0 && H5Dread(d, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, values.data()) < 0)
       ExitWithMessage("Cannot read " + sig_path + " in " + path);

@@ -212,6 +212,23 @@ static MappingParams ToParams(const smhost_map_params *p) {
   return m;
 }
 
+int64_t smhost_print_alignment(const uint8_t *codes, uint64_t n, char *out, uint64_t cap) {
+  const std::string c = sigmap::PrintAlignment(codes, (size_t)n);
+  if (out && cap) {
+    const size_t k = std::min<size_t>(c.size(), (size_t)cap - 1);
+    memcpy(out, c.data(), k);
+    out[k] = 0;
+  }
+  return (int64_t)c.size();
+}
+
+void smhost_shard_range(uint64_t n_items, int rank, int world, uint64_t *lo, uint64_t *hi) {
+  size_t a = 0, b = 0;
+  sigmap::ShardRange((size_t)n_items, rank, world, &a, &b);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+
 int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p) {
   return ShouldStopMapping(*r, ToParams(p)) ? 1 : 0;
 }

@@ -1,6 +1,55 @@
 #include "mapping_logic.h"
 
 namespace sigmap {
+void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi) {
+  if (world < 1) world = 1;
+  // item i belongs to part floor(i * world / n): part r starts at ceil(r * n / world)
+  auto start = [&](int r) { return r >= world ? n_items : (size_t)(((unsigned __int128)n_items * (unsigned)r + world - 1) / world); };
+  if (lo) *lo = start(rank);
+  if (hi) *hi = start(rank + 1);
+}
+
+std::string PrintAlignment(const uint8_t *codes, size_t n) {
+  if (n == 0) return "";
+  // One string per base.  `state` is the kind of run in progress: 1 = signals matched to the current
+  // base (a code 0 cell opens it, code 1 cells extend it: both print as M), 2 = skipped signals (I),
+  // 3 = a skipped base (D).
+  static const char kLetter[] = {'?', 'M', 'I', 'D'};
+  std::vector<std::string> bases;
+  int state;
+  size_t run = 1;
+  if (codes[0] == 3) {
+    bases.push_back("1D");
+    state = 3;
+  } else {
+    state = codes[0] == 0 ? 1 : 2;
+  }
+  bases.emplace_back();
+  for (size_t i = 1; i < n; ++i) {
+    const int c = codes[i];
+    if (c == 1 || c == 2) {  // still inside the current base
+      if (c == state) {
+        ++run;
+      } else {
+        bases.back() += std::to_string(run) + kLetter[state];
+        run = 1;
+        state = c;
+      }
+      continue;
+    }
+    // code 0 / 3: the current base is complete, the next one starts (matched / skipped)
+    bases.back() += std::to_string(run) + kLetter[state];
+    state = c == 0 ? 1 : 3;
+    if (i != n - 1) {
+      bases.emplace_back();
+      run = 1;
+    }
+  }
+  std::string cigar;
+  for (const auto &base : bases) cigar += "(" + base + ")";
+  return cigar;
+}
+
 bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p) {
   if (r.n_chains >= 2) {
     if (r.chains[0].score / r.chains[1].score >= p.stop_mapping_ratio) return true;

@@ -23,6 +23,15 @@ struct MappingParams {  // CLI defaults, sigmap.cc:1380-1419
   float output_mapping_mean_ratio = 5;
 };
 
+// Contiguous block of items for part `rank` of `world` (read i -> GPU i * world / n):
+// [*lo, *hi).  Either pointer may be null.
+void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi);
+
+// Per-base CIGAR of a DTW path (print_alignment, fast_dtw.cc:160-209): codes 0 one-to-one, 1 one base
+// to several signals, 2 skip one signal, 3 skip one base; "(2M)(1M3I)(1D)...".  The format, including
+// that the run still open when the path ends is not written, is the reference's.
+std::string PrintAlignment(const uint8_t *codes, size_t n);
+
 // true = stop feeding chunks of this read (sigmap.cc:667-687).  Only meaningful when the
 // chunk produced more than 50 features (the caller checks n_features like sigmap.cc:660).
 bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p);

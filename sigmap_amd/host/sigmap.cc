@@ -60,8 +60,22 @@ class Sigmap {
     index.Save();
   }
 
-  void StreamingMap(int device, size_t max_batch_chunks, int sdtw_band, int num_streams) {
+  // Pinned arena of the raw reads (SignalBatch::KeepRaw): a run of reads is one DMA.
+  static void *PinnedAlloc(size_t bytes) {
+    void *p = nullptr;
+    return smhip_host_alloc(&p, bytes) == SMHIP_OK ? p : nullptr;
+  }
+  static void PinnedFree(void *p) { smhip_host_free(p); }
+
+  void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams) {
+    num_gpus = std::max(1, num_gpus);
+    num_streams = std::max(1, num_streams);
+    if (device < 0 || device + num_gpus > smhip_device_count())
+      ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
+                      std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
+                      " visible): this build has no CPU mapping path.");
     SignalBatch reads;
+    reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree);  // ADC counts stay 2 bytes/sample; the GPU converts
     reads.InitializeLoading(signal_directory_);
     const size_t num_reads = reads.LoadAllReadSignals();
     SequenceBatch reference;  // names and lengths for PAF; the pore model is only needed by -i
@@ -72,27 +86,37 @@ class Sigmap {
     SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
     index.Load();
 
-    // `num_streams` device contexts (one HIP stream each) share the resident index: the first owns
-    // it, the others borrow its arrays.  Reads are independent (one taskloop over all reads,
-    // sigmap.cc:618-666), so every context maps its own batches, driven by its own host thread:
-    // one context's host work (batch assembly, downloads, stop rules) and the tail of its kernels
-    // overlap the other contexts' kernels.
-    num_streams = std::max(1, num_streams);
-    std::vector<smhip_ctx *> ctxs((size_t)num_streams, nullptr);
-    for (auto &c : ctxs)
-      if (smhip_init(device, &c) != SMHIP_OK)
-        ExitWithMessage("No usable MI355X GPU (smhip_init failed): this build has no CPU mapping path.");
-    if (smhip_index_upload(ctxs[0], index.dimension(), index.values().data(), index.positions().data(),
+    // ctxs[g][k]: context k (one HIP stream each) of GPU device + g.  The first context of GPU 0
+    // uploads the index; the first contexts of the other GPUs receive it by one RCCL broadcast per
+    // array (smhip_index_bcast); the further contexts of a GPU borrow its arrays.
+    // Reads are independent (one taskloop over all reads, sigmap.cc:618-666): every GPU maps a
+    // contiguous block of the reads (read i -> GPU i * G / n), every context of a GPU takes batches
+    // from that block, driven by its own host thread.
+    std::vector<std::vector<smhip_ctx *>> ctxs((size_t)num_gpus, std::vector<smhip_ctx *>((size_t)num_streams, nullptr));
+    for (int g = 0; g < num_gpus; ++g)
+      for (auto &c : ctxs[g])
+        if (smhip_init(device + g, &c) != SMHIP_OK)
+          ExitWithMessage("smhip_init failed for GPU " + std::to_string(device + g) +
+                          ": this build has no CPU mapping path.");
+    if (smhip_index_upload(ctxs[0][0], index.dimension(), index.values().data(), index.positions().data(),
                            index.values().size(), index.tree().vind.data(), index.tree().m_size,
                            index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
-      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0]));
-    {
+      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0][0]));
+    if (num_gpus > 1) {
+      const double t0 = GetRealTime();
+      std::vector<smhip_ctx *> firsts;
+      for (int g = 0; g < num_gpus; ++g) firsts.push_back(ctxs[g][0]);
+      if (smhip_index_bcast(firsts.data(), num_gpus, 0) != SMHIP_OK)
+        ExitWithMessage(std::string("Index broadcast failed: ") + smhip_last_error(ctxs[0][0]));
+      std::cerr << "Broadcast index to " << num_gpus << " GPUs in " << GetRealTime() - t0 << "s.\n";
+    }
+    for (int g = 0; g < num_gpus; ++g) {
       smhip_index_dev shared;
-      if (smhip_index_export(ctxs[0], &shared) != SMHIP_OK)
-        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[0]));
-      for (size_t k = 1; k < ctxs.size(); ++k)
-        if (smhip_index_attach(ctxs[k], &shared) != SMHIP_OK)
-          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[k]));
+      if (smhip_index_export(ctxs[g][0], &shared) != SMHIP_OK)
+        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[g][0]));
+      for (size_t k = 1; k < ctxs[g].size(); ++k)
+        if (smhip_index_attach(ctxs[g][k], &shared) != SMHIP_OK)
+          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][k]));
     }
     if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
       PoreModel pore_model;
@@ -109,9 +133,10 @@ class Sigmap {
         ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
         off.push_back(sig.size());
       }
-      for (smhip_ctx *c : ctxs)
-        if (smhip_reference_upload(c, sig.data(), off.data(), num_refs) != SMHIP_OK)
-          ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
+      for (auto &gpu : ctxs)
+        for (smhip_ctx *c : gpu)
+          if (smhip_reference_upload(c, sig.data(), off.data(), num_refs) != SMHIP_OK)
+            ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
     }
     smhip_params dp;
     smhip_default_params(&dp);
@@ -122,7 +147,7 @@ class Sigmap {
     struct ReadState {
       uint32_t chunk_index = 0;  // next chunk to process
       uint32_t num_events = 0;
-      bool active = true;
+      uint32_t slot = 0;         // resident slot on the read's context while it is in flight
       smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
       float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
       bool has_dt = false;
@@ -130,117 +155,182 @@ class Sigmap {
       double start_time = 0;
     };
     std::vector<ReadState> st(num_reads);
-    std::vector<uint32_t> num_chunks(num_reads);
-    for (size_t r = 0; r < num_reads; ++r) {
-      num_chunks[r] = (uint32_t)(reads.GetSignalLengthAt(r) / chunk_size);
-      memset(&st[r].last, 0, sizeof(smhip_chunk_result));
-      if (num_chunks[r] == 0 || params_.max_num_chunks <= 0) st[r].active = false;
-    }
-    const double t_map = GetRealTime();
-    size_t cursor = 0;  // reads are admitted in order; a read stays with the context that admitted it
-    std::mutex cursor_mutex;
+    std::vector<uint32_t> num_chunks(num_reads, 0);
+    for (size_t r = 0; r < num_reads; ++r) memset(&st[r].last, 0, sizeof(smhip_chunk_result));
+    const uint32_t max_chunks = (uint32_t)std::max(0, params_.max_num_chunks);
     // every context gets an equal share of the batch budget, so that `max_batch_chunks` bounds the
-    // chunks in flight on the GPU as it does with one context
-    const size_t lane_budget = std::max<size_t>(1, max_batch_chunks / ctxs.size());
-    auto lane = [&](smhip_ctx *ctx) {
+    // chunks in flight on a GPU as it does with one context; a slot keeps the samples of the chunks
+    // a read may use (sigmap.cc:647: at most max_num_chunks), within 8 GiB of slots per context
+    const uint32_t keep = std::max<uint32_t>(1, std::min<uint32_t>(max_chunks, 1u << 16)) * chunk_size;
+    size_t lane_budget = std::max<size_t>(1, max_batch_chunks / (size_t)num_streams);
+    lane_budget = std::max<size_t>(1, std::min<size_t>(lane_budget, ((size_t)8 << 30) / ((size_t)keep * sizeof(float))));
+    // read slots of every context: set-up like the index, before the mapping span
+    for (auto &gpu : ctxs)
+      for (smhip_ctx *c : gpu)
+        if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK)
+          ExitWithMessage(std::string("Read slots: ") + smhip_last_error(c));
+    const double t_map = GetRealTime();
+    // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
+    // in order and stay with the context that admitted them (chain carry-over is per read)
+    std::vector<size_t> block((size_t)num_gpus + 1), cursor((size_t)num_gpus);
+    for (int g = 0; g <= num_gpus; ++g) ShardRange(num_reads, g, num_gpus, g < num_gpus ? &block[g] : nullptr, nullptr);
+    block[num_gpus] = num_reads;
+    for (int g = 0; g < num_gpus; ++g) cursor[g] = block[g];
+    std::vector<std::mutex> cursor_mutex((size_t)num_gpus);
+    auto lane = [&](int g, smhip_ctx *ctx) {
+      std::vector<uint32_t> free_slots(lane_budget);
+      for (size_t k = 0; k < lane_budget; ++k) free_slots[k] = (uint32_t)(lane_budget - 1 - k);
       std::vector<size_t> batch, in_flight;
-      std::vector<float> samples;
-      std::vector<uint32_t> offsets, qstart, carried_off;
+      std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, up_slots, pa_len;
+      std::vector<uint64_t> raw_off;
+      std::vector<float> dig, rng, ofs;
       std::vector<smhip_carried_anchor> carried, out_anchors;
       std::vector<smhip_chunk_result> results;
       std::vector<uint64_t> out_off;
+      std::vector<float> dts;
+      std::vector<int64_t> dte;
+      auto finish = [&](size_t r) {
+        ReadState &s = st[r];
+        free_slots.push_back(s.slot);
+        s.anchors.clear();
+        s.anchors.shrink_to_fit();
+        s.start_time = (GetRealTime() - s.start_time) * 1000;
+      };
       while (true) {
-        {  // admit new reads up to this context's budget
-          std::lock_guard<std::mutex> lock(cursor_mutex);
-          while (in_flight.size() < lane_budget && cursor < num_reads) {
-            if (st[cursor].active) {
-              st[cursor].start_time = GetRealTime();
-              in_flight.push_back(cursor);
-            }
-            ++cursor;
-          }
+        size_t a = 0, b = 0;
+        {  // admit new reads up to the free slots of this context
+          std::lock_guard<std::mutex> lock(cursor_mutex[g]);
+          a = cursor[g];
+          b = std::min(block[g + 1], a + free_slots.size());
+          cursor[g] = b;
         }
-        if (in_flight.empty()) break;
+        // their ADC counts go to the device, one DMA per run of reads inside one arena block
+        for (size_t r0 = a; r0 < b;) {
+          size_t r1 = r0;
+          const uint32_t blk = reads.GetSignalAt(r0).raw_block;
+          const int16_t *base = reads.RawBlockBase(blk);
+          raw_off.clear(); dig.clear(); rng.clear(); ofs.clear(); up_slots.clear();
+          const double now = GetRealTime();
+          for (; r1 < b && reads.GetSignalAt(r1).raw_block == blk; ++r1) {
+            const Signal &sig = reads.GetSignalAt(r1);
+            raw_off.push_back((uint64_t)(sig.raw - base));
+            dig.push_back(sig.digitisation);
+            rng.push_back(sig.range);
+            ofs.push_back(sig.offset);
+            st[r1].slot = free_slots.back();
+            free_slots.pop_back();
+            up_slots.push_back(st[r1].slot);
+            st[r1].start_time = now;
+          }
+          const Signal &last = reads.GetSignalAt(r1 - 1);
+          raw_off.push_back((uint64_t)(last.raw - base) + last.n_raw);
+          pa_len.resize(r1 - r0);
+          if (smhip_reads_upload_raw(ctx, base, raw_off.data(), dig.data(), rng.data(), ofs.data(), up_slots.data(),
+                                     (uint32_t)(r1 - r0), pa_len.data()) != SMHIP_OK)
+            ExitWithMessage(std::string("Read upload failed: ") + smhip_last_error(ctx));
+          for (size_t r = r0; r < r1; ++r) {
+            reads.SetFilteredLengthAt(r, pa_len[r - r0]);            // Signal::signal_values.size() of the reference
+            num_chunks[r] = (uint32_t)(pa_len[r - r0] / chunk_size);  // sigmap.cc:643
+            if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
+            else in_flight.push_back(r);
+          }
+          r0 = r1;
+        }
+        if (in_flight.empty()) {
+          if (a == b) break;  // nothing in flight, nothing left to admit
+          continue;
+        }
         batch = in_flight;
-        samples.clear();
-        offsets.assign(1, 0);
-        qstart.clear();
-        carried.clear();
+        slots.clear(); chunk_idx.clear(); qstart.clear(); carried.clear();
         carried_off.assign(1, 0);
         for (size_t r : batch) {
-          const Signal &sig = reads.GetSignalAt(r);
-          const size_t b = (size_t)chunk_size * st[r].chunk_index;
-          samples.insert(samples.end(), sig.signal_values.begin() + b, sig.signal_values.begin() + b + chunk_size);
-          offsets.push_back((uint32_t)samples.size());
+          slots.push_back(st[r].slot);
+          chunk_idx.push_back(st[r].chunk_index);
           qstart.push_back(st[r].num_events);
           carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
           carried_off.push_back((uint32_t)carried.size());
         }
         results.resize(batch.size());
         out_off.resize(batch.size() + 1);
-        int rc = smhip_batch_upload(ctx, samples.data(), offsets.data(), (uint32_t)batch.size(), qstart.data(),
+        int rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)batch.size(), qstart.data(),
                                     carried.empty() ? nullptr : carried.data(),
                                     carried.empty() ? nullptr : carried_off.data());
         if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
         if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
         if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
-        std::vector<float> dts(batch.size());
-        std::vector<int64_t> dte(batch.size());
+        dts.resize(batch.size());
+        dte.resize(batch.size());
         if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
-        uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
-        while (rc == SMHIP_OK) {
-          out_anchors.resize(cap);
-          rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
-          if (rc != SMHIP_ECAP) break;
-          cap *= 4;
-          rc = SMHIP_OK;
-        }
+        // the result records first; the anchors of the chains (the next chunk's carry-over,
+        // spatial_index.cc:303-322) only when some read of the batch goes on to another chunk
+        if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
         if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+        bool any_continues = false;
+        for (size_t bi = 0; bi < batch.size() && !any_continues; ++bi) {
+          const size_t r = batch[bi];
+          const smhip_chunk_result &res = results[bi];
+          const bool stop = res.n_features > 50 && ShouldStopMapping(res, params_);
+          any_continues = !stop && st[r].chunk_index + 1 < num_chunks[r] && st[r].chunk_index + 1 < max_chunks;
+        }
+        if (any_continues) {
+          uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
+          while (rc == SMHIP_OK) {
+            out_anchors.resize(cap);
+            rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
+            if (rc != SMHIP_ECAP) break;
+            cap *= 4;
+            rc = SMHIP_OK;
+          }
+          if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+        }
         in_flight.clear();
         for (size_t bi = 0; bi < batch.size(); ++bi) {
           const size_t r = batch[bi];
           ReadState &s = st[r];
           const smhip_chunk_result &res = results[bi];
+          // a device-side capacity was exceeded: the records of this chunk may differ from the
+          // reference's, so nothing is written from them (the flags are not expected on any input)
           if (res.status & ~SMHIP_ST_FEW_PEAKS)
-            std::cerr << "warning: read " << reads.GetSignalNameAt(r) << ": device capacity flag " << res.status << "\n";
+            ExitWithMessage(std::string("read ") + reads.GetSignalNameAt(r) + ": device capacity flag " +
+                            std::to_string(res.status) + " (include/sigmap_hip.h, SMHIP_ST_*)");
           bool stop = false;
           if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
             s.last = res;
             s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
             s.dt = dts[bi];
-            s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
             s.num_events += res.n_features;
             stop = ShouldStopMapping(res, params_);
+            if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
+              s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
           }
           if (!stop) {
             ++s.chunk_index;
-            if (s.chunk_index < num_chunks[r] && s.chunk_index < (uint32_t)params_.max_num_chunks) {
+            if (s.chunk_index < num_chunks[r] && s.chunk_index < max_chunks) {
               in_flight.push_back(r);
               continue;
             }
           }
-          s.active = false;
-          s.anchors.clear();
-          s.anchors.shrink_to_fit();
-          s.start_time = (GetRealTime() - s.start_time) * 1000;
+          finish(r);
         }
       }
     };
     {
       std::vector<std::thread> workers;
-      for (size_t k = 1; k < ctxs.size(); ++k) workers.emplace_back(lane, ctxs[k]);
-      lane(ctxs[0]);
+      for (int g = 0; g < num_gpus; ++g)
+        for (size_t k = 0; k < ctxs[g].size(); ++k)
+          if (g || k) workers.emplace_back(lane, g, ctxs[g][k]);
+      lane(0, ctxs[0][0]);
       for (auto &w : workers) w.join();
     }
     std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
 
     // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
+    // (whichever GPU and context mapped a read)
     std::vector<std::vector<std::string>> rows(std::max<uint32_t>(num_refs, 1));
     for (size_t r = 0; r < num_reads; ++r) {
       ReadState &s = st[r];
       uint32_t chunk_index = s.chunk_index;  // sigmap.cc:690-693
-      if (chunk_index > 0 && (chunk_index == num_chunks[r] || chunk_index == (uint32_t)params_.max_num_chunks))
-        --chunk_index;
+      if (chunk_index > 0 && (chunk_index == num_chunks[r] || chunk_index == max_chunks)) --chunk_index;
       uint32_t bucket = 0;
       const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
                                        (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
@@ -253,7 +343,8 @@ class Sigmap {
     for (auto &g : rows)
       for (auto &line : g) fputs(line.c_str(), out);
     fclose(out);
-    for (size_t k = ctxs.size(); k-- > 0;) smhip_destroy(ctxs[k]);  // borrowers first
+    for (int g = num_gpus; g-- > 0;)
+      for (size_t k = ctxs[g].size(); k-- > 0;) smhip_destroy(ctxs[g][k]);  // borrowers first
   }
 
  protected:
@@ -287,7 +378,9 @@ const char *kHelp =
     "      --stop-mapping-mean FLOAT   best/mean chaining score ratio to stop mapping [5]\n"
     "      --stop-mapping-mean-output FLOAT  best/mean ratio to output mappings [5]\n"
     "      --sdtw-band INT             banded sDTW refinement of the best chain, adds dt:f: [0 = off]\n"
-    "      --device INT                GPU ordinal [0]\n      --batch-chunks INT          chunks in flight on the GPU [16384]\n"
+    "      --device INT                first GPU ordinal [0]\n"
+    "      --gpus INT                  GPUs to map on: the index is broadcast over xGMI (RCCL), reads shard [1]\n"
+    "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
     "      --streams INT               device contexts / HIP streams that share the index and the chunk budget [2]\n"
     "  -h, --help  Print help\n";
 }  // namespace
@@ -354,10 +447,11 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const std::string out = need("output", "No output file specified!");
     omp_set_num_threads(std::max(1, num_threads));
     const int device = a.Has("device") ? std::stoi(a.Str("device")) : 0;
-    const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 16384;
+    const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 32768;
     const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
     const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : 2;
-    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, batch, sdtw_band, streams);
+    const int gpus = a.Has("gpus") ? std::stoi(a.Str("gpus")) : 1;
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams);
   } else {
     std::cerr << kHelp;
   }

@@ -7,8 +7,6 @@ is how the world_size-2 tests exercise them without GPUs.
 A process that uses torch on the GPU together with this package must `import torch` BEFORE the
 first DeviceMapper is created (bench.py does): torch brings its own HIP runtime, and the process has
 to end up with one runtime, the one loaded first."""
-import ctypes as C
-
 import numpy as np
 
 from . import _abi
@@ -60,20 +58,14 @@ def broadcast_host_index(ix_arrays, rank, dist):
     return out
 
 
-def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rc = hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes, 3)  # hipMemcpyDeviceToDevice
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpy D2D failed: {rc}")
-
-
 def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
     uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive.
-    `device` / `copy_fn(dst_ptr, src_ptr, nbytes)` default to this rank's GPU and a device-to-device
-    hipMemcpy; the world_size-2 gloo test passes "cpu" and a host copy to run this very function."""
+    Rank 0 copies an exported array into the broadcast tensor with smhip_index_export_copy (the
+    library's own HIP runtime and stream); `device` / `copy_fn(array_id, dst_ptr, src_ptr, nbytes)` let
+    the world_size-2 gloo test run this very function with host buffers.  A failure on rank 0 before
+    the broadcasts is announced to the peers (they raise instead of waiting in a collective)."""
     if world == 1:
         dev.upload_index(ix)
         return None
@@ -81,19 +73,28 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
     on_gpu = device is None
     if on_gpu:
         device = torch.device("cuda", local_rank)
-    copy_fn = copy_fn or _hip_memcpy_d2d
-    meta = [0] * (len(_SCALARS) + len(_ARRAYS))
+    if copy_fn is None:
+        copy_fn = lambda array_id, dst_ptr, src_ptr, nbytes: dev.export_copy(array_id, dst_ptr, nbytes)
+    meta = [0] * (1 + len(_SCALARS) + len(_ARRAYS))   # [0]: 1 = rank 0 has its index, -1 = it failed
     d = None
+    err = None
     if rank == 0:
-        dev.upload_index(ix)
-        d = dev.export_index()
-        meta = [int(getattr(d, f)) for f in _SCALARS] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
+        try:
+            dev.upload_index(ix)
+            d = dev.export_index()
+            meta = [1] + [int(getattr(d, f)) for f in _SCALARS] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
+        except Exception as e:   # tell the peers before raising
+            err = e
+            meta[0] = -1
     meta = broadcast_meta(meta, rank, dist, device)
+    if meta[0] != 1:
+        raise RuntimeError(f"rank {rank}: index upload failed on rank 0" + (f": {err}" if err else ""))
+    meta = meta[1:]
     tensors = []
-    for a, nbytes in zip(_ARRAYS, meta[len(_SCALARS):]):
+    for k, (a, nbytes) in enumerate(zip(_ARRAYS, meta[len(_SCALARS):])):
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if rank == 0:
-            copy_fn(t.data_ptr(), getattr(d, a), nbytes)
+            copy_fn(k, t.data_ptr(), getattr(d, a), nbytes)
         dist.broadcast(t, src=0)  # RCCL broadcast over xGMI
         tensors.append(t)
     if on_gpu:
@@ -105,6 +106,9 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
         for a, t, nbytes in zip(_ARRAYS, tensors, meta[len(_SCALARS):]):
             setattr(nd, a, t.data_ptr())
             setattr(nd, a + "_bytes", nbytes)
-        dev.attach_index(nd)
+        try:
+            dev.attach_index(nd)
+        except Exception as e:
+            raise RuntimeError(f"rank {rank}: cannot attach the broadcast index: {e}") from e
         return tensors  # the context borrows this memory
     return None

@@ -114,6 +114,16 @@ class PinnedArray:
             pass
 
 
+def print_alignment(codes):
+    """The reference's per-base CIGAR of a DTW path (host library, print_alignment fast_dtw.cc:160-209)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    L = _abi.host_lib()
+    n = L.smhost_print_alignment(ptr(codes), len(codes), None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    L.smhost_print_alignment(ptr(codes), len(codes), buf, int(n) + 1)
+    return buf.value.decode()
+
+
 def default_params():
     p = _abi.Params()
     _abi.hip_lib().smhip_default_params(C.byref(p))
@@ -147,6 +157,11 @@ class DeviceMapper:
         d = _abi.IndexDev()
         self._check(self.L.smhip_index_export(self._h, C.byref(d)), "smhip_index_export")
         return d
+
+    def export_copy(self, array_id, dst_ptr, nbytes):
+        """Copy walker array `array_id` (order of multigpu._ARRAYS) into caller-owned device memory."""
+        self._check(self.L.smhip_index_export_copy(self._h, array_id, C.c_void_p(dst_ptr), nbytes),
+                    "smhip_index_export_copy")
 
     def attach_index(self, d):
         self._check(self.L.smhip_index_attach(self._h, C.byref(d)), "smhip_index_attach")
@@ -236,6 +251,25 @@ class DeviceMapper:
 
     def refine(self, band=64, pad=32):
         self._check(self.L.smhip_refine_run(self._h, band, pad), "smhip_refine_run")
+
+    def refine_path(self, band=64, pad=32):
+        self._check(self.L.smhip_refine_path_run(self._h, band, pad), "smhip_refine_path_run")
+
+    def refine_path_download(self):
+        """dist, end, start (0-based absolute target indices) and the list of path-code arrays."""
+        n = self.n_chunks
+        dist = np.zeros(n, np.float32)
+        end = np.zeros(n, np.int64)
+        start = np.zeros(n, np.int64)
+        plen = np.zeros(n, np.uint32)
+        poff = np.zeros(n + 1, np.uint64)
+        # first call: sizes only (SMHIP_ECAP when there are codes to fetch); second: with the buffer
+        rc = self.L.smhip_refine_path_download(self._h, ptr(dist), ptr(end), ptr(start), ptr(plen), ptr(poff), None, 0)
+        self._check(rc, "smhip_refine_path_download")
+        codes = np.zeros(max(int(poff[-1]), 1), np.uint8)
+        self._check(self.L.smhip_refine_path_download(self._h, ptr(dist), ptr(end), ptr(start), ptr(plen), ptr(poff),
+                                                      ptr(codes), len(codes)), "smhip_refine_path_download")
+        return dist, end, start, [codes[int(poff[i]):int(poff[i]) + int(plen[i])].copy() for i in range(n)]
 
     def refine_download(self):
         dist = np.zeros(self.n_chunks, dtype=np.float32)
@@ -328,6 +362,29 @@ class DeviceMapper:
         self._check(self.L.smhip_sdtw_banded(self._h, ptr(target), ptr(t_off), ptr(query), ptr(q_off),
                                              ptr(lo), ptr(hi), n, ptr(dist), ptr(end)), "smhip_sdtw_banded")
         return dist, end
+
+    def dtw_path(self, target, t_off, query, q_off, lo, hi):
+        """fast_dtw.cc::DTW over per-row windows (smhip_dtw_path): dist, end (0-based target), the list
+        of path-code arrays (start -> end) and the 0-based target coordinate of each path's first cell."""
+        target = np.ascontiguousarray(target, dtype=np.float32)
+        query = np.ascontiguousarray(query, dtype=np.float32)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        lo = np.ascontiguousarray(lo, dtype=np.uint32)
+        hi = np.ascontiguousarray(hi, dtype=np.uint32)
+        n = len(t_off) - 1
+        cap = (np.diff(t_off) + np.diff(q_off)).astype(np.uint64)
+        p_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+        dist = np.zeros(n, np.float32)
+        end = np.zeros(n, np.int64)
+        codes = np.zeros(max(int(p_off[-1]), 1), np.uint8)
+        plen = np.zeros(n, np.uint32)
+        start = np.zeros(n, np.int64)
+        self._check(self.L.smhip_dtw_path(self._h, ptr(target), ptr(t_off), ptr(query), ptr(q_off), ptr(lo), ptr(hi), n,
+                                          ptr(dist), ptr(end), ptr(codes), ptr(p_off), ptr(plen), ptr(start)),
+                    "smhip_dtw_path")
+        paths = [codes[int(p_off[i]):int(p_off[i]) + int(plen[i])].copy() for i in range(n)]
+        return dist, end, paths, start
 
     def close(self):
         if self._h:

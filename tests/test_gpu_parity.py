@@ -370,11 +370,11 @@ def test_index_export_copy_attach_gives_identical_results(device, small_world):
     for f in multigpu._SCALARS:
         setattr(nd, f, getattr(d, f))
     keep = []
-    for a in multigpu._ARRAYS:
+    for k, a in enumerate(multigpu._ARRAYS):
         nbytes = int(getattr(d, a + "_bytes"))
         t = C.c_void_p()
         assert hip.hipMalloc(C.byref(t), nbytes) == 0
-        multigpu._hip_memcpy_d2d(t.value, getattr(d, a), nbytes)  # hipMemcpy: synchronous
+        device.export_copy(k, t.value, nbytes)   # smhip_index_export_copy: what replicate_index uses on rank 0
         setattr(nd, a, t.value)
         setattr(nd, a + "_bytes", nbytes)
         keep.append(t)
@@ -390,6 +390,15 @@ def test_index_export_copy_attach_gives_identical_results(device, small_world):
     peer.close()
     for t in keep:
         hip.hipFree(t)
+    # the C-ABI broadcast with one GPU is a no-op that leaves the index usable; two contexts of one GPU are refused
+    L = _abi.hip_lib()
+    arr = (C.c_void_p * 1)(device._h)
+    assert L.smhip_index_bcast(arr, 1, 0) == 0
+    assert np.array_equal(device.map_chunks(samples, offsets, n_refs=3).tobytes(), base.tobytes())
+    other = pipeline.DeviceMapper(0)
+    arr2 = (C.c_void_p * 2)(device._h, other._h)
+    assert L.smhip_index_bcast(arr2, 2, 0) != 0 and b"one context per GPU" in L.smhip_last_error(device._h)
+    other.close()
 
 
 def test_mapper_pool_batches_in_flight_give_serial_results(device, small_world):
@@ -732,6 +741,10 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     raw3, _ = synth.simulate_reads(genome, lm, 10, 5, n_chunks=3)
     raw1, _ = synth.simulate_reads(genome, lm, 10, 6, n_chunks=1)
     raws = [r for r in raw3] + [r for r in raw1] + [np.full(4000, 600, np.int16)]  # + a flat read
+    # + reads with ADC samples outside (30, 200) pA: the device drops them (signal_batch.cc:141-147) and the
+    # chunk boundaries move with the FILTERED array; the second one is a sample short of a third chunk
+    raws.append(np.insert(raw3[0], 500, np.full(100, 32767, np.int16)))
+    raws.append(np.concatenate([raw3[1][:6000], np.full(37, -32768, np.int16), raw3[1][6000:11999]]))
     os.makedirs(tmp_path / "reads")
     synth.write_sgr(str(tmp_path / "reads" / "a.sgr"), raws)
     r = subprocess.run([exe, "-i", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
@@ -781,9 +794,11 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     nodt = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith(("mt:f:", "dt:f:")))
     assert [nodt(l) for l in got2] == exp
     assert sum(1 for l in got2 if "\tdt:f:" in l) >= 18
-    # the number of device contexts / streams and the chunk budget never show in the output
-    # (default above: 2 streams; here one stream, and three streams with 3-chunk batches each)
-    for k, extra in enumerate((["--streams", "1"], ["--streams", "3", "--batch-chunks", "9", "--sdtw-band", "64"])):
+    # the number of GPUs, of device contexts / streams and the chunk budget never show in the output
+    # (default above: 1 GPU, 2 streams; here one stream, three streams with 3-chunk batches each, and
+    # the multi-GPU code path with one GPU)
+    for k, extra in enumerate((["--streams", "1"], ["--streams", "3", "--batch-chunks", "9", "--sdtw-band", "64"],
+                               ["--gpus", "1", "--streams", "2"])):
         r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
                             "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"),
                             "-o", str(tmp_path / ("out_s%d.paf" % k))] + extra, capture_output=True, text=True)
@@ -793,6 +808,18 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
         if "--sdtw-band" in extra:
             dt = lambda l: [f for f in l.split("\t") if f.startswith("dt:f:")]
             assert [dt(l) for l in gots] == [dt(l) for l in got2]
+    # more GPUs than the box has: a loud failure, no partial output
+    n_gpu = _abi.hip_lib().smhip_device_count()
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out_g.paf"),
+                        "--gpus", str(n_gpu + 1)], capture_output=True, text=True)
+    assert r.returncode != 0 and "GPU" in r.stderr and not os.path.exists(tmp_path / "out_g.paf")
+    if n_gpu >= 2:   # (never on the 1-GPU test boxes) index broadcast over RCCL + read sharding
+        r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                            "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out_g2.paf"),
+                            "--gpus", "2"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert [nodt(l) for l in open(tmp_path / "out_g2.paf").read().splitlines()] == exp
 
 
 # ------------------------------------------------------------------ sDTW refinement of chain 0 (D4/D5)

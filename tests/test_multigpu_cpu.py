@@ -125,7 +125,7 @@ def _replicate_worker(rank, world, port, q):
     try:
         dev = _FakeContext()
         keep = multigpu.replicate_index(dev, None, rank, world, rank, dist, device="cpu",
-                                        copy_fn=lambda dst, src, n: C.memmove(dst, src, n))
+                                        copy_fn=lambda k, dst, src, n: C.memmove(dst, src, n))
         if rank == 0:
             d = dev.exported
             want = {f: int(getattr(d, f)) for f in multigpu._SCALARS}
@@ -155,3 +155,23 @@ def test_world2_gloo_replicate_index_hands_the_peer_identical_arrays():
         assert p.exitcode == 0
     assert got[1] is not None and got[1] == got[0]
 
+
+
+def test_shard_range_is_the_contiguous_block_partition():
+    """`sigmap -m --gpus N` (host/sigmap.cc) and bench.py shard reads the same way: part r of N gets
+    the contiguous block of reads i with i * N // n == r (SURVEY.md 8e); the parts tile [0, n)."""
+    import ctypes as C
+    from sigmap_amd import _abi, multigpu
+    L = _abi.host_lib()
+    for n in (0, 1, 7, 1000, 1001, 100000, 2 ** 33 + 5):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = C.c_uint64(), C.c_uint64()
+                L.smhost_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == multigpu.shard_range(n, r, world)
+                assert lo.value == prev and hi.value >= lo.value
+                prev = hi.value
+                if n and n < 2000:
+                    assert [i for i in range(n) if i * world // n == r] == list(range(lo.value, hi.value))
+            assert prev == n

@@ -1,6 +1,6 @@
 """Turns gpurun_out/prof/ (raw rocprofv3 output of tools/collect_profiles.sh) into the small
 committed files under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_per_launch.csv,
-<tag>_bench.json and pmc_traffic.json (read by bench.py for roofline.traffic)."""
+<tag>_bench.json and <tag>_pmc_traffic.json (read by bench.py for roofline.traffic)."""
 import collections
 import csv
 import glob
@@ -56,21 +56,26 @@ def main(tag):
             w.writerow([k] + ["%.6g" % per[k].get(c, float("nan")) for c in counters])
     seed = next((k for k in per if k.startswith("SeedWalkKernel<false>")), None)
     out = {}
-    if seed and "FETCH_SIZE" in per[seed]:
-        fetch_kb, write_kb = per[seed]["FETCH_SIZE"], per[seed].get("WRITE_SIZE", 0.0)
+    if seed and "TCC_EA0_RDREQ_sum" in per[seed]:
+        # profiles/r2_calibration.json: on gfx950 EVERY L2 read miss goes to the fabric as one 128-byte
+        # request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for 64-byte records, 32-byte records, leaf lines
+        # and streams alike), and FETCH_SIZE tallies it at 64 bytes; WRITE_SIZE counts 32-byte write
+        # requests exactly.  HBM-side bytes = 128 * read requests + WRITE_SIZE.
+        rd = per[seed]["TCC_EA0_RDREQ_sum"]
+        write_kb = per[seed].get("WRITE_SIZE", 0.0)
         out = {
             "kernel": seed,
-            "seed_lookup_hbm_bytes_per_launch": int((fetch_kb + write_kb) * 1024),
-            "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-            "upper_bound_bytes_if_every_read_request_were_128B": int((2 * fetch_kb + write_kb) * 1024),
-            "note": "rocprofv3 FETCH_SIZE/WRITE_SIZE (KB) per launch, separate --pmc passes; FETCH_SIZE = "
-                    "TCC_EA0_RDREQ x 64 B.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a "
-                    "wide coalesced stream; this kernel issues 16-byte gathers, for which the counter is "
-                    "uncalibrated: node records are fetched as single 64-byte sectors (counted exactly), point blocks "
-                    "as 128-byte requests (counted half), so the figure is the uncorrected count and the true "
-                    "bytes lie between it and the upper bound given here.",
+            "seed_lookup_hbm_bytes_per_launch": int(rd * 128 + write_kb * 1024),
+            "read_requests_128B": rd, "read_bytes": int(rd * 128),
+            "fetch_size_kb_as_reported": per[seed].get("FETCH_SIZE"), "write_size_kb": write_kb,
+            "rdreq_128B": per[seed].get("TCC_EA0_RDREQ_128B_sum"), "rdreq_64B": per[seed].get("TCC_EA0_RDREQ_64B_sum"),
+            "l2_hit_rate": (per[seed]["TCC_HIT_sum"] / (per[seed]["TCC_HIT_sum"] + per[seed]["TCC_MISS_sum"])
+                            if "TCC_HIT_sum" in per[seed] else None),
+            "source": f"profiles/{tag}_pmc_per_launch.csv: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) "
+                      f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1; mean per launch of {seed}; "
+                      "calibration profiles/r2_calibration.json",
         }
-        json.dump(out, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_default.json", "kt_bench.json", "kt_serial_bench.json"):
         p = os.path.join(SRC, name)
         if os.path.exists(p) and os.path.getsize(p):
@@ -80,4 +85,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r1")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r2")
