@@ -81,21 +81,27 @@ def cpu_baseline(ix, pa_list, n_refs, ref_lens, seconds):
         return n_sample / dt, dt
 
     probe, _ = run(1, 8)                                   # sizes the samples (about `seconds` per leg)
-    n1 = max(16, int(probe * seconds))
-    r1, s1 = run(1, n1)
-    pilot, _ = run(cores, cores * 2)                       # the parallel rate is not cores x the serial one
-    nall = max(cores * 4, int(pilot * seconds))
-    rall, sall = run(cores, nall)
+    legs = []
+    for nt in sorted({1, min(32, cores), cores}):
+        pilot = probe if nt == 1 else run(nt, nt * 2)[0]    # the parallel rate is not nt x the serial one
+        n = max(nt * 4, 16, int(pilot * seconds))
+        rate, sec = run(nt, n)
+        legs.append({"threads": nt, "chunks": n, "seconds": round(sec, 1), "chunks_per_s": round(rate, 2),
+                     "per_thread": round(rate / nt, 2)})
     tree.close()
-    return {"value": round(rall, 2), "unit": "chunks/s", "cores": cores, "kind": "port",
-            "sample": f"{nall} chunks (the same synthetic 4000-sample reads, same 12 Mb index) through "
-                      f"oracle/sigmap_oracle.c so_map_reads (OpenMP) on {cores} threads in {sall:.1f} s; "
-                      f"-t 1 leg: {n1} chunks in {s1:.1f} s",
-            "t1_value": round(r1, 2), "per_core": round(rall / cores, 2),
-            "reference_t1_chunks_per_s": REF_CHUNKS_PER_S_PER_CORE,
-            "t1_vs_reference_t1": round(r1 / REF_CHUNKS_PER_S_PER_CORE, 3),
+    best = max(legs, key=lambda l: l["chunks_per_s"])
+    t1 = legs[0]["chunks_per_s"]
+    return {"value": best["chunks_per_s"], "unit": "chunks/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['chunks']} chunks (the same synthetic 4000-sample reads, same 12 Mb index) through "
+                      f"oracle/sigmap_oracle.c so_map_reads (OpenMP loop over reads) on {best['threads']} threads in "
+                      f"{best['seconds']} s -- the fastest of the legs below ({cores} hardware threads available)",
+            "legs": legs, "host_threads_available": cores,
+            "t1_value": t1, "reference_t1_chunks_per_s": REF_CHUNKS_PER_S_PER_CORE,
+            "t1_vs_reference_t1": round(t1 / REF_CHUNKS_PER_S_PER_CORE, 3),
             "note": "reference_t1 = the unmodified reference with -t 1 on the survey container's Xeon 2.1 GHz "
-                    "(BASELINE.md section 2); the port does the same work per read (same node visits, same hits)"}
+                    "(BASELINE.md section 2); the port does the same work per read (same node visits, same hits).  "
+                    "The path is a DRAM-latency-bound pointer chase over a shared 0.7 GB index: on this two-socket "
+                    "host it stops scaling near 32 threads (tools/oracle_scaling.py)"}
 
 
 def main():

@@ -205,6 +205,11 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
  * floats; n_kept = samples held (<= keep_samples), n_total = filtered length of the whole read. */
 int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t cap, uint32_t *n_kept,
                             uint32_t *n_total);
+/* Optional set-up step: allocate now the scratch a batch of n_chunks chunks with about
+ * queries_per_chunk seeds each will need (it otherwise grows on first use; device allocations beyond a
+ * few GB take 40 ms per GB on this platform -- tools/micro/malloc_cost.hip -- which a caller that times
+ * its mapping phase wants outside that span, like the index load). */
+int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_chunk);
 /* Pinned (page-locked) host memory for the raw reads: DMA at link rate, truly asynchronous copies. */
 int smhip_host_alloc(void **out, size_t bytes);
 void smhip_host_free(void *p);

@@ -92,6 +92,8 @@ def lib():
         L.so_point_cloud_one_direction.argtypes = [C.c_int, C.c_uint32, vp, vp, sz, C.c_int, vp, vp, sz]
         L.so_kdtree_build.restype = vp
         L.so_kdtree_build.argtypes = [vp, u64, C.c_int, C.c_int]
+        L.so_kdtree_from_preorder.restype = vp
+        L.so_kdtree_from_preorder.argtypes = [vp, u64, C.c_int, u64, vp, u64, vp, u64, vp]
         L.so_kdtree_free.argtypes = [vp]
         L.so_kdtree_save.argtypes = [vp, C.c_char_p]
         L.so_kdtree_load.restype = vp
@@ -187,6 +189,20 @@ class OracleTree:
         values = np.ascontiguousarray(values, dtype=np.float32)
         h = lib().so_kdtree_load(path.encode(), _p(values), len(values))
         return cls(values, dim=dim, handle=h)
+
+    @classmethod
+    def from_host_index(cls, ix):
+        """The oracle's tree over the arrays of a host index (pipeline.HostIndex): the content of its
+        .si file handed over in memory (so_kdtree_from_preorder)."""
+        values = np.ascontiguousarray(ix.values, dtype=np.float32)
+        vind = np.ascontiguousarray(ix.vind, dtype=np.uint32)
+        nodes = np.ascontiguousarray(ix.nodes)
+        bbox = np.ascontiguousarray(ix.bbox, dtype=np.float32)
+        h = lib().so_kdtree_from_preorder(_p(values), len(values), ix.dim, ix.max_leaf, _p(vind), len(vind),
+                                          _p(nodes), len(nodes), _p(bbox))
+        t = cls(values, dim=ix.dim, handle=h)
+        t._keep = (vind, nodes, bbox)
+        return t
 
     def save(self, path):
         assert lib().so_kdtree_save(self.h, path.encode()) == 0

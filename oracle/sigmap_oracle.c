@@ -11,6 +11,7 @@
 
 #include <assert.h>
 #include <float.h>
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -698,6 +699,55 @@ bad:
   fclose(f);
   so_kdtree_free(t);
   return NULL;
+}
+
+/* The tree of loadIndex_ (nanoflann.hpp:1035-1072) from the SAME content as a .si file, handed over
+ * in memory instead of through the file: vind as uint32, the pre-order node stream as 16-byte records
+ * {int32 feat (-1 = leaf); uint32 a, b (leaf: left, right; inner: divlow, divhigh bits); uint32
+ * child2 (inner: index of the second child; child1 = self + 1)}, root box {low0, high0, low1, ...}.
+ * (A 250 Mb index is 14 GB of .pt/.si on disk and 7 minutes to write; the tests that need the oracle on
+ * it hand the arrays over directly.) */
+so_kdtree *so_kdtree_from_preorder(const float *values, uint64_t n_values, int dim, uint64_t leaf_max,
+                                   const uint32_t *vind, uint64_t m_size, const void *nodes16, uint64_t n_nodes,
+                                   const float *bbox) {
+  if (dim > 16 || n_values < (uint64_t)dim || m_size != n_values - (uint64_t)dim + 1 || n_nodes == 0) return NULL;
+  const struct {
+    int32_t feat;
+    uint32_t a, b, child2;
+  } *in = nodes16;
+  so_kdtree *t = (so_kdtree *)calloc(1, sizeof(so_kdtree));
+  t->dim = dim;
+  t->leaf_max = leaf_max;
+  t->values = values;
+  t->n_values = n_values;
+  t->m_size = m_size;
+  t->bbox_low = (float *)malloc(sizeof(float) * (size_t)dim);
+  t->bbox_high = (float *)malloc(sizeof(float) * (size_t)dim);
+  for (int d = 0; d < dim; ++d) {
+    t->bbox_low[d] = bbox[2 * d];
+    t->bbox_high[d] = bbox[2 * d + 1];
+  }
+  t->vind = (uint64_t *)malloc(m_size * sizeof(uint64_t));
+  for (uint64_t i = 0; i < m_size; ++i) t->vind[i] = vind[i];
+  t->nodes = (so_node *)calloc(n_nodes, sizeof(so_node));
+  t->n_nodes = t->cap_nodes = n_nodes;
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    so_node *nd = &t->nodes[i];
+    if (in[i].feat < 0) {
+      nd->is_leaf = 1;
+      nd->left = in[i].a;
+      nd->right = in[i].b;
+      nd->child1 = nd->child2 = -1;
+    } else {
+      nd->is_leaf = 0;
+      nd->divfeat = in[i].feat;
+      memcpy(&nd->divlow, &in[i].a, 4);
+      memcpy(&nd->divhigh, &in[i].b, 4);
+      nd->child1 = (int64_t)i + 1;
+      nd->child2 = (int64_t)in[i].child2;
+    }
+  }
+  return t;
 }
 
 /* spatial_index.cc:105-123: Point = {uint64 position; float value; 4 B pad} */
@@ -1390,6 +1440,13 @@ void so_map_reads(const so_kdtree *t, const uint64_t *positions, const float *si
                   size_t n, size_t n_refs, const uint32_t *ref_lens, const so_map_params *p, so_mapping *out,
                   int n_threads) {
   long i;
+  /* Per-read scratch is malloc'd and freed inside so_map_read (the reference keeps its scratch vectors
+   * per thread, sigmap.cc:625-627).  Keep freed memory in the threads' arenas instead of handing it back
+   * to the kernel after every read: with dozens of threads the mmap / munmap / page-fault traffic on the
+   * process's address space otherwise serialises them (measured: 32 threads faster than 256). */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
 #endif

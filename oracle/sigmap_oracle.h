@@ -101,6 +101,10 @@ void so_kdtree_free(so_kdtree *t);
 /* nanoflann.hpp:1051-1058, 1025-1033 (.si layout) */
 int so_kdtree_save(const so_kdtree *t, const char *path);
 so_kdtree *so_kdtree_load(const char *path, const float *values, uint64_t n_values);
+/* the same tree as so_kdtree_load builds, from the .si content handed over in memory (see .c) */
+so_kdtree *so_kdtree_from_preorder(const float *values, uint64_t n_values, int dim, uint64_t leaf_max,
+                                   const uint32_t *vind, uint64_t m_size, const void *nodes16, uint64_t n_nodes,
+                                   const float *bbox);
 /* spatial_index.cc:105-123 / :132-146 (.pt layout) */
 int so_points_save(const char *path, int dim, int max_leaf, const uint64_t *positions,
                    const float *values, uint64_t n);

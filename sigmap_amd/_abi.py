@@ -19,7 +19,7 @@ HIP_SYMBOLS = [
     "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
-    "smhip_host_alloc", "smhip_host_free", "smhip_index_export_copy", "smhip_index_bcast", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
+    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -203,6 +203,7 @@ def hip_lib():
         L.smhip_reads_upload_raw.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
         L.smhip_batch_select.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
         L.smhip_reads_download_pa.argtypes = [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.smhip_batch_reserve.argtypes = [vp, u32, u32]
         L.smhip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
         L.smhip_host_free.argtypes = [vp]
         L.smhip_host_free.restype = None

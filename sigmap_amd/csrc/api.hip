@@ -216,7 +216,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->reads_pa,
                     &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
-                    &ctx->dl_off, &ctx->dl_compact, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
+                    &ctx->dl_off, &ctx->dl_compact, &ctx->sort_tmp, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
                     &ctx->rp_qoff, &ctx->rp_qlen, &ctx->rp_lo, &ctx->rp_hi, &ctx->rp_width, &ctx->rp_celloff, &ctx->rp_codes,
                     &ctx->rp_dist, &ctx->rp_end, &ctx->rp_path, &ctx->rp_plen, &ctx->rp_start,
                     &ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
@@ -255,6 +255,9 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   std::vector<uint32_t> ref_of(n_nodes), depth(n_nodes, 0);
   uint64_t n_inner = 0, n_leaves = 0, n_slots = 0, leaf_points = 0;
   uint32_t max_depth = 0;
+  // Record numbers: leaves by ordinal in tree order, inner nodes in pre-order among the inner nodes (a
+  // node's first child is the next record, i.e. in the same 128-byte L2 line half of the time; numbering
+  // siblings as adjacent, line-aligned pairs instead was measured and lost: DESIGN.md section 10).
   for (uint64_t i = 0; i < n_nodes; ++i) {
     if (nodes[i].feat >= 0) ref_of[i] = (uint32_t)n_inner++;
     else ref_of[i] = kLeafTag | (uint32_t)n_leaves++;
@@ -718,6 +721,28 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   return SMHIP_OK;
 }
 
+int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_chunk) {
+  if (!ctx) return SMHIP_EINVAL;
+  if (n_chunks == 0 || queries_per_chunk == 0) return Fail(ctx, SMHIP_EINVAL, "counts must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  smhip_params p;
+  smhip_default_params(&p);
+  const uint64_t R = n_chunks, nq = R * queries_per_chunk;
+  // the buffers smhip_map_run sizes from the chunk and query counts (the anchor-sized ones depend on
+  // the index and stay lazy); the per-query hit slots are by far the largest
+  HIPCHK(ctx->feat.Reserve(R * kFeatStride * sizeof(float)));
+  HIPCHK(ctx->results.Reserve(R * sizeof(smhip_chunk_result)));
+  HIPCHK(ctx->q_count.Reserve(nq * sizeof(uint32_t)));
+  HIPCHK(ctx->q_nodes.Reserve(nq * sizeof(uint32_t)));
+  HIPCHK(ctx->q_points.Reserve(nq * sizeof(uint32_t)));
+  HIPCHK(ctx->ovf_list.Reserve(nq * sizeof(uint32_t)));
+  HIPCHK(ctx->q_ovf_off.Reserve(nq * kOvfLevels * sizeof(uint32_t)));
+  HIPCHK(ctx->region.Reserve(nq * p.hits_per_query_fast * sizeof(Hit)));
+  HIPCHK(ctx->qrec.Reserve(nq * 32));
+  HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * sizeof(Hit)));
+  return SMHIP_OK;
+}
+
 int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t cap, uint32_t *n_kept, uint32_t *n_total) {
   if (!ctx || !pa) return Fail(ctx, SMHIP_EINVAL, "null argument");
   if (slot >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
@@ -846,7 +871,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   sa.results = results;
   {
     ScopedTimer t(ctx, T_SORT);
-    HIPCHK(LaunchSort(ctx, sa, R));
+    HIPCHK(LaunchSort(ctx, sa, R, NA));
   }
   ChainArgs ca;
   ca.anchor_off = sa.anchor_off;

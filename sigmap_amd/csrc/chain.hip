@@ -56,58 +56,91 @@ constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else thro
 // any other anchor.  Those anchors ("isolated", ~94 % of a noise bucket) are finished here in
 // parallel (score, predecessor, bucket maximum); the rest are flagged (used = 2) and listed in
 // index order for the sequential kernels.
-constexpr uint32_t kLdsGroups = 1024;  // bucket maxima kept in LDS by the classify kernel (LDS per workgroup decides its occupancy)
-
-__global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float radius, int dim, int max_gap_length,
-                                                           int max_target_gap_length, int chaining_band_length,
-                                                           int max_num_skips, uint32_t *__restrict__ n_pending) {
-  __shared__ uint32_t s_gmax[kLdsGroups];  // positive floats order like their bit patterns
-  __shared__ uint32_t s_wave[4];
-  __shared__ uint32_t s_run;
-  __shared__ int32_t s_t[512], s_q[512];
-  __shared__ uint32_t s_g[512], s_gstart[1024];
-  const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t base = a.anchor_off[c];
-  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
-  const uint32_t G = a.n_groups[c];
-  const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
-  const uint32_t *gstart = a.group_start + base;
-  const float *dist = a.s_dist + base;
-  float *score = a.score + base;
-  uint32_t *pred = a.pred + base;
-  uint8_t *used = a.used + base;
-  uint32_t *pending = a.pending + base;
-  uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
-  const bool lds_max = G <= kLdsGroups;
-  const bool lds_gs = G <= 1024;  // bucket starts staged for the ordinal search
-  for (uint32_t g = tid; g < G; g += 256) {
-    if (lds_max) s_gmax[g] = 0; else gmax_g[g] = 0;
-    if (lds_gs) s_gstart[g] = gstart[g];
+// One workgroup per TILE of 256 anchors (any chunk): the tile and the 256 anchors before it are staged
+// in LDS (the backward scans rarely leave that window; older predecessors are read from memory), so
+// the number of workgroups follows the number of anchors, not of chunks -- a 250 Mb reference has
+// 181 000 anchors per chunk in two buckets.
+__device__ __forceinline__ uint32_t ChunkOfFlat(const uint32_t *__restrict__ off, uint32_t n_chunks, uint32_t x) {
+  uint32_t lo = 0, hi = n_chunks;  // chunk c with off[c] <= x < off[c + 1]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= x) lo = mid; else hi = mid;
   }
-  if (tid == 0) s_run = 0;
-  __syncthreads();
-  // The tile and the 256 anchors before it live in an LDS ring of 512 entries (anchor p in slot
-  // p & 511): the backward scans rarely leave that window, a tile overwrites the older half, and
-  // its records (and distances) were fetched into registers while the previous tile was processed.
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void ChainTileCountKernel(ChainArgs a, uint32_t n_chunks, uint32_t *__restrict__ tiles) {
+  for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += gridDim.x * 256) {
+    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - a.anchor_off[c]);
+    tiles[c] = (n + 255u) / 256u;
+    // bucket maxima of the chunk (positive floats order like their bit patterns): zeroed for the atomics below
+    uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * a.anchor_off[c]);
+    const uint32_t G = a.n_groups[c];
+    for (uint32_t g = 0; g < G; ++g) gmax_g[g] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t n_chunks,
+                                                           const uint32_t *__restrict__ tile_off, float radius, int dim,
+                                                           int max_gap_length, int max_target_gap_length,
+                                                           int chaining_band_length, int max_num_skips) {
+  __shared__ uint32_t s_gmax[258];  // maxima of the buckets the tile touches, relative to its first bucket
+  __shared__ int32_t s_t[512], s_q[512];
+  __shared__ uint32_t s_g[512];
+  __shared__ uint32_t s_first, s_last, s_wcnt[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // Every workgroup takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1,
+  // ...): one search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p
+  // in slot p & 511) already holds the previous tile, so a tile loads only its own 256 records.
+  const uint32_t total_tiles = tile_off[n_chunks];
+  const uint32_t per = (total_tiles + gridDim.x - 1) / gridDim.x;
+  uint32_t tile = blockIdx.x * per;
+  const uint32_t tile_end = min(total_tiles, tile + per);
+  if (tile >= tile_end) return;
+  uint32_t c = ChunkOfFlat(tile_off, n_chunks, tile);
+  bool ring_valid = false;  // the ring holds [t0 - 256, t0) of chunk c
+  uint32_t ord_carry = 0;   // bucket ordinal of the last anchor of the previous tile (ring_valid)
+  // the records (and distance) of the next tile of the same chunk are fetched into registers while the
+  // current one is processed
+  bool have_nx = false;
   uint32_t nx_t = 0, nx_q = 0, nx_g = 0;
   float nx_d = 0.0f;
-  if (tid < n) {
-    nx_t = tpos[tid];
-    nx_q = qpos[tid];
-    nx_g = grp[tid];
-    nx_d = dist[tid];
-  }
-  for (uint32_t t0 = 0; t0 < n; t0 += 256) {
-    const uint32_t w0 = t0 >= 256 ? t0 - 256 : 0;
-    __syncthreads();  // the scans of the previous tile are done with the half that is overwritten
-    const float my_dist = nx_d;
-    if (t0 + tid < n) {
-      s_t[(t0 + tid) & 511u] = (int32_t)nx_t;
-      s_q[(t0 + tid) & 511u] = (int32_t)nx_q;
-      s_g[(t0 + tid) & 511u] = nx_g;
+  for (; tile < tile_end; ++tile) {
+    while (tile >= tile_off[c + 1]) {  // next chunk (chunks without anchors have no tiles)
+      ++c;
+      ring_valid = false;
+      have_nx = false;
     }
-    {
-      const uint32_t gi = t0 + 256 + tid;  // next tile
+    const uint32_t t0 = (tile - tile_off[c]) * 256u;
+    const uint64_t base = a.anchor_off[c];
+    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+    const uint32_t G = a.n_groups[c];
+    const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base, *grp = a.s_grp + base;
+    const uint32_t *gstart = a.group_start + base;
+    const float *dist = a.s_dist + base;
+    float *score = a.score + base;
+    uint32_t *pred = a.pred + base;
+    uint8_t *used = a.used + base;
+    uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
+    const uint32_t w0 = t0 >= 256 ? t0 - 256 : 0;
+    const uint32_t ai = t0 + tid;
+    __syncthreads();  // the previous tile is done with the half of the ring that is overwritten, and with s_*
+    float my_dist = 0.0f;
+    if (ai < n) {
+      if (!have_nx) {
+        nx_t = tpos[ai];
+        nx_q = qpos[ai];
+        nx_g = grp[ai];
+        nx_d = dist[ai];
+      }
+      s_t[ai & 511u] = (int32_t)nx_t;
+      s_q[ai & 511u] = (int32_t)nx_q;
+      s_g[ai & 511u] = nx_g;
+      my_dist = nx_d;
+    }
+    have_nx = tile + 1 < tile_end && tile + 1 < tile_off[c + 1];
+    if (have_nx) {
+      const uint32_t gi = ai + 256u;
       if (gi < n) {
         nx_t = tpos[gi];
         nx_q = qpos[gi];
@@ -115,9 +148,39 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
         nx_d = dist[gi];
       }
     }
+    if (!ring_valid && t0 > 0) {  // first tile of this workgroup in the middle of a chunk
+      const uint32_t p = w0 + tid;
+      s_t[p & 511u] = (int32_t)tpos[p];
+      s_q[p & 511u] = (int32_t)qpos[p];
+      s_g[p & 511u] = grp[p];
+    }
+    for (uint32_t g = tid; g < 258; g += 256) s_gmax[g] = 0;
+    // bucket ordinal of the tile's first anchor: carried over from the previous tile, or one search
+    // (last bucket start <= t0); the others follow from the bucket changes inside the tile
+    if (tid == 0 && !ring_valid) {
+      uint32_t lo = 0, hi = G;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gstart[mid] <= t0) lo = mid; else hi = mid;
+      }
+      s_first = lo;
+    }
     __syncthreads();
-    const uint32_t ai = t0 + tid;
-    bool pend = false;
+    uint32_t ord = 0;
+    {
+      // (with a valid ring the anchor before the tile is in LDS too: its bucket starts the count)
+      const bool change = ai < n && (ai > t0 || ring_valid) && s_g[ai & 511u] != s_g[(ai - 1) & 511u];
+      const unsigned long long m = __ballot(change);
+      if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t before = 0;
+      for (uint32_t w2 = 0; w2 < wave; ++w2) before += s_wcnt[w2];
+      const uint32_t o0 = ring_valid ? ord_carry : s_first;
+      ord = o0 + before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));  // changes up to and including ai
+      if (tid == 255) s_last = ord;  // (lanes past the end carry the last anchor's ordinal)
+      if (tid == 0 && ring_valid) s_first = ord;  // ordinal of the tile's first anchor
+    }
+    __syncthreads();
     if (ai < n) {
       const uint32_t g = s_g[ai & 511u];
       const int32_t ct = s_t[ai & 511u], cq = s_q[ai & 511u];
@@ -163,55 +226,114 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, float ra
         score[ai] = sc;
         pred[ai] = ai;
         used[ai] = 0;
-        uint32_t lo = 0, hi = G;  // bucket ordinal: last bucket start <= ai
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if ((lds_gs ? s_gstart[mid] : gstart[mid]) <= ai) lo = mid; else hi = mid;
-        }
-        if (lds_max) atomicMax(&s_gmax[lo], __float_as_uint(sc)); else atomicMax(&gmax_g[lo], __float_as_uint(sc));
+        atomicMax(&s_gmax[ord - s_first], __float_as_uint(sc));  // (a tile of 256 anchors touches <= 256 buckets)
       } else {
-        used[ai] = 2;
-        pend = true;
+        used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
       }
     }
-    // ordered compaction of the pending anchors of this tile
-    const unsigned long long m = __ballot(pend);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t off = s_run;
+    if (tid <= s_last - s_first && s_gmax[tid] != 0) atomicMax(&gmax_g[s_first + tid], s_gmax[tid]);
+    ord_carry = s_last;
+    ring_valid = true;
+  }
+}
+
+// ---- C0b: the anchors left for the sequential DP, listed per chunk in index order (one workgroup per
+// chunk: an ordered compaction of the flags), and cut into ITEMS: maximal runs of listed anchors of one
+// bucket in which consecutive ones lie within max_target_gap_length on the target.  The predecessor
+// scan of an anchor stops at the first predecessor farther than that (spatial_index.cc:476-479, targets
+// are sorted), so an anchor never reads the score of a listed anchor of an earlier item: items are
+// independent DP problems.  A noise bucket of a large reference falls into thousands of items of two or
+// three anchors; the true locus of a read is one long item.
+__global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_target_gap_length,
+                                                          uint32_t *__restrict__ n_pending,
+                                                          uint32_t *__restrict__ n_items) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_run;
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t base = a.anchor_off[c];
+  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+  const uint32_t *tpos = a.s_tpos + base, *grp = a.s_grp + base;
+  const uint8_t *used = a.used + base;
+  uint32_t *pending = a.pending + base;
+  uint32_t *items = a.lists + base;  // (ChainEndsKernel reuses this array for the chains' anchor lists afterwards)
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  // 1024 flags per pass: a thread takes four consecutive anchors, a wave scan of the counts places them
+  for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+    const uint32_t a0 = t0 + 4 * tid;
+    uint32_t f = 0;  // bit k: anchor a0 + k is listed
+    if (a0 + 3 < n && ((reinterpret_cast<uintptr_t>(used + a0) & 3u) == 0)) {
+      const uint32_t w4 = *reinterpret_cast<const uint32_t *>(used + a0);
+      f = ((w4 & 0xFFu) == 2u ? 1u : 0u) | (((w4 >> 8) & 0xFFu) == 2u ? 2u : 0u) | (((w4 >> 16) & 0xFFu) == 2u ? 4u : 0u) |
+          ((w4 >> 24) == 2u ? 8u : 0u);
+    } else {
+      for (uint32_t k = 0; k < 4; ++k)
+        if (a0 + k < n && used[a0 + k] == 2) f |= 1u << k;
+    }
+    const uint32_t cnt = (uint32_t)__popc(f);
+    uint32_t incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = s_run + incl - cnt;
     for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
-    if (pend) pending[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ai;
+    for (uint32_t k = 0; k < 4; ++k)
+      if (f & (1u << k)) pending[off++] = a0 + k;
     __syncthreads();
     if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
   }
-  if (lds_max)
-    for (uint32_t g = tid; g < G; g += 256) gmax_g[g] = s_gmax[g];
-  if (tid == 0) n_pending[c] = s_run;
+  const uint32_t npend = s_run;
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    n_pending[c] = npend;
+    s_run = 0;
+  }
+  __syncthreads();
+  for (uint32_t p0 = 0; p0 < npend; p0 += 256) {
+    const uint32_t pi = p0 + tid;
+    bool start = false;
+    if (pi < npend) {
+      if (pi == 0) {
+        start = true;
+      } else {
+        const uint32_t x = pending[pi - 1], y = pending[pi];
+        start = grp[x] != grp[y] || tpos[x] + (uint32_t)max_target_gap_length < tpos[y];
+      }
+    }
+    const unsigned long long m = __ballot(start);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = s_run;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+    if (start) items[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pi;
+    __syncthreads();
+    if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) n_items[c] = s_run;
 }
 
-// ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER (chunk, bucket), flattened over
-// the whole batch so that the few long buckets (the true locus) are spread over many waves.
+// ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER ITEM, flattened over the whole batch.
 // Predecessor records are fetched kPf at a time so the dependent chain sees one memory latency
 // per block instead of one per predecessor.
-__global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t *__restrict__ goff, uint32_t n_chunks,
+__global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
                                                     float radius, int dim, int max_gap_length,
                                                     int max_target_gap_length, int chaining_band_length,
                                                     int max_num_skips, uint32_t *__restrict__ big_list,
                                                     uint32_t *__restrict__ big_count,
                                                     const uint32_t *__restrict__ n_pending) {
   __shared__ uint32_t s_ids[kBigPendingMin][64];  // each lane's pending anchor ids
-  const uint32_t total_groups = goff[n_chunks];
-  // grid-stride over buckets (the bucket total is only known on the device)
-  for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_groups; gi += gridDim.x * 64) {
-  uint32_t lo = 0, hi = n_chunks;  // chunk c with goff[c] <= gi < goff[c+1]
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (goff[mid] <= gi) lo = mid; else hi = mid;
-  }
-  const uint32_t c = lo, g = gi - goff[c];
+  const uint32_t total_items = ioff[n_chunks];
+  // grid-stride over items (their total is only known on the device)
+  for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_items; gi += gridDim.x * 64) {
+  const uint32_t c = ChunkOfFlat(ioff, n_chunks, gi), k_item = gi - ioff[c];
   const uint64_t base = a.anchor_off[c];
-  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
   const uint32_t G = a.n_groups[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base;
   const float *dist = a.s_dist + base;
@@ -219,21 +341,25 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
   float *score = a.score + base;
   uint32_t *pred = a.pred + base;
   uint8_t *used = a.used + base;
-  float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
-  const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
-  // this bucket's slice of the chunk's pending list (sorted by anchor index)
+  uint32_t *gmax = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
   const uint32_t *pending = a.pending + base;
+  const uint32_t *items = a.lists + base;
   const uint32_t npend = n_pending[c];
-  uint32_t p0, p1;
+  const uint32_t n_it = ioff[c + 1] - ioff[c];
+  // this item's slice of the chunk's pending list (sorted by anchor index), its bucket's first anchor
+  const uint32_t p0 = items[k_item], p1 = k_item + 1 < n_it ? items[k_item + 1] : npend;
+  uint32_t g;
   {
-    uint32_t lo2 = 0, hi2 = npend;
-    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
-    p0 = lo2;
-    hi2 = npend;
-    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < e) lo2 = mid + 1; else hi2 = mid; }
-    p1 = lo2;
+    const uint32_t first = pending[p0];
+    uint32_t lo = 0, hi = G;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (gstart[mid] <= first) lo = mid; else hi = mid;
+    }
+    g = lo;
   }
-  // a bucket with many unsettled anchors (the true locus of a read) goes to the wave-parallel kernel
+  const uint32_t s = gstart[g];
+  // an item with many anchors (the true locus of a read) goes to the wave-parallel kernel
   if (p1 - p0 > (uint32_t)kBigPendingMin) {
     big_list[atomicAdd(big_count, 1u)] = gi;
     continue;
@@ -341,7 +467,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     cur = nxt;
    }
   }
-  if (gm > gmax[g]) gmax[g] = gm;  // the classify kernel stored the maximum over the settled anchors
+  atomicMax(&gmax[g], __float_as_uint(gm));  // (several items of a bucket run at the same time; scores are positive)
   }
 }
 
@@ -356,10 +482,11 @@ template <bool kLds>
 __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t s, const uint32_t *__restrict__ pend,
                                             uint32_t npend, int32_t *l_t, int32_t *l_q, float *l_s, float *l_d,
                                             const uint32_t *tpos, const uint32_t *qpos, const float *dist,
-                                            float *score, uint32_t *pred, float *gmax_slot, float radius, int dim,
+                                            float *score, uint32_t *pred, uint8_t *used, uint32_t *gmax_slot,
+                                            float radius, int dim,
                                             int max_gap_length, int max_target_gap_length, int chaining_band_length,
                                             int max_num_skips) {
-  float gm = *gmax_slot;  // maximum over the anchors the classify kernel settled
+  float gm = 0.0f;
   // kLds: the whole bucket is staged (index = bucket-local anchor).  Otherwise the LDS arrays are a
   // RING over the bucket (slot = anchor & (kBigGroupCap - 1)) that follows the unsettled anchors:
   // before anchor ai is chained, the anchors up to ai that are not in the ring yet are staged, so
@@ -454,15 +581,16 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
       l_s[am] = best;
       score[ai] = best;
       pred[ai] = s + best_pred;  // chunk-local absolute index
+      used[ai] = 0;
     }
     gm = fmaxf(gm, best);
     __syncthreads();  // (one wave per workgroup) the new score is visible to the next anchor's scan
     if (!kLds) __threadfence_block();
   }
-  if (lane == 0) *gmax_slot = gm;
+  if (lane == 0) atomicMax(gmax_slot, __float_as_uint(gm));  // (other items of the bucket run at the same time)
 }
 
-__global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ goff,
+__global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ ioff,
                                                        uint32_t n_chunks, float radius, int dim, int max_gap_length,
                                                        int max_target_gap_length, int chaining_band_length,
                                                        int max_num_skips, const uint32_t *__restrict__ big_list,
@@ -474,16 +602,26 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
   const uint32_t nbig = *big_count;
   for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
     const uint32_t gi = big_list[b];
-    uint32_t lo = 0, hi = n_chunks;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (goff[mid] <= gi) lo = mid; else hi = mid;
-    }
-    const uint32_t c = lo, g = gi - goff[c];
+    const uint32_t c = ChunkOfFlat(ioff, n_chunks, gi), k_item = gi - ioff[c];
     const uint64_t base = a.anchor_off[c];
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint32_t G = a.n_groups[c];
     const uint32_t *gstart = a.group_start + base;
+    const uint32_t *pending = a.pending + base;
+    const uint32_t *items = a.lists + base;
+    const uint32_t npend = n_pending[c];
+    const uint32_t n_it = ioff[c + 1] - ioff[c];
+    const uint32_t p0 = items[k_item], p1 = k_item + 1 < n_it ? items[k_item + 1] : npend;
+    uint32_t g;
+    {
+      const uint32_t first = pending[p0];
+      uint32_t lo = 0, hi = G;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gstart[mid] <= first) lo = mid; else hi = mid;
+      }
+      g = lo;
+    }
     const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
     const uint32_t ng = e - s;
     const uint32_t *tpos = a.s_tpos + base + s, *qpos = a.s_qpos + base + s;
@@ -491,36 +629,23 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
     float *score = a.score + base + s;
     uint32_t *pred = a.pred + base + s;
     uint8_t *used = a.used + base + s;
-    float *gmax = reinterpret_cast<float *>(a.scratch + 2 * base);
-    // this bucket's slice of the chunk's pending list (sorted by anchor index)
-    const uint32_t *pending = a.pending + base;
-    const uint32_t npend = n_pending[c];
-    uint32_t p0, p1;
-    {
-      uint32_t lo2 = 0, hi2 = npend;
-      while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < s) lo2 = mid + 1; else hi2 = mid; }
-      p0 = lo2;
-      hi2 = npend;
-      while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (pending[mid] < e) lo2 = mid + 1; else hi2 = mid; }
-      p1 = lo2;
-    }
+    uint32_t *gmax = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
+    // a small bucket is staged whole; otherwise the LDS arrays are a ring that follows the item's anchors
     const bool in_lds = ng <= (uint32_t)kBigGroupCap;
     __syncthreads();
-    for (uint32_t i = lane; i < ng; i += 64) {
-      if (in_lds) {
+    if (in_lds)
+      for (uint32_t i = lane; i < ng; i += 64) {
         l_t[i] = (int32_t)tpos[i];
         l_q[i] = (int32_t)qpos[i];
         l_d[i] = dist[i];
-        l_s[i] = score[i];  // valid for the anchors the classify kernel settled
+        l_s[i] = score[i];  // valid for the anchors the classify kernel settled (others are not read before they are set)
       }
-      used[i] = 0;
-    }
     __syncthreads();
     if (in_lds)
-      DpBigBucket<true>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, &gmax[g],
-                        radius, dim, max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
+      DpBigBucket<true>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
+                        &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
     else
-      DpBigBucket<false>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred,
+      DpBigBucket<false>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
                          &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length,
                          max_num_skips);
   }
@@ -1102,14 +1227,15 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
                        uint64_t n_anchors_total, uint32_t n_refs) {
   if (n_chunks == 0) return hipSuccess;
   ChainArgs a = a_in;
-  // every bucket holds at least one anchor, so the anchor total bounds the bucket total; buckets
-  // sent to the wave-parallel kernel hold > kBigPendingMin anchors each
+  // an item of the wave-parallel kernel holds > kBigPendingMin anchors
   const uint64_t max_big = n_anchors_total / kBigPendingMin + 1;
-  hipError_t e = ctx->chain_cnt.Reserve(((size_t)n_chunks * 3 + 4 + max_big) * sizeof(uint32_t));
+  hipError_t e = ctx->chain_cnt.Reserve(((size_t)n_chunks * 7 + 8 + max_big) * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   uint32_t *n_chains = ctx->chain_cnt.as<uint32_t>(), *goff = n_chains + n_chunks;
   uint32_t *n_pending = goff + n_chunks + 1;
-  uint32_t *big_count = n_pending + n_chunks, *big_list = big_count + 1;
+  uint32_t *tiles = n_pending + n_chunks, *tile_off = tiles + n_chunks;
+  uint32_t *n_items = tile_off + n_chunks + 1, *ioff = n_items + n_chunks;
+  uint32_t *big_count = ioff + n_chunks + 1, *big_list = big_count + 1;
   if ((e = hipMemsetAsync(big_count, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   if ((e = LaunchScanU32(ctx, a.n_groups, n_chunks, goff)) != hipSuccess) return e;
   // candidate chains: 3 per bucket, a bucket holds >= 1 anchor and there are <= 2 per contig; second
@@ -1119,15 +1245,22 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   a.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
   a.chain_sorted = a.chain_tmp + max_cand;
   a.chain_off = goff;
-  const uint64_t max_groups = n_anchors_total;
-  const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((max_groups + 63) / 64, 16384);
-  hipLaunchKernelGGL(ChainClassifyKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.search_radius, kMaxDim,
-                     p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips, n_pending);
+  hipLaunchKernelGGL(ChainTileCountKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, a, n_chunks, tiles);
+  if ((e = LaunchScanU32(ctx, tiles, n_chunks, tile_off)) != hipSuccess) return e;
+  const uint64_t max_tiles = n_anchors_total / 256 + n_chunks;
+  const uint32_t tile_blocks = (uint32_t)std::min<uint64_t>(max_tiles, 256u * 8u * 2u);  // two waves of the chip's 8 per CU
+  hipLaunchKernelGGL(ChainClassifyKernel, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
+                     p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
+                     p.max_num_skips);
+  hipLaunchKernelGGL(ChainPendingKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.max_target_gap_length, n_pending,
+                     n_items);
+  if ((e = LaunchScanU32(ctx, n_items, n_chunks, ioff)) != hipSuccess) return e;
+  const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((n_anchors_total + 63) / 64, 16384);
   if (dp_blocks > 0)
-    hipLaunchKernelGGL(ChainDpKernel, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
+    hipLaunchKernelGGL(ChainDpKernel, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
                        kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
                        big_list, big_count, n_pending);
-  hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, goff, n_chunks, p.search_radius,
+  hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
                      kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
                      big_list, big_count, n_pending);
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,

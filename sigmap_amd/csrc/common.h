@@ -129,7 +129,7 @@ struct smhip_ctx {
   smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
-      group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact;
+      group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact, sort_tmp;
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
   // sDTW refinement
@@ -219,7 +219,7 @@ struct SortArgs {
   uint32_t *group_start, *n_groups;
   smhip_chunk_result *results;
 };
-hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks);
+hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint64_t n_anchors_total);
 struct ChainArgs {
   const uint64_t *anchor_off;
   const uint32_t *s_tpos, *s_qpos, *s_grp;

@@ -66,7 +66,7 @@ PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std:
                        uint32_t read_length, uint32_t chunk_index, uint32_t num_events,
                        const std::vector<uint32_t> &ref_lengths, const MappingParams &p,
                        bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket,
-                       const float *sdtw_distance) {
+                       const float *sdtw_distance, const std::string *cigar) {
   const uint32_t bp_per_sec = 450, sample_rate = 4000, chunk_size = 4000;
   const float read_position_scale =
       ((float)(chunk_index + 1) * chunk_size / num_events) / ((float)sample_rate / bp_per_sec);
@@ -91,6 +91,7 @@ PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std:
     tags.append("\tat:f:" + std::to_string(at));
     tags.append("\taq:f:" + std::to_string(aq));
     if (sdtw_distance) tags.append("\tdt:f:" + std::to_string(*sdtw_distance));
+    if (cigar && !cigar->empty()) tags.append("\tcg:Z:" + *cigar);
   }
   const bool output =
       (r.n_chains >= 2 && (r.chains[0].score / r.chains[1].score >= p.output_mapping_ratio ||

@@ -41,11 +41,12 @@ bool ShouldStopMapping(const smhip_chunk_result &r, const MappingParams &p);
 // (sigmap.cc:690-693), num_events = features consumed over all chunks with > 50 features.
 // include_time_tag: prepend "mt:f:<ms>" like the reference (wall clock; excluded from parity).
 // sdtw_distance: when given, appended as the extra tag dt:f: (banded sDTW refinement of chain 0;
-// not part of the reference's PAF).
+// not part of the reference's PAF).  cigar: when given, appended as cg:Z: (print_alignment's per-base
+// CIGAR of the banded fast_dtw.cc::DTW() path over the same window).
 PAFMapping MakeMapping(const smhip_chunk_result &r, uint32_t read_id, const std::string &read_name,
                        uint32_t read_length, uint32_t chunk_index, uint32_t num_events,
                        const std::vector<uint32_t> &ref_lengths, const MappingParams &p,
                        bool include_time_tag, double mapping_time_ms, uint32_t *out_ref_bucket,
-                       const float *sdtw_distance = nullptr);
+                       const float *sdtw_distance = nullptr, const std::string *cigar = nullptr);
 }  // namespace sigmap
 #endif

@@ -67,7 +67,8 @@ class Sigmap {
   }
   static void PinnedFree(void *p) { smhip_host_free(p); }
 
-  void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams) {
+  void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
+                    bool sdtw_cigar) {
     num_gpus = std::max(1, num_gpus);
     num_streams = std::max(1, num_streams);
     if (device < 0 || device + num_gpus > smhip_device_count())
@@ -151,6 +152,7 @@ class Sigmap {
       smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
       float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
       bool has_dt = false;
+      std::string cigar;               // per-base CIGAR of DTW()'s banded path (when --sdtw-cigar)
       std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
       double start_time = 0;
     };
@@ -167,7 +169,8 @@ class Sigmap {
     // read slots of every context: set-up like the index, before the mapping span
     for (auto &gpu : ctxs)
       for (smhip_ctx *c : gpu)
-        if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK)
+        if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
+            smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
           ExitWithMessage(std::string("Read slots: ") + smhip_last_error(c));
     const double t_map = GetRealTime();
     // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
@@ -187,8 +190,11 @@ class Sigmap {
       std::vector<smhip_carried_anchor> carried, out_anchors;
       std::vector<smhip_chunk_result> results;
       std::vector<uint64_t> out_off;
-      std::vector<float> dts;
-      std::vector<int64_t> dte;
+      std::vector<float> dts, pdist;
+      std::vector<int64_t> dte, pend, pstart;
+      std::vector<uint32_t> plen;
+      std::vector<uint64_t> poff;
+      std::vector<uint8_t> pcodes;
       auto finish = [&](size_t r) {
         ReadState &s = st[r];
         free_slots.push_back(s.slot);
@@ -257,10 +263,21 @@ class Sigmap {
                                     carried.empty() ? nullptr : carried_off.data());
         if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
         if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
+        if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
         if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
         dts.resize(batch.size());
         dte.resize(batch.size());
         if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
+        if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) {
+          pdist.resize(batch.size()); pend.resize(batch.size()); pstart.resize(batch.size());
+          plen.resize(batch.size()); poff.resize(batch.size() + 1);
+          rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(), nullptr, 0);
+          if (rc == SMHIP_OK) {
+            pcodes.resize(std::max<uint64_t>(poff[batch.size()], 1));
+            rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(),
+                                            pcodes.data(), pcodes.size());
+          }
+        }
         // the result records first; the anchors of the chains (the next chunk's carry-over,
         // spatial_index.cc:303-322) only when some read of the batch goes on to another chunk
         if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
@@ -298,6 +315,8 @@ class Sigmap {
             s.last = res;
             s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
             s.dt = dts[bi];
+            s.cigar.clear();
+            if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen[bi]);
             s.num_events += res.n_features;
             stop = ShouldStopMapping(res, params_);
             if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
@@ -334,7 +353,8 @@ class Sigmap {
       uint32_t bucket = 0;
       const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
                                        (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
-                                       params_, true, s.start_time, &bucket, s.has_dt ? &s.dt : nullptr);
+                                       params_, true, s.start_time, &bucket, s.has_dt ? &s.dt : nullptr,
+                                       sdtw_cigar ? &s.cigar : nullptr);
       rows[bucket].push_back(FormatPAF(m, num_refs ? reference.GetSequenceNameAt(bucket) : "*",
                                        num_refs ? ref_lengths[bucket] : 0));
     }
@@ -378,6 +398,7 @@ const char *kHelp =
     "      --stop-mapping-mean FLOAT   best/mean chaining score ratio to stop mapping [5]\n"
     "      --stop-mapping-mean-output FLOAT  best/mean ratio to output mappings [5]\n"
     "      --sdtw-band INT             banded sDTW refinement of the best chain, adds dt:f: [0 = off]\n"
+    "      --sdtw-cigar                with --sdtw-band: also the banded DTW() path's per-base CIGAR, cg:Z:\n"
     "      --device INT                first GPU ordinal [0]\n"
     "      --gpus INT                  GPUs to map on: the index is broadcast over xGMI (RCCL), reads shard [1]\n"
     "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
@@ -389,7 +410,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
   static const std::map<std::string, std::string> shorts = {
       {"i", "build-index"}, {"d", "dimension"}, {"l", "max-leaf"}, {"m", "map"}, {"t", "num-threads"},
       {"r", "ref"}, {"p", "pore-model"}, {"x", "ref-index"}, {"s", "sig-dir"}, {"o", "output"}, {"h", "help"}};
-  static const std::vector<std::string> flags = {"build-index", "map", "help"};
+  static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar"};
   Args a;
   for (int i = 1; i < argc; ++i) {
     std::string k = argv[i];
@@ -451,7 +472,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
     const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : 2;
     const int gpus = a.Has("gpus") ? std::stoi(a.Str("gpus")) : 1;
-    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams);
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams, a.Has("sdtw-cigar"));
   } else {
     std::cerr << kHelp;
   }

@@ -794,6 +794,16 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     nodt = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith(("mt:f:", "dt:f:")))
     assert [nodt(l) for l in got2] == exp
     assert sum(1 for l in got2 if "\tdt:f:" in l) >= 18
+    # --sdtw-cigar adds the banded DTW() path's per-base CIGAR (fast_dtw.cc print_alignment) and nothing else
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out3.paf"),
+                        "--sdtw-band", "64", "--sdtw-cigar"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got3 = open(tmp_path / "out3.paf").read().splitlines()
+    nocg = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith(("mt:f:", "cg:Z:")))
+    assert [nocg(l) for l in got3] == ["\t".join(f for f in l.split("\t") if not f.startswith("mt:f:")) for l in got2]
+    cgs = [f for l in got3 for f in l.split("\t") if f.startswith("cg:Z:")]
+    assert len(cgs) >= 18 and all(c.startswith("cg:Z:(") and c.endswith(")") and c.count("M") > 50 for c in cgs)
     # the number of GPUs, of device contexts / streams and the chunk budget never show in the output
     # (default above: 1 GPU, 2 streams; here one stream, three streams with 3-chunk batches each, and
     # the multi-GPU code path with one GPU)

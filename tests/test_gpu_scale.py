@@ -1,0 +1,174 @@
+"""BASELINE.json configs at their full sizes on one GPU (`-m gpu`): configs[3] -- 50 000 reads vs one
+4.6 Mb contig, sDTW band sweep 32 / 64 / 128 -- and configs[4]'s per-GPU shard -- 25 000 of the 200 000
+reads vs one 250 Mb contig (4.98e8 points, 27 GB resident), where more than half of the reads hold a
+query with more than 5000 hits, i.e. where the ORDER of the radius search decides which hits survive
+the cap (spatial_index.cc:371-372) and with it the PAF.  Every read goes through the device; a sample
+is re-mapped by the oracle (PAF row, anchor and hit counts, refined distance bit for bit); the rest is
+held to size-independent properties."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from conftest import bits
+from oracle import pyoracle as po
+from sigmap_amd import _abi, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _paf_line(res_row, name, read_len, names, ref_lens):
+    L = _abi.host_lib()
+    mp = _abi.MapParams(); L.smhost_default_map_params(C.byref(mp))
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    r = np.array([res_row], dtype=_abi.RESULT_DTYPE)
+    nev = int(r["n_features"][0]) if r["n_features"][0] > 50 else 0
+    buf = C.create_string_buffer(2048)
+    L.smhost_format_paf(_abi.ptr(r), name.encode(), read_len, 0, nev, arr, _abi.ptr(ref_lens), len(names), C.byref(mp),
+                        buf, 2048, None)
+    return buf.value.decode()
+
+
+def _map_all(dev, raw, n_refs, batch, bands=(), pad=32):
+    """Every read through the device in batches of `batch` resident reads; returns the result records and,
+    per band, (dist, end) of the refinement."""
+    n = len(raw)
+    dev.configure_reads(batch, 4000)
+    res = np.zeros(n, dtype=_abi.RESULT_DTYPE)
+    refined = {b: (np.zeros(n, np.float32), np.zeros(n, np.int64)) for b in bands}
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        flat = np.ascontiguousarray(raw[lo:hi].reshape(-1))
+        ro = (np.arange(hi - lo + 1, dtype=np.uint64) * raw.shape[1])
+        lens = dev.upload_raw(flat, ro, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        assert (lens == raw.shape[1]).all()
+        dev.select(np.arange(hi - lo), np.zeros(hi - lo))
+        dev.run(n_refs); dev.sync()
+        res[lo:hi] = dev.download()
+        for b in bands:
+            dev.refine(band=b, pad=pad); dev.sync()
+            d, e = dev.refine_download()
+            refined[b][0][lo:hi] = d
+            refined[b][1][lo:hi] = e
+            assert dev.download().tobytes() == res[lo:hi].tobytes()   # the refinement never touches the records
+    return res, refined
+
+
+def _oracle_refine(r, x, sig, offs, band, pad):
+    """smhip_refine_run's window and band (include/sigmap_hip.h) evaluated by the oracle."""
+    c0 = r["chains"][0]
+    strand = 0 if c0["direction"] == 1 else 1
+    so, se = int(offs[2 * c0["ref"] + strand]), int(offs[2 * c0["ref"] + strand + 1])
+    start, endp = int(c0["start"]), int(c0["end"])
+    t0 = max(0, start - pad); t1 = min(se - so, endp + 6 + pad)
+    q, _ = po.generate_events(x)
+    qa, qb = int(r["c0_last_qpos"]), int(r["c0_first_qpos"])
+    den = max(1, endp - start)
+    ta = np.arange(t0, t1, dtype=np.int64)
+    centre = 1 + qa + ((ta - start) * (qb - qa)) // den
+    lo = np.clip(centre - band // 2, 1, None).astype(np.int64)
+    hi = np.maximum(np.clip(centre + band // 2, None, len(q)), 0).astype(np.int64)
+    d, e = po.sdtw_banded(sig[so + t0:so + t1], q, lo.astype(np.uint32), hi.astype(np.uint32))
+    return d, (t0 + e if e >= 0 else -1)
+
+
+def test_config3_ecoli_band_sweep_full_size():
+    """BASELINE configs[3]: 50 000 reads vs 1 x 4.6 Mb, bands 32 / 64 / 128."""
+    genome = synth.make_genome(11, [4600000])
+    lm = synth.make_pore_model()
+    n = 50000
+    raw, truth = synth.simulate_reads(genome, lm, n, 77)
+    ix = pipeline.HostIndex.build(genome, lm, threads=0)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    sig, offs = pipeline.reference_signals(genome, lm)
+    dev.upload_reference(sig, offs)
+    res, refined = _map_all(dev, raw, 1, 12500, bands=(32, 64, 128))
+    assert (res["status"] == 0).all()
+    c0 = res["chains"][:, 0]
+    ok = (res["n_chains"] > 0) & ((c0["direction"] == 1) == (truth["strand"] == 0))
+    assert ok.mean() > 0.95
+    # properties over all 50 000: a wider band admits a superset of warping paths
+    d32, d64, d128 = (refined[b][0] for b in (32, 64, 128))
+    r32 = refined[32][1] >= 0
+    assert r32.mean() > 0.9 and (refined[64][1] >= 0)[r32].all() and (refined[128][1] >= 0)[refined[64][1] >= 0].all()
+    assert (d64[r32] <= d32[r32]).all() and (d128[r32] <= d64[r32]).all() and (d128[r32] < d32[r32]).any()
+    # oracle sample: 64 reads per band (disjoint thirds of 192), PAF + dt bit-exact
+    tree = po.OracleTree.from_host_index(ix)
+    ref_lens = np.array([len(genome[0])], np.uint32)
+    names = ["contig0"]
+    rng = np.random.default_rng(5)
+    sample = rng.choice(n, 192, replace=False)
+    refined_checked = 0
+    for k, i in enumerate(sample):
+        x = pipeline.raw_to_pa(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        m = po.map_read(tree, ix.positions, x, 1, ref_lens)
+        assert _paf_line(res[i], "read%d" % i, len(x), names, ref_lens) == po.format_paf(m, "read%d" % i, names, ref_lens)
+        assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+        band = (32, 64, 128)[k % 3]
+        if res[i]["n_chains"] == 0:
+            assert refined[band][1][i] == -1
+            continue
+        d, e = _oracle_refine(res[i], x, sig, offs, band, 32)
+        if e < 0:
+            assert refined[band][1][i] == -1
+        else:
+            assert bits(refined[band][0][i]) == bits(np.float32(d)) and refined[band][1][i] == e, (i, band)
+            refined_checked += 1
+    assert refined_checked >= 150
+    tree.close()
+    dev.close()
+
+
+def test_config4_chr1_250mb_shard():
+    """BASELINE configs[4], one GPU's shard: 25 000 reads vs 1 x 250 Mb."""
+    t0 = time.time()
+    genome = synth.make_genome(13, [250000000])
+    lm = synth.make_pore_model()
+    n = 25000
+    raw, truth = synth.simulate_reads(genome, lm, n, 99)
+    ix = pipeline.HostIndex.build(genome, lm, threads=0)
+    assert ix.n_points > 4.9e8
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    res, _ = _map_all(dev, raw, 1, 12500)          # two batches of 12 500 (<= 20 000 chunks each)
+    assert (res["status"] == 0).all()               # no capacity flag: nothing was truncated on the device
+    c0 = res["chains"][:, 0]
+    ok = (res["n_chains"] > 0) & ((c0["direction"] == 1) == (truth["strand"] == 0)) & \
+         (np.abs(c0["start"].astype(np.int64) - np.where(truth["strand"] == 0, truth["pos"],
+                                                         len(genome[0]) - truth["pos"] - 450)) < 2000)
+    assert ok.mean() > 0.9, ok.mean()
+    # a chunk holds a query beyond the 5000-hit cap iff it lost hits: hits_total > anchors (no carry-over here)
+    over = res["hits_total"] > res["n_anchors"]
+    assert over.mean() > 0.3, over.mean()
+    sample = np.concatenate([np.flatnonzero(over)[:24], np.flatnonzero(~over)[:8]])
+    assert over[sample].sum() >= 16
+    tree = po.OracleTree.from_host_index(ix)
+    ref_lens = np.array([len(genome[0])], np.uint32)
+    names = ["chr1"]
+    proved = 0
+    for i in sample:
+        x = pipeline.raw_to_pa(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        m = po.map_read(tree, ix.positions, x, 1, ref_lens)
+        assert _paf_line(res[i], "read%d" % i, len(x), names, ref_lens) == po.format_paf(m, "read%d" % i, names, ref_lens), i
+        assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
+        proved += int(m.stats.hits > m.stats.anchors)   # the oracle, too, cut a query at 5000 hits
+    assert proved >= 16
+    # idempotence / order independence at full size: the second batch again, in reverse read order
+    back = np.ascontiguousarray(raw[12500:][::-1])
+    again, _ = _map_all(dev, back, 1, 12500)
+    assert again[::-1].tobytes() == res[12500:].tobytes()
+    # the census walk (exactly nanoflann's node set) returns the same records on 2 000 chunks
+    dev.params.reference_walk = 1
+    try:
+        census, _ = _map_all(dev, raw[:2000], 1, 2000)
+    finally:
+        dev.params.reference_walk = 0
+    for k in census.dtype.names:
+        if k not in ("nodes_visited", "points_tested"):
+            assert np.array_equal(census[k], res[:2000][k]), k
+    assert (census["nodes_visited"] >= res[:2000]["nodes_visited"]).all()
+    tree.close()
+    dev.close()
+    print("config4 shard test: %.0f s" % (time.time() - t0))

@@ -191,3 +191,26 @@ def test_paf_logic_matches_oracle(small_world, oracle_tree):
         assert L.smhost_should_stop(_abi.ptr(r), C.byref(mp)) in (0, 1)
         checked += m.mapped
     assert checked >= 20
+
+
+def test_oracle_tree_from_host_index_arrays_equals_oracle_build():
+    """so_kdtree_from_preorder (the .si content handed to the oracle in memory, used by the full-size GPU
+    tests) gives the tree the oracle builds itself: same radius-search results in the same order, same
+    node / leaf / point counts."""
+    from oracle import pyoracle as po
+    from sigmap_amd import pipeline, synth
+    genome = synth.make_genome(23, [60000, 30000])
+    lm = synth.make_pore_model()
+    ix = pipeline.HostIndex.build(genome, lm, threads=3)
+    built = po.OracleTree(ix.values.copy())
+    handed = po.OracleTree.from_host_index(ix)
+    assert built.depth() == handed.depth()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        i = int(rng.integers(0, ix.m_size))
+        q = ix.values[i:i + 6] + rng.normal(0, 0.05, 6).astype(np.float32)
+        a = built.radius_search(q, 0.08)
+        b = handed.radius_search(q, 0.08)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+        assert a[3] == b[3]
+    built.close(); handed.close()
