@@ -202,7 +202,7 @@ def main():
     def kernel_times(devs):
         # per-kernel device time (HIP events on each context's stream)
         kern = {}
-        for name in ["convert", "events", "seed_lookup", "sort", "chain", "sdtw"]:
+        for name in ["convert", "events", "seed_order", "seed_lookup", "sort", "chain", "sdtw"]:
             got = [dv.timing_get(name) for dv in devs]  # (mean ms, launches) per context
             n = sum(int(g[1]) for g in got)
             ms = sum(g[0] * g[1] for g in got) / max(n, 1)
@@ -341,7 +341,8 @@ def main():
                           "the walker's own algorithmic bytes (no counter profile found under profiles/)"),
                 "frac_of_measured_streaming_ceiling": round(achieved / HBM_STREAM_GBS, 4),
                 "launch_ms": round(seed_ms, 4),
-                "measured": "HIP events on the context stream, serial pass of this run (one batch in flight)",
+                "measured": "HIP events on the context stream around the SeedWalkKernel launch, serial pass of this run "
+                            "(one batch in flight)",
                 "launch_ms_bracket_in_timed_region": round(kern["seed_lookup"]["mean_ms"], 4),
                 "own_algorithmic_bytes_per_launch": own_bytes,
                 "own_algorithmic_gbs": round(own_bytes / (seed_ms * 1e-3) / 1e9, 1) if seed_ms > 0 else None,

@@ -232,7 +232,8 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
                      const uint32_t *carried_offsets, smhip_chunk_result *results);
 /* Mean device time (ms) of the named kernel over the launches since the last
  * smhip_timing_reset(), measured with HIP events on the context stream.
- * names: "convert", "events", "seed_lookup", "sort", "chain", "sdtw". */
+ * names: "convert", "events", "seed_order" (the queries' visiting order), "seed_lookup" (the tree-walk
+ * launch alone), "sort", "chain", "sdtw". */
 /* ---- banded sDTW refinement of the best chain ----
  * The reference computes the z-scored expected signal of every contig strand at map time
  * (sigmap.cc:566-591) and aligns against it with Sigmap::sDTW (sigmap.cc:1259-1291) in its

@@ -37,9 +37,6 @@ const EnvKnobs &Knobs() {
 }  // namespace smhip
 
 namespace {
-const char *kTimerNames[] = {"events", "seed_lookup", "seed_overflow", "sort", "chain", "sdtw", "convert"};
-enum { T_EVENTS = 0, T_SEED, T_OVF, T_SORT, T_CHAIN, T_SDTW, T_CONVERT, T_COUNT };
-
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
   return code;
@@ -53,33 +50,6 @@ int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
     hipError_t _e = (expr);                            \
     if (_e != hipSuccess) return HipFail(ctx, _e, #expr); \
   } while (0)
-
-struct ScopedTimer {  // brackets one kernel with HIP events on the context stream
-  smhip_ctx *ctx;
-  int id;
-  hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(smhip_ctx *c, int i) : ctx(c), id(i) {
-    if (!ctx->timing) return;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!ctx->event_pool.empty()) {
-        e = ctx->event_pool.back();
-        ctx->event_pool.pop_back();
-      } else {
-        (void)hipEventCreate(&e);
-      }
-      return e;
-    };
-    a = get();
-    b = get();
-    (void)hipEventRecord(a, ctx->stream);
-  }
-  ~ScopedTimer() {
-    if (!ctx->timing) return;
-    (void)hipEventRecord(b, ctx->stream);
-    ctx->pending.push_back({id, a, b});
-  }
-};
 
 void ResolveTimers(smhip_ctx *ctx) {
   for (auto &p : ctx->pending) {
@@ -815,13 +785,11 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   for (int attempt = 0;; ++attempt) {
     HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
-    {
-      ScopedTimer t(ctx, T_SEED);
-      HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
-                              ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
-                              ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
-                              pool_cap));
-    }
+    // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
+    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
+                            ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
+                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
+                            pool_cap));
     HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
                              ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(),
                              R, ctx->chunk_anchor_cnt.as<uint32_t>(), results));
@@ -1334,7 +1302,6 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   if (e == hipSuccess) {
-    ScopedTimer t(ctx, T_SEED);
     step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, d_region.as<Hit>(), d_cnt.as<uint32_t>(),
                              d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>(), d_qrec.p));
   }

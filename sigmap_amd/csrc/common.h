@@ -152,6 +152,37 @@ struct smhip_ctx {
 };
 
 namespace smhip {
+// Per-stage device timers (smhip_timing_get names); a ScopedTimer brackets what is enqueued on the
+// context stream during its lifetime with two HIP events.
+constexpr const char *kTimerNames[] = {"events", "seed_order", "seed_lookup", "sort", "chain", "sdtw", "convert"};
+enum { T_EVENTS = 0, T_ORDER, T_SEED, T_SORT, T_CHAIN, T_SDTW, T_CONVERT, T_COUNT };
+struct ScopedTimer {
+  smhip_ctx *ctx;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(smhip_ctx *c, int i) : ctx(c), id(i) {
+    if (!ctx->timing) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!ctx->event_pool.empty()) {
+        e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ScopedTimer() {
+    if (!ctx->timing) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({id, a, b});
+  }
+};
+
 // Experiment knobs from the environment (speed only, never results), read once per process under
 // std::call_once (api.hip) -- contexts are driven by concurrent host threads.
 struct EnvKnobs {

@@ -804,8 +804,13 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr, *range_end = nullptr;
   uint32_t range_stride = 0;
-  hipError_t e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order, &range_end, &range_stride);
+  hipError_t e;
+  {
+    ScopedTimer t(ctx, T_ORDER);
+    e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order, &range_end, &range_stride);
+  }
   if (e != hipSuccess) return e;
+  ScopedTimer t(ctx, T_SEED);  // the walker launch alone: what rocprofv3's kernel trace reports for SeedWalkKernel
   return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                     range_stride);
 }
@@ -822,6 +827,7 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
   Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
+  ScopedTimer t(ctx, T_SEED);
   return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
 }
 }  // namespace smhip
