@@ -7,6 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -57,6 +61,11 @@ struct IndexView {
   uint32_t root_ref;          // 0 (inner record 0), or kLeafTag for a tree that is a single leaf
 };
 
+inline bool TraceAlloc() {
+  static const bool on = getenv("SMHIP_TRACE_ALLOC") != nullptr;  // (magic static: initialised once, thread-safe)
+  return on;
+}
+
 // Grow-only device buffer.
 struct DevBuf {
   void *p = nullptr;
@@ -67,7 +76,12 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
+    const bool trace = TraceAlloc();
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (trace)  // SMHIP_TRACE_ALLOC=1: device allocations beyond a few GB take tens of ms per GB here
+      fprintf(stderr, "[smhip] hipMalloc %.3f GB: %.1f ms\n", (double)want / (1ull << 30),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipSuccess) cap = want;
     return e;
   }
