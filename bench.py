@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive timed region")
     ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="transport of the N > 1 run: nccl = RCCL over xGMI (one rank per GPU); gloo = through host "
+                         "memory, ranks may share a GPU (a way to exercise the multi-rank flow on a one-GPU box)")
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
@@ -118,11 +121,16 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if local_rank >= torch.cuda.device_count():
-            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs visible")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=600))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # ranks may share a GPU
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        else:
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs visible")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=600))
 
     from sigmap_amd import pipeline, synth
     from sigmap_amd.multigpu import replicate_index
@@ -146,7 +154,8 @@ def main():
         # (torch.distributed.run exports OMP_NUM_THREADS=1: ask for the cores explicitly)
         ix = pipeline.HostIndex.build(genome, lm, threads=max(1, (os.cpu_count() or 1) // max(world, 1)))
         t_build = time.perf_counter() - t0
-    keepalive = replicate_index(dev, ix, rank, world, local_rank, dist)  # RCCL broadcast when world > 1
+    keepalive = replicate_index(dev, ix, rank, world, local_rank, dist,   # RCCL broadcast when world > 1
+                                via_host=(args.backend == "gloo"))
     pool.share_index()  # the other contexts of this GPU borrow the same arrays
 
     R = args.reads
@@ -212,7 +221,7 @@ def main():
     def max_over_ranks(dt):
         if dist is None:
             return dt
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -306,6 +315,8 @@ def main():
                             f"{'+banded sDTW (band %d)' % args.sdtw_band if args.sdtw_band > 0 else ''} on GPU; "
                             "inputs resident in HBM (pcie_inclusive: copied from pinned host RAM every step)",
                 "chunks_per_gpu_per_step": R,
+                "transport": ("rccl" if args.backend == "nccl" else "gloo (test transport; ranks may share a GPU)")
+                             if world > 1 else None,
                 "batches_in_flight": len(pool.devs),
                 "contexts_agree": bool(contexts_agree),
                 "index_points": int(ix.n_points) if ix is not None else None,

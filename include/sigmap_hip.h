@@ -113,8 +113,8 @@ typedef struct {
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
 /* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in);
-/* Copy exported array `array_id` (0 nodes, 1 leaf_tab, 2 leaf_pts, 3 leaf_vind, 4 bbox) into device
- * memory the caller owns on the same GPU -- e.g. a torch tensor that torch.distributed then broadcasts
+/* Copy exported array `array_id` (0 nodes, 1 leaf_tab, 2 leaf_pts, 3 leaf_vind, 4 bbox) into memory
+ * the caller owns (device memory of the same GPU, or host memory) -- e.g. a torch tensor that torch.distributed then broadcasts
  * (the copy runs on this library's HIP runtime and stream, not through a second runtime handle). */
 int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint64_t dst_bytes);
 /* Replicate the index of ctxs[root] onto the other contexts, ONE context per GPU of this process:

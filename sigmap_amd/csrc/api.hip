@@ -373,7 +373,8 @@ int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint
   if (array_id < 0 || array_id > 4) return Fail(ctx, SMHIP_EINVAL, "array_id must be 0..4");
   if (dst_bytes < bytes[array_id]) return Fail(ctx, SMHIP_EINVAL, "destination smaller than the array");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(dst_device, src[array_id], bytes[array_id], hipMemcpyDeviceToDevice, ctx->stream));
+  // (hipMemcpyDefault: the destination may also be host memory -- the gloo test transport of bench.py)
+  HIPCHK(hipMemcpyAsync(dst_device, src[array_id], bytes[array_id], hipMemcpyDefault, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SMHIP_OK;
 }

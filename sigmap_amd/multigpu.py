@@ -58,21 +58,28 @@ def broadcast_host_index(ix_arrays, rank, dist):
     return out
 
 
-def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None):
+def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None, via_host=False):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
     uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive.
     Rank 0 copies an exported array into the broadcast tensor with smhip_index_export_copy (the
     library's own HIP runtime and stream); `device` / `copy_fn(array_id, dst_ptr, src_ptr, nbytes)` let
     the world_size-2 gloo test run this very function with host buffers.  A failure on rank 0 before
-    the broadcasts is announced to the peers (they raise instead of waiting in a collective)."""
+    the broadcasts is announced to the peers (they raise instead of waiting in a collective).
+    via_host=True (bench.py --backend gloo, a transport for testing the N > 1 flow where RCCL cannot run,
+    e.g. several ranks on one GPU): the arrays travel as CPU tensors and every peer copies what it received
+    into device memory of its own before attaching."""
     if world == 1:
         dev.upload_index(ix)
         return None
     import torch
     on_gpu = device is None
-    if on_gpu:
-        device = torch.device("cuda", local_rank)
+    gpu = torch.device("cuda", local_rank) if (on_gpu or via_host) else None
+    if via_host:
+        device = "cpu"
+        on_gpu = False
+    elif on_gpu:
+        device = gpu
     if copy_fn is None:
         copy_fn = lambda array_id, dst_ptr, src_ptr, nbytes: dev.export_copy(array_id, dst_ptr, nbytes)
     meta = [0] * (1 + len(_SCALARS) + len(_ARRAYS))   # [0]: 1 = rank 0 has its index, -1 = it failed
@@ -103,6 +110,9 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
         nd = _abi.IndexDev()
         for f, v in zip(_SCALARS, meta):
             setattr(nd, f, v)
+        if via_host:
+            tensors = [t.to(gpu) for t in tensors]   # H2D into this rank's own device memory
+            torch.cuda.synchronize()
         for a, t, nbytes in zip(_ARRAYS, tensors, meta[len(_SCALARS):]):
             setattr(nd, a, t.data_ptr())
             setattr(nd, a + "_bytes", nbytes)

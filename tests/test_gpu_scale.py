@@ -172,3 +172,84 @@ def test_config4_chr1_250mb_shard():
     tree.close()
     dev.close()
     print("config4 shard test: %.0f s" % (time.time() - t0))
+
+
+def test_cli_streaming_600_multichunk_reads(tmp_path, small_world):
+    """Multi-chunk streaming at a size where every branch is taken many times: 600 reads of 2-4 chunks
+    through `sigmap -m`, a third of them starting with 4000-9000 samples of junk (chains of early chunks
+    that do not stop the read are carried into the next chunk, spatial_index.cc:303-322), some with ADC
+    samples the (30,200) pA filter removes (chunk boundaries follow the FILTERED array), against the
+    oracle's streaming result, whole PAF in the reference's order."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "sigmap_amd", "bin", "sigmap")
+    genome, lm = small_world["genome"], small_world["lm"]
+    names = ["contig0", "contig1", "contig2"]
+    synth.write_fasta(str(tmp_path / "ref.fa"), genome, names)
+    synth.write_pore_model(str(tmp_path / "model.txt"), lm)
+    rng = np.random.default_rng(21)
+    raws = []
+    for k, nch in enumerate((2, 3, 4)):
+        raw, _ = synth.simulate_reads(genome, lm, 200, 300 + k, n_chunks=nch)
+        for i, r in enumerate(raw):
+            if i % 3 == 0:      # junk first: the read only maps from a later chunk on
+                junk = rng.integers(350, 1000, size=int(rng.integers(4000, 9000))).astype(np.int16)
+                r = np.concatenate([junk, r])[:len(r)]
+            if i % 7 == 0:      # samples outside (30, 200) pA somewhere in the read
+                at = int(rng.integers(0, len(r) - 200))
+                r = np.insert(r, at, np.full(int(rng.integers(1, 150)), 32767 if i % 2 else -2000, np.int16))
+            raws.append(np.ascontiguousarray(r, dtype=np.int16))
+    os.makedirs(tmp_path / "reads")
+    synth.write_sgr(str(tmp_path / "reads" / "a.sgr"), raws)
+    r = subprocess.run([exe, "-i", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-o", str(tmp_path / "idx")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out.paf"),
+                        "--batch-chunks", "500", "--streams", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    strip = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith("mt:f:"))
+    got = [strip(l) for l in open(tmp_path / "out.paf").read().splitlines()]
+    ix = small_world["ix"]
+    tree = po.OracleTree.from_host_index(ix)
+    ref_lens = small_world["ref_lens"]
+    rows, used_chunks = [], []
+    for i, rw in enumerate(raws):
+        pa = pipeline.raw_to_pa(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        m = po.map_read(tree, ix.positions, pa, 3, ref_lens)
+        used_chunks.append(m.chunks_used)
+        rows.append((m.ref, i, po.format_paf(m, "read%d" % i, names, ref_lens).rstrip("\n")))
+    rows.sort(key=lambda t: (t[0], t[1]))
+    assert got == [t[2] for t in rows]
+    used_chunks = np.array(used_chunks)
+    assert (used_chunks >= 2).sum() >= 150 and (used_chunks >= 3).sum() >= 40   # carry-over really happened
+    tree.close()
+
+
+def test_bench_two_ranks_flow_on_one_gpu():
+    """bench.py's N > 1 flow end to end with two ranks (launched like the driver launches it): rank 0
+    builds the index, the five walker arrays are broadcast, the peer attaches what it received, every
+    rank maps its own shard, barrier, max-over-ranks time, one JSON line.  RCCL refuses two ranks on one
+    GPU, so on a one-GPU box the arrays travel through `--backend gloo`; everything else is the N > 1
+    path the driver runs."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--reads", "1500", "--contigs", "4", "--contig-len", "300000", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["contexts_agree"] and j["config"]["census_results_identical"]
+    assert j["config"]["chunks_with_capacity_flags"] == 0 and j["config"]["mapped_fraction"] > 0.95
+    assert j["pcie_inclusive"]["results_identical"]
+    assert abs(j["value"] - 2 * 1500 * 2 / (j["ms_per_step"] * 2 * 1e-3)) < 1e-3 * j["value"]
