@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_PATH = os.path.join(_HERE, "libsigmap_oracle.so")
+ORACLE_PATH = os.environ.get("SM_ORACLE_LIB") or os.path.join(_HERE, "libsigmap_oracle.so")
 REF_PATH = os.path.join(_HERE, "_ref", "libsigmap_ref.so")
 
 

@@ -67,11 +67,14 @@ class Sigmap {
   }
   static void PinnedFree(void *p) { smhip_host_free(p); }
 
+  // share_device (development option --gpus-share-device): the N "GPUs" are all GPU `device` and borrow
+  // one resident index, so that the read sharding, the per-GPU lanes and the merge of `--gpus N` can be
+  // exercised on a one-GPU machine (RCCL itself refuses two ranks on one device).
   void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
-                    bool sdtw_cigar) {
+                    bool sdtw_cigar, bool share_device) {
     num_gpus = std::max(1, num_gpus);
     num_streams = std::max(1, num_streams);
-    if (device < 0 || device + num_gpus > smhip_device_count())
+    if (device < 0 || device + (share_device ? 1 : num_gpus) > smhip_device_count())
       ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
                       std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
                       " visible): this build has no CPU mapping path.");
@@ -96,14 +99,21 @@ class Sigmap {
     std::vector<std::vector<smhip_ctx *>> ctxs((size_t)num_gpus, std::vector<smhip_ctx *>((size_t)num_streams, nullptr));
     for (int g = 0; g < num_gpus; ++g)
       for (auto &c : ctxs[g])
-        if (smhip_init(device + g, &c) != SMHIP_OK)
+        if (smhip_init(share_device ? device : device + g, &c) != SMHIP_OK)
           ExitWithMessage("smhip_init failed for GPU " + std::to_string(device + g) +
                           ": this build has no CPU mapping path.");
     if (smhip_index_upload(ctxs[0][0], index.dimension(), index.values().data(), index.positions().data(),
                            index.values().size(), index.tree().vind.data(), index.tree().m_size,
                            index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
       ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0][0]));
-    if (num_gpus > 1) {
+    if (num_gpus > 1 && share_device) {
+      smhip_index_dev shared;
+      if (smhip_index_export(ctxs[0][0], &shared) != SMHIP_OK)
+        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[0][0]));
+      for (int g = 1; g < num_gpus; ++g)
+        if (smhip_index_attach(ctxs[g][0], &shared) != SMHIP_OK)
+          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][0]));
+    } else if (num_gpus > 1) {
       const double t0 = GetRealTime();
       std::vector<smhip_ctx *> firsts;
       for (int g = 0; g < num_gpus; ++g) firsts.push_back(ctxs[g][0]);
@@ -401,6 +411,7 @@ const char *kHelp =
     "      --sdtw-cigar                with --sdtw-band: also the banded DTW() path's per-base CIGAR, cg:Z:\n"
     "      --device INT                first GPU ordinal [0]\n"
     "      --gpus INT                  GPUs to map on: the index is broadcast over xGMI (RCCL), reads shard [1]\n"
+    "      --gpus-share-device         (development) the --gpus are all GPU --device and share one index\n"
     "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
     "      --streams INT               device contexts / HIP streams that share the index and the chunk budget [2]\n"
     "  -h, --help  Print help\n";
@@ -410,7 +421,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
   static const std::map<std::string, std::string> shorts = {
       {"i", "build-index"}, {"d", "dimension"}, {"l", "max-leaf"}, {"m", "map"}, {"t", "num-threads"},
       {"r", "ref"}, {"p", "pore-model"}, {"x", "ref-index"}, {"s", "sig-dir"}, {"o", "output"}, {"h", "help"}};
-  static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar"};
+  static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar", "gpus-share-device"};
   Args a;
   for (int i = 1; i < argc; ++i) {
     std::string k = argv[i];
@@ -472,7 +483,8 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
     const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : 2;
     const int gpus = a.Has("gpus") ? std::stoi(a.Str("gpus")) : 1;
-    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams, a.Has("sdtw-cigar"));
+    Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams, a.Has("sdtw-cigar"),
+                                                               a.Has("gpus-share-device"));
   } else {
     std::cerr << kHelp;
   }

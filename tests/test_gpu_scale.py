@@ -211,6 +211,14 @@ def test_cli_streaming_600_multichunk_reads(tmp_path, small_world):
     assert r.returncode == 0, r.stderr
     strip = lambda l: "\t".join(f for f in l.split("\t") if not f.startswith("mt:f:"))
     got = [strip(l) for l in open(tmp_path / "out.paf").read().splitlines()]
+    # the multi-GPU code path of the CLI -- contiguous read blocks per "GPU", lanes per GPU, rows merged
+    # by (reference, read) -- with three "GPUs" that are all this box's one GPU: the same PAF
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out3.paf"),
+                        "--gpus", "3", "--gpus-share-device", "--batch-chunks", "400", "--streams", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [strip(l) for l in open(tmp_path / "out3.paf").read().splitlines()] == got
     ix = small_world["ix"]
     tree = po.OracleTree.from_host_index(ix)
     ref_lens = small_world["ref_lens"]
