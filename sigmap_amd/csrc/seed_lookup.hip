@@ -152,17 +152,21 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
 #pragma unroll
   for (int k = 0; k < 12; ++k)
     root_box[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[k])));
-  float box_base[6], box_step[6];  // grid of the children's quantised boxes (wave-uniform too)
+  float box_base[6], box_step[6], box_inv[6];  // grid of the children's quantised boxes (wave-uniform too)
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     box_base[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[12 + k])));
     box_step[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[18 + k])));
+    const float inv = box_step[k] > 0.0f ? 1.0f / box_step[k] : 0.0f;
+    box_inv[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv)));
   }
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
   float mind = 0;
   uint32_t node = 0, sp = 0, hits = 0, nn = 0, np = 0, qi = 0;
+  // the query on the box grid, two dimensions per word like the records: the nearest grid index
+  uint32_t qc01 = 0, qc23 = 0, qc45 = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[2][2][kSeedThreads];
   // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
@@ -349,6 +353,13 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
         SM_INIT_DIM(5, d5)
         node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
+        {
+          uint32_t gc[6];
+#define SM_GRID(k) gc[k] = (uint32_t)fminf(fmaxf(rintf((q##k - box_base[k]) * box_inv[k]), 0.0f), 65535.0f);
+          SM_GRID(0) SM_GRID(1) SM_GRID(2) SM_GRID(3) SM_GRID(4) SM_GRID(5)
+#undef SM_GRID
+          qc01 = gc[0] | (gc[1] << 16); qc23 = gc[2] | (gc[3] << 16); qc45 = gc[4] | (gc[5] << 16);
+        }
         mode = M_NODE;
       }
       pool_next += take;
@@ -393,31 +404,47 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const uint4 *mine = stage_w + lane * 4;
         const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
         ++nn;
-        // squared distances from the query to the children's boxes, accumulated like evalMetric
-        // (nanoflann.hpp:391-406): lower bounds of every point's f32 distance (monotone ops; the
-        // boxes are rounded outwards).  b0 = c1.lo[0..5], c1.hi[0..1]; b1 = c1.hi[2..5], c2.lo[0..3];
+        // Lower bounds of the squared distance from the query to the children's boxes, on the 16-bit
+        // grid the boxes are stored on (two dimensions per word, packed u16 arithmetic): per dimension
+        // the gap in grid steps, max(ql - hi, lo - qh, 0) with saturating subtractions, times the step.
+        // ql / qh = the query's nearest grid index -/+ 3 (saturating): a margin of more than two grid steps
+        // around the query, which covers the float rounding of the query's grid index, of the grid values
+        // fma(k, step, base) and of the sums below many times over
+        // (a step is 1.5e-5 of the box's extent, an f32 rounding 6e-8 of the value): the result is a lower
+        // bound of the f32 distance nanoflann computes for ANY point of the box, so a child whose bound is
+        // >= radius holds no hit.  b0 = c1.lo[0..5], c1.hi[0..1]; b1 = c1.hi[2..5], c2.lo[0..3];
         // b2 = c2.lo[4..5], c2.hi[0..5]
-#define SM_DQ(word, half, k) __fmaf_rn((float)(((word) >> (16 * (half))) & 0xFFFFu), box_step[k], box_base[k])
-#define SM_BOX(qq, lo, hi) fmaxf(fmaxf((qq) - (hi), (lo) - (qq)), 0.0f)
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#define SM_GAP(qlw, hiw, low, qhw)                                                                    \
+  __builtin_elementwise_max(__builtin_elementwise_sub_sat(qlw, __builtin_bit_cast(us2, hiw)), \
+                            __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, low), qhw))
+        const us2 k3 = {3, 3};
+        const us2 ql01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc01), k3),
+                  ql23 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc23), k3),
+                  ql45 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc45), k3);
+        const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
+                  qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
+                  qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
         float lb1, lb2;
         {
-          const float e0 = SM_BOX(q0, SM_DQ(b0.x, 0, 0), SM_DQ(b0.w, 0, 0)), e1 = SM_BOX(q1, SM_DQ(b0.x, 1, 1), SM_DQ(b0.w, 1, 1));
-          const float e2 = SM_BOX(q2, SM_DQ(b0.y, 0, 2), SM_DQ(b1.x, 0, 2)), e3 = SM_BOX(q3, SM_DQ(b0.y, 1, 3), SM_DQ(b1.x, 1, 3));
-          const float e4 = SM_BOX(q4, SM_DQ(b0.z, 0, 4), SM_DQ(b1.y, 0, 4)), e5 = SM_BOX(q5, SM_DQ(b0.z, 1, 5), SM_DQ(b1.y, 1, 5));
-          lb1 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-          lb1 += e4 * e4;
-          lb1 += e5 * e5;
+          const us2 g01 = SM_GAP(ql01, b0.w, b0.x, qh01), g23 = SM_GAP(ql23, b1.x, b0.y, qh23),
+                    g45 = SM_GAP(ql45, b1.y, b0.z, qh45);
+          const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
+                      e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
+          lb1 = e0 * e0;
+          lb1 = __fmaf_rn(e1, e1, lb1); lb1 = __fmaf_rn(e2, e2, lb1); lb1 = __fmaf_rn(e3, e3, lb1);
+          lb1 = __fmaf_rn(e4, e4, lb1); lb1 = __fmaf_rn(e5, e5, lb1);
         }
         {
-          const float e0 = SM_BOX(q0, SM_DQ(b1.z, 0, 0), SM_DQ(b2.y, 0, 0)), e1 = SM_BOX(q1, SM_DQ(b1.z, 1, 1), SM_DQ(b2.y, 1, 1));
-          const float e2 = SM_BOX(q2, SM_DQ(b1.w, 0, 2), SM_DQ(b2.z, 0, 2)), e3 = SM_BOX(q3, SM_DQ(b1.w, 1, 3), SM_DQ(b2.z, 1, 3));
-          const float e4 = SM_BOX(q4, SM_DQ(b2.x, 0, 4), SM_DQ(b2.w, 0, 4)), e5 = SM_BOX(q5, SM_DQ(b2.x, 1, 5), SM_DQ(b2.w, 1, 5));
-          lb2 = e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-          lb2 += e4 * e4;
-          lb2 += e5 * e5;
+          const us2 g01 = SM_GAP(ql01, b2.y, b1.z, qh01), g23 = SM_GAP(ql23, b2.z, b1.w, qh23),
+                    g45 = SM_GAP(ql45, b2.w, b2.x, qh45);
+          const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
+                      e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
+          lb2 = e0 * e0;
+          lb2 = __fmaf_rn(e1, e1, lb2); lb2 = __fmaf_rn(e2, e2, lb2); lb2 = __fmaf_rn(e3, e3, lb2);
+          lb2 = __fmaf_rn(e4, e4, lb2); lb2 = __fmaf_rn(e5, e5, lb2);
         }
-#undef SM_BOX
-#undef SM_DQ
+#undef SM_GAP
         const uint32_t idx = (hd.z >> 28) & 7u;
         const uint32_t ref1 = hd.z & (kLeafTag | kIdxMask), ref2 = hd.w & (kLeafTag | kIdxMask);
         // q[idx], dists[idx]: a balanced tree of selects on the bits of idx (5 per value)
