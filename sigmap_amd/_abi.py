@@ -6,7 +6,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB_PATH = os.path.join(LIB_DIR, "libsigmap_hip.so")
+# (SMHIP_LIB: an alternative build of the device library, for A/B experiments)
+HIP_LIB_PATH = os.environ.get("SMHIP_LIB") or os.path.join(LIB_DIR, "libsigmap_hip.so")
 # (SMHOST_LIB: an alternative build of the host library, e.g. the ASan/UBSan one of tools/sanitize_cpu.sh)
 HOST_LIB_PATH = os.environ.get("SMHOST_LIB") or os.path.join(LIB_DIR, "libsigmap_host.so")
 
