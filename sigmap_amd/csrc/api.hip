@@ -119,6 +119,30 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
   }
   return SMHIP_OK;
 }
+
+// The hit slots of nq queries (fast_cap each) as segments of <= 2 GiB; the pointer table goes to the device
+// when a segment was (re)allocated.
+int ReserveRegion(smhip_ctx *ctx, uint64_t nq, uint32_t fast_cap, HitSlots *out) {
+  uint32_t qshift = 0;
+  while (qshift < 31 && ((uint64_t)2 << qshift) * fast_cap * sizeof(Hit) <= (1ull << 31)) ++qshift;
+  const uint64_t per_seg = 1ull << qshift;
+  const size_t n_seg = (size_t)std::max<uint64_t>((nq + per_seg - 1) / per_seg, 1);
+  if (ctx->region_segs.size() < n_seg) ctx->region_segs.resize(n_seg);
+  std::vector<void *> tab(ctx->region_segs.size(), nullptr);
+  for (size_t k = 0; k < n_seg; ++k) {
+    const uint64_t q_here = std::min<uint64_t>(per_seg, nq - std::min<uint64_t>(nq, k * per_seg));
+    HIPCHK(ctx->region_segs[k].Reserve(std::max<uint64_t>(q_here, 1) * fast_cap * sizeof(Hit)));
+  }
+  for (size_t k = 0; k < ctx->region_segs.size(); ++k) tab[k] = ctx->region_segs[k].p;
+  if (tab != ctx->h_region_tab) {
+    HIPCHK(ctx->region_tab.Reserve(tab.size() * sizeof(void *)));
+    ctx->h_region_tab = tab;
+    HIPCHK(hipMemcpyAsync(ctx->region_tab.p, ctx->h_region_tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice,
+                          ctx->stream));
+  }
+  *out = HitSlots{ctx->region_tab.as<Hit *>(), qshift, fast_cap};
+  return SMHIP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -184,7 +208,8 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
   if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
-  DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->reads_pa,
+  for (DevBuf &b : ctx->pa_segs) b.Free();
+  DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->pa_tab,
                     &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
                     &ctx->dl_off, &ctx->dl_compact, &ctx->sort_tmp, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
                     &ctx->rp_qoff, &ctx->rp_qlen, &ctx->rp_lo, &ctx->rp_hi, &ctx->rp_width, &ctx->rp_celloff, &ctx->rp_codes,
@@ -192,12 +217,13 @@ void smhip_destroy(smhip_ctx *ctx) {
                     &ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
-                    &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region, &ctx->ovf_list,
+                    &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region_tab, &ctx->ovf_list,
                     &ctx->ovf_pool, &ctx->counters, &ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp,
                     &ctx->keys, &ctx->s_tpos, &ctx->s_qpos, &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred,
                     &ctx->used, &ctx->group_start, &ctx->chain_tmp, &ctx->chain_cnt, &ctx->out_anchors,
                     &ctx->out_anchor_cnt};
   for (DevBuf *b : bufs) b->Free();
+  for (DevBuf &b : ctx->region_segs) b.Free();
   for (auto &p : ctx->pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -579,7 +605,22 @@ int smhip_reads_configure(smhip_ctx *ctx, uint32_t n_slots, uint32_t keep_sample
   if (n_slots == 0 || keep_samples == 0) return Fail(ctx, SMHIP_EINVAL, "n_slots and keep_samples must be positive");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx->reads_pa.Reserve((uint64_t)n_slots * keep_samples * sizeof(float)));
+  // the slots in segments of <= 2 GiB (device allocations beyond 4 GB are slow: HitSlots, common.h)
+  uint32_t sshift = 0;
+  while (sshift < 31 && ((uint64_t)2 << sshift) * keep_samples * sizeof(float) <= (1ull << 31)) ++sshift;
+  const uint64_t per_seg = 1ull << sshift;
+  const size_t n_seg = (size_t)((n_slots + per_seg - 1) / per_seg);
+  if (ctx->pa_segs.size() < n_seg) ctx->pa_segs.resize(n_seg);
+  for (size_t k = 0; k < n_seg; ++k) {
+    const uint64_t here = std::min<uint64_t>(per_seg, n_slots - k * per_seg);
+    HIPCHK(ctx->pa_segs[k].Reserve(here * keep_samples * sizeof(float)));
+  }
+  ctx->h_pa_tab.assign(ctx->pa_segs.size(), nullptr);
+  for (size_t k = 0; k < ctx->pa_segs.size(); ++k) ctx->h_pa_tab[k] = ctx->pa_segs[k].as<float>();
+  HIPCHK(ctx->pa_tab.Reserve(ctx->h_pa_tab.size() * sizeof(float *)));
+  HIPCHK(hipMemcpyAsync(ctx->pa_tab.p, ctx->h_pa_tab.data(), ctx->h_pa_tab.size() * sizeof(float *), hipMemcpyHostToDevice,
+                        ctx->stream));
+  ctx->pa_sshift = sshift;
   HIPCHK(ctx->slot_len.Reserve((uint64_t)n_slots * sizeof(uint32_t)));
   HIPCHK(hipMemsetAsync(ctx->slot_len.p, 0, (uint64_t)n_slots * sizeof(uint32_t), ctx->stream));
   ctx->n_slots = n_slots;
@@ -641,7 +682,8 @@ int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *r
     ScopedTimer t(ctx, T_CONVERT);
     HIPCHK(LaunchRawConvert(ctx, ctx->reads_raw.as<int16_t>(), ctx->reads_meta.as<RawReadMeta>(),
                             ctx->reads_segstart.as<uint32_t>(), n_reads, (uint32_t)n_segs, ctx->reads_seg.as<uint32_t>(),
-                            ctx->reads_seg.as<uint32_t>() + n_segs, ctx->reads_pa.as<float>(), ctx->reads_keep,
+                            ctx->reads_seg.as<uint32_t>() + n_segs,
+                            SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
                             ctx->slot_len.as<uint32_t>(), ctx->reads_len.as<uint32_t>()));
   }
   HIPCHK(hipEventRecord(ctx->convert_done, ctx->stream));
@@ -676,9 +718,9 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   HIPCHK(hipMemcpyAsync(ctx->sel_chunk.p, chunk_index, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice,
                         ctx->stream));
   HIPCHK(LaunchSelectChunks(ctx, ctx->sel_slots.as<uint32_t>(), ctx->sel_chunk.as<uint32_t>(), n_chunks, chunk_size,
-                            ctx->reads_keep, ctx->slot_len.as<uint32_t>(), ctx->chunk_begin.as<uint64_t>(),
-                            ctx->chunk_len.as<uint32_t>()));
-  ctx->chunk_src = ctx->reads_pa.as<float>();
+                            SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
+                            ctx->slot_len.as<uint32_t>(), ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>()));
+  ctx->chunk_src = nullptr;  // chunk_begin holds addresses (in floats)
   int rc = UploadBatchSideInputs(ctx, n_chunks, query_start_offsets, carried, carried_offsets);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned: safe to reuse on return
@@ -708,7 +750,11 @@ int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_
   HIPCHK(ctx->q_points.Reserve(nq * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_list.Reserve(nq * sizeof(uint32_t)));
   HIPCHK(ctx->q_ovf_off.Reserve(nq * kOvfLevels * sizeof(uint32_t)));
-  HIPCHK(ctx->region.Reserve(nq * p.hits_per_query_fast * sizeof(Hit)));
+  {
+    HitSlots hs;
+    int rc = ReserveRegion(ctx, nq, p.hits_per_query_fast, &hs);
+    if (rc) return rc;
+  }
   HIPCHK(ctx->qrec.Reserve(nq * 32));
   HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * sizeof(Hit)));
   return SMHIP_OK;
@@ -722,7 +768,9 @@ int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t c
   HIPCHK(hipMemcpyAsync(&total, ctx->slot_len.as<uint32_t>() + slot, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const uint32_t kept = std::min(total, ctx->reads_keep), n = std::min(kept, cap);
-  HIPCHK(hipMemcpyAsync(pa, ctx->reads_pa.as<float>() + (size_t)slot * ctx->reads_keep, (size_t)n * sizeof(float),
+  const float *src = ctx->h_pa_tab[slot >> ctx->pa_sshift] +
+                     (size_t)(slot & ((1u << ctx->pa_sshift) - 1u)) * ctx->reads_keep;
+  HIPCHK(hipMemcpyAsync(pa, src, (size_t)n * sizeof(float),
                         hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (n_kept) *n_kept = kept;
@@ -770,7 +818,11 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->q_nodes.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->q_points.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_list.Reserve(nq_cap * sizeof(uint32_t)));
-  HIPCHK(ctx->region.Reserve(nq_cap * p->hits_per_query_fast * sizeof(Hit)));
+  HitSlots hit_slots;
+  {
+    int rc = ReserveRegion(ctx, nq_cap, p->hits_per_query_fast, &hit_slots);
+    if (rc) return rc;
+  }
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
   HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
   // Overflow pool (hits beyond a query's fast slots).  The walker keeps adding the sizes of the
@@ -787,7 +839,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
     // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
-    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, ctx->region.as<Hit>(),
+    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, hit_slots,
                             ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
                             ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
                             pool_cap));
@@ -819,7 +871,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   sa.qstart = ctx->qstart.as<uint32_t>();
   sa.carried_off = ctx->carried_off.as<uint32_t>();
   sa.carried = ctx->carried.as<smhip_carried_anchor>();
-  sa.region = ctx->region.as<Hit>();
+  sa.region = hit_slots;
   sa.ovf_pool = ctx->ovf_pool.as<Hit>();
   sa.anchor_off = ctx->anchor_off.as<uint64_t>();
   sa.fast_cap = p->hits_per_query_fast;
@@ -1282,10 +1334,10 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (n_queries == 0) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
   if (p->walk_blocks_per_cu > 8) return Fail(ctx, SMHIP_EINVAL, "walk_blocks_per_cu must be 0..8");
-  DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist, d_qrec;
+  DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist, d_qrec, d_tab;
   const uint64_t total = (uint64_t)n_queries * cap;
   auto free_all = [&]() {
-    for (DevBuf *b : {&d_q, &d_region, &d_cnt, &d_nodes, &d_pts, &d_idx, &d_dist, &d_qrec}) b->Free();
+    for (DevBuf *b : {&d_q, &d_region, &d_cnt, &d_nodes, &d_pts, &d_idx, &d_dist, &d_qrec, &d_tab}) b->Free();
   };
   hipError_t e = hipSuccess;
   auto step = [&](hipError_t r) {
@@ -1293,6 +1345,9 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   };
   step(d_q.Reserve((uint64_t)n_queries * 6 * sizeof(float)));
   step(d_region.Reserve(total * sizeof(Hit)));
+  step(d_tab.Reserve(sizeof(void *)));
+  void *h_tab[1] = {d_region.p};  // one segment holds every query of this test entry point (qshift 31)
+  if (e == hipSuccess) step(hipMemcpyAsync(d_tab.p, h_tab, sizeof h_tab, hipMemcpyHostToDevice, ctx->stream));
   step(d_cnt.Reserve((uint64_t)n_queries * 4));
   step(d_nodes.Reserve((uint64_t)n_queries * 4));
   step(d_pts.Reserve((uint64_t)n_queries * 4));
@@ -1303,7 +1358,7 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   if (e == hipSuccess) {
-    step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, d_region.as<Hit>(), d_cnt.as<uint32_t>(),
+    step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, HitSlots{d_tab.as<Hit *>(), 31u, cap}, d_cnt.as<uint32_t>(),
                              d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>(), d_qrec.p));
   }
   if (e == hipSuccess) {

@@ -39,6 +39,29 @@ struct RawReadMeta {  // one read of smhip_reads_upload_raw (32 B)
   uint32_t pad;
 };
 
+// Per-query hit slots (fast_cap hits of 16 B per query).  The whole array is 20-30 GB for a batch of
+// 16 384 chunks, and a device allocation beyond 4 GB costs tens of ms per GB on this platform
+// (tools/micro/malloc_chunks.hip: 8 x 3.9 GB in 1.4 ms, one 27 GB block in 3 s), so it is cut into
+// segments of at most 2 GiB: queries [k << qshift, (k + 1) << qshift) live in segment k.
+struct HitSlots {
+  Hit *const *seg;   // device array of segment base pointers
+  uint32_t qshift;   // queries per segment = 1 << qshift
+  uint32_t fast_cap;
+  __device__ __forceinline__ Hit *At(uint32_t q, uint32_t ord) const {
+    return seg[q >> qshift] + ((size_t)(q & ((1u << qshift) - 1u)) * fast_cap + ord);
+  }
+};
+
+// Resident read slots (keep floats each), cut into segments of at most 2 GiB like HitSlots.
+struct SlotView {
+  float *const *seg;  // device array of segment base pointers
+  uint32_t sshift;    // slots per segment = 1 << sshift
+  uint32_t keep;
+  __device__ __forceinline__ float *At(uint32_t slot) const {
+    return seg[slot >> sshift] + (size_t)(slot & ((1u << sshift) - 1u)) * keep;
+  }
+};
+
 struct ChainTmp {
   float score;
   uint32_t ref, start, end, n_anchors, direction;
@@ -117,12 +140,16 @@ struct smhip_ctx {
   uint64_t n_samples = 0, n_carried = 0;
   bool batch_ready = false, run_done = false;
   // chunk c of the batch = chunk_src[chunk_begin[c] .. + chunk_len[c]): chunk_src is `samples` (pA uploaded
-  // with the batch, smhip_batch_upload) or `reads_pa` (resident reads, smhip_reads_upload_raw + smhip_batch_select)
+  // with the batch, smhip_batch_upload), or null with chunk_begin = the chunk's device address / 4 (resident
+  // reads in their slot segments, smhip_reads_upload_raw + smhip_batch_select)
   smhip::DevBuf samples, chunk_begin, chunk_len, qstart, carried, carried_off;
   const float *chunk_src = nullptr;
   // resident reads (SignalBatch::AddSignal on the device): raw ADC staging, per-read records, segment
   // counts / bases, the slots' filtered pA samples (n_slots x reads_keep floats) and their lengths
-  smhip::DevBuf reads_raw, reads_meta, reads_segstart, reads_seg, reads_pa, slot_len, reads_len, sel_slots, sel_chunk;
+  smhip::DevBuf reads_raw, reads_meta, reads_segstart, reads_seg, slot_len, reads_len, sel_slots, sel_chunk, pa_tab;
+  std::vector<smhip::DevBuf> pa_segs;  // the slots' segments (SlotView); pa_tab = their pointers on the device
+  std::vector<float *> h_pa_tab;
+  uint32_t pa_sshift = 0;
   hipStream_t copy_stream = nullptr;   // H2D of raw reads, overlapped with the kernels on `stream`
   hipEvent_t copy_done = nullptr, convert_done = nullptr;
   uint32_t n_slots = 0, reads_keep = 0;
@@ -140,7 +167,10 @@ struct smhip_ctx {
   } ev_rows;
   smhip::DevBuf ev_scratch, feat, stdv, results, nq, q_off, chunk_anchor_cnt, anchor_off, n_groups;
   // per-query
-  smhip::DevBuf q_count, q_ovf_off, region, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
+  std::vector<smhip::DevBuf> region_segs;  // the hit slots' segments (HitSlots) ...
+  std::vector<void *> h_region_tab;        // ... their pointers as last uploaded to region_tab
+  smhip::DevBuf region_tab;
+  smhip::DevBuf q_count, q_ovf_off, ovf_list, ovf_pool, counters, qrec, walk_stack, q_keys, q_order, q_hist, q_nodes, q_points;
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact, sort_tmp;
@@ -229,21 +259,21 @@ hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *clen, uint32_t *ev_s
 // signal.hip: raw ADC -> filtered pA of n_reads reads (n_segs segments in all) into their slots
 uint32_t RawSegments(uint32_t n_raw);
 hipError_t LaunchRawConvert(smhip_ctx *ctx, const int16_t *raw, const RawReadMeta *meta, const uint32_t *seg_start,
-                            uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, float *pa,
-                            uint32_t keep, uint32_t *slot_len, uint32_t *read_len);
+                            uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, SlotView pa,
+                            uint32_t *slot_len, uint32_t *read_len);
 hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t n_chunks,
-                              uint32_t chunk_size, uint32_t keep, const uint32_t *slot_len, uint64_t *cbegin,
+                              uint32_t chunk_size, SlotView pa, const uint32_t *slot_len, uint64_t *cbegin,
                               uint32_t *clen);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
-                            uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
+                            uint32_t n_chunks, uint64_t n_queries_max, HitSlots region, uint32_t *q_count,
                             uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap);
 // explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
-                               uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
+                               uint32_t cap, HitSlots region, uint32_t *q_count, uint32_t *q_nodes,
                                uint32_t *q_points, uint32_t *counters, void *qrec);
 hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32_t *q_off,
                              const uint32_t *q_count, const uint32_t *q_nodes, const uint32_t *q_points,
@@ -253,7 +283,8 @@ hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, ui
 struct SortArgs {
   const uint32_t *q_off, *q_count, *ovf_tab, *qstart, *carried_off;
   const smhip_carried_anchor *carried;
-  const Hit *region, *ovf_pool;
+  HitSlots region;
+  const Hit *ovf_pool;
   const uint64_t *anchor_off;
   uint32_t fast_cap, nnp, step, n_refs;
   uint32_t *a_tpos, *a_qpos, *a_grp;

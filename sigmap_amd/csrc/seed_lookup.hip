@@ -75,7 +75,7 @@ struct QueryRec {  // 32 B
 };
 
 struct Sink {
-  Hit *region;          // [n_queries][fast_cap]
+  HitSlots region;      // [n_queries][fast_cap], in segments
   uint32_t fast_cap;    // slots per query before the overflow pool
   uint32_t nnp;         // num_nearest_points
   uint32_t *q_count;    // total hits per query
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         h.dist = res;
         h.slot = (mine.x >> 1) + t;
         const bool emit = hit && ord < sink.nnp;
-        if (emit && ord < sink.fast_cap) sink.region[(size_t)oqi * sink.fast_cap + ord] = h;
+        if (emit && ord < sink.fast_cap) *sink.region.At(oqi, ord) = h;
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
         for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
           if (lane == (uint32_t)__builtin_ctzll(ovm)) {
@@ -823,7 +823,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
 }  // namespace
 
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
-                            uint32_t n_chunks, uint64_t n_queries_max, Hit *region, uint32_t *q_count,
+                            uint32_t n_chunks, uint64_t n_queries_max, HitSlots region, uint32_t *q_count,
                             uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap) {
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
@@ -843,7 +843,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
-                               uint32_t cap, Hit *region, uint32_t *q_count, uint32_t *q_nodes,
+                               uint32_t cap, HitSlots region, uint32_t *q_count, uint32_t *q_nodes,
                                uint32_t *q_points, uint32_t *counters, void *qrec) {
   QueryRec *qr = reinterpret_cast<QueryRec *>(qrec);
   hipLaunchKernelGGL(QueryExpandRawKernel, dim3(256), dim3(256), 0, ctx->stream, queries, n, qr);

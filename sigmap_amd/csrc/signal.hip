@@ -35,8 +35,7 @@ template <bool kScatter>
 __global__ __launch_bounds__(256) void RawConvertKernel(const int16_t *__restrict__ raw, const RawReadMeta *__restrict__ meta,
                                                         const uint32_t *__restrict__ seg_start, uint32_t n_reads,
                                                         uint32_t *__restrict__ seg_count,
-                                                        const uint32_t *__restrict__ seg_base, float *__restrict__ pa,
-                                                        uint32_t keep) {
+                                                        const uint32_t *__restrict__ seg_base, SlotView pa) {
   __shared__ uint32_t wave_cnt[4];
   const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t r = FindRead(seg_start, n_reads, s);
@@ -45,7 +44,8 @@ __global__ __launch_bounds__(256) void RawConvertKernel(const int16_t *__restric
   const uint32_t n = min(kSeg, m.n_raw - first);
   const int16_t *x = raw + m.raw_off + first;
   const float scale = m.range / m.digitisation;
-  float *out = kScatter ? pa + (size_t)m.slot * keep : nullptr;
+  const uint32_t keep = pa.keep;
+  float *out = kScatter ? pa.At(m.slot) : nullptr;
   uint32_t run = kScatter ? seg_base[s] : 0u;  // survivors before the current round (of the read / of the segment)
   for (uint32_t i0 = 0; i0 < n; i0 += 256) {
     const uint32_t i = i0 + tid;
@@ -89,15 +89,16 @@ __global__ __launch_bounds__(64) void RawSegScanKernel(const RawReadMeta *__rest
 // Batch descriptors from (slot, chunk index): chunk c = the slot's filtered samples
 // [chunk_index * chunk_size, + chunk_size) (sigmap.cc:647-652), clipped to what the slot holds.
 __global__ void SelectChunksKernel(const uint32_t *__restrict__ slots, const uint32_t *__restrict__ chunk_index,
-                                   uint32_t n_chunks, uint32_t chunk_size, uint32_t keep,
+                                   uint32_t n_chunks, uint32_t chunk_size, SlotView pa,
                                    const uint32_t *__restrict__ slot_len, uint64_t *__restrict__ cbegin,
                                    uint32_t *__restrict__ clen) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const uint32_t slot = slots[c];
   const uint64_t b = (uint64_t)chunk_index[c] * chunk_size;
-  const uint32_t have = min(slot_len[slot], keep);
-  cbegin[c] = (uint64_t)slot * keep + b;
+  const uint32_t have = min(slot_len[slot], pa.keep);
+  // (the batch's chunk source is the null pointer: begin = the chunk's address in floats)
+  cbegin[c] = (uint64_t)(reinterpret_cast<uintptr_t>(pa.At(slot)) / sizeof(float)) + b;
   clen[c] = b < have ? (uint32_t)min<uint64_t>(chunk_size, have - b) : 0u;
 }
 }  // namespace
@@ -105,24 +106,24 @@ __global__ void SelectChunksKernel(const uint32_t *__restrict__ slots, const uin
 uint32_t RawSegments(uint32_t n_raw) { return n_raw ? (n_raw + kSeg - 1) / kSeg : 1u; }
 
 hipError_t LaunchRawConvert(smhip_ctx *ctx, const int16_t *raw, const RawReadMeta *meta, const uint32_t *seg_start,
-                            uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, float *pa,
-                            uint32_t keep, uint32_t *slot_len, uint32_t *read_len) {
+                            uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, SlotView pa,
+                            uint32_t *slot_len, uint32_t *read_len) {
   if (n_reads == 0) return hipSuccess;
   hipLaunchKernelGGL(RawConvertKernel<false>, dim3(n_segs), dim3(256), 0, ctx->stream, raw, meta, seg_start, n_reads,
-                     seg_count, nullptr, nullptr, keep);
+                     seg_count, nullptr, pa);
   hipLaunchKernelGGL(RawSegScanKernel, dim3((n_reads + 63) / 64), dim3(64), 0, ctx->stream, meta, seg_start, n_reads,
                      seg_count, seg_base, slot_len, read_len);
   hipLaunchKernelGGL(RawConvertKernel<true>, dim3(n_segs), dim3(256), 0, ctx->stream, raw, meta, seg_start, n_reads,
-                     seg_count, seg_base, pa, keep);
+                     seg_count, seg_base, pa);
   return hipGetLastError();
 }
 
 hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t n_chunks,
-                              uint32_t chunk_size, uint32_t keep, const uint32_t *slot_len, uint64_t *cbegin,
+                              uint32_t chunk_size, SlotView pa, const uint32_t *slot_len, uint64_t *cbegin,
                               uint32_t *clen) {
   if (n_chunks == 0) return hipSuccess;
   hipLaunchKernelGGL(SelectChunksKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, slots, chunk_index,
-                     n_chunks, chunk_size, keep, slot_len, cbegin, clen);
+                     n_chunks, chunk_size, pa, slot_len, cbegin, clen);
   return hipGetLastError();
 }
 }  // namespace smhip

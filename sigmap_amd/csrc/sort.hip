@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
       const uint32_t i = i0 + u * kSortThreads;
       zero[u] = false;
       kq[u] = lo[u];
-      src[u] = reinterpret_cast<const uint4 *>(a.region);  // harmless default for lanes past the end
+      src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool);  // harmless default for lanes past the end
       if (live[u]) {
         if (i < ncar) {
           src[u] = reinterpret_cast<const uint4 *>(a.carried + car0 + i);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
           const uint32_t h = i - ncar - qoff[lo[u]];
           const uint32_t qi = q0 + lo[u];
           if (h < a.fast_cap) {
-            src[u] = reinterpret_cast<const uint4 *>(a.region + (size_t)qi * a.fast_cap + h);
+            src[u] = reinterpret_cast<const uint4 *>(a.region.At(qi, h));
           } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow)
             const uint32_t kk = h - a.fast_cap;
             const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));

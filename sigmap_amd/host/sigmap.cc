@@ -78,10 +78,17 @@ class Sigmap {
       ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
                       std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
                       " visible): this build has no CPU mapping path.");
+    double t_phase = GetRealTime();
+    auto phase = [&t_phase](const char *what) {  // set-up timeline on stderr, like the reference's "Loaded ... in"
+      const double now = GetRealTime();
+      std::cerr << what << " in " << now - t_phase << "s.\n";
+      t_phase = now;
+    };
     SignalBatch reads;
     reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree);  // ADC counts stay 2 bytes/sample; the GPU converts
     reads.InitializeLoading(signal_directory_);
     const size_t num_reads = reads.LoadAllReadSignals();
+    phase("Loaded read signals (first device use included)");
     SequenceBatch reference;  // names and lengths for PAF; the pore model is only needed by -i
     reference.InitializeLoading(reference_file_path_);
     const uint32_t num_refs = reference.LoadAllSequences();
@@ -89,6 +96,7 @@ class Sigmap {
     for (uint32_t i = 0; i < num_refs; ++i) ref_lengths[i] = reference.GetSequenceLengthAt(i);
     SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
     index.Load();
+    phase("Loaded reference and index");
 
     // ctxs[g][k]: context k (one HIP stream each) of GPU device + g.  The first context of GPU 0
     // uploads the index; the first contexts of the other GPUs receive it by one RCCL broadcast per
@@ -129,6 +137,7 @@ class Sigmap {
         if (smhip_index_attach(ctxs[g][k], &shared) != SMHIP_OK)
           ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][k]));
     }
+    phase("Index resident on the device(s)");
     if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
       PoreModel pore_model;
       pore_model.Load(pore_model_file_path_);
@@ -182,6 +191,7 @@ class Sigmap {
         if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
             smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
           ExitWithMessage(std::string("Read slots: ") + smhip_last_error(c));
+    phase("Reserved read slots and batch buffers");
     const double t_map = GetRealTime();
     // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
     // in order and stay with the context that admitted them (chain carry-over is per read)
