@@ -374,11 +374,28 @@ def main():
             pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw[:4096]]
             out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+        phase_prof()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     del keepalive
     pinned.close()
+
+
+def phase_prof():
+    """Development builds only (tools/phase_prof.sh: -DSMHIP_PHASE_PROF library given by SMHIP_LIB): the clock
+    ticks thread 0 of every workgroup spent between the marks of an instrumented kernel, on stderr."""
+    import ctypes
+    from sigmap_amd import _abi
+    fn = getattr(_abi.hip_lib(), "smhip_debug_phase_prof", None)
+    if fn is None:
+        return
+    buf = (ctypes.c_ulonglong * 32)()
+    if fn(buf, 1) == 0:
+        tot = float(sum(buf)) or 1.0
+        print("phase_prof (wall_clock64 ticks, share): " +
+              "  ".join("[%d] %.3g (%.1f%%)" % (k, buf[k], 100.0 * buf[k] / tot) for k in range(32) if buf[k]),
+              file=sys.stderr, flush=True)
 
 
 def walker_stats(dev):

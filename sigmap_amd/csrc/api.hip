@@ -218,7 +218,7 @@ void smhip_destroy(smhip_ctx *ctx) {
                     &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region_tab, &ctx->ovf_list,
-                    &ctx->ovf_pool, &ctx->counters, &ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp,
+                    &ctx->ovf_pool, &ctx->counters, &ctx->max_tpos, &ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp,
                     &ctx->keys, &ctx->s_tpos, &ctx->s_qpos, &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred,
                     &ctx->used, &ctx->group_start, &ctx->chain_tmp, &ctx->chain_cnt, &ctx->out_anchors,
                     &ctx->out_anchor_cnt};
@@ -363,6 +363,7 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   ctx->index = IndexView{ctx->ix_nodes.as<uint4>(), ctx->ix_tab.as<uint32_t>(), ctx->ix_pts.as<float>(),
                          ctx->ix_vind.as<uint32_t>(), ctx->ix_bbox.as<float>(), n_inner, n_leaves, m_size, root_ref};
   ctx->have_index = true;
+  ctx->max_tpos_valid = false;
   ctx->index_owned = true;
   return SMHIP_OK;
 }
@@ -512,6 +513,7 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
     p->leaf_pts_bytes = ctx->leaf_pts_bytes;
     p->leaf_vind_bytes = ctx->leaf_vind_bytes;
     p->have_index = true;
+    p->max_tpos_valid = false;
     p->index_owned = true;
   }
   return SMHIP_OK;
@@ -541,6 +543,7 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->leaf_vind_bytes = in->leaf_vind_bytes;
   ctx->have_index = true;
+  ctx->max_tpos_valid = false;
   ctx->index_owned = false;
   return SMHIP_OK;
 }
@@ -878,6 +881,14 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   sa.nnp = (uint32_t)p->num_nearest_points;
   sa.step = (uint32_t)p->step_size;
   sa.n_refs = n_refs;
+  HIPCHK(ctx->max_tpos.Reserve(2 * sizeof(uint32_t)));
+  if (!ctx->max_tpos_valid) {  // once per index
+    HIPCHK(LaunchIndexMaxTarget(ctx, ctx->max_tpos.as<uint32_t>()));
+    ctx->max_tpos_valid = true;
+  }
+  HIPCHK(LaunchCarriedMaxTarget(ctx, sa.carried, ctx->n_carried, ctx->max_tpos.as<uint32_t>(),
+                                ctx->max_tpos.as<uint32_t>() + 1));
+  sa.span_bound = ctx->max_tpos.as<uint32_t>() + 1;
   sa.a_tpos = ctx->a_tpos.as<uint32_t>();
   sa.a_qpos = ctx->a_qpos.as<uint32_t>();
   sa.a_grp = ctx->a_grp.as<uint32_t>();

@@ -135,6 +135,8 @@ struct smhip_ctx {
   smhip::IndexView index{};
   smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, scan_tmp;
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
+  smhip::DevBuf max_tpos;       // [0] largest target position of the resident index, [1] ... and of the batch's carried anchors
+  bool max_tpos_valid = false;  // [0] computed for the index that is resident now
   // batch inputs
   uint32_t n_chunks = 0;
   uint64_t n_samples = 0, n_carried = 0;
@@ -287,6 +289,7 @@ struct SortArgs {
   const Hit *ovf_pool;
   const uint64_t *anchor_off;
   uint32_t fast_cap, nnp, step, n_refs;
+  const uint32_t *span_bound;  // device: largest target position of the index and of this batch's carried anchors
   uint32_t *a_tpos, *a_qpos, *a_grp;
   float *a_dist;
   uint64_t *keys;
@@ -296,6 +299,9 @@ struct SortArgs {
   smhip_chunk_result *results;
 };
 hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint64_t n_anchors_total);
+hipError_t LaunchIndexMaxTarget(smhip_ctx *ctx, uint32_t *out);
+hipError_t LaunchCarriedMaxTarget(smhip_ctx *ctx, const smhip_carried_anchor *carried, uint64_t n_carried,
+                                  const uint32_t *index_max, uint32_t *out);
 struct ChainArgs {
   const uint64_t *anchor_off;
   const uint32_t *s_tpos, *s_qpos, *s_grp;

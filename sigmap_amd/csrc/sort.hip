@@ -32,10 +32,50 @@ constexpr uint32_t kMaxBucket = 512;  // largest bucket one wave rank-sorts (8 k
 // LDS, by a workgroup of SortPartKernel: the per-anchor cost of the large-reference sort is the LDS
 // path's plus one more read and write of the key.  A part that does not fit the LDS (a skewed target
 // distribution) is sorted by a bitonic network in its own slice of the key scratch.
-constexpr uint32_t kPartTarget = 5632;  // keys per part aimed at (a part sorts in LDS up to 8192 keys)
-constexpr uint32_t kMaxParts = 256;     // parts per chunk (chunks of up to ~1.5 M anchors; more: bigger parts)
+constexpr uint32_t kPartTarget = 384;   // keys per part aimed at: one WAVE sorts a part of up to 512 keys in registers
+constexpr uint32_t kMaxParts = 1024;    // parts per chunk (chunks of up to ~400 000 anchors; more: bigger parts)
+constexpr uint32_t kPartBits = 10;      // work item = (chunk << kPartBits) | part
+static_assert((1u << kPartBits) == kMaxParts, "part field of a work item");
 constexpr uint32_t kPartTab = kMaxParts + 4;  // per chunk: part starts [P + 1], then [kMaxParts + 1] = P, [+ 2] = max target
+// parts by size: <= 512 keys (8 per lane) and <= 1024 keys (16 per lane) are sorted by one wave each
+// (SortPartWaveKernel), larger ones -- a skewed target distribution -- by a workgroup (SortPartKernel)
+constexpr uint32_t kWaveCap0 = 512, kWaveCap1 = 1024;
 constexpr uint32_t kPerThread = (kLdsKeys + kSortThreads - 1) / kSortThreads;  // 16 keys per thread in registers
+
+// -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
+// the clock ticks between the marks of the part sort to g_phase_prof (smhip_debug_phase_prof reads them).
+#ifdef SMHIP_PHASE_PROF
+__device__ unsigned long long g_phase_prof[32];
+#define PHASE_DECL()                    \
+  unsigned long long prof_acc[16] = {}; \
+  unsigned long long prof_t = wall_clock64()
+#define PHASE_INIT() prof_t = wall_clock64()
+#define PHASE_MARK(k)                                 \
+  do {                                                \
+    const unsigned long long prof_n = wall_clock64(); \
+    prof_acc[k] += prof_n - prof_t;                   \
+    prof_t = prof_n;                                  \
+  } while (0)
+#define PHASE_FLUSH()                                                    \
+  do {                                                                   \
+    if (threadIdx.x == 0)                                                \
+      for (int pk = 0; pk < 16; ++pk)                                    \
+        if (prof_acc[pk]) atomicAdd(&g_phase_prof[pk], prof_acc[pk]);    \
+  } while (0)
+#else
+#define PHASE_DECL() \
+  do {               \
+  } while (0)
+#define PHASE_INIT() \
+  do {               \
+  } while (0)
+#define PHASE_MARK(k) \
+  do {                \
+  } while (0)
+#define PHASE_FLUSH() \
+  do {                \
+  } while (0)
+#endif
 
 template <typename KeyPtr>
 __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t tid) {
@@ -127,7 +167,7 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
     for (uint32_t it = 0; it < kPerThread; ++it)
       if (tid + it * kSortThreads < n) lds_keys[bstart[myb[it]] + atomicAdd(&hist[myb[it]], 1u)] = mykeys[it];
     __syncthreads();
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
     // Four buckets per pass of a wave, sixteen lanes each: a rank sort reads every key of a bucket
     // once as an LDS broadcast, and a 64-lane 8-byte read occupies the LDS for four clocks however
     // many lanes use it -- with one small bucket per wave the phase was bound by exactly that.
@@ -182,7 +222,7 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
     }
     if (tid < kBuckets && bstart[tid + 1] - bstart[tid] > 64) big_list[atomicAdd(&n_big, 1u)] = tid;
     __syncthreads();
-    static_assert(kMaxBucket <= kSortThreads, "one key per thread in a heavy bucket");
+      static_assert(kMaxBucket <= kSortThreads, "one key per thread in a heavy bucket");
     for (uint32_t bi = 0; bi < n_big; ++bi) {
       const uint32_t bb = big_list[bi];
       const uint32_t b0 = bstart[bb], m = bstart[bb + 1] - b0;
@@ -204,7 +244,7 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
       __syncthreads();
     }
     __syncthreads();
-  }
+    }
   if (!bucketed) {
     uint32_t npad = 1;
     while (npad < n) npad <<= 1;
@@ -221,10 +261,11 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
 // query position and distance of the unsorted anchor the key's low bits name), then runs of equal
 // (group, target) are ordered by (query, distance): insertion sort by the thread that owns the run's
 // first element.
+// (u_qpos / u_dist are read at index from * pay_stride: 1 for columns, 4 for the {key, qpos, dist} records of a part)
 template <typename KeyPtr>
 __device__ __forceinline__ void EmitSorted(KeyPtr keys, uint32_t n, uint32_t ibits, const uint32_t *u_qpos,
-                                           const float *u_dist, uint32_t *s_tpos, uint32_t *s_qpos, uint32_t *s_grp,
-                                           float *s_dist, uint32_t tid) {
+                                           const float *u_dist, uint32_t pay_stride, uint32_t *s_tpos,
+                                           uint32_t *s_qpos, uint32_t *s_grp, float *s_dist, uint32_t tid) {
   const uint64_t idx_mask = (1ull << ibits) - 1;
   constexpr int kSc = 4;  // elements per pass: one wait per gather level
   for (uint32_t i0 = tid; i0 < n; i0 += kSc * kSortThreads) {
@@ -236,8 +277,8 @@ __device__ __forceinline__ void EmitSorted(KeyPtr keys, uint32_t n, uint32_t ibi
 #pragma unroll
     for (int u = 0; u < kSc; ++u) {
       const uint32_t from = (uint32_t)(key[u] & idx_mask);
-      gq[u] = u_qpos[from];
-      gd[u] = u_dist[from];
+      gq[u] = u_qpos[(size_t)from * pay_stride];
+      gd[u] = u_dist[(size_t)from * pay_stride];
     }
 #pragma unroll
     for (int u = 0; u < kSc; ++u) {
@@ -279,10 +320,138 @@ __device__ __forceinline__ uint32_t PartOf(uint64_t key, uint64_t span, uint32_t
 
 struct BigSortWork {   // global scratch of the large-chunk path (LaunchSort)
   uint32_t *part_tab;  // [n_chunks][kPartTab]
-  uint32_t *items;     // (chunk << 8) | part
+  uint4 *recs[2];      // parts of the two wave classes: {A lo, A hi | m << 16, dlo lo, dlo hi}, A = first element of the
+                       // part (m elements) in the anchor columns and in the chunk's {key, qpos, dist} records, dlo =
+                       // smallest dense key group * span + target the part can hold
+  uint32_t *items;     // parts of the workgroup class: (chunk << kPartBits) | part
   uint32_t *big_chunks;
-  uint32_t *counters;  // [0] items, [1] big chunks
+  uint32_t *counters;  // [0..2] items per class, [3] big chunks
 };
+
+// ---- decode: anchor i of a chunk = carried anchor i, or hit (i - ncar - qoff[k]) of the chunk's query k, k
+// found by binary search in the LDS offsets.  kDecodeWidth anchors (i0 + u * kSortThreads) per call: their
+// searches advance together, then the 16-byte records (a hit, or a carried anchor: same size) are fetched
+// with one wait.
+constexpr int kDecodeWidth = 4;
+struct DecodeCtx {
+  const uint32_t *qoff;  // LDS: exclusive offsets of the queries' anchor runs, [nq + 1]
+  uint32_t q0, nq, ncar, n, qso, search_steps;
+  uint64_t car0;
+  const Hit *seg;  // the hit-slot segment that holds all of the chunk's queries (the rule), or null
+  __device__ DecodeCtx(const SortArgs &a, const uint32_t *qoff_, uint32_t q0_, uint32_t nq_, uint32_t ncar_, uint32_t n_,
+                       uint32_t c)
+      : qoff(qoff_), q0(q0_), nq(nq_), ncar(ncar_), n(n_), qso(a.qstart ? a.qstart[c] : 0u), search_steps(0),
+        car0(a.carried_off ? a.carried_off[c] : 0), seg(nullptr) {
+    while ((1u << search_steps) < nq + 1) ++search_steps;  // binary-search steps that cover nq + 1 offsets
+    if (nq && (q0 >> a.region.qshift) == ((q0 + nq - 1) >> a.region.qshift)) seg = a.region.seg[q0 >> a.region.qshift];
+  }
+};
+struct Decoded {
+  uint32_t grp, tpos, qpos;
+  float dist;
+};
+template <uint32_t NT>
+__device__ __forceinline__ void DecodeAnchors(const SortArgs &a, const DecodeCtx &dc, uint32_t i0,
+                                              Decoded (&out)[kDecodeWidth]) {
+  constexpr int kDec = kDecodeWidth;
+  const uint32_t *qoff = dc.qoff;
+  const uint32_t nq = dc.nq, ncar = dc.ncar, n = dc.n, q0 = dc.q0;
+  uint32_t lo[kDec], kq[kDec];
+  const uint4 *src[kDec];
+  bool live[kDec], zero[kDec];
+#pragma unroll
+  for (int u = 0; u < kDec; ++u) {
+    lo[u] = 0;
+    live[u] = i0 + u * NT < n;
+  }
+  for (uint32_t st = dc.search_steps; st-- > 0;) {  // largest k with qoff[k] <= h0 (qoff[0] = 0)
+#pragma unroll
+    for (int u = 0; u < kDec; ++u) {
+      const uint32_t i = i0 + u * NT;
+      const uint32_t h0 = i >= ncar ? i - ncar : 0;
+      const uint32_t mid = lo[u] + (1u << st);
+      if (mid < nq && qoff[mid] <= h0) lo[u] = mid;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kDec; ++u) {
+    const uint32_t i = i0 + u * NT;
+    zero[u] = false;
+    kq[u] = lo[u];
+    src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool);  // harmless default for lanes past the end
+    if (live[u]) {
+      if (i < ncar) {
+        src[u] = reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
+      } else {
+        const uint32_t h = i - ncar - qoff[lo[u]];
+        const uint32_t qi = q0 + lo[u];
+        if (h < a.fast_cap) {
+          const Hit *slot = dc.seg ? dc.seg + ((size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap + h)
+                                   : a.region.At(qi, h);
+          src[u] = reinterpret_cast<const uint4 *>(slot);
+        } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow)
+          const uint32_t kk = h - a.fast_cap;
+          const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+          const uint32_t first = a.fast_cap * ((1u << level) - 1u);
+          const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
+          if (seg != 0xFFFFFFFFu) src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
+          else zero[u] = true;
+        }
+      }
+    }
+  }
+  uint4 raw[kDec];
+#pragma unroll
+  for (int u = 0; u < kDec; ++u) raw[u] = *src[u];
+#pragma unroll
+  for (int u = 0; u < kDec; ++u) {
+    const uint32_t i = i0 + u * NT;
+    out[u] = Decoded{0u, 0u, 0u, 0.0f};
+    if (!live[u]) continue;
+    if (i < ncar) {  // smhip_carried_anchor {ref_strand, target_position, query_position, distance}
+      out[u].grp = raw[u].x;
+      out[u].tpos = raw[u].y;
+      out[u].qpos = raw[u].z;
+      out[u].dist = __uint_as_float(raw[u].w);
+    } else {  // Hit {uint64 position, dist, slot}
+      const uint64_t position = zero[u] ? 0ull : ((uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32));
+      const uint32_t ref = (uint32_t)(position >> 33);
+      out[u].tpos = (uint32_t)(position >> 1);
+      out[u].grp = (ref << 1) | (uint32_t)(position & 1);
+      out[u].qpos = (kq[u] + 1) * a.step + dc.qso;  // position + query_start_offset
+      out[u].dist = zero[u] ? 0.0f : __uint_as_float(raw[u].z);
+    }
+  }
+}
+
+// Exclusive offsets of the queries' anchor runs into LDS: qoff[k] = sum over j < k of min(hits of query q0 + j,
+// num_nearest_points), qoff[nq] = the total.  Every thread takes ceil(nq / threads) consecutive queries; scan
+// inside the waves by shuffles, the wave totals through `wtot`.  Ends with a barrier.
+template <uint32_t NT>
+__device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0, uint32_t nq, uint32_t *qoff,
+                                                 uint32_t *wtot, uint32_t tid) {
+  const uint32_t per = (nq + NT - 1) / NT;
+  const uint32_t qb = min(nq, tid * per), qe = min(nq, qb + per);
+  uint32_t sum = 0;
+  for (uint32_t k = qb; k < qe; ++k) sum += min(a.q_count[q0 + k], a.nnp);
+  uint32_t incl = sum;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)lane >= d) incl += o;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t k = 0; k < wave; ++k) before += wtot[k];
+  uint32_t run = before + incl - sum;
+  for (uint32_t k = qb; k < qe; ++k) {
+    qoff[k] = run;
+    run += min(a.q_count[q0 + k], a.nnp);
+  }
+  if (tid == NT - 1) qoff[nq] = run;
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t gbits, uint32_t ibits, BigSortWork w) {
   extern __shared__ __align__(16) uint64_t lds_keys[];
@@ -304,206 +473,60 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
     n_big = 0;
   }
   if (n == 0) return;
-  if (n > (1u << ibits) || nq > kMaxQueriesPerChunk || c >= (1u << 24)) {  // the key cannot index this many anchors
+  if (n > (1u << ibits) || nq > kMaxQueriesPerChunk || c >= (1u << (32 - kPartBits))) {  // the key cannot index this many anchors
     if (tid == 0) {
       a.results[c].status |= SMHIP_ST_SORT_CAP;
       a.results[c].n_anchors = 0;
     }
     return;
   }
-  const bool in_lds = n <= kLdsKeys;
-  uint64_t *gkeys = a.keys + 2 * base;  // per-chunk scratch of 2n keys
+  if (n > kLdsKeys) {  // large chunk: SortBigKernel cuts it into parts, the part kernels sort them
+    if (tid == 0) w.big_chunks[atomicAdd(&w.counters[3], 1u)] = c;
+    return;
+  }
   uint32_t *u_qpos = a.a_qpos + base;  // (target and group travel in the key)
   float *u_dist = a.a_dist + base;
   // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts) into LDS
   // (the key array is not in use yet: its tail holds the nq+1 offsets during the decode)
   uint32_t *qoff = reinterpret_cast<uint32_t *>(lds_keys) + 2 * kLdsKeys - (kMaxQueriesPerChunk + 2);
-  const uint32_t per = (nq + kSortThreads - 1) / kSortThreads;
-  const uint32_t qb = min(nq, tid * per), qe = min(nq, qb + per);
-  uint32_t s = 0;
-  for (uint32_t k = qb; k < qe; ++k) s += min(a.q_count[q0 + k], a.nnp);
-  part[tid] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
-    const uint32_t v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  {
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t k = qb; k < qe; ++k) {
-      qoff[k] = run;
-      run += min(a.q_count[q0 + k], a.nnp);
-    }
-    if (tid == kSortThreads - 1) qoff[nq] = part[tid];
-  }
-  __syncthreads();
+  ScanQueryOffsets<kSortThreads>(a, q0, nq, qoff, part, tid);
   // ---- decode: carried anchors, then each query's hits in traversal order.  One thread per
   // anchor (binary search of its query in the LDS offsets), so the hit records of a query are
   // read by consecutive lanes.  Keys go to registers first: they overwrite the offsets' LDS.
-  const uint32_t qso = a.qstart ? a.qstart[c] : 0;
   uint64_t mykeys[kPerThread];
-  const bool reg_keys = in_lds;  // LDS path: n <= kLdsKeys, so kPerThread registers suffice
   uint32_t local_maxt = 0;
-  uint32_t search_steps = 0;  // binary-search steps that cover nq + 1 offsets
-  while ((1u << search_steps) < nq + 1) ++search_steps;
-  const uint64_t car0 = a.carried_off ? a.carried_off[c] : 0;
-  // kDec anchors per pass: their query searches advance together, then the 16-byte records (a hit,
-  // or a carried anchor: same size) are fetched with one wait, then the keys.
-  constexpr int kDec = 4;
+  constexpr int kDec = kDecodeWidth;
+  const DecodeCtx dc(a, qoff, q0, nq, ncar, n, c);
   auto decode4 = [&](uint32_t i0, uint64_t (&keys4)[kDec]) {
-    uint32_t lo[kDec], kq[kDec];
-    const uint4 *src[kDec];
-    bool live[kDec], zero[kDec];
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) {
-      lo[u] = 0;
-      live[u] = i0 + u * kSortThreads < n;
-    }
-    for (uint32_t st = search_steps; st-- > 0;) {  // largest k with qoff[k] <= h0 (qoff[0] = 0)
-#pragma unroll
-      for (int u = 0; u < kDec; ++u) {
-        const uint32_t i = i0 + u * kSortThreads;
-        const uint32_t h0 = i >= ncar ? i - ncar : 0;
-        const uint32_t mid = lo[u] + (1u << st);
-        if (mid < nq && qoff[mid] <= h0) lo[u] = mid;
-      }
-    }
+    Decoded dv[kDec];
+    DecodeAnchors<kSortThreads>(a, dc, i0, dv);
 #pragma unroll
     for (int u = 0; u < kDec; ++u) {
       const uint32_t i = i0 + u * kSortThreads;
-      zero[u] = false;
-      kq[u] = lo[u];
-      src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool);  // harmless default for lanes past the end
-      if (live[u]) {
-        if (i < ncar) {
-          src[u] = reinterpret_cast<const uint4 *>(a.carried + car0 + i);
-        } else {
-          const uint32_t h = i - ncar - qoff[lo[u]];
-          const uint32_t qi = q0 + lo[u];
-          if (h < a.fast_cap) {
-            src[u] = reinterpret_cast<const uint4 *>(a.region.At(qi, h));
-          } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow)
-            const uint32_t kk = h - a.fast_cap;
-            const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
-            const uint32_t first = a.fast_cap * ((1u << level) - 1u);
-            const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-            if (seg != 0xFFFFFFFFu) src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
-            else zero[u] = true;
-          }
-        }
-      }
-    }
-    uint4 raw[kDec];
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) raw[u] = *src[u];
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) {
-      const uint32_t i = i0 + u * kSortThreads;
-      if (!live[u]) continue;
-      uint32_t tpos, qpos, grp;
-      float dist;
-      if (i < ncar) {  // smhip_carried_anchor {ref_strand, target_position, query_position, distance}
-        grp = raw[u].x;
-        tpos = raw[u].y;
-        qpos = raw[u].z;
-        dist = __uint_as_float(raw[u].w);
-      } else {  // Hit {uint64 position, dist, slot}
-        const uint64_t position = zero[u] ? 0ull : ((uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32));
-        const uint32_t ref = (uint32_t)(position >> 33);
-        tpos = (uint32_t)(position >> 1);
-        grp = (ref << 1) | (uint32_t)(position & 1);
-        qpos = (kq[u] + 1) * a.step + qso;  // position + query_start_offset
-        dist = zero[u] ? 0.0f : __uint_as_float(raw[u].z);
-      }
-      local_maxt = max(local_maxt, tpos);
-      u_qpos[i] = qpos;
-      u_dist[i] = dist;
-      keys4[u] = ((uint64_t)grp << (32 + ibits)) | ((uint64_t)tpos << ibits) | i;
+      if (i >= n) continue;
+      local_maxt = max(local_maxt, dv[u].tpos);
+      u_qpos[i] = dv[u].qpos;
+      u_dist[i] = dv[u].dist;
+      keys4[u] = ((uint64_t)dv[u].grp << (32 + ibits)) | ((uint64_t)dv[u].tpos << ibits) | i;
     }
   };
-  if (reg_keys) {  // statically indexed registers (a run-time index would put the array in scratch)
+  // (statically indexed registers: a run-time index would put the array in scratch)
 #pragma unroll
-    for (uint32_t bt = 0; bt < kPerThread / kDec; ++bt) {
-      uint64_t k4[kDec];
+  for (uint32_t bt = 0; bt < kPerThread / kDec; ++bt) {
+    uint64_t k4[kDec];
 #pragma unroll
-      for (int u = 0; u < kDec; ++u) k4[u] = ~0ull;
-      if (tid + bt * kDec * kSortThreads < n) decode4(tid + bt * kDec * kSortThreads, k4);
+    for (int u = 0; u < kDec; ++u) k4[u] = ~0ull;
+    if (tid + bt * kDec * kSortThreads < n) decode4(tid + bt * kDec * kSortThreads, k4);
 #pragma unroll
-      for (int u = 0; u < kDec; ++u) mykeys[bt * kDec + u] = k4[u];
-    }
-  } else {
-    for (uint32_t i0 = tid; i0 < n; i0 += kDec * kSortThreads) {
-      uint64_t k4[kDec];
-      decode4(i0, k4);
-#pragma unroll
-      for (int u = 0; u < kDec; ++u)
-        if (i0 + u * kSortThreads < n) gkeys[i0 + u * kSortThreads] = k4[u];
-    }
+    for (int u = 0; u < kDec; ++u) mykeys[bt * kDec + u] = k4[u];
   }
   atomicMax(&s_maxt, local_maxt);
   __syncthreads();  // everyone is done with the offsets; s_maxt ready
   const uint64_t span = (uint64_t)s_maxt + 1ull;
   const uint64_t range = span << gbits;  // dense keys are < range
-  if (in_lds) {
-    LdsSortKeys(mykeys, n, lds_keys, hist, bstart, big_list, s_maxb, n_big, span, 0ull, range, ibits, tid);
-    EmitSorted(lds_keys, n, ibits, u_qpos, u_dist, a.s_tpos + base, a.s_qpos + base, a.s_grp + base, a.s_dist + base,
-               tid);
-  } else {
-    // ---- large chunk: cut the keys (in gkeys[0, n)) into P parts by dense-key range, parts
-    // contiguous in gkeys[n, 2n); SortPartKernel sorts the parts, GroupStartKernel lists the groups
-    uint32_t *pcount = reinterpret_cast<uint32_t *>(lds_keys);  // [kMaxParts] counts, then cursors
-    uint32_t *pstart = pcount + kMaxParts;                       // [kMaxParts + 1]
-    const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
-    // as many parts as n / kPartTarget of them are non-empty: dense keys only reach range / 2^rbits of the scale
-    const uint64_t want = ((uint64_t)(n + kPartTarget - 1) / kPartTarget << rbits) / range + 1;
-    const uint32_t P = (uint32_t)min<uint64_t>(want, kMaxParts);
-    if (tid < kMaxParts) pcount[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&pcount[PartOf(gkeys[i], span, ibits, P, rbits)], 1u);
-    __syncthreads();
-    if (tid < 64) {  // exclusive scan of the part sizes by one wave
-      constexpr uint32_t kPer = kMaxParts / 64;
-      uint32_t h[kPer], sum = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < kPer; ++k) {
-        h[k] = pcount[kPer * tid + k];
-        sum += h[k];
-      }
-      uint32_t incl = sum;
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)tid >= d) incl += o;
-      }
-      uint32_t run = incl - sum;
-#pragma unroll
-      for (uint32_t k = 0; k < kPer; ++k) {
-        pstart[kPer * tid + k] = run;
-        run += h[k];
-        pcount[kPer * tid + k] = 0;  // becomes the insertion cursor
-      }
-      if (tid == 63) pstart[kMaxParts] = run;  // == n
-    }
-    __syncthreads();
-    uint64_t *gk2 = gkeys + n;
-    for (uint32_t i = tid; i < n; i += kSortThreads) {
-      const uint64_t key = gkeys[i];
-      const uint32_t b = PartOf(key, span, ibits, P, rbits);
-      gk2[pstart[b] + atomicAdd(&pcount[b], 1u)] = key;
-    }
-    uint32_t *tab = w.part_tab + (size_t)c * kPartTab;
-    if (tid <= P) tab[tid] = pstart[tid];
-    if (tid == 0) {
-      tab[kMaxParts + 1] = P;
-      tab[kMaxParts + 2] = s_maxt;
-      s_maxb = atomicAdd(&w.counters[0], P);  // (reused as the base of this chunk's work items)
-      w.big_chunks[atomicAdd(&w.counters[1], 1u)] = c;
-    }
-    __syncthreads();
-    if (tid < P) w.items[s_maxb + tid] = (c << 8) | tid;
-    return;
-  }
+  LdsSortKeys(mykeys, n, lds_keys, hist, bstart, big_list, s_maxb, n_big, span, 0ull, range, ibits, tid);
+  EmitSorted(lds_keys, n, ibits, u_qpos, u_dist, 1u, a.s_tpos + base, a.s_qpos + base, a.s_grp + base, a.s_dist + base,
+             tid);
   // ---- group boundaries, in order: every element that starts a group appends its index to the
   // list (coalesced, order-free), then the list - one entry per (reference, strand) present - is
   // rank-sorted.  Chunks with more groups than the rank sort handles count and write in index order.
@@ -556,6 +579,201 @@ __global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t 
 }
 
 
+// ---- large chunks (more anchors than the LDS sort holds): cut into PARTS by ranges of the dense key
+// group * span + target, span = *a.span_bound (largest target of the index or of a carried anchor, + 1: known
+// before the decode, so that an anchor's part is known the moment it is decoded).  Two passes over the hits,
+// nothing written in between: count the parts' sizes; then decode again and write key, query position and
+// distance straight into the part's slice (the hit records of a chunk - a few hundred KB - are still in the
+// caches).  The key's index field becomes the position INSIDE the part, and the payload travels with the key in
+// one 16-byte record: a part's sorter reads its own slice once.  Work items for the part sorters: one record per part, by size
+// class.  One workgroup per large chunk at a time.
+constexpr uint32_t kBigThreads = 1024;  // (256 / 512: 4.2 / 4.4 ms against 3.6 ms at 32 Mb)
+__global__ __launch_bounds__(kBigThreads, 8) void SortBigKernel(SortArgs a, uint32_t gbits, uint32_t ibits,
+                                                                 BigSortWork w) {
+  __shared__ uint32_t qoff[kMaxQueriesPerChunk + 2];
+  __shared__ uint32_t part[kBigThreads / 64];
+  __shared__ uint32_t pcount[kMaxParts], pstart[kMaxParts + 1];
+  __shared__ uint32_t cls_n[4], cls_base[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_big = w.counters[3];
+  const uint64_t span = (uint64_t)*a.span_bound + 1ull;
+  const uint64_t range = span << gbits;  // dense keys are < range
+  const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
+  const uint64_t idx_mask = (1ull << ibits) - 1ull;
+  PHASE_DECL();
+  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    PHASE_INIT();
+    const uint32_t c = w.big_chunks[bi];
+    const uint64_t base = a.anchor_off[c];
+    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+    const uint32_t q0 = a.q_off[c], nq = a.q_off[c + 1] - q0;
+    const uint32_t ncar = a.carried_off ? a.carried_off[c + 1] - a.carried_off[c] : 0;
+    __syncthreads();  // the previous chunk is done with the shared arrays
+    for (uint32_t k = tid; k < kMaxParts; k += kBigThreads) pcount[k] = 0;
+    ScanQueryOffsets<kBigThreads>(a, q0, nq, qoff, part, tid);
+    const DecodeCtx dc(a, qoff, q0, nq, ncar, n, c);
+    PHASE_MARK(8);
+    // as many parts as n / kPartTarget of them are non-empty: dense keys only reach range / 2^rbits of the scale
+    const uint64_t want = ((uint64_t)(n + kPartTarget - 1) / kPartTarget << rbits) / range + 1;
+    const uint32_t P = (uint32_t)min<uint64_t>(want, kMaxParts);
+    auto part_of = [&](const Decoded &dv) {  // floor(dense * P / 2^rbits), dense < range <= 2^rbits: monotone in the key
+      const uint64_t dense = (uint64_t)dv.grp * span + min((uint64_t)dv.tpos, span - 1ull);
+      return min((uint32_t)((dense * P) >> rbits), P - 1u);  // (the clamps only ever act on invalid carried anchors)
+    };
+    // Both passes visit the anchors QUERY BY QUERY, a wave per query, its lanes over the query's hits (a large
+    // chunk has ~100 hits per query): no search for the query of an anchor, slot addresses and query position
+    // are wave-uniform, the hit records of a query are read by consecutive lanes.  fn(decoded anchor).
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    auto for_each_anchor = [&](auto &&fn) {
+      for (uint32_t i = tid; i < ncar; i += kBigThreads) {  // smhip_carried_anchor {ref_strand, target, query, distance}
+        const uint4 raw = *reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
+        fn(Decoded{raw.x, raw.y, raw.z, __uint_as_float(raw.w)});
+      }
+      for (uint32_t k = wave; k < nq; k += kBigThreads / 64) {
+        const uint32_t cnt = qoff[k + 1] - qoff[k];
+        const uint32_t qi = q0 + k;
+        const Hit *slots = dc.seg ? dc.seg + (size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap : a.region.At(qi, 0);
+        const uint32_t qpos = (k + 1) * a.step + dc.qso;  // position + query_start_offset
+        for (uint32_t h0 = 0; h0 < cnt; h0 += 128) {  // two hits per lane in flight
+          uint4 raw[2];
+          bool live[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t h = h0 + 64 * u + lane;
+            live[u] = h < cnt;
+            raw[u] = make_uint4(0, 0, 0, 0);
+            if (!live[u]) continue;
+            if (h < a.fast_cap) {
+              raw[u] = *reinterpret_cast<const uint4 *>(slots + h);
+            } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow); a missing segment reads as zeros
+              const uint32_t kk = h - a.fast_cap;
+              const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+              const uint32_t first = a.fast_cap * ((1u << level) - 1u);
+              const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
+              if (seg != 0xFFFFFFFFu) raw[u] = *reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const uint64_t position = (uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32);  // Hit {uint64 position, dist, slot}
+            fn(Decoded{(uint32_t)((position >> 33) << 1) | (uint32_t)(position & 1), (uint32_t)(position >> 1), qpos,
+                       __uint_as_float(raw[u].z)});
+          }
+        }
+      }
+    };
+    // ---- pass 1: part sizes
+    for_each_anchor([&](const Decoded &dv) { atomicAdd(&pcount[part_of(dv)], 1u); });
+    __syncthreads();
+    PHASE_MARK(9);
+    if (tid < 64) {  // exclusive scan of the part sizes by one wave
+      constexpr uint32_t kPer = kMaxParts / 64;
+      uint32_t h[kPer], tot = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        h[k] = pcount[kPer * tid + k];
+        tot += h[k];
+      }
+      uint32_t incl = tot;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+      }
+      uint32_t run = incl - tot;
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        pstart[kPer * tid + k] = run;
+        run += h[k];
+        pcount[kPer * tid + k] = 0;  // becomes the insertion cursor
+      }
+      if (tid == 63) pstart[kMaxParts] = run;  // == n
+    }
+    if (tid < 3) cls_n[tid] = 0;
+    __syncthreads();
+    // ---- work items, one list per size class.  Narrow parts: dense key minus the part's lower bound, shifted
+    // over a 9-bit index, fits 32 bits
+    uint32_t *tab = w.part_tab + (size_t)c * kPartTab;
+    for (uint32_t k = tid; k <= P; k += kBigThreads) tab[k] = pstart[k];
+    const bool narrow = ((1ull << rbits) / P) + 2ull <= (1ull << 23);
+    constexpr uint32_t kPartsPerThread = kMaxParts / kBigThreads;
+    uint32_t my_cls[kPartsPerThread], my_pos[kPartsPerThread], my_m[kPartsPerThread];
+#pragma unroll
+    for (uint32_t j = 0; j < kPartsPerThread; ++j) {
+      const uint32_t pi = tid + j * kBigThreads;
+      my_cls[j] = 3;
+      my_pos[j] = my_m[j] = 0;
+      if (pi < P) {
+        my_m[j] = pstart[pi + 1] - pstart[pi];
+        if (my_m[j]) {
+          my_cls[j] = (my_m[j] <= kWaveCap0 && narrow) ? 0u : my_m[j] <= kWaveCap1 ? 1u : 2u;
+          my_pos[j] = atomicAdd(&cls_n[my_cls[j]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 3) cls_base[tid] = cls_n[tid] ? atomicAdd(&w.counters[tid], cls_n[tid]) : 0u;
+    if (tid == 0) {
+      tab[kMaxParts + 1] = P;
+      tab[kMaxParts + 2] = (uint32_t)(span - 1ull);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kPartsPerThread; ++j) {
+      const uint32_t pi = tid + j * kBigThreads;
+      if (my_cls[j] == 2) {
+        w.items[cls_base[2] + my_pos[j]] = (c << kPartBits) | pi;
+      } else if (my_cls[j] < 2) {
+        const uint64_t A = base + pstart[pi];
+        const uint64_t dlo = (((uint64_t)pi << rbits) + P - 1) / P;  // part_of(.) == pi  <=>  dlo <= dense < the next dlo
+        (my_cls[j] ? w.recs[1] : w.recs[0])[cls_base[my_cls[j]] + my_pos[j]] =
+            make_uint4((uint32_t)A, (uint32_t)(A >> 32) | (my_m[j] << 16), (uint32_t)dlo, (uint32_t)(dlo >> 32));
+      }
+    }
+    PHASE_MARK(10);
+    // ---- pass 2: decode again, into the parts' slices of the chunk's records {key, query position, distance}
+    // (16 bytes, ONE scattered store per anchor: three separate columns cost 4.0 ms instead of 3.0 at 32 Mb -
+    // the pass is bound by write requests, not bytes).  The records take the room of the chunk's 2n keys.
+    uint4 *recs_out = reinterpret_cast<uint4 *>(a.keys) + base;
+    for_each_anchor([&](const Decoded &dv) {
+      const uint32_t b = part_of(dv);
+      const uint32_t pos = atomicAdd(&pcount[b], 1u);
+      const uint32_t dst = pstart[b] + pos;
+      const uint64_t key = (((uint64_t)dv.grp << (32 + ibits)) | ((uint64_t)dv.tpos << ibits)) | ((uint64_t)pos & idx_mask);
+      recs_out[dst] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), dv.qpos, __float_as_uint(dv.dist));
+    });
+    PHASE_MARK(11);
+  }
+  PHASE_FLUSH();
+}
+
+// Largest target position of the resident index (once per index: LaunchSort's span bound), and of a batch's
+// carried anchors on top of it (every batch)
+__global__ void IndexMaxTargetKernel(const uint32_t *__restrict__ leaf_tab, const float4 *__restrict__ leaf_pts,
+                                     uint64_t n_leaves, uint32_t *__restrict__ out) {
+  uint32_t mx = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_leaves; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t tab = leaf_tab[k];
+    const uint32_t n = tab >> 27, rn = (n + 7u) & ~7u;
+    const uint64_t boff = (uint64_t)(tab & 0x07FFFFFFu) << 4;
+    for (uint32_t t = 0; t < n; ++t) {
+      const float4 v = leaf_pts[boff + rn + t];  // {v4, v5, position lo, position hi}
+      const uint64_t pos = (uint64_t)__float_as_uint(v.z) | ((uint64_t)__float_as_uint(v.w) << 32);
+      mx = max(mx, (uint32_t)(pos >> 1));
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  if ((threadIdx.x & 63u) == 0 && mx) atomicMax(out, mx);
+}
+__global__ void CarriedMaxTargetKernel(const smhip_carried_anchor *__restrict__ carried, uint64_t n_carried,
+                                       const uint32_t *__restrict__ index_max, uint32_t *__restrict__ out) {
+  uint32_t mx = *index_max;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_carried; k += (uint64_t)gridDim.x * blockDim.x)
+    mx = max(mx, carried[k].target_position);
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  if ((threadIdx.x & 63u) == 0) atomicMax(out, mx);
+}
+
 // One part of a large chunk per workgroup pass: keys gk2[b0, b0 + m) -> sorted outputs [b0, b0 + m).
 constexpr uint32_t kPartPerThread = 8;                              // keys per thread of a part ...
 constexpr uint32_t kPartLdsKeys = kPartPerThread * kSortThreads;    // ... 8192 keys = 64 KB of LDS: two workgroups per CU
@@ -567,23 +785,21 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
   __shared__ uint32_t big_list[kBuckets];
   __shared__ unsigned long long s_dmin, s_dmax;
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_items = w.counters[0];
+  const uint32_t n_items = w.counters[2];
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const uint32_t item = w.items[it], c = item >> 8, pi = item & 0xFFu;
+    const uint32_t item = w.items[it], c = item >> kPartBits, pi = item & (kMaxParts - 1u);
     const uint32_t *tab = w.part_tab + (size_t)c * kPartTab;
     const uint32_t b0 = tab[pi], m = tab[pi + 1] - b0;
     if (m == 0) continue;  // (uniform)
     const uint64_t base = a.anchor_off[c];
-    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint64_t span = (uint64_t)tab[kMaxParts + 2] + 1ull;
-    uint64_t *gk1 = a.keys + 2 * base + b0;  // the same index range in the first half: dead, this part's scratch
-    uint64_t *gk2 = a.keys + 2 * base + n + b0;
-    const uint32_t *u_qpos = a.a_qpos + base;
-    const float *u_dist = a.a_dist + base;
+    uint4 *recs = reinterpret_cast<uint4 *>(a.keys) + base + b0;  // the part's records {key, qpos, dist} (SortBigKernel)
+    const uint32_t *u_qpos = reinterpret_cast<const uint32_t *>(recs) + 2;
+    const float *u_dist = reinterpret_cast<const float *>(recs) + 3;
     uint32_t *s_tpos = a.s_tpos + base + b0, *s_qpos = a.s_qpos + base + b0, *s_grp = a.s_grp + base + b0;
     float *s_dist = a.s_dist + base + b0;
     __syncthreads();  // the previous item is done with the shared arrays
-    if (m <= kPartLdsKeys) {
+      if (m <= kPartLdsKeys) {
       if (tid == 0) {
         s_dmin = ~0ull;
         s_dmax = 0ull;
@@ -594,7 +810,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
 #pragma unroll
       for (uint32_t k = 0; k < kPartPerThread; ++k) {
         const uint32_t i = tid + k * kSortThreads;
-        mykeys[k] = i < m ? gk2[i] : ~0ull;
+        mykeys[k] = i < m ? *reinterpret_cast<const uint64_t *>(recs + i) : ~0ull;
         if (i < m) {
           const unsigned long long dense = (mykeys[k] >> (32 + ibits)) * span + ((mykeys[k] >> ibits) & 0xFFFFFFFFull);
           lmin = min(lmin, dense);
@@ -611,25 +827,360 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
       }
       __syncthreads();
       const uint64_t dlo = s_dmin, range = s_dmax - s_dmin + 1ull;
-      LdsSortKeys(mykeys, m, lds_keys, hist, bstart, big_list, s_maxb, n_big, span, dlo, range, ibits, tid);
-      EmitSorted(lds_keys, m, ibits, u_qpos, u_dist, s_tpos, s_qpos, s_grp, s_dist, tid);
+          LdsSortKeys(mykeys, m, lds_keys, hist, bstart, big_list, s_maxb, n_big, span, dlo, range, ibits, tid);
+      EmitSorted(lds_keys, m, ibits, u_qpos, u_dist, 4u, s_tpos, s_qpos, s_grp, s_dist, tid);
     } else {
-      // a part beyond the LDS (skewed targets): bitonic network over gk2[b0, b0 + m) padded into the dead
-      // first-half slice gk1[b0, b0 + m) (npad < 2m)
+      // a part beyond the LDS (skewed targets): bitonic network over the keys where they lie in the records,
+      // padded (npad < 2m) into the part's slices of two columns nobody uses at this point
       struct Split {
-        uint64_t *lo, *hi;
-        uint32_t m;
-        __device__ uint64_t &operator[](uint32_t i) const { return i < m ? lo[i] : hi[i - m]; }
+        uint4 *rec;
+        uint64_t *pad_a, *pad_b;
+        uint32_t m, half;
+        __device__ uint64_t &operator[](uint32_t i) const {
+          if (i < m) return *reinterpret_cast<uint64_t *>(rec + i);
+          i -= m;
+          return i < half ? pad_a[i] : pad_b[i - half];
+        }
       };
       uint32_t npad = 1;
       while (npad < m) npad <<= 1;
-      const Split keys{gk2, gk1, m};
+      const Split keys{recs, reinterpret_cast<uint64_t *>(a.a_qpos + base + b0),
+                       reinterpret_cast<uint64_t *>(a.a_dist + base + b0), m, m / 2};
       for (uint32_t i = m + tid; i < npad; i += kSortThreads) keys[i] = ~0ull;
       __syncthreads();
       BitonicSort(keys, npad, tid);
-      EmitSorted(gk2, m, ibits, u_qpos, u_dist, s_tpos, s_qpos, s_grp, s_dist, tid);
+      EmitSorted(keys, m, ibits, u_qpos, u_dist, 4u, s_tpos, s_qpos, s_grp, s_dist, tid);
     }
   }
+}
+
+// ---- one part per WAVE: bitonic network over KPL keys per lane (element e = lane * KPL + r), the payload
+// (query position, distance) staged in LDS, no workgroup barriers.  Strides below KPL are compare-exchanges
+// between registers of a lane, larger ones between lanes (ds_bpermute).
+template <int KPL>
+__device__ __forceinline__ void BitonicWave(uint64_t (&k)[KPL], uint32_t lane) {
+  constexpr int N = 64 * KPL;
+#pragma unroll
+  for (int kk = 2; kk <= N; kk <<= 1) {
+    // ascending block?  (element index & kk) == 0: a register bit below KPL, a lane bit from there on
+    const bool up_lane = kk >= N ? true : (((lane * (uint32_t)KPL) & (uint32_t)kk) == 0u);
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= KPL) {
+        const int lj = j / KPL;
+        const bool keep_min = ((lane & (uint32_t)lj) == 0u) == up_lane;
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+          const uint64_t o = (uint64_t)__shfl_xor((long long)k[r], lj, 64);
+          const bool lt = k[r] < o;
+          k[r] = (lt == keep_min) ? k[r] : o;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+          if ((r & j) != 0) continue;
+          const bool up = kk < KPL ? ((r & kk) == 0) : up_lane;
+          const uint64_t x = k[r], y = k[r | j];
+          const bool sw = (x > y) == up;
+          k[r] = sw ? y : x;
+          k[r | j] = sw ? x : y;
+        }
+      }
+    }
+  }
+}
+
+// ---- the same network on 32-bit keys, 8 per lane (512 keys), written out stage by stage in its "mirror" form
+// (the first step of every merge compares element i with its mirror image in the block, all later steps i with
+// i ^ j: every comparison then keeps the minimum at the lower index).  Exchanges between lanes of a row of 16
+// are DPP operands of v_min_u32 / v_max_u32 -- where the lower / upper lanes are whole banks of four lanes, one
+// instruction each -- and only the three steps that cross rows go through ds_bpermute: 664 instructions per
+// 512 keys against ~1800 for the generic 64-bit version (tools/micro/bitonic_wave.hip: 416 G keys/s).
+#define CE(a, b)                                   \
+  do {                                             \
+    const uint32_t lo_ = min(k[a], k[b]);          \
+    const uint32_t hi_ = max(k[a], k[b]);          \
+    k[a] = lo_;                                    \
+    k[b] = hi_;                                    \
+  } while (0)
+
+__device__ __forceinline__ void InLane4(uint32_t (&k)[8]) { CE(0, 4); CE(1, 5); CE(2, 6); CE(3, 7); }
+__device__ __forceinline__ void InLane2(uint32_t (&k)[8]) { CE(0, 2); CE(1, 3); CE(4, 6); CE(5, 7); }
+__device__ __forceinline__ void InLane1(uint32_t (&k)[8]) { CE(0, 1); CE(2, 3); CE(4, 5); CE(6, 7); }
+__device__ __forceinline__ void Mirror4(uint32_t (&k)[8]) { CE(0, 3); CE(1, 2); CE(4, 7); CE(5, 6); }
+__device__ __forceinline__ void Mirror8(uint32_t (&k)[8]) { CE(0, 7); CE(1, 6); CE(2, 5); CE(3, 4); }
+
+// exchange with the lane a quad permutation names; lower lanes keep the minimum
+template <int CTRL, bool REV>
+__device__ __forceinline__ void QuadStage(uint32_t (&k)[8], bool lower) {
+  uint32_t o[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = k[r];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o[REV ? 7 - r : r], CTRL, 0xF, 0xF, true);
+    k[r] = lower ? min(o[r], p) : max(o[r], p);
+  }
+}
+// exchange inside a row of 16 lanes where the lower / upper lanes are whole banks of four lanes: the
+// minimum is computed in the lower banks and the maximum in the upper ones, one DPP instruction each
+#define BANK_ASM4(CL, BL, CH, BH, r0, r1, r2, r3, s0, s1, s2, s3)                                             \
+  asm volatile("s_nop 1\n\t"                                                                                   \
+               "v_min_u32_dpp %0, %8, %4 " CL " row_mask:0xf bank_mask:" BL "\n\t"                             \
+               "v_min_u32_dpp %1, %9, %5 " CL " row_mask:0xf bank_mask:" BL "\n\t"                             \
+               "v_min_u32_dpp %2, %10, %6 " CL " row_mask:0xf bank_mask:" BL "\n\t"                            \
+               "v_min_u32_dpp %3, %11, %7 " CL " row_mask:0xf bank_mask:" BL "\n\t"                            \
+               "v_max_u32_dpp %0, %8, %4 " CH " row_mask:0xf bank_mask:" BH "\n\t"                             \
+               "v_max_u32_dpp %1, %9, %5 " CH " row_mask:0xf bank_mask:" BH "\n\t"                             \
+               "v_max_u32_dpp %2, %10, %6 " CH " row_mask:0xf bank_mask:" BH "\n\t"                            \
+               "v_max_u32_dpp %3, %11, %7 " CH " row_mask:0xf bank_mask:" BH                                   \
+               : "=&v"(k[r0]), "=&v"(k[r1]), "=&v"(k[r2]), "=&v"(k[r3])                                        \
+               : "v"(o[r0]), "v"(o[r1]), "v"(o[r2]), "v"(o[r3]), "v"(o[s0]), "v"(o[s1]), "v"(o[s2]), "v"(o[s3]))
+#define BANK_STAGE(CL, BL, CH, BH, REV)                        \
+  do {                                                         \
+    uint32_t o[8];                                             \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) o[r] = k[r]; \
+    if (REV) {                                                 \
+      BANK_ASM4(CL, BL, CH, BH, 0, 1, 2, 3, 7, 6, 5, 4);       \
+      BANK_ASM4(CL, BL, CH, BH, 4, 5, 6, 7, 3, 2, 1, 0);       \
+    } else {                                                   \
+      BANK_ASM4(CL, BL, CH, BH, 0, 1, 2, 3, 0, 1, 2, 3);       \
+      BANK_ASM4(CL, BL, CH, BH, 4, 5, 6, 7, 4, 5, 6, 7);       \
+    }                                                          \
+  } while (0)
+template <bool REV>
+__device__ __forceinline__ void PermStage(uint32_t (&k)[8], int addr, bool lower) {
+  uint32_t o[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = k[r];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)o[REV ? 7 - r : r]);
+    k[r] = lower ? min(o[r], p) : max(o[r], p);
+  }
+}
+
+__device__ __forceinline__ void BitonicWave32(uint32_t (&k)[8], uint32_t lane) {
+  const bool l1 = (lane & 1u) == 0, l2 = (lane & 2u) == 0, l4 = (lane & 4u) == 0, l8 = (lane & 8u) == 0;
+  const bool l16 = (lane & 16u) == 0, l32 = (lane & 32u) == 0;
+  InLane1(k);                         // k = 2
+  Mirror4(k); InLane1(k);             // 4
+  Mirror8(k); InLane2(k); InLane1(k); // 8
+  // 16: lanes in pairs
+  QuadStage<0xB1, true>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  // 32: lanes in quads
+  QuadStage<0x1B, true>(k, l2);
+  QuadStage<0xB1, false>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  // 64: 8 lanes
+  BANK_STAGE("row_half_mirror", "0x5", "row_half_mirror", "0xa", true);
+  QuadStage<0x4E, false>(k, l2);
+  QuadStage<0xB1, false>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  // 128: 16 lanes
+  BANK_STAGE("row_mirror", "0x3", "row_mirror", "0xc", true);
+  BANK_STAGE("row_shl:4", "0x5", "row_shr:4", "0xa", false);
+  QuadStage<0x4E, false>(k, l2);
+  QuadStage<0xB1, false>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  // 256: 32 lanes
+  PermStage<true>(k, (int)((lane ^ 31u) << 2), l16);
+  BANK_STAGE("row_shl:8", "0x3", "row_shr:8", "0xc", false);
+  BANK_STAGE("row_shl:4", "0x5", "row_shr:4", "0xa", false);
+  QuadStage<0x4E, false>(k, l2);
+  QuadStage<0xB1, false>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  // 512: 64 lanes
+  PermStage<true>(k, (int)((lane ^ 63u) << 2), l32);
+  PermStage<false>(k, (int)((lane ^ 16u) << 2), l16);
+  BANK_STAGE("row_shl:8", "0x3", "row_shr:8", "0xc", false);
+  BANK_STAGE("row_shl:4", "0x5", "row_shr:4", "0xa", false);
+  QuadStage<0x4E, false>(k, l2);
+  QuadStage<0xB1, false>(k, l1);
+  InLane4(k); InLane2(k); InLane1(k);
+  (void)l4; (void)l8;
+}
+
+// s_waitcnt for the records fetched by inline assembly (the prefetch of SortPartWaveKernel); the operands tie
+// every later use of them to it
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void WaitRecs(u32x4 (&k)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7])::"memory");
+}
+
+// LDS column index of element e: one pad word per 32, so that the lanes' blocked accesses (stride KPL words)
+// spread over the banks
+__device__ __forceinline__ uint32_t Pad(uint32_t e) { return e + (e >> 5); }
+
+template <int KPL, bool NARROW>
+__global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ibits, BigSortWork w, int cls) {
+  static_assert(!NARROW || KPL == 8, "the 32-bit network is written for 8 keys per lane");
+  constexpr uint32_t CAP = 64 * KPL, COL = CAP + CAP / 32;
+  // columns of the part in LDS; the keys pass through the room of the target / group columns on their way
+  // from the coalesced loads (element lane + 64 t) to the network's layout (element lane * KPL + r), one pad
+  // slot per KPL keys so that both access shapes spread over the banks
+  constexpr uint32_t KEYCOL = CAP + 64;
+  __shared__ uint32_t col_q[COL], col_d[COL];
+  __shared__ __align__(8) uint32_t col_tg[2 * KEYCOL];
+  static_assert(2 * KEYCOL >= 2 * COL, "target and group columns fit the key staging room");
+  uint32_t *col_t = col_tg, *col_g = col_tg + COL;
+  uint64_t *key_stage = reinterpret_cast<uint64_t *>(col_tg);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n_items = w.counters[cls];
+  const uint4 *recs = cls ? w.recs[1] : w.recs[0];
+  const uint64_t idx_mask = (1ull << ibits) - 1ull;
+  uint32_t it = blockIdx.x;
+  if (it >= n_items) return;
+  PHASE_DECL();
+  // A part = m records {key, query position, distance} (SortBigKernel) at record index A of the key scratch.
+  // KPL == 8 (nearly every part) is software-pipelined: the records of the NEXT part are in flight while the
+  // current one runs through the network, part descriptors are fetched two parts ahead; no branch around any
+  // load (a join would make the compiler wait for everything in flight): indices beyond the part are clamped
+  // into it and the values replaced after the fact.
+  constexpr bool PREFETCH = KPL == 8;
+  const uint4 *rec_base = reinterpret_cast<const uint4 *>(a.keys);
+  const uint64_t span = (uint64_t)*a.span_bound + 1ull;
+  auto prefetch = [&](const uint4 &rc, u32x4 (&dst)[8]) {
+    const uint4 *src0 = rec_base + ((uint64_t)rc.x | ((uint64_t)(rc.y & 0xFFFFu) << 32));
+    const uint32_t m = rc.y >> 16;
+    // (as inline assembly, or the compiler sinks the loads below the network to save registers; the matching
+    // wait is WaitRecs)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint4 *src = src0 + min(lane + 64u * t, m - 1u);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[t]) : "v"(src) : "memory");
+    }
+  };
+  const uint32_t last = n_items - 1u;
+  // (the descriptors are wave-uniform, and the compiler would move each into scalar registers the moment it is
+  // loaded - a wait for everything in flight; an opaque zero in the index keeps them in vector registers)
+  uint32_t opaque0;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+  uint4 rec = recs[it + opaque0];
+  uint4 rec_next = recs[min(it + gridDim.x, last) + opaque0];
+  u32x4 kn[8];
+  if (PREFETCH) prefetch(rec, kn);
+  for (;;) {
+    const uint64_t A = (uint64_t)rec.x | ((uint64_t)(rec.y & 0xFFFFu) << 32);
+    const uint32_t m = rec.y >> 16;  // 0 < m <= CAP
+    PHASE_INIT();
+    // records -> LDS: keys into the staging room (then read back in the network's layout), payload columns
+    if (PREFETCH) WaitRecs(kn);
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+      const uint32_t i = lane + 64u * t;
+      uint4 rv;
+      if (PREFETCH) rv = make_uint4(kn[t & 7].x, kn[t & 7].y, kn[t & 7].z, kn[t & 7].w);
+      else rv = rec_base[A + min(i, m - 1u)];
+      key_stage[i + i / KPL] = i < m ? ((uint64_t)rv.x | ((uint64_t)rv.y << 32)) : ~0ull;
+      col_q[Pad(i)] = rv.z;  // (slots beyond the part get the clamped copies: never read)
+      col_d[Pad(i)] = rv.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t k[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) k[r] = key_stage[lane * (KPL + 1) + r];
+    uint32_t k32[KPL];
+    if (NARROW) {  // (dense key - the part's lower bound) << 9 | element: unique, ordered like the 64-bit keys
+      const uint64_t dlo = (uint64_t)rec.z | ((uint64_t)rec.w << 32);
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) {
+        const uint32_t e = lane * KPL + r;
+        const uint64_t dense = (k[r] >> (32 + ibits)) * span + ((k[r] >> ibits) & 0xFFFFFFFFull);
+        k32[r] = e < m ? (((uint32_t)(dense - dlo) << 9) | e) : 0xFFFFFFFFu;
+      }
+    }
+    PHASE_MARK(5);
+    const uint32_t it_next = it + gridDim.x;
+    const bool more = it_next < n_items;
+    if (PREFETCH) prefetch(rec_next, kn);  // (past the end: the last part again, unused)
+    const uint4 rec_next2 = recs[min(it_next + gridDim.x, last) + opaque0];
+    __builtin_amdgcn_sched_barrier(0);  // all of the above is ISSUED before the network starts
+    PHASE_MARK(0);
+    if constexpr (NARROW) BitonicWave32(k32, lane);
+    else BitonicWave<KPL>(k, lane);
+    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that waits for them is hoisted into it
+    PHASE_MARK(1);
+    // payload of the sorted keys (index field = position inside the part), then everything back into the
+    // columns in sorted order
+    uint32_t q[KPL], d[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      // (padding keys: any slot)
+      const uint32_t from = NARROW ? (k32[r] & (CAP - 1u)) : min((uint32_t)(k[r] & idx_mask), CAP - 1u);
+      q[r] = col_q[Pad(from)];
+      d[r] = col_d[Pad(from)];
+      if (NARROW) k[r] = key_stage[from + from / KPL];  // the 64-bit key of that element: its target and group
+      // (!NARROW: the sorted 64-bit keys are in registers; the staging room is simply overwritten below)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      const uint32_t e = Pad(lane * KPL + r);
+      col_q[e] = q[r];
+      col_d[e] = d[r];
+      col_t[e] = (uint32_t)(k[r] >> ibits);
+      col_g[e] = (uint32_t)(k[r] >> (32 + ibits));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    PHASE_MARK(2);
+    // runs of equal (group, target): ordered by (query, distance) by the lane that owns the run's first element
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+      const uint32_t e = lane * KPL + r;
+      if (e + 1 >= m) continue;
+      const uint32_t t = col_t[Pad(e)], g = col_g[Pad(e)];
+      if (col_t[Pad(e + 1)] != t || col_g[Pad(e + 1)] != g) continue;        // no run here
+      if (e > 0 && col_t[Pad(e - 1)] == t && col_g[Pad(e - 1)] == g) continue;  // not its first element
+      uint32_t end = e + 2;
+      while (end < m && col_t[Pad(end)] == t && col_g[Pad(end)] == g) ++end;
+      for (uint32_t x = e + 1; x < end; ++x) {
+        const uint32_t kq = col_q[Pad(x)];
+        const float kd = __uint_as_float(col_d[Pad(x)]);
+        uint32_t y = x;
+        while (y > e && (col_q[Pad(y - 1)] > kq ||
+                         (col_q[Pad(y - 1)] == kq && __uint_as_float(col_d[Pad(y - 1)]) > kd))) {
+          col_q[Pad(y)] = col_q[Pad(y - 1)];
+          col_d[Pad(y)] = col_d[Pad(y - 1)];
+          --y;
+        }
+        col_q[Pad(y)] = kq;
+        col_d[Pad(y)] = __float_as_uint(kd);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    PHASE_MARK(3);
+    uint32_t *s_tpos = a.s_tpos + A, *s_qpos = a.s_qpos + A, *s_grp = a.s_grp + A;
+    uint32_t *s_dist = reinterpret_cast<uint32_t *>(a.s_dist + A);
+#pragma unroll
+    for (int t = 0; t < KPL; ++t) {
+      const uint32_t i = lane + 64 * t;
+#ifdef EXP_NOSTORE
+      if (i < m && col_t[Pad(i)] == 0xFFFFFFF3u) {
+#else
+      if (i < m) {
+#endif
+        s_tpos[i] = col_t[Pad(i)];
+        s_grp[i] = col_g[Pad(i)];
+        s_qpos[i] = col_q[Pad(i)];
+        s_dist[i] = col_d[Pad(i)];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the columns are free for the next part
+    PHASE_MARK(4);
+    if (!more) break;
+    it = it_next;
+    rec = rec_next;
+    rec_next = rec_next2;
+  }
+  PHASE_FLUSH();
 }
 
 // Group boundaries of the large chunks, from the sorted group column: every element that starts a
@@ -640,7 +1191,7 @@ __global__ __launch_bounds__(kSortThreads) void GroupStartKernel(SortArgs a, Big
   __shared__ uint32_t part[kSortThreads];
   __shared__ uint32_t s_cnt;
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_bigc = w.counters[1];
+  const uint32_t n_bigc = w.counters[3];
   for (uint32_t it = blockIdx.x; it < n_bigc; it += gridDim.x) {
     const uint32_t c = w.big_chunks[it];
     const uint64_t base = a.anchor_off[c];
@@ -737,6 +1288,22 @@ hipError_t LaunchAnchorCount(smhip_ctx *ctx, const smhip_params &p, const uint32
   return hipGetLastError();
 }
 
+hipError_t LaunchIndexMaxTarget(smhip_ctx *ctx, uint32_t *out) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), ctx->stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(IndexMaxTargetKernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->index.leaf_tab,
+                     reinterpret_cast<const float4 *>(ctx->index.leaf_pts), ctx->index.n_leaves, out);
+  return hipGetLastError();
+}
+hipError_t LaunchCarriedMaxTarget(smhip_ctx *ctx, const smhip_carried_anchor *carried, uint64_t n_carried,
+                                  const uint32_t *index_max, uint32_t *out) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), ctx->stream);
+  if (e != hipSuccess) return e;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_carried + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(CarriedMaxTargetKernel, dim3(grid), dim3(256), 0, ctx->stream, carried, n_carried, index_max, out);
+  return hipGetLastError();
+}
+
 hipError_t InitSortAttributes() {  // per device (smhip_init): the sorts keep up to kLdsKeys keys in LDS
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)kLdsKeys * sizeof(uint64_t)));
@@ -755,18 +1322,28 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   // than the anchors allow), the list of large chunks, two counters
   const uint64_t max_items = std::min<uint64_t>((uint64_t)n_chunks * kMaxParts,
                                                 2 * (n_anchors_total / kPartTarget) + 3ull * n_chunks + 4);
-  const size_t words = (size_t)n_chunks * kPartTab + max_items + n_chunks + 4;
+  const size_t words = (size_t)n_chunks * kPartTab + 9 * max_items + n_chunks + 8;
   hipError_t e = ctx->sort_tmp.Reserve(words * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   BigSortWork w;
   w.counters = ctx->sort_tmp.as<uint32_t>();
   w.part_tab = w.counters + 4;
-  w.items = w.part_tab + (size_t)n_chunks * kPartTab;
+  w.recs[0] = reinterpret_cast<uint4 *>(w.part_tab + (((size_t)n_chunks * kPartTab + 3) & ~(size_t)3));  // (16-byte aligned:
+  w.recs[1] = w.recs[0] + max_items;                                                                       // counters is)
+  w.items = reinterpret_cast<uint32_t *>(w.recs[1] + max_items);
   w.big_chunks = w.items + max_items;
   if ((e = hipMemsetAsync(w.counters, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(SortKernel, dim3(n_chunks), dim3(kSortThreads), lds, ctx->stream, a, gbits, ibits, w);
   if (n_anchors_total > kLdsKeys) {  // some chunk may be large
-    const uint32_t part_grid = (uint32_t)std::min<uint64_t>(max_items, 4096);
+    hipLaunchKernelGGL(SortBigKernel, dim3(std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads))), dim3(kBigThreads), 0,
+                       ctx->stream, a, gbits, ibits, w);
+    // one wave per part (persistent: the grid fills the chip, every wave takes parts in turn); the parts beyond
+    // a wave's registers - rare - go to the workgroup version
+    const uint32_t wave_grid = (uint32_t)std::min<uint64_t>(max_items, 256 * 18);
+    hipLaunchKernelGGL((SortPartWaveKernel<8, true>), dim3(wave_grid), dim3(64), 0, ctx->stream, a, ibits, w, 0);
+    hipLaunchKernelGGL((SortPartWaveKernel<16, false>), dim3(std::min<uint32_t>(wave_grid, 256 * 9)), dim3(64), 0,
+                       ctx->stream, a, ibits, w, 1);
+    const uint32_t part_grid = (uint32_t)std::min<uint64_t>(max_items, 1024);
     hipLaunchKernelGGL(SortPartKernel, dim3(part_grid), dim3(kSortThreads), (size_t)kPartLdsKeys * sizeof(uint64_t),
                        ctx->stream, a, gbits, ibits, w);
     hipLaunchKernelGGL(GroupStartKernel, dim3(std::min<uint32_t>(n_chunks, 1024)), dim3(kSortThreads), 0, ctx->stream, a, w);
@@ -774,3 +1351,15 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   return hipGetLastError();
 }
 }  // namespace smhip
+
+#ifdef SMHIP_PHASE_PROF
+extern "C" int smhip_debug_phase_prof(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(smhip::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smhip::g_phase_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
