@@ -9,29 +9,23 @@
 // (spatial_index.cc:421-423), so the device produces ONE array per chunk ordered by
 // (group = ref*2 + strand, target, query, distance) plus the list of group boundaries.
 //
-// Method: 64-bit keys [group | target_position | unsorted index].  Up to 16384 keys are sorted in
-// LDS in two levels (counting sort into 1024 buckets of a dense monotone key, then a rank sort of
-// every bucket); a key set with a heavy bucket falls back to a bitonic network in LDS.  A chunk with
-// more keys is first cut into parts of that size by key range (below).  Runs of equal (group, target)
-// - short - are then ordered by (query, distance) in place.  Every comparison key is total, so the
-// result is the unique sorted sequence the reference's std::sort produces.
+// Method: 64-bit keys [group | target_position | index].  A chunk's anchors are cut into PARTS of ~384 by
+// ranges of the dense key group * span + target (SortPartitionKernel: two passes over the hits, count and
+// scatter); one WAVE sorts a part in registers with a bitonic network (SortPartWaveKernel); parts that a skewed
+// target distribution makes larger than 1024 keys go to a workgroup (SortPartKernel: two-level LDS sort -
+// counting sort into 1024 buckets, rank sort of every bucket - or a bitonic network in memory beyond 8192).
+// Runs of equal (group, target) - short - are then ordered by (query, distance) in place.  Every comparison
+// key is total, so the result is the unique sorted sequence the reference's std::sort produces.
 #include "common.h"
 
 namespace smhip {
 namespace {
 
 constexpr int kSortThreads = 1024;
-constexpr uint32_t kLdsKeys = 16384;  // 128 KB of LDS
 constexpr uint32_t kMaxQueriesPerChunk = (kFeatStride - 5) / 1 + 1;  // step >= 1
 constexpr uint32_t kBucketBits = 10;
 constexpr uint32_t kBuckets = 1u << kBucketBits;  // buckets of the two-level sort (~9 keys each: four per wave pass)
 constexpr uint32_t kMaxBucket = 512;  // largest bucket one wave rank-sorts (8 keys per lane)
-// A chunk with more than kLdsKeys anchors (large references: 23 000 per chunk at 32 Mb, 181 000 at
-// 250 Mb) is cut into PARTS by ranges of the dense key group * (max target + 1) + target -- one counting
-// pass over its keys -- and every part, about kPartTarget keys, is then sorted like a small chunk, in
-// LDS, by a workgroup of SortPartKernel: the per-anchor cost of the large-reference sort is the LDS
-// path's plus one more read and write of the key.  A part that does not fit the LDS (a skewed target
-// distribution) is sorted by a bitonic network in its own slice of the key scratch.
 constexpr uint32_t kPartTarget = 384;   // keys per part aimed at: one WAVE sorts a part of up to 512 keys in registers
 constexpr uint32_t kMaxParts = 1024;    // parts per chunk (chunks of up to ~400 000 anchors; more: bigger parts)
 constexpr uint32_t kPartBits = 10;      // work item = (chunk << kPartBits) | part
@@ -40,7 +34,6 @@ constexpr uint32_t kPartTab = kMaxParts + 4;  // per chunk: part starts [P + 1],
 // parts by size: <= 512 keys (8 per lane) and <= 1024 keys (16 per lane) are sorted by one wave each
 // (SortPartWaveKernel), larger ones -- a skewed target distribution -- by a workgroup (SortPartKernel)
 constexpr uint32_t kWaveCap0 = 512, kWaveCap1 = 1024;
-constexpr uint32_t kPerThread = (kLdsKeys + kSortThreads - 1) / kSortThreads;  // 16 keys per thread in registers
 
 // -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
 // the clock ticks between the marks of the part sort to g_phase_prof (smhip_debug_phase_prof reads them).
@@ -98,7 +91,7 @@ __device__ __forceinline__ void BitonicSort(KeyPtr keys, uint32_t npad, uint32_t
 }
 
 
-// Two-level LDS sort of n <= kLdsKeys keys that the threads hold in registers (mykeys[it] = key of
+// Two-level LDS sort of n <= PT * kSortThreads keys that the threads hold in registers (mykeys[it] = key of
 // element tid + it * kSortThreads, ~0 beyond n).  dense_lo / range: the dense keys
 // group * span + target of these keys lie in [dense_lo, dense_lo + range).  On return lds_keys[0, n) is
 // sorted.  Every thread of the workgroup calls it; hist / bstart / big_list / s_maxb / n_big are the
@@ -312,37 +305,25 @@ __device__ __forceinline__ void EmitSorted(KeyPtr keys, uint32_t n, uint32_t ibi
   }
 }
 
-// part of a key: floor(dense * P / 2^rbits), dense < range <= 2^rbits (monotone in the key)
-__device__ __forceinline__ uint32_t PartOf(uint64_t key, uint64_t span, uint32_t ibits, uint32_t P, uint32_t rbits) {
-  const uint64_t dense = (key >> (32 + ibits)) * span + ((key >> ibits) & 0xFFFFFFFFull);
-  return (uint32_t)((dense * P) >> rbits);
-}
-
 struct BigSortWork {   // global scratch of the large-chunk path (LaunchSort)
   uint32_t *part_tab;  // [n_chunks][kPartTab]
   uint4 *recs[2];      // parts of the two wave classes: {A lo, A hi | m << 16, dlo lo, dlo hi}, A = first element of the
                        // part (m elements) in the anchor columns and in the chunk's {key, qpos, dist} records, dlo =
                        // smallest dense key group * span + target the part can hold
   uint32_t *items;     // parts of the workgroup class: (chunk << kPartBits) | part
-  uint32_t *big_chunks;
-  uint32_t *counters;  // [0..2] items per class, [3] big chunks
+  uint32_t *counters;  // [0..2] items per class
 };
 
-// ---- decode: anchor i of a chunk = carried anchor i, or hit (i - ncar - qoff[k]) of the chunk's query k, k
-// found by binary search in the LDS offsets.  kDecodeWidth anchors (i0 + u * kSortThreads) per call: their
-// searches advance together, then the 16-byte records (a hit, or a carried anchor: same size) are fetched
-// with one wait.
-constexpr int kDecodeWidth = 4;
+// ---- decode: anchor i of a chunk = carried anchor i, or hit (i - ncar - qoff[k]) of the chunk's query k
 struct DecodeCtx {
   const uint32_t *qoff;  // LDS: exclusive offsets of the queries' anchor runs, [nq + 1]
-  uint32_t q0, nq, ncar, n, qso, search_steps;
+  uint32_t q0, nq, ncar, n, qso;
   uint64_t car0;
   const Hit *seg;  // the hit-slot segment that holds all of the chunk's queries (the rule), or null
   __device__ DecodeCtx(const SortArgs &a, const uint32_t *qoff_, uint32_t q0_, uint32_t nq_, uint32_t ncar_, uint32_t n_,
                        uint32_t c)
-      : qoff(qoff_), q0(q0_), nq(nq_), ncar(ncar_), n(n_), qso(a.qstart ? a.qstart[c] : 0u), search_steps(0),
+      : qoff(qoff_), q0(q0_), nq(nq_), ncar(ncar_), n(n_), qso(a.qstart ? a.qstart[c] : 0u),
         car0(a.carried_off ? a.carried_off[c] : 0), seg(nullptr) {
-    while ((1u << search_steps) < nq + 1) ++search_steps;  // binary-search steps that cover nq + 1 offsets
     if (nq && (q0 >> a.region.qshift) == ((q0 + nq - 1) >> a.region.qshift)) seg = a.region.seg[q0 >> a.region.qshift];
   }
 };
@@ -350,80 +331,6 @@ struct Decoded {
   uint32_t grp, tpos, qpos;
   float dist;
 };
-template <uint32_t NT>
-__device__ __forceinline__ void DecodeAnchors(const SortArgs &a, const DecodeCtx &dc, uint32_t i0,
-                                              Decoded (&out)[kDecodeWidth]) {
-  constexpr int kDec = kDecodeWidth;
-  const uint32_t *qoff = dc.qoff;
-  const uint32_t nq = dc.nq, ncar = dc.ncar, n = dc.n, q0 = dc.q0;
-  uint32_t lo[kDec], kq[kDec];
-  const uint4 *src[kDec];
-  bool live[kDec], zero[kDec];
-#pragma unroll
-  for (int u = 0; u < kDec; ++u) {
-    lo[u] = 0;
-    live[u] = i0 + u * NT < n;
-  }
-  for (uint32_t st = dc.search_steps; st-- > 0;) {  // largest k with qoff[k] <= h0 (qoff[0] = 0)
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) {
-      const uint32_t i = i0 + u * NT;
-      const uint32_t h0 = i >= ncar ? i - ncar : 0;
-      const uint32_t mid = lo[u] + (1u << st);
-      if (mid < nq && qoff[mid] <= h0) lo[u] = mid;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kDec; ++u) {
-    const uint32_t i = i0 + u * NT;
-    zero[u] = false;
-    kq[u] = lo[u];
-    src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool);  // harmless default for lanes past the end
-    if (live[u]) {
-      if (i < ncar) {
-        src[u] = reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
-      } else {
-        const uint32_t h = i - ncar - qoff[lo[u]];
-        const uint32_t qi = q0 + lo[u];
-        if (h < a.fast_cap) {
-          const Hit *slot = dc.seg ? dc.seg + ((size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap + h)
-                                   : a.region.At(qi, h);
-          src[u] = reinterpret_cast<const uint4 *>(slot);
-        } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow)
-          const uint32_t kk = h - a.fast_cap;
-          const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
-          const uint32_t first = a.fast_cap * ((1u << level) - 1u);
-          const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-          if (seg != 0xFFFFFFFFu) src[u] = reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
-          else zero[u] = true;
-        }
-      }
-    }
-  }
-  uint4 raw[kDec];
-#pragma unroll
-  for (int u = 0; u < kDec; ++u) raw[u] = *src[u];
-#pragma unroll
-  for (int u = 0; u < kDec; ++u) {
-    const uint32_t i = i0 + u * NT;
-    out[u] = Decoded{0u, 0u, 0u, 0.0f};
-    if (!live[u]) continue;
-    if (i < ncar) {  // smhip_carried_anchor {ref_strand, target_position, query_position, distance}
-      out[u].grp = raw[u].x;
-      out[u].tpos = raw[u].y;
-      out[u].qpos = raw[u].z;
-      out[u].dist = __uint_as_float(raw[u].w);
-    } else {  // Hit {uint64 position, dist, slot}
-      const uint64_t position = zero[u] ? 0ull : ((uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32));
-      const uint32_t ref = (uint32_t)(position >> 33);
-      out[u].tpos = (uint32_t)(position >> 1);
-      out[u].grp = (ref << 1) | (uint32_t)(position & 1);
-      out[u].qpos = (kq[u] + 1) * a.step + dc.qso;  // position + query_start_offset
-      out[u].dist = zero[u] ? 0.0f : __uint_as_float(raw[u].z);
-    }
-  }
-}
-
 // Exclusive offsets of the queries' anchor runs into LDS: qoff[k] = sum over j < k of min(hits of query q0 + j,
 // num_nearest_points), qoff[nq] = the total.  Every thread takes ceil(nq / threads) consecutive queries; scan
 // inside the waves by shuffles, the wave totals through `wtot`.  Ends with a barrier.
@@ -453,161 +360,42 @@ __device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kSortThreads) void SortKernel(SortArgs a, uint32_t gbits, uint32_t ibits, BigSortWork w) {
-  extern __shared__ __align__(16) uint64_t lds_keys[];
-  __shared__ uint32_t part[kSortThreads];
-  __shared__ uint32_t hist[kBuckets + 1], bstart[kBuckets + 1];
-  __shared__ uint32_t s_maxt, s_maxb, n_big;
-  __shared__ uint32_t big_list[kBuckets];
-  const uint32_t c = blockIdx.x;
-  const uint32_t tid = threadIdx.x;
-  const uint64_t base = a.anchor_off[c];
-  const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
-  const uint32_t q0 = a.q_off[c], nq = a.q_off[c + 1] - q0;
-  const uint32_t ncar = a.carried_off ? a.carried_off[c + 1] - a.carried_off[c] : 0;
-  if (tid == 0) {
-    a.results[c].n_anchors = n;
-    a.n_groups[c] = 0;
-    s_maxt = 0;
-    s_maxb = 0;
-    n_big = 0;
-  }
-  if (n == 0) return;
-  if (n > (1u << ibits) || nq > kMaxQueriesPerChunk || c >= (1u << (32 - kPartBits))) {  // the key cannot index this many anchors
-    if (tid == 0) {
-      a.results[c].status |= SMHIP_ST_SORT_CAP;
-      a.results[c].n_anchors = 0;
-    }
-    return;
-  }
-  if (n > kLdsKeys) {  // large chunk: SortBigKernel cuts it into parts, the part kernels sort them
-    if (tid == 0) w.big_chunks[atomicAdd(&w.counters[3], 1u)] = c;
-    return;
-  }
-  uint32_t *u_qpos = a.a_qpos + base;  // (target and group travel in the key)
-  float *u_dist = a.a_dist + base;
-  // ---- exclusive offsets of the queries' anchor runs (block scan over nq counts) into LDS
-  // (the key array is not in use yet: its tail holds the nq+1 offsets during the decode)
-  uint32_t *qoff = reinterpret_cast<uint32_t *>(lds_keys) + 2 * kLdsKeys - (kMaxQueriesPerChunk + 2);
-  ScanQueryOffsets<kSortThreads>(a, q0, nq, qoff, part, tid);
-  // ---- decode: carried anchors, then each query's hits in traversal order.  One thread per
-  // anchor (binary search of its query in the LDS offsets), so the hit records of a query are
-  // read by consecutive lanes.  Keys go to registers first: they overwrite the offsets' LDS.
-  uint64_t mykeys[kPerThread];
-  uint32_t local_maxt = 0;
-  constexpr int kDec = kDecodeWidth;
-  const DecodeCtx dc(a, qoff, q0, nq, ncar, n, c);
-  auto decode4 = [&](uint32_t i0, uint64_t (&keys4)[kDec]) {
-    Decoded dv[kDec];
-    DecodeAnchors<kSortThreads>(a, dc, i0, dv);
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) {
-      const uint32_t i = i0 + u * kSortThreads;
-      if (i >= n) continue;
-      local_maxt = max(local_maxt, dv[u].tpos);
-      u_qpos[i] = dv[u].qpos;
-      u_dist[i] = dv[u].dist;
-      keys4[u] = ((uint64_t)dv[u].grp << (32 + ibits)) | ((uint64_t)dv[u].tpos << ibits) | i;
-    }
-  };
-  // (statically indexed registers: a run-time index would put the array in scratch)
-#pragma unroll
-  for (uint32_t bt = 0; bt < kPerThread / kDec; ++bt) {
-    uint64_t k4[kDec];
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) k4[u] = ~0ull;
-    if (tid + bt * kDec * kSortThreads < n) decode4(tid + bt * kDec * kSortThreads, k4);
-#pragma unroll
-    for (int u = 0; u < kDec; ++u) mykeys[bt * kDec + u] = k4[u];
-  }
-  atomicMax(&s_maxt, local_maxt);
-  __syncthreads();  // everyone is done with the offsets; s_maxt ready
-  const uint64_t span = (uint64_t)s_maxt + 1ull;
-  const uint64_t range = span << gbits;  // dense keys are < range
-  LdsSortKeys(mykeys, n, lds_keys, hist, bstart, big_list, s_maxb, n_big, span, 0ull, range, ibits, tid);
-  EmitSorted(lds_keys, n, ibits, u_qpos, u_dist, 1u, a.s_tpos + base, a.s_qpos + base, a.s_grp + base, a.s_dist + base,
-             tid);
-  // ---- group boundaries, in order: every element that starts a group appends its index to the
-  // list (coalesced, order-free), then the list - one entry per (reference, strand) present - is
-  // rank-sorted.  Chunks with more groups than the rank sort handles count and write in index order.
-  {
-    const uint32_t gsh = 32 + ibits;
-    auto grp_of = [&](uint32_t i) { return (uint32_t)(lds_keys[i] >> gsh); };
-    uint32_t *gs = a.group_start + base;
-    __syncthreads();
-    if (tid == 0) s_maxb = 0;  // reused as the list length
-    __syncthreads();
-    uint32_t mine_cnt = 0;
-    for (uint32_t i = tid; i < n; i += kSortThreads) mine_cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1u : 0u;
-    if (mine_cnt) atomicAdd(&s_maxb, mine_cnt);
-    __syncthreads();
-    const uint32_t G = s_maxb;
-    if (G <= kSortThreads) {
-      __syncthreads();
-      if (tid == 0) s_maxt = 0;  // reused as the append cursor
-      __syncthreads();
-      for (uint32_t i = tid; i < n; i += kSortThreads)
-        if (i == 0 || grp_of(i - 1) != grp_of(i)) part[atomicAdd(&s_maxt, 1u)] = i;
-      __syncthreads();
-      if (tid < G) {
-        const uint32_t v = part[tid];
-        uint32_t rank = 0;
-        for (uint32_t x = 0; x < G; ++x) rank += part[x] < v ? 1u : 0u;
-        gs[rank] = v;
-      }
-      if (tid == 0) a.n_groups[c] = G;
-    } else {
-      const uint32_t per_a = (n + kSortThreads - 1) / kSortThreads;
-      const uint32_t ab = min(n, tid * per_a), ae = min(n, ab + per_a);
-      uint32_t cnt = 0;
-      for (uint32_t i = ab; i < ae; ++i) cnt += (i == 0 || grp_of(i - 1) != grp_of(i)) ? 1 : 0;
-      __syncthreads();
-      part[tid] = cnt;
-      __syncthreads();
-      for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-      }
-      uint32_t w = tid ? part[tid - 1] : 0;
-      for (uint32_t i = ab; i < ae; ++i)
-        if (i == 0 || grp_of(i - 1) != grp_of(i)) gs[w++] = i;
-      if (tid == kSortThreads - 1) a.n_groups[c] = part[tid];
-    }
-  }
-}
 
-
-// ---- large chunks (more anchors than the LDS sort holds): cut into PARTS by ranges of the dense key
-// group * span + target, span = *a.span_bound (largest target of the index or of a carried anchor, + 1: known
-// before the decode, so that an anchor's part is known the moment it is decoded).  Two passes over the hits,
-// nothing written in between: count the parts' sizes; then decode again and write key, query position and
-// distance straight into the part's slice (the hit records of a chunk - a few hundred KB - are still in the
-// caches).  The key's index field becomes the position INSIDE the part, and the payload travels with the key in
-// one 16-byte record: a part's sorter reads its own slice once.  Work items for the part sorters: one record per part, by size
-// class.  One workgroup per large chunk at a time.
+// ---- every chunk is cut into PARTS by ranges of the dense key group * span + target, span = *a.span_bound
+// (largest target of the index or of a carried anchor, + 1: known before the decode, so that an anchor's part is
+// known the moment it is decoded).  Two passes over the hits, nothing written in between: count the parts' sizes;
+// then decode again and write key, query position and distance straight into the part's slice (the hit records
+// of a chunk - a few hundred KB - are still in the caches).  The key's index field becomes the position INSIDE
+// the part, and the payload travels with the key in one 16-byte record: a part's sorter reads its own slice
+// once.  Work items for the part sorters: one record per part, by size class.  One workgroup per chunk at a
+// time, two per CU.
 constexpr uint32_t kBigThreads = 1024;  // (256 / 512: 4.2 / 4.4 ms against 3.6 ms at 32 Mb)
-__global__ __launch_bounds__(kBigThreads, 8) void SortBigKernel(SortArgs a, uint32_t gbits, uint32_t ibits,
-                                                                 BigSortWork w) {
+__global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a, uint32_t n_chunks, uint32_t gbits,
+                                                                       uint32_t ibits, BigSortWork w) {
   __shared__ uint32_t qoff[kMaxQueriesPerChunk + 2];
   __shared__ uint32_t part[kBigThreads / 64];
   __shared__ uint32_t pcount[kMaxParts], pstart[kMaxParts + 1];
   __shared__ uint32_t cls_n[4], cls_base[4];
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_big = w.counters[3];
   const uint64_t span = (uint64_t)*a.span_bound + 1ull;
   const uint64_t range = span << gbits;  // dense keys are < range
   const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
   const uint64_t idx_mask = (1ull << ibits) - 1ull;
   PHASE_DECL();
-  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     PHASE_INIT();
-    const uint32_t c = w.big_chunks[bi];
     const uint64_t base = a.anchor_off[c];
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint32_t q0 = a.q_off[c], nq = a.q_off[c + 1] - q0;
     const uint32_t ncar = a.carried_off ? a.carried_off[c + 1] - a.carried_off[c] : 0;
+    // the key cannot index this many anchors / queries / chunks: flagged, no anchors
+    const bool cap = n > (1u << ibits) || nq > kMaxQueriesPerChunk || c >= (1u << (32 - kPartBits));
+    if (tid == 0) {
+      a.results[c].n_anchors = cap ? 0u : n;
+      a.n_groups[c] = 0;
+      if (cap) a.results[c].status |= SMHIP_ST_SORT_CAP;
+    }
+    if (n == 0 || cap) continue;  // (uniform)
     __syncthreads();  // the previous chunk is done with the shared arrays
     for (uint32_t k = tid; k < kMaxParts; k += kBigThreads) pcount[k] = 0;
     ScanQueryOffsets<kBigThreads>(a, q0, nq, qoff, part, tid);
@@ -793,7 +581,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
     if (m == 0) continue;  // (uniform)
     const uint64_t base = a.anchor_off[c];
     const uint64_t span = (uint64_t)tab[kMaxParts + 2] + 1ull;
-    uint4 *recs = reinterpret_cast<uint4 *>(a.keys) + base + b0;  // the part's records {key, qpos, dist} (SortBigKernel)
+    uint4 *recs = reinterpret_cast<uint4 *>(a.keys) + base + b0;  // the part's records {key, qpos, dist} (SortPartitionKernel)
     const uint32_t *u_qpos = reinterpret_cast<const uint32_t *>(recs) + 2;
     const float *u_dist = reinterpret_cast<const float *>(recs) + 3;
     uint32_t *s_tpos = a.s_tpos + base + b0, *s_qpos = a.s_qpos + base + b0, *s_grp = a.s_grp + base + b0;
@@ -1034,7 +822,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
   uint32_t it = blockIdx.x;
   if (it >= n_items) return;
   PHASE_DECL();
-  // A part = m records {key, query position, distance} (SortBigKernel) at record index A of the key scratch.
+  // A part = m records {key, query position, distance} (SortPartitionKernel) at record index A of the key scratch.
   // KPL == 8 (nearly every part) is software-pipelined: the records of the NEXT part are in flight while the
   // current one runs through the network, part descriptors are fetched two parts ahead; no branch around any
   // load (a join would make the compiler wait for everything in flight): indices beyond the part are clamped
@@ -1187,15 +975,14 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
 // group appends its index to a list (coalesced, order-free), then the list - one entry per
 // (reference, strand) present - is rank-sorted; more groups than the list holds: counted and written
 // in index order.
-__global__ __launch_bounds__(kSortThreads) void GroupStartKernel(SortArgs a, BigSortWork w) {
+__global__ __launch_bounds__(kSortThreads) void GroupStartKernel(SortArgs a, uint32_t n_chunks) {
   __shared__ uint32_t part[kSortThreads];
   __shared__ uint32_t s_cnt;
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_bigc = w.counters[3];
-  for (uint32_t it = blockIdx.x; it < n_bigc; it += gridDim.x) {
-    const uint32_t c = w.big_chunks[it];
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const uint64_t base = a.anchor_off[c];
-    const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
+    const uint32_t n = a.results[c].n_anchors;  // (0 for a flagged chunk)
+    if (n == 0) continue;  // (uniform)
     const uint32_t *grp = a.s_grp + base;
     uint32_t *gs = a.group_start + base;
     __syncthreads();
@@ -1304,10 +1091,7 @@ hipError_t LaunchCarriedMaxTarget(smhip_ctx *ctx, const smhip_carried_anchor *ca
   return hipGetLastError();
 }
 
-hipError_t InitSortAttributes() {  // per device (smhip_init): the sorts keep up to kLdsKeys keys in LDS
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)((size_t)kLdsKeys * sizeof(uint64_t)));
-  if (e != hipSuccess) return e;
+hipError_t InitSortAttributes() {  // per device (smhip_init): the workgroup part sort keeps up to 8192 keys in LDS
   return hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)((size_t)kPartLdsKeys * sizeof(uint64_t)));
 }
@@ -1317,12 +1101,12 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   while ((1ull << gbits) < 2ull * a.n_refs) ++gbits;
   if (gbits > 24) return hipErrorInvalidValue;
   const uint32_t ibits = 64 - 32 - gbits;
-  const size_t lds = (size_t)kLdsKeys * sizeof(uint64_t);
-  // scratch of the large-chunk path: part tables, work items (at most kMaxParts per chunk, and no more
-  // than the anchors allow), the list of large chunks, two counters
+  if (n_chunks == 0) return hipSuccess;
+  // scratch: part tables, part descriptors / work items per size class (at most kMaxParts per chunk, and no
+  // more than the anchors allow), three counters
   const uint64_t max_items = std::min<uint64_t>((uint64_t)n_chunks * kMaxParts,
                                                 2 * (n_anchors_total / kPartTarget) + 3ull * n_chunks + 4);
-  const size_t words = (size_t)n_chunks * kPartTab + 9 * max_items + n_chunks + 8;
+  const size_t words = (size_t)n_chunks * kPartTab + 9 * max_items + 8;
   hipError_t e = ctx->sort_tmp.Reserve(words * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   BigSortWork w;
@@ -1331,23 +1115,20 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   w.recs[0] = reinterpret_cast<uint4 *>(w.part_tab + (((size_t)n_chunks * kPartTab + 3) & ~(size_t)3));  // (16-byte aligned:
   w.recs[1] = w.recs[0] + max_items;                                                                       // counters is)
   w.items = reinterpret_cast<uint32_t *>(w.recs[1] + max_items);
-  w.big_chunks = w.items + max_items;
   if ((e = hipMemsetAsync(w.counters, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(SortKernel, dim3(n_chunks), dim3(kSortThreads), lds, ctx->stream, a, gbits, ibits, w);
-  if (n_anchors_total > kLdsKeys) {  // some chunk may be large
-    hipLaunchKernelGGL(SortBigKernel, dim3(std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads))), dim3(kBigThreads), 0,
-                       ctx->stream, a, gbits, ibits, w);
-    // one wave per part (persistent: the grid fills the chip, every wave takes parts in turn); the parts beyond
-    // a wave's registers - rare - go to the workgroup version
-    const uint32_t wave_grid = (uint32_t)std::min<uint64_t>(max_items, 256 * 18);
-    hipLaunchKernelGGL((SortPartWaveKernel<8, true>), dim3(wave_grid), dim3(64), 0, ctx->stream, a, ibits, w, 0);
-    hipLaunchKernelGGL((SortPartWaveKernel<16, false>), dim3(std::min<uint32_t>(wave_grid, 256 * 9)), dim3(64), 0,
-                       ctx->stream, a, ibits, w, 1);
-    const uint32_t part_grid = (uint32_t)std::min<uint64_t>(max_items, 1024);
-    hipLaunchKernelGGL(SortPartKernel, dim3(part_grid), dim3(kSortThreads), (size_t)kPartLdsKeys * sizeof(uint64_t),
-                       ctx->stream, a, gbits, ibits, w);
-    hipLaunchKernelGGL(GroupStartKernel, dim3(std::min<uint32_t>(n_chunks, 1024)), dim3(kSortThreads), 0, ctx->stream, a, w);
-  }
+  hipLaunchKernelGGL(SortPartitionKernel, dim3(std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads))), dim3(kBigThreads),
+                     0, ctx->stream, a, n_chunks, gbits, ibits, w);
+  // one wave per part (persistent: the grid fills the chip, every wave takes parts in turn); the parts beyond
+  // a wave's registers - rare - go to the workgroup version
+  const uint32_t wave_grid = (uint32_t)std::min<uint64_t>(max_items, 256 * 18);
+  hipLaunchKernelGGL((SortPartWaveKernel<8, true>), dim3(wave_grid), dim3(64), 0, ctx->stream, a, ibits, w, 0);
+  hipLaunchKernelGGL((SortPartWaveKernel<16, false>), dim3(std::min<uint32_t>(wave_grid, 256 * 9)), dim3(64), 0,
+                     ctx->stream, a, ibits, w, 1);
+  const uint32_t part_grid = (uint32_t)std::min<uint64_t>(max_items, 1024);
+  hipLaunchKernelGGL(SortPartKernel, dim3(part_grid), dim3(kSortThreads), (size_t)kPartLdsKeys * sizeof(uint64_t),
+                     ctx->stream, a, gbits, ibits, w);
+  hipLaunchKernelGGL(GroupStartKernel, dim3(std::min<uint32_t>(n_chunks, 1024)), dim3(kSortThreads), 0, ctx->stream, a,
+                     n_chunks);
   return hipGetLastError();
 }
 }  // namespace smhip
