@@ -387,6 +387,15 @@ def phase_prof():
     ticks thread 0 of every workgroup spent between the marks of an instrumented kernel, on stderr."""
     import ctypes
     from sigmap_amd import _abi
+    fw = getattr(_abi.hip_lib(), "smhip_debug_walk_prof", None)
+    if fw is not None:
+        wb = (ctypes.c_ulonglong * 8)()
+        if fw(wb, 1) == 0 and wb[0]:
+            names = ["all", "scan phase", "query hand-out", "node fetch wait", "visit logic", None, "scan set-up",
+                     "scan point-load wait"]
+            print("walk_prof (shader-clock ticks summed over %d waves): " % wb[5] +
+                  "  ".join("%s %.3g (%.1f%%)" % (names[k], wb[k], 100.0 * wb[k] / wb[0]) for k in range(8) if names[k]),
+                  file=sys.stderr, flush=True)
     fn = getattr(_abi.hip_lib(), "smhip_debug_phase_prof", None)
     if fn is None:
         return

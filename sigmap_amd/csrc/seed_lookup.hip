@@ -130,6 +130,13 @@ __device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint
   if (ovf_base != 0xFFFFFFFFu) sink.pool[(size_t)ovf_base + (k - first)] = h;
 }
 
+#ifdef SMHIP_PHASE_PROF  // tools/phase_prof.sh: shader-clock ticks per wave in the phases of the walker
+__device__ unsigned long long g_walk_prof[8];
+#define WALK_T() clock64()
+#else
+#define WALK_T() 0ull
+#endif
+
 template <bool kStrict>
 __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
@@ -189,7 +196,10 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   // (a wave whose own range is exhausted takes from the other ranges), so that neither a lane nor
   // a wave nor an XCD idles while another still has a backlog.
   uint32_t pool_next = 0, pool_end = 0, victim = 0;
+  unsigned long long pt_scan = 0, pt_wait = 0, pt_fetchq = 0, pt_visit = 0, pt_scan_setup = 0, pt_scan_load = 0;
+  const unsigned long long pt_begin = WALK_T();
   for (;;) {
+    const unsigned long long pt0 = WALK_T();
     const bool blocked = fifo_cnt == (uint32_t)kFifo || mode == M_DRAIN;
     const bool active = !blocked && mode != M_IDLE;
     const uint64_t act = __ballot(active);
@@ -197,11 +207,11 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     if (act == 0 && pend == 0) break;
     if (act == 0 || (uint32_t)__popcll(__ballot(blocked)) >= scan_threshold) {
       // ---- scan phase (nanoflann.hpp:1350-1369, 391-406): the pending leaves of all lanes are
-      // listed in (lane, arrival) order and scanned three per iteration, 21 lanes each, ONE POINT
-      // PER LANE (a leaf holds <= 20 points), so the loads of a leaf are one contiguous run and
-      // every lane that works tests a point.  A hit's ordinal within its query = the query's hits
-      // so far + hits of the same query in earlier leaves of this iteration + its rank among the
-      // leaf's hits (ballot), i.e. exactly the order in which searchLevel reports them.
+      // listed in (lane, arrival) order and scanned ONE POINT PER LANE, so the loads of a leaf are
+      // one contiguous run and every lane that works tests a point.  A hit's ordinal within its
+      // query = the query's hits so far + hits of the same query in earlier leaves of this
+      // iteration + its rank among the leaf's hits (ballot), i.e. exactly the order in which
+      // searchLevel reports them.
       const uint32_t c = fifo_cnt;
       const uint64_t lt = (1ull << lane) - 1ull;
       const uint64_t cb0 = __ballot(c & 1u), cb1 = __ballot(c & 2u), cb2 = __ballot(c & 4u);
@@ -211,15 +221,30 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {boff, owner lane | n << 8}
       float4 *own_a = reinterpret_cast<float4 *>(stage_w + 128);  // [64] q0..q3 of the owning lane
       uint4 *own_b = stage_w + 192;                                // [64] q4, q5, query id, hits so far
+      uint32_t n_points;  // points of all pending leaves (wave-uniform)
       {
         uint32_t tab[kFifo];
 #pragma unroll
         for (int e = 0; e < kFifo; ++e) tab[e] = (uint32_t)e < c ? ix.leaf_tab[fifo[e][threadIdx.x]] : 0u;
+        // position of every entry's first point in the flat sequence of all pending points
+        uint32_t mine_pts = 0;
+#pragma unroll
+        for (int e = 0; e < kFifo; ++e) mine_pts += tab[e] >> 27;
+        uint32_t incl = mine_pts;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+          if ((int)lane >= d) incl += o;
+        }
+        n_points = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t run = incl - mine_pts;
 #pragma unroll
         for (int e = 0; e < kFifo; ++e)
           if ((uint32_t)e < c) {
             const uint32_t nleaf = tab[e] >> 27;
-            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 4, lane | (nleaf << 8));
+            // {first 16-byte slot of the leaf's block, owner lane | points << 8 | flat position << 13}
+            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 4, lane | (nleaf << 8) | (run << 13));
+            run += nleaf;
             if (!kStrict) np += nleaf;  // (strict: counted when the leaf was visited)
           }
       }
@@ -231,30 +256,81 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const uint32_t grp = lane / 21u, t = lane - grp * 21u;  // lane 63: grp 3, idle
+      // The points of all pending leaves form one flat sequence (leaf after leaf in entry order), scanned 64
+      // at a time, ONE POINT PER LANE, whatever the leaf boundaries: leaves hold 1..20 points (12.5 on average:
+      // fixed groups of 21 lanes per leaf left 35 % of the lanes idle).  The window of an iteration starts in
+      // entry eb; the flat positions of the next kWin entries are read as LDS broadcasts and a lane's entry is
+      // the number of them at or below its point.  (A window reaches at most the start of entry eb + kWin.)
+      constexpr int kWin = 8;
       const uint32_t hits_word = 3;
-      for (uint32_t it = 0; it < n_ent; it += 3) {
+      pt_scan_setup += WALK_T() - pt0;
+      // window -> {this lane's entry record, its entry's index relative to the window's first entry, has a point}
+      struct Win {
+        uint2 mine;
+        uint32_t e_rel;
+        bool pt;
+      };
+      auto lookup = [&](uint32_t eb_, uint32_t p0_) {
+        const uint32_t p = p0_ + lane;
+        uint32_t e_rel = 0, limit = n_points;
+#pragma unroll
+        for (int i = 1; i <= kWin; ++i) {
+          const bool have = eb_ + (uint32_t)i < n_ent;
+          const uint32_t st_i = have ? (ents[eb_ + (uint32_t)i].y >> 13) : 0xFFFFFFFFu;  // (uniform address)
+          if (i < kWin) e_rel += st_i <= p ? 1u : 0u;
+          else limit = min(limit, st_i);
+        }
+        return Win{ents[min(eb_ + e_rel, 255u)], e_rel, p < limit};  // (pt: then t < n, the next entry starts above p)
+      };
+      uint32_t eb = 0, p0 = 0;
+      Win w = lookup(0u, 0u);
+      while (p0 < n_points) {
         ++st_scan;
-        // the three entries of this iteration (uniform addresses: LDS broadcasts); a missing one
-        // repeats its predecessor with n = 0
-        const uint2 e0 = ents[it];
-        uint2 e1 = it + 1 < n_ent ? ents[it + 1] : make_uint2(e0.x, e0.y & 0xFFu);
-        uint2 e2 = it + 2 < n_ent ? ents[it + 2] : make_uint2(e1.x, e1.y & 0xFFu);
-        const uint2 mine = grp == 0 ? e0 : (grp == 1 ? e1 : e2);
-        const uint32_t owner = mine.y & 0xFFu, n = grp < 3 ? (mine.y >> 8) : 0u;
-        const bool pt = t < n;
-        st_scan_lanes += (uint32_t)__popcll(__ballot(pt));
+        const uint2 mine = w.mine;
+        const uint32_t owner = mine.y & 0xFFu, n = (mine.y >> 8) & 31u, t = p0 + lane - (mine.y >> 13);
+        const bool pt = w.pt;
+        const uint64_t pb = __ballot(pt);  // (a prefix of the lanes)
+        st_scan_lanes += (uint32_t)__popcll(pb);
+        // next window: from the end of this one (p0 + 64, or the start of entry eb + kWin if that came first);
+        // its first entry is the last lane's, or the one after it when the lane had the entry's last point
+        const uint32_t nl = (uint32_t)__popcll(pb);  // >= 1
+        {
+          const uint32_t e_last = (uint32_t)__builtin_amdgcn_readlane((int)w.e_rel, 63);
+          const uint32_t full = (uint32_t)__builtin_amdgcn_readlane((int)(t + 1u == n ? 1u : 0u), 63);
+          eb += nl == 64u ? e_last + full : (uint32_t)kWin;  // (nl < 64: the window ended at entry eb + kWin, or it was the last)
+        }
         bool hit = false;
         float res = 0.0f;
         uint4 sv = make_uint4(0, 0, 0, 0);
-        uint32_t oqi = 0;
+        uint32_t oqi = 0, hbase = 0;
+#ifdef SMHIP_PHASE_PROF
+        const unsigned long long ptl = clock64();
+        uint4 rv_p = make_uint4(0, 0, 0, 0);
         if (pt) {
           const uint4 *fh = pts4 + (size_t)mine.x + t;
-          const uint4 rv = fh[0];
+          rv_p = fh[0];
           sv = fh[(n + 7u) & ~7u];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        pt_scan_load += clock64() - ptl;
+#endif
+        uint4 rv = make_uint4(0, 0, 0, 0);
+#ifdef SMHIP_PHASE_PROF
+        rv = rv_p;
+#else
+        if (pt) {
+          const uint4 *fh = pts4 + (size_t)mine.x + t;
+          rv = fh[0];
+          sv = fh[(n + 7u) & ~7u];
+        }
+#endif
+        // the next window's entries are looked up (LDS only) while the point loads are in flight
+        const Win w_next = lookup(eb, p0 + nl);
+        if (pt) {
           const float4 oa = own_a[owner];
           const uint4 ob = own_b[owner];
           oqi = ob.z;
+          hbase = ob.w;
           const float f0 = oa.x - __uint_as_float(rv.x), f1 = oa.y - __uint_as_float(rv.y);
           const float f2 = oa.z - __uint_as_float(rv.z), f3 = oa.w - __uint_as_float(rv.w);
           res = f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3; /* 0 + s == s exactly */
@@ -265,23 +341,23 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           hit = res < radius; /* RadiusResultSet::addPoint */
         }
         const uint64_t hb = __ballot(hit);
-        const uint32_t m21 = 0x1FFFFFu;
-        const uint32_t c0 = (uint32_t)__popc((uint32_t)hb & m21), c1 = (uint32_t)__popc((uint32_t)(hb >> 21) & m21),
-                       c2 = (uint32_t)__popc((uint32_t)(hb >> 42) & m21);
-        const uint32_t o0 = e0.y & 0xFFu, o1 = e1.y & 0xFFu, o2 = e2.y & 0xFFu;
-        uint32_t *h0 = reinterpret_cast<uint32_t *>(&own_b[o0]) + hits_word;
-        uint32_t *h1 = reinterpret_cast<uint32_t *>(&own_b[o1]) + hits_word;
-        uint32_t *h2 = reinterpret_cast<uint32_t *>(&own_b[o2]) + hits_word;
-        const uint32_t base0 = *h0;
-        const uint32_t base1 = o1 == o0 ? base0 + c0 : *h1;
-        const uint32_t base2 = o2 == o1 ? base1 + c1 : *h2;
-        if (lane == 0) {  // in this order: equal owners end with the full sum
-          *h0 = base0 + c0;
-          *h1 = base1 + c1;
-          *h2 = base2 + c2;
+        // runs of lanes with the same owner (the entries of an owner are consecutive); ordinal = the owner's
+        // hits so far + the hits in the lanes of its run below this one (earlier leaves of the owner in this
+        // iteration and the lower points of this leaf)
+        const uint32_t prev_owner = (uint32_t)__shfl_up((int)owner, 1, 64);
+        const uint64_t rb = __ballot(pt && (lane == 0 || owner != prev_owner));  // first lanes of the runs
+        const uint64_t lowmask = (2ull << lane) - 1ull, below = (1ull << lane) - 1ull;
+        const uint32_t run_first = 63u - (uint32_t)__clzll((long long)((rb & lowmask) | 1ull));
+        const uint32_t in_run_below = (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
+        const uint32_t ord = hbase + in_run_below;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // every lane has read its owner's count
+        // the last lane of a run adds the run's hits to the owner's count
+        const uint64_t next_is_first_or_idle = (rb | ~pb) >> 1;  // bit L: lane L + 1 starts a run or has no point
+        if (pt && (lane == 63u || ((next_is_first_or_idle >> lane) & 1ull) != 0)) {
+          const uint32_t cnt = in_run_below + (hit ? 1u : 0u);
+          if (cnt) *(reinterpret_cast<uint32_t *>(&own_b[owner]) + hits_word) = hbase + cnt;
         }
-        const uint32_t ord = (grp == 0 ? base0 : (grp == 1 ? base1 : base2)) +
-                             (uint32_t)__popc((uint32_t)(hb >> (21u * grp)) & m21 & ((1u << t) - 1u));
         Hit h;
         h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);
         h.dist = res;
@@ -299,6 +375,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        p0 += nl;
+        w = w_next;
       }
       if (c > 0) {
         hits = own_b[lane].w;
@@ -311,6 +389,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         if (sink.q_points) sink.q_points[qi] = np;
         mode = M_FETCH;
       }
+      pt_scan += WALK_T() - pt0;
       continue;
     }
     // ---- walk phase: one node visit per active lane ----
@@ -365,6 +444,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       pool_next += take;
       need = __ballot(active && mode == M_FETCH);
     }
+    const unsigned long long pt1 = WALK_T();
+    pt_fetchq += pt1 - pt0;
     {
       const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
       uint32_t nsrc[4];
@@ -382,6 +463,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
     }
+    const unsigned long long pt2 = WALK_T();
+    pt_wait += pt2 - pt1;
     if (rf_pending) {  // the refill issued by the previous pop has landed too: it is the oldest cached entry
       const uint32_t slot = tcnt == 0 ? thead : thead ^ 1u;
       tos[slot][0][threadIdx.x] = rf_a;
@@ -527,6 +610,22 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       }
     }
   }
+#ifdef SMHIP_PHASE_PROF
+  if (!kStrict && lane == 0) {
+    const unsigned long long pt_all = clock64() - pt_begin;
+    atomicAdd(&g_walk_prof[0], pt_all);
+    atomicAdd(&g_walk_prof[1], pt_scan);
+    atomicAdd(&g_walk_prof[2], pt_fetchq);
+    atomicAdd(&g_walk_prof[3], pt_wait);
+    atomicAdd(&g_walk_prof[4], pt_all - pt_scan - pt_fetchq - pt_wait);  // visit logic
+    atomicAdd(&g_walk_prof[5], 1ull);
+    atomicAdd(&g_walk_prof[6], pt_scan_setup);
+    atomicAdd(&g_walk_prof[7], pt_scan_load);
+  }
+#endif
+  (void)pt_visit;
+  (void)pt_scan_setup;
+  (void)pt_scan_load;
   if (lane == 0) {  // occupancy statistics of the two phases (smhip_debug_counters)
     unsigned long long *st = reinterpret_cast<unsigned long long *>(sink.counters + 8);
     atomicAdd(&st[0], (unsigned long long)st_walk);
@@ -858,3 +957,14 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
 }
 }  // namespace smhip
+
+#ifdef SMHIP_PHASE_PROF
+extern "C" int smhip_debug_walk_prof(unsigned long long *out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(smhip::g_walk_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smhip::g_walk_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

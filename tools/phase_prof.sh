@@ -17,5 +17,5 @@ if [ "$1" = build ]; then
   echo built sigmap_amd/lib/libsigmap_hip_prof.so
 else
   shift
-  SMHIP_LIB=$PWD/sigmap_amd/lib/libsigmap_hip_prof.so python bench.py --steps 3 --warmup 1 --no-cpu --no-pcie --depth 1 "$@" 2>&1 | grep phase_prof
+  SMHIP_LIB=$PWD/sigmap_amd/lib/libsigmap_hip_prof.so python bench.py --steps 3 --warmup 1 --no-cpu --no-pcie --depth 1 "$@" 2>&1 | grep -E "phase_prof|walk_prof"
 fi
