@@ -396,15 +396,16 @@ def phase_prof():
             print("walk_prof (shader-clock ticks summed over %d waves): " % wb[5] +
                   "  ".join("%s %.3g (%.1f%%)" % (names[k], wb[k], 100.0 * wb[k] / wb[0]) for k in range(8) if names[k]),
                   file=sys.stderr, flush=True)
-    fn = getattr(_abi.hip_lib(), "smhip_debug_phase_prof", None)
-    if fn is None:
-        return
-    buf = (ctypes.c_ulonglong * 32)()
-    if fn(buf, 1) == 0:
-        tot = float(sum(buf)) or 1.0
-        print("phase_prof (wall_clock64 ticks, share): " +
-              "  ".join("[%d] %.3g (%.1f%%)" % (k, buf[k], 100.0 * buf[k] / tot) for k in range(32) if buf[k]),
-              file=sys.stderr, flush=True)
+    for name in ("smhip_debug_phase_prof", "smhip_debug_chain_prof"):
+        fn = getattr(_abi.hip_lib(), name, None)
+        if fn is None:
+            continue
+        buf = (ctypes.c_ulonglong * 32)()
+        if fn(buf, 1) == 0:
+            tot = float(sum(buf)) or 1.0
+            print("phase_prof %s (wall_clock64 ticks, share): " % name[12:-5] +
+                  "  ".join("[%d] %.3g (%.1f%%)" % (k, buf[k], 100.0 * buf[k] / tot) for k in range(32) if buf[k]),
+                  file=sys.stderr, flush=True)
 
 
 def walker_stats(dev):

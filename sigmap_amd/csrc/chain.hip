@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void ChainTileCountKernel(ChainArgs a, uint32_
   }
 }
 
+#ifdef SMHIP_PHASE_PROF
+__device__ unsigned long long g_phase_prof[32];  // (the PHASE_* macros of common.h)
+#endif
+
 __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t n_chunks,
                                                            const uint32_t *__restrict__ tile_off, float radius, int dim,
                                                            int max_gap_length, int max_target_gap_length,
@@ -105,7 +109,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   bool have_nx = false;
   uint32_t nx_t = 0, nx_q = 0, nx_g = 0;
   float nx_d = 0.0f;
+  PHASE_DECL();
   for (; tile < tile_end; ++tile) {
+    PHASE_INIT();
     while (tile >= tile_off[c + 1]) {  // next chunk (chunks without anchors have no tiles)
       ++c;
       ring_valid = false;
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       s_first = lo;
     }
     __syncthreads();
+    PHASE_MARK(0);
     uint32_t ord = 0;
     {
       // (with a valid ring the anchor before the tile is in LDS too: its bucket starts the count)
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       if (tid == 0 && ring_valid) s_first = ord;  // ordinal of the tile's first anchor
     }
     __syncthreads();
+    PHASE_MARK(1);
     if (ai < n) {
       const uint32_t g = s_g[ai & 511u];
       const int32_t ct = s_t[ai & 511u], cq = s_q[ai & 511u];
@@ -220,6 +228,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         }
         if (++skips > max_num_skips) break;
       }
+      PHASE_MARK(2);
       if (isolated) {
         const float coef = (float)(1 - 0.2 * (double)my_dist / (double)radius);
         const float sc = coef * (float)dim;
@@ -231,11 +240,15 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
       }
     }
+    PHASE_MARK(3);
     __syncthreads();
+    PHASE_MARK(4);
     if (tid <= s_last - s_first && s_gmax[tid] != 0) atomicMax(&gmax_g[s_first + tid], s_gmax[tid]);
     ord_carry = s_last;
     ring_valid = true;
+    PHASE_MARK(5);
   }
+  PHASE_FLUSH();
 }
 
 // ---- C0b: the anchors left for the sequential DP, listed per chunk in index order (one workgroup per
@@ -1269,3 +1282,15 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   return hipGetLastError();
 }
 }  // namespace smhip
+
+#ifdef SMHIP_PHASE_PROF
+extern "C" int smhip_debug_chain_prof(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(smhip::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smhip::g_phase_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

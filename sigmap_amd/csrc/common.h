@@ -89,6 +89,41 @@ inline bool TraceAlloc() {
   return on;
 }
 
+// -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
+// the clock ticks between the marks of an instrumented kernel to its translation unit's g_phase_prof[32]
+// (read by smhip_debug_phase_prof / smhip_debug_chain_prof).
+#ifdef SMHIP_PHASE_PROF
+#define PHASE_DECL()                    \
+  unsigned long long prof_acc[16] = {}; \
+  unsigned long long prof_t = wall_clock64()
+#define PHASE_INIT() prof_t = wall_clock64()
+#define PHASE_MARK(k)                                 \
+  do {                                                \
+    const unsigned long long prof_n = wall_clock64(); \
+    prof_acc[k] += prof_n - prof_t;                   \
+    prof_t = prof_n;                                  \
+  } while (0)
+#define PHASE_FLUSH()                                                    \
+  do {                                                                   \
+    if (threadIdx.x == 0)                                                \
+      for (int pk = 0; pk < 16; ++pk)                                    \
+        if (prof_acc[pk]) atomicAdd(&g_phase_prof[pk], prof_acc[pk]);    \
+  } while (0)
+#else
+#define PHASE_DECL() \
+  do {               \
+  } while (0)
+#define PHASE_INIT() \
+  do {               \
+  } while (0)
+#define PHASE_MARK(k) \
+  do {                \
+  } while (0)
+#define PHASE_FLUSH() \
+  do {                \
+  } while (0)
+#endif
+
 // Grow-only device buffer.
 struct DevBuf {
   void *p = nullptr;

@@ -35,39 +35,8 @@ constexpr uint32_t kPartTab = kMaxParts + 4;  // per chunk: part starts [P + 1],
 // (SortPartWaveKernel), larger ones -- a skewed target distribution -- by a workgroup (SortPartKernel)
 constexpr uint32_t kWaveCap0 = 512, kWaveCap1 = 1024;
 
-// -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
-// the clock ticks between the marks of the part sort to g_phase_prof (smhip_debug_phase_prof reads them).
 #ifdef SMHIP_PHASE_PROF
-__device__ unsigned long long g_phase_prof[32];
-#define PHASE_DECL()                    \
-  unsigned long long prof_acc[16] = {}; \
-  unsigned long long prof_t = wall_clock64()
-#define PHASE_INIT() prof_t = wall_clock64()
-#define PHASE_MARK(k)                                 \
-  do {                                                \
-    const unsigned long long prof_n = wall_clock64(); \
-    prof_acc[k] += prof_n - prof_t;                   \
-    prof_t = prof_n;                                  \
-  } while (0)
-#define PHASE_FLUSH()                                                    \
-  do {                                                                   \
-    if (threadIdx.x == 0)                                                \
-      for (int pk = 0; pk < 16; ++pk)                                    \
-        if (prof_acc[pk]) atomicAdd(&g_phase_prof[pk], prof_acc[pk]);    \
-  } while (0)
-#else
-#define PHASE_DECL() \
-  do {               \
-  } while (0)
-#define PHASE_INIT() \
-  do {               \
-  } while (0)
-#define PHASE_MARK(k) \
-  do {                \
-  } while (0)
-#define PHASE_FLUSH() \
-  do {                \
-  } while (0)
+__device__ unsigned long long g_phase_prof[32];  // (the PHASE_* macros of common.h)
 #endif
 
 template <typename KeyPtr>
