@@ -42,6 +42,8 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
   return a.end > b.end;
 }
 
+constexpr uint32_t kTile = 64;    // anchors per tile of the classify kernel: one per lane
+constexpr uint32_t kRing = 128;   // its LDS ring per wave: the tile and the 64 anchors before it
 constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
 constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else through an LDS ring of that many anchors
@@ -56,10 +58,10 @@ constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else thro
 // any other anchor.  Those anchors ("isolated", ~94 % of a noise bucket) are finished here in
 // parallel (score, predecessor, bucket maximum); the rest are flagged (used = 2) and listed in
 // index order for the sequential kernels.
-// One workgroup per TILE of 256 anchors (any chunk): the tile and the 256 anchors before it are staged
-// in LDS (the backward scans rarely leave that window; older predecessors are read from memory), so
-// the number of workgroups follows the number of anchors, not of chunks -- a 250 Mb reference has
-// 181 000 anchors per chunk in two buckets.
+// One WAVE per TILE of 64 anchors (any chunk): the tile and the 64 anchors before it are staged in an LDS ring of
+// the wave (the backward scans rarely leave that window; older predecessors are read from memory), so the
+// parallelism follows the number of anchors, not of chunks -- a 250 Mb reference has 181 000 anchors per chunk
+// in two buckets -- and no wave waits for another.
 __device__ __forceinline__ uint32_t ChunkOfFlat(const uint32_t *__restrict__ off, uint32_t n_chunks, uint32_t x) {
   uint32_t lo = 0, hi = n_chunks;  // chunk c with off[c] <= x < off[c + 1]
   while (hi - lo > 1) {
@@ -72,7 +74,7 @@ __device__ __forceinline__ uint32_t ChunkOfFlat(const uint32_t *__restrict__ off
 __global__ __launch_bounds__(256) void ChainTileCountKernel(ChainArgs a, uint32_t n_chunks, uint32_t *__restrict__ tiles) {
   for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += gridDim.x * 256) {
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - a.anchor_off[c]);
-    tiles[c] = (n + 255u) / 256u;
+    tiles[c] = (n + kTile - 1u) / kTile;
     // bucket maxima of the chunk (positive floats order like their bit patterns): zeroed for the atomics below
     uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * a.anchor_off[c]);
     const uint32_t G = a.n_groups[c];
@@ -88,21 +90,26 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
                                                            const uint32_t *__restrict__ tile_off, float radius, int dim,
                                                            int max_gap_length, int max_target_gap_length,
                                                            int chaining_band_length, int max_num_skips) {
-  __shared__ uint32_t s_gmax[258];  // maxima of the buckets the tile touches, relative to its first bucket
-  __shared__ int32_t s_t[512], s_q[512];
-  __shared__ uint32_t s_g[512];
-  __shared__ uint32_t s_first, s_last, s_wcnt[4];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  // Every workgroup takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1,
-  // ...): one search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p
-  // in slot p & 511) already holds the previous tile, so a tile loads only its own 256 records.
+  // Every WAVE works on its own: no workgroup barrier anywhere (the 256-anchor tiles of the first version spent a
+  // fifth of their time waiting at the barrier behind the wave with the longest backward scan).
+  __shared__ uint32_t s_gmax_all[4][kTile + 2];  // maxima of the buckets the tile touches, relative to its first bucket
+  __shared__ int32_t s_t_all[4][kRing], s_q_all[4][kRing];
+  __shared__ uint32_t s_g_all[4][kRing];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t *s_gmax = s_gmax_all[wave];
+  int32_t *s_t = s_t_all[wave], *s_q = s_q_all[wave];
+  uint32_t *s_g = s_g_all[wave];
+  // Every wave takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1, ...): one
+  // search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p in slot p & 127)
+  // already holds the previous tile, so a tile loads only its own 64 records.
   const uint32_t total_tiles = tile_off[n_chunks];
-  const uint32_t per = (total_tiles + gridDim.x - 1) / gridDim.x;
-  uint32_t tile = blockIdx.x * per;
+  const uint32_t n_waves = gridDim.x * 4u, gw = blockIdx.x * 4u + wave;
+  const uint32_t per = (total_tiles + n_waves - 1) / n_waves;
+  uint32_t tile = gw * per;
   const uint32_t tile_end = min(total_tiles, tile + per);
   if (tile >= tile_end) return;
   uint32_t c = ChunkOfFlat(tile_off, n_chunks, tile);
-  bool ring_valid = false;  // the ring holds [t0 - 256, t0) of chunk c
+  bool ring_valid = false;  // the ring holds [t0 - 64, t0) of chunk c
   uint32_t ord_carry = 0;   // bucket ordinal of the last anchor of the previous tile (ring_valid)
   // the records (and distance) of the next tile of the same chunk are fetched into registers while the
   // current one is processed
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       ring_valid = false;
       have_nx = false;
     }
-    const uint32_t t0 = (tile - tile_off[c]) * 256u;
+    const uint32_t t0 = (tile - tile_off[c]) * kTile;
     const uint64_t base = a.anchor_off[c];
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint32_t G = a.n_groups[c];
@@ -128,9 +135,8 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     uint32_t *pred = a.pred + base;
     uint8_t *used = a.used + base;
     uint32_t *gmax_g = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
-    const uint32_t w0 = t0 >= 256 ? t0 - 256 : 0;
-    const uint32_t ai = t0 + tid;
-    __syncthreads();  // the previous tile is done with the half of the ring that is overwritten, and with s_*
+    const uint32_t w0 = t0 >= kTile ? t0 - kTile : 0;
+    const uint32_t ai = t0 + lane;
     float my_dist = 0.0f;
     if (ai < n) {
       if (!have_nx) {
@@ -139,14 +145,14 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         nx_g = grp[ai];
         nx_d = dist[ai];
       }
-      s_t[ai & 511u] = (int32_t)nx_t;
-      s_q[ai & 511u] = (int32_t)nx_q;
-      s_g[ai & 511u] = nx_g;
+      s_t[ai & (kRing - 1)] = (int32_t)nx_t;
+      s_q[ai & (kRing - 1)] = (int32_t)nx_q;
+      s_g[ai & (kRing - 1)] = nx_g;
       my_dist = nx_d;
     }
     have_nx = tile + 1 < tile_end && tile + 1 < tile_off[c + 1];
     if (have_nx) {
-      const uint32_t gi = ai + 256u;
+      const uint32_t gi = ai + kTile;
       if (gi < n) {
         nx_t = tpos[gi];
         nx_q = qpos[gi];
@@ -154,44 +160,42 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         nx_d = dist[gi];
       }
     }
-    if (!ring_valid && t0 > 0) {  // first tile of this workgroup in the middle of a chunk
-      const uint32_t p = w0 + tid;
-      s_t[p & 511u] = (int32_t)tpos[p];
-      s_q[p & 511u] = (int32_t)qpos[p];
-      s_g[p & 511u] = grp[p];
+    if (!ring_valid && t0 > 0) {  // first tile of this wave in the middle of a chunk
+      const uint32_t p = w0 + lane;
+      s_t[p & (kRing - 1)] = (int32_t)tpos[p];
+      s_q[p & (kRing - 1)] = (int32_t)qpos[p];
+      s_g[p & (kRing - 1)] = grp[p];
     }
-    for (uint32_t g = tid; g < 258; g += 256) s_gmax[g] = 0;
+    s_gmax[lane] = 0;
+    if (lane < 2) s_gmax[kTile + lane] = 0;
     // bucket ordinal of the tile's first anchor: carried over from the previous tile, or one search
     // (last bucket start <= t0); the others follow from the bucket changes inside the tile
-    if (tid == 0 && !ring_valid) {
-      uint32_t lo = 0, hi = G;
+    uint32_t first_ord = ord_carry;
+    if (!ring_valid) {
+      uint32_t lo = 0, hi = G;  // (wave-uniform)
       while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (gstart[mid] <= t0) lo = mid; else hi = mid;
       }
-      s_first = lo;
+      first_ord = lo;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PHASE_MARK(0);
-    uint32_t ord = 0;
+    uint32_t ord = 0, ord_last = 0;
     {
       // (with a valid ring the anchor before the tile is in LDS too: its bucket starts the count)
-      const bool change = ai < n && (ai > t0 || ring_valid) && s_g[ai & 511u] != s_g[(ai - 1) & 511u];
+      const bool change = ai < n && (ai > t0 || ring_valid) && s_g[ai & (kRing - 1)] != s_g[(ai - 1) & (kRing - 1)];
       const unsigned long long m = __ballot(change);
-      if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
-      __syncthreads();
-      uint32_t before = 0;
-      for (uint32_t w2 = 0; w2 < wave; ++w2) before += s_wcnt[w2];
-      const uint32_t o0 = ring_valid ? ord_carry : s_first;
-      ord = o0 + before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));  // changes up to and including ai
-      if (tid == 255) s_last = ord;  // (lanes past the end carry the last anchor's ordinal)
-      if (tid == 0 && ring_valid) s_first = ord;  // ordinal of the tile's first anchor
+      ord = first_ord + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));  // changes up to and including ai
+      ord_last = first_ord + (uint32_t)__popcll(m);                       // ordinal of the tile's last anchor
+      first_ord += (uint32_t)(m & 1ull);                                  // ordinal of the tile's first anchor
     }
-    __syncthreads();
     PHASE_MARK(1);
     if (ai < n) {
-      const uint32_t g = s_g[ai & 511u];
-      const int32_t ct = s_t[ai & 511u], cq = s_q[ai & 511u];
+      const uint32_t g = s_g[ai & (kRing - 1)];
+      const int32_t ct = s_t[ai & (kRing - 1)], cq = s_q[ai & (kRing - 1)];
       bool isolated = true;
       int32_t skips = 0;
       uint32_t steps = 0;
@@ -199,9 +203,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       // three words together, so that a step of the scan does not wait for LDS
       auto rec = [&](uint32_t pj, uint32_t &rg, int32_t &rt, int32_t &rq) {
         if (pj >= w0) {
-          rg = s_g[pj & 511u];
-          rt = s_t[pj & 511u];
-          rq = s_q[pj & 511u];
+          rg = s_g[pj & (kRing - 1)];
+          rt = s_t[pj & (kRing - 1)];
+          rq = s_q[pj & (kRing - 1)];
         } else {
           rg = grp[pj];
           rt = (int32_t)tpos[pj];
@@ -235,18 +239,22 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         score[ai] = sc;
         pred[ai] = ai;
         used[ai] = 0;
-        atomicMax(&s_gmax[ord - s_first], __float_as_uint(sc));  // (a tile of 256 anchors touches <= 256 buckets)
+        atomicMax(&s_gmax[ord - first_ord], __float_as_uint(sc));  // (a tile of 64 anchors touches <= 64 buckets)
       } else {
         used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
       }
     }
     PHASE_MARK(3);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PHASE_MARK(4);
-    if (tid <= s_last - s_first && s_gmax[tid] != 0) atomicMax(&gmax_g[s_first + tid], s_gmax[tid]);
-    ord_carry = s_last;
+    if (lane <= ord_last - first_ord && s_gmax[lane] != 0) atomicMax(&gmax_g[first_ord + lane], s_gmax[lane]);
+    ord_carry = ord_last;
     ring_valid = true;
     PHASE_MARK(5);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the ring half and the maxima are free for the next tile
   }
   PHASE_FLUSH();
 }
@@ -1260,8 +1268,8 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   a.chain_off = goff;
   hipLaunchKernelGGL(ChainTileCountKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, a, n_chunks, tiles);
   if ((e = LaunchScanU32(ctx, tiles, n_chunks, tile_off)) != hipSuccess) return e;
-  const uint64_t max_tiles = n_anchors_total / 256 + n_chunks;
-  const uint32_t tile_blocks = (uint32_t)std::min<uint64_t>(max_tiles, 256u * 8u * 2u);  // two waves of the chip's 8 per CU
+  const uint64_t max_tiles = n_anchors_total / kTile + n_chunks;
+  const uint32_t tile_blocks = (uint32_t)std::min<uint64_t>((max_tiles + 3) / 4, 256u * 8u * 2u);  // four waves (tile ranges) each
   hipLaunchKernelGGL(ChainClassifyKernel, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                      p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
                      p.max_num_skips);
