@@ -556,7 +556,10 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
     uint32_t *s_tpos = a.s_tpos + base + b0, *s_qpos = a.s_qpos + base + b0, *s_grp = a.s_grp + base + b0;
     float *s_dist = a.s_dist + base + b0;
     __syncthreads();  // the previous item is done with the shared arrays
-      if (m <= kPartLdsKeys) {
+#ifdef SMHIP_PHASE_PROF
+    if (tid == 0) atomicAdd(&g_phase_prof[m <= kPartLdsKeys ? 20 : 21], 1ull);  // coverage: parts of the workgroup paths
+#endif
+    if (m <= kPartLdsKeys) {
       if (tid == 0) {
         s_dmin = ~0ull;
         s_dmax = 0ull;
@@ -822,6 +825,9 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
   for (;;) {
     const uint64_t A = (uint64_t)rec.x | ((uint64_t)(rec.y & 0xFFFFu) << 32);
     const uint32_t m = rec.y >> 16;  // 0 < m <= CAP
+#ifdef SMHIP_PHASE_PROF
+    if (lane == 0) atomicAdd(&g_phase_prof[NARROW ? 22 : (m <= 512u ? 23 : 24)], 1ull);  // coverage: parts per wave path
+#endif
     PHASE_INIT();
     // records -> LDS: keys into the staging room (then read back in the network's layout), payload columns
     if (PREFETCH) WaitRecs(kn);

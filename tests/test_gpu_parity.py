@@ -496,6 +496,46 @@ def test_pipeline_heavy_ties_large_chunks(small_world):
     tree.close(); dev.close()
 
 
+def test_pipeline_wide_key_ranges_and_medium_parts(small_world):
+    """The two remaining routes of the part sort (tools/sort_path_coverage.py counts them): target positions
+    stretched by 997 make a part's dense-key range wider than 2^23, so its keys do not fit the 32-bit form
+    (the 64-bit wave network for parts of <= 512 anchors); 12 copies of contig 0's + strand at the same
+    positions put a few thousand anchors of a read from that strand into one part (the workgroup LDS sort:
+    1 025 .. 8 192 keys).  Chunk records and chains against the oracle."""
+    base_ix, truth = small_world["ix"], small_world["truth"]
+    pos = np.asarray(base_ix.positions).copy()
+    ref_of = pos >> np.uint64(33)
+    n0 = int(np.argmax(ref_of != 0))  # the cloud starts with contig 0's + strand
+    stretch = lambda p: (p & ~np.uint64((1 << 33) - 1)) | ((((p >> np.uint64(1)) & np.uint64(0xFFFFFFFF)) * np.uint64(997)) << np.uint64(1)) | (p & np.uint64(1))
+    pos_w = stretch(pos)
+    assert int(((pos_w >> np.uint64(1)) & np.uint64(0xFFFFFFFF)).max()) < 2**32 - 1
+    copies = 12
+    vals0 = np.ascontiguousarray(base_ix.values[:n0])
+    values = np.concatenate([np.asarray(base_ix.values)] + [vals0 + np.float32(2e-5 * k) for k in range(1, copies)]).astype(np.float32)
+    positions = np.concatenate([pos_w] + [pos_w[:n0]] * (copies - 1))
+    ix = pipeline.HostIndex.from_points(positions, values, threads=4)
+    n_refs = int(ref_of.max()) + 1
+    pick = [i for i in range(len(truth)) if truth["contig"][i] == 0 and truth["strand"][i] == 0][:2]
+    pick += [i for i in range(len(truth)) if truth["contig"][i] != 0][:2]
+    pa = [small_world["pa"][i] for i in pick]
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    samples, offsets = _batch(pa)
+    res = dev.map_chunks(samples, offsets, n_refs=n_refs)
+    assert (res["status"] == 0).all()
+    tree = po.OracleTree(ix.values.copy())
+    for i, x in enumerate(pa):
+        f, _ = po.generate_events(x)
+        chains, st = po.generate_chains(tree, ix.positions, f, n_refs)
+        assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits
+        assert res[i]["n_chains"] == len(chains)
+        for k, c in enumerate(chains[:4]):
+            g = res[i]["chains"][k]
+            assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
+            assert g["n_anchors"] == c["n_anchors"] and g["ref"] == c["ref"] and g["direction"] == c["direction"]
+    tree.close(); dev.close()
+
+
 def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tree):
     """A wide search radius gives every chunk more anchors than the LDS sort holds (> 16384: the
     L2-scratch two-level sort) and, with 32 fast slots per query, far more overflow hits than the
