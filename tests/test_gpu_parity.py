@@ -461,10 +461,10 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
 
 def test_pipeline_heavy_ties_large_chunks(small_world):
     """160 copies of contig 0's + strand point cloud at the SAME reference positions: a read from
-    that strand gets tens of thousands of anchors per chunk (the L2-scratch sort), every (group,
-    target) value repeated a hundred times (buckets beyond a wave's LDS slice: the global bitonic
-    fallback; tie runs of a hundred ordered by (query, distance)), and one bucket holding every
-    anchor of the chunk for the chaining kernels."""
+    that strand gets tens of thousands of anchors per chunk, every (group, target) value repeated a
+    hundred times (a part of the sort far beyond what a wave or the workgroup LDS sort holds: the
+    in-memory bitonic fallback; tie runs of a hundred ordered by (query, distance)), and one bucket
+    holding every anchor of the chunk for the chaining kernels."""
     base_ix, truth = small_world["ix"], small_world["truth"]
     ref_of = np.asarray(base_ix.positions) >> np.uint64(33)
     n0 = int(np.argmax(ref_of != 0))  # the cloud starts with contig 0's + strand
@@ -537,8 +537,8 @@ def test_pipeline_wide_key_ranges_and_medium_parts(small_world):
 
 
 def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tree):
-    """A wide search radius gives every chunk more anchors than the LDS sort holds (> 16384: the
-    L2-scratch two-level sort) and, with 32 fast slots per query, far more overflow hits than the
+    """A wide search radius gives every chunk tens of thousands of anchors (dozens of parts for the
+    sort) and, with 32 fast slots per query, far more overflow hits than the
     initial pool (the pool is grown to the measured demand and the search repeated).  Results must
     still equal the oracle run with the same radius."""
     pa, ix, ref_lens = small_world["pa"][:16], small_world["ix"], small_world["ref_lens"]
