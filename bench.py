@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N > 1 run: nccl = RCCL over xGMI (one rank per GPU); gloo = through host "
                          "memory, ranks may share a GPU (a way to exercise the multi-rank flow on a one-GPU box)")
-    ap.add_argument("--depth", type=int, default=2,
+    ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
     return ap.parse_args()
