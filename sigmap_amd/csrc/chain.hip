@@ -44,7 +44,8 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 
 constexpr uint32_t kTile = 64;    // anchors per tile of the classify kernel: one per lane
 constexpr uint32_t kRing = 128;   // its LDS ring per wave: the tile and the 64 anchors before it
-constexpr int kPf = 8;            // predecessors fetched ahead of the sequential scan
+constexpr int kPf = 4;            // predecessors fetched ahead of the sequential scan: one 16-byte load per column
+static_assert(kPf == 4, "the lane DP fetches a block of predecessors as one uint4");
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
 constexpr int kBigGroupCap = 512;  // ... staged in LDS when they fit, else through an LDS ring of that many anchors
 
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         atomicMax(&s_gmax[ord - first_ord], __float_as_uint(sc));  // (a tile of 64 anchors touches <= 64 buckets)
       } else {
         used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
+        pred[ai] = ord;  // (until the DP writes the predecessor: the anchor's bucket ordinal, which the DP needs)
       }
     }
     PHASE_MARK(3);
@@ -351,11 +353,21 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
                                                     const uint32_t *__restrict__ n_pending) {
   __shared__ uint32_t s_ids[kBigPendingMin][64];  // each lane's pending anchor ids
   const uint32_t total_items = ioff[n_chunks];
+  PHASE_DECL();
   // grid-stride over items (their total is only known on the device)
   for (uint32_t gi = blockIdx.x * 64 + threadIdx.x; gi < total_items; gi += gridDim.x * 64) {
-  const uint32_t c = ChunkOfFlat(ioff, n_chunks, gi), k_item = gi - ioff[c];
+  PHASE_INIT();
+  // chunk of the item: chunks hold similar numbers of items, so a proportional guess and a few steps either way
+  // replace the 14 dependent loads of a binary search (which remains for a guess that is far off)
+  uint32_t c = (uint32_t)(((uint64_t)gi * n_chunks) / total_items);
+  {
+    uint32_t steps = 0;
+    while (c > 0 && ioff[c] > gi && steps < 8) { --c; ++steps; }
+    while (c + 1 < n_chunks && ioff[c + 1] <= gi && steps < 8) { ++c; ++steps; }
+    if (ioff[c] > gi || ioff[c + 1] <= gi) c = ChunkOfFlat(ioff, n_chunks, gi);
+  }
+  const uint32_t k_item = gi - ioff[c];
   const uint64_t base = a.anchor_off[c];
-  const uint32_t G = a.n_groups[c];
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base;
   const float *dist = a.s_dist + base;
   const uint32_t *gstart = a.group_start + base;
@@ -369,17 +381,9 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
   const uint32_t n_it = ioff[c + 1] - ioff[c];
   // this item's slice of the chunk's pending list (sorted by anchor index), its bucket's first anchor
   const uint32_t p0 = items[k_item], p1 = k_item + 1 < n_it ? items[k_item + 1] : npend;
-  uint32_t g;
-  {
-    const uint32_t first = pending[p0];
-    uint32_t lo = 0, hi = G;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (gstart[mid] <= first) lo = mid; else hi = mid;
-    }
-    g = lo;
-  }
+  const uint32_t g = pred[pending[p0]];  // the bucket's ordinal, left there by the classify kernel
   const uint32_t s = gstart[g];
+  PHASE_MARK(8);
   // an item with many anchors (the true locus of a read) goes to the wave-parallel kernel
   if (p1 - p0 > (uint32_t)kBigPendingMin) {
     big_list[atomicAdd(big_count, 1u)] = gi;
@@ -390,8 +394,8 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
   // its first kPf predecessors -- is fetched while the previous anchor is being chained, so an
   // anchor costs one memory round trip (the scores) instead of four dependent ones.
   const uint32_t npl = p1 - p0;  // <= kBigPendingMin
-#pragma unroll
-  for (int k = 0; k < kBigPendingMin; ++k) s_ids[k][threadIdx.x] = pending[min(p0 + (uint32_t)k, npend ? npend - 1 : 0u)];
+  // (most items hold one or two anchors: 1.14 on average)
+  for (uint32_t k = 0; k < npl; ++k) s_ids[k][threadIdx.x] = pending[p0 + k];
   struct Pre {
     uint32_t ai;
     float d;
@@ -405,13 +409,33 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     P.cq = (int32_t)qpos[ai];
     const int32_t aidx = (int32_t)(ai - s);
     const int32_t sidx = aidx > chaining_band_length ? aidx - chaining_band_length : 0;
+    // (the kernel is bound by the NUMBER of scattered requests - a lane per item, items anywhere in the chunk:
+    // the kPf predecessors of an anchor are its neighbours in the sorted columns, so one unaligned 16-byte load
+    // per column fetches them all; near the bucket's start the clamped single loads remain)
+    if (aidx - kPf >= sidx) {
+      const uint4 vt = *reinterpret_cast<const uint4 *>(tpos + s + aidx - kPf);
+      const uint4 vq = *reinterpret_cast<const uint4 *>(qpos + s + aidx - kPf);
+      P.pt[0] = (int32_t)vt.w; P.pt[1] = (int32_t)vt.z; P.pt[2] = (int32_t)vt.y; P.pt[3] = (int32_t)vt.x;
+      P.pq[0] = (int32_t)vq.w; P.pq[1] = (int32_t)vq.z; P.pq[2] = (int32_t)vq.y; P.pq[3] = (int32_t)vq.x;
+    } else {
 #pragma unroll
-    for (int j = 0; j < kPf; ++j) {
-      const int32_t pj = max(max(aidx - 1 - j, sidx), 0);  // clamped: always a valid address
-      P.pt[j] = (int32_t)tpos[s + pj];
-      P.pq[j] = (int32_t)qpos[s + pj];
+      for (int j = 0; j < kPf; ++j) {
+        const int32_t pj = max(max(aidx - 1 - j, sidx), 0);  // clamped: always a valid address
+        P.pt[j] = (int32_t)tpos[s + pj];
+        P.pq[j] = (int32_t)qpos[s + pj];
+      }
     }
   };
+#ifdef SMHIP_PHASE_PROF  // lane utilisation of the lane-per-item DP: sum of item lengths / (64 x the longest of the wave)
+  {
+    uint32_t mx = npl;
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    atomicAdd(&g_phase_prof[16], (unsigned long long)npl);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_phase_prof[17], (unsigned long long)mx * 64ull);
+    atomicAdd(&g_phase_prof[18], 1ull);
+  }
+#endif
+  PHASE_MARK(9);
   float gm = 0.0f;
   Pre cur{}, nxt{};
   if (npl > 0) issue(0, cur);
@@ -432,19 +456,36 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     for (int32_t pj0 = (int32_t)anchor_index - 1; pj0 >= start_idx && !done; pj0 -= kPf) {
       int32_t pt[kPf], pq[kPf];
       float ps[kPf];
-#pragma unroll
-      for (int kk = 0; kk < kPf; ++kk) {
-        // unconditional loads from a clamped index: a conditional load compiles to a branch with
-        // its own s_waitcnt, i.e. one memory round trip per predecessor instead of one per block
-        const int32_t pj = max(pj0 - kk, start_idx);
+      if (pj0 - (kPf - 1) >= start_idx) {  // a whole block inside the bucket / band: one 16-byte load per column
+        const uint4 vs = *reinterpret_cast<const uint4 *>(score + s + pj0 - (kPf - 1));
+        ps[0] = __uint_as_float(vs.w); ps[1] = __uint_as_float(vs.z); ps[2] = __uint_as_float(vs.y); ps[3] = __uint_as_float(vs.x);
         if (first) {
-          pt[kk] = cur.pt[kk];
-          pq[kk] = cur.pq[kk];
+#pragma unroll
+          for (int kk = 0; kk < kPf; ++kk) {
+            pt[kk] = cur.pt[kk];
+            pq[kk] = cur.pq[kk];
+          }
         } else {
-          pt[kk] = (int32_t)tpos[s + pj];
-          pq[kk] = (int32_t)qpos[s + pj];
+          const uint4 vt = *reinterpret_cast<const uint4 *>(tpos + s + pj0 - (kPf - 1));
+          const uint4 vq = *reinterpret_cast<const uint4 *>(qpos + s + pj0 - (kPf - 1));
+          pt[0] = (int32_t)vt.w; pt[1] = (int32_t)vt.z; pt[2] = (int32_t)vt.y; pt[3] = (int32_t)vt.x;
+          pq[0] = (int32_t)vq.w; pq[1] = (int32_t)vq.z; pq[2] = (int32_t)vq.y; pq[3] = (int32_t)vq.x;
         }
-        ps[kk] = score[s + pj];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < kPf; ++kk) {
+          // unconditional loads from a clamped index: a conditional load compiles to a branch with
+          // its own s_waitcnt, i.e. one memory round trip per predecessor instead of one per block
+          const int32_t pj = max(pj0 - kk, start_idx);
+          if (first) {
+            pt[kk] = cur.pt[kk];
+            pq[kk] = cur.pq[kk];
+          } else {
+            pt[kk] = (int32_t)tpos[s + pj];
+            pq[kk] = (int32_t)qpos[s + pj];
+          }
+          ps[kk] = score[s + pj];
+        }
       }
       first = false;
 #pragma unroll
@@ -488,8 +529,11 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
     cur = nxt;
    }
   }
+  PHASE_MARK(10);
   atomicMax(&gmax[g], __float_as_uint(gm));  // (several items of a bucket run at the same time; scores are positive)
+  PHASE_MARK(11);
   }
+  PHASE_FLUSH();
 }
 
 // ---- C1b: the same DP for LONG buckets (the true locus of a read), one WAVE per bucket with the
@@ -633,16 +677,7 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
     const uint32_t npend = n_pending[c];
     const uint32_t n_it = ioff[c + 1] - ioff[c];
     const uint32_t p0 = items[k_item], p1 = k_item + 1 < n_it ? items[k_item + 1] : npend;
-    uint32_t g;
-    {
-      const uint32_t first = pending[p0];
-      uint32_t lo = 0, hi = G;
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (gstart[mid] <= first) lo = mid; else hi = mid;
-      }
-      g = lo;
-    }
+    const uint32_t g = (a.pred + base)[pending[p0]];  // the bucket's ordinal, left there by the classify kernel
     const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
     const uint32_t ng = e - s;
     const uint32_t *tpos = a.s_tpos + base + s, *qpos = a.s_qpos + base + s;
