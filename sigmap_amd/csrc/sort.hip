@@ -339,12 +339,17 @@ __device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0,
 // once.  Work items for the part sorters: one record per part, by size class.  One workgroup per chunk at a
 // time, two per CU.
 constexpr uint32_t kBigThreads = 1024;  // (256 / 512: 4.2 / 4.4 ms against 3.6 ms at 32 Mb)
+constexpr uint32_t kGroupsLds = 1024;  // (reference, strand) groups counted in LDS by the partition kernel; more: GroupStartKernel
 __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a, uint32_t n_chunks, uint32_t gbits,
                                                                        uint32_t ibits, BigSortWork w) {
   __shared__ uint32_t qoff[kMaxQueriesPerChunk + 2];
   __shared__ uint32_t part[kBigThreads / 64];
   __shared__ uint32_t pcount[kMaxParts], pstart[kMaxParts + 1];
   __shared__ uint32_t cls_n[4], cls_base[4];
+  // anchors per group: whole parts are added part by part, the anchors of the few parts that straddle a group
+  // boundary one by one (second pass); the group boundaries of the sorted chunk are the prefix sums
+  __shared__ uint32_t gcnt[kGroupsLds];
+  const bool fold_groups = (1u << gbits) <= kGroupsLds;
   const uint32_t tid = threadIdx.x;
   const uint64_t span = (uint64_t)*a.span_bound + 1ull;
   const uint64_t range = span << gbits;  // dense keys are < range
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
     if (n == 0 || cap) continue;  // (uniform)
     __syncthreads();  // the previous chunk is done with the shared arrays
     for (uint32_t k = tid; k < kMaxParts; k += kBigThreads) pcount[k] = 0;
+    for (uint32_t k = tid; k < kGroupsLds; k += kBigThreads) gcnt[k] = 0;
     ScanQueryOffsets<kBigThreads>(a, q0, nq, qoff, part, tid);
     const DecodeCtx dc(a, qoff, q0, nq, ncar, n, c);
     PHASE_MARK(8);
@@ -487,6 +493,21 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
             make_uint4((uint32_t)A, (uint32_t)(A >> 32) | (my_m[j] << 16), (uint32_t)dlo, (uint32_t)(dlo >> 32));
       }
     }
+    if (fold_groups) {
+      __syncthreads();  // tab / records have read pstart: its top bit now marks the parts that straddle a group boundary
+#pragma unroll
+      for (uint32_t j = 0; j < kPartsPerThread; ++j) {
+        const uint32_t pi = tid + j * kBigThreads;
+        if (pi < P && my_m[j]) {
+          const uint64_t lo = (((uint64_t)pi << rbits) + P - 1) / P;  // dense keys of the part: [lo, hi)
+          const uint64_t hi = min<uint64_t>(((((uint64_t)pi + 1) << rbits) + P - 1) / P, range);
+          const uint32_t g_lo = (uint32_t)(lo / span), g_hi = (uint32_t)((hi - 1) / span);
+          if (g_lo == g_hi) atomicAdd(&gcnt[min(g_lo, kGroupsLds - 1u)], my_m[j]);
+          else pstart[pi] |= 0x80000000u;
+        }
+      }
+      __syncthreads();
+    }
     PHASE_MARK(10);
     // ---- pass 2: decode again, into the parts' slices of the chunk's records {key, query position, distance}
     // (16 bytes, ONE scattered store per anchor: three separate columns cost 4.0 ms instead of 3.0 at 32 Mb -
@@ -495,10 +516,42 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
     for_each_anchor([&](const Decoded &dv) {
       const uint32_t b = part_of(dv);
       const uint32_t pos = atomicAdd(&pcount[b], 1u);
-      const uint32_t dst = pstart[b] + pos;
+      const uint32_t ps = pstart[b];
+      const uint32_t dst = (ps & 0x7FFFFFFFu) + pos;
+      if (ps >> 31) atomicAdd(&gcnt[min(dv.grp, kGroupsLds - 1u)], 1u);  // (a part with a group boundary inside)
       const uint64_t key = (((uint64_t)dv.grp << (32 + ibits)) | ((uint64_t)dv.tpos << ibits)) | ((uint64_t)pos & idx_mask);
       recs_out[dst] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), dv.qpos, __float_as_uint(dv.dist));
     });
+    if (fold_groups) {  // group boundaries of the sorted chunk: exclusive prefix sums of the non-empty groups' sizes
+      __syncthreads();
+      if (tid < 64) {
+        constexpr uint32_t kPer = kGroupsLds / 64;
+        uint32_t h[kPer], tot = 0, ne = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+          h[k] = gcnt[kPer * tid + k];
+          tot += h[k];
+          ne += h[k] ? 1u : 0u;
+        }
+        uint32_t incl = tot, incl_ne = ne;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64), o2 = (uint32_t)__shfl_up((int)incl_ne, d, 64);
+          if ((int)tid >= d) {
+            incl += o;
+            incl_ne += o2;
+          }
+        }
+        uint32_t run = incl - tot, rank = incl_ne - ne;
+        uint32_t *gs = a.group_start + base;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k)
+          if (h[k]) {
+            gs[rank++] = run;
+            run += h[k];
+          }
+        if (tid == 63) a.n_groups[c] = incl_ne;
+      }
+    }
     PHASE_MARK(11);
   }
   PHASE_FLUSH();
@@ -1102,8 +1155,9 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   const uint32_t part_grid = (uint32_t)std::min<uint64_t>(max_items, 1024);
   hipLaunchKernelGGL(SortPartKernel, dim3(part_grid), dim3(kSortThreads), (size_t)kPartLdsKeys * sizeof(uint64_t),
                      ctx->stream, a, gbits, ibits, w);
-  hipLaunchKernelGGL(GroupStartKernel, dim3(std::min<uint32_t>(n_chunks, 1024)), dim3(kSortThreads), 0, ctx->stream, a,
-                     n_chunks);
+  if ((1u << gbits) > kGroupsLds)  // (else the partition kernel has listed the group boundaries)
+    hipLaunchKernelGGL(GroupStartKernel, dim3(std::min<uint32_t>(n_chunks, 1024)), dim3(kSortThreads), 0, ctx->stream, a,
+                       n_chunks);
   return hipGetLastError();
 }
 }  // namespace smhip
