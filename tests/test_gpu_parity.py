@@ -339,6 +339,37 @@ def test_many_contigs_more_than_128_candidate_chains():
     dev.close()
 
 
+def test_more_contigs_than_the_partition_kernel_counts_groups_for():
+    """600 contigs = 1200 (reference, strand) groups: beyond the 1024 group counters the sort's partition
+    kernel keeps in LDS, so the bucket boundaries come from GroupStartKernel's pass over the sorted group
+    column.  Reads from a segment that 40 of the contigs share chain in all of those; records and PAF rows
+    against the oracle."""
+    NC, NSH = 600, 40
+    shared = synth.make_genome(201, [5000])[0]
+    uniq = synth.make_genome(202, [1500] * (2 * NC))
+    genome = [uniq[2 * i] + (shared if i % (NC // NSH) == 0 else shared[:0]) + uniq[2 * i + 1] for i in range(NC)]
+    lm = synth.make_pore_model()
+    raw, _ = synth.simulate_reads([shared], lm, 6, seed=9)
+    raw2, _ = synth.simulate_reads(genome, lm, 6, seed=10)
+    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in list(raw) + list(raw2)]
+    ix = pipeline.HostIndex.build(genome, lm, threads=4)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    tree = po.OracleTree(ix.values.copy())
+    ref_lens = np.array([len(g) for g in genome], np.uint32)
+    names = ["contig%d" % i for i in range(NC)]
+    samples, offsets = _batch(pa)
+    res = dev.map_chunks(samples, offsets, n_refs=NC)
+    lines = _paf_lines(res, pa, names, ref_lens)
+    for i, x in enumerate(pa):
+        m = po.map_read(tree, ix.positions, x, NC, ref_lens)
+        assert res[i]["status"] == 0
+        assert res[i]["n_chains"] == m.n_chains and res[i]["n_anchors"] == m.stats.anchors
+        assert lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+    tree.close()
+    dev.close()
+
+
 def test_pipeline_small_fast_cap_uses_overflow_pass(device, small_world):
     """Queries with more hits than the fast slots are re-walked into exact-size segments:
     results must not depend on the capacity."""
