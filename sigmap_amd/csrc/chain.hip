@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
 __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_target_gap_length,
                                                           uint32_t *__restrict__ n_pending,
                                                           uint32_t *__restrict__ n_items) {
-  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_wave[4], s_wave8[8][4];
   __shared__ uint32_t s_run;
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
@@ -282,32 +282,56 @@ __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_t
   uint32_t *items = a.lists + base;  // (ChainEndsKernel reuses this array for the chains' anchor lists afterwards)
   if (tid == 0) s_run = 0;
   __syncthreads();
-  // 1024 flags per pass: a thread takes four consecutive anchors, a wave scan of the counts places them
-  for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
-    const uint32_t a0 = t0 + 4 * tid;
-    uint32_t f = 0;  // bit k: anchor a0 + k is listed
-    if (a0 + 3 < n && ((reinterpret_cast<uintptr_t>(used + a0) & 3u) == 0)) {
-      const uint32_t w4 = *reinterpret_cast<const uint32_t *>(used + a0);
-      f = ((w4 & 0xFFu) == 2u ? 1u : 0u) | (((w4 >> 8) & 0xFFu) == 2u ? 2u : 0u) | (((w4 >> 16) & 0xFFu) == 2u ? 4u : 0u) |
-          ((w4 >> 24) == 2u ? 8u : 0u);
-    } else {
-      for (uint32_t k = 0; k < 4; ++k)
-        if (a0 + k < n && used[a0 + k] == 2) f |= 1u << k;
+  // 8192 flags per round: a thread takes one aligned word (four consecutive anchors) of each of eight
+  // 1024-flag rows; the eight loads are in flight together and the eight rows are scanned side by side, so a
+  // round costs one memory round trip and three barriers (a row at a time: nine dependent rounds for a 12 Mb
+  // chunk, twenty-three for a 32 Mb one)
+  const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(used) & 3u);  // flags are read as aligned words
+  const uint32_t *used_w = reinterpret_cast<const uint32_t *>(used - shift);
+  const uint32_t n_words = (n + shift + 3u) / 4u;
+  for (uint32_t w0 = 0; w0 < n_words; w0 += 8 * 256) {
+    uint32_t f[8], cnt[8], incl[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t wi = w0 + (uint32_t)p * 256u + tid;
+      const uint32_t w4 = wi < n_words ? used_w[wi] : 0u;
+      const int64_t i0 = (int64_t)wi * 4 - (int64_t)shift;  // anchor of the word's first byte
+      uint32_t bits = ((w4 & 0xFFu) == 2u ? 1u : 0u) | (((w4 >> 8) & 0xFFu) == 2u ? 2u : 0u) |
+                      (((w4 >> 16) & 0xFFu) == 2u ? 4u : 0u) | ((w4 >> 24) == 2u ? 8u : 0u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < 0 || i0 + k >= (int64_t)n) bits &= ~(1u << k);  // bytes before the first / after the last anchor
+      f[p] = bits;
+      cnt[p] = (uint32_t)__popc(bits);
+      incl[p] = cnt[p];
     }
-    const uint32_t cnt = (uint32_t)__popc(f);
-    uint32_t incl = cnt;
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if ((int)lane >= d) incl += o;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl[p], d, 64);
+        if ((int)lane >= d) incl[p] += o;
+      }
     }
-    if (lane == 63) s_wave[wave] = incl;
+    if (lane == 63) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) s_wave8[p][wave] = incl[p];
+    }
     __syncthreads();
-    uint32_t off = s_run + incl - cnt;
-    for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
-    for (uint32_t k = 0; k < 4; ++k)
-      if (f & (1u << k)) pending[off++] = a0 + k;
+    uint32_t row_base = s_run, total = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      uint32_t off = row_base + incl[p] - cnt[p];
+      for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave8[p][w2];
+      const uint32_t row_total = s_wave8[p][0] + s_wave8[p][1] + s_wave8[p][2] + s_wave8[p][3];
+      const uint32_t i0 = (w0 + (uint32_t)p * 256u + tid) * 4u - shift;  // (only used where a flag is set: then in range)
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k)
+        if (f[p] & (1u << k)) pending[off++] = i0 + k;
+      row_base += row_total;
+      total += row_total;
+    }
     __syncthreads();
-    if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (tid == 0) s_run += total;
     __syncthreads();
   }
   const uint32_t npend = s_run;
