@@ -289,49 +289,35 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         return Win{ents[min(eb_ + e_rel, 255u)], e_rel, p < limit};  // (pt: then t < n, the next entry starts above p)
       };
       uint32_t eb = 0, p0 = 0;
-      Win w = lookup(0u, 0u);
-      while (p0 < n_points) {
+      // the window's point loads (both halves of the point: v0..v3, then v4, v5, position), from a valid address
+      // for the lanes without a point: no branch around a load, so nothing waits for it before its use
+      auto load_points = [&](const Win &w_, uint32_t p0_, uint4 &rv_, uint4 &sv_) {
+        const uint32_t n_ = (w_.mine.y >> 8) & 31u, t_ = p0_ + lane - (w_.mine.y >> 13);
+        const uint4 *fh = pts4 + (w_.pt ? (size_t)w_.mine.x + t_ : (size_t)0);
+        rv_ = fh[0];
+        sv_ = fh[w_.pt ? ((n_ + 7u) & ~7u) : 0u];
+      };
+      // number of lanes with a point, and the first entry of the next window (from the end of this one: p0 + 64,
+      // or the start of entry eb + kWin if that came first; its first entry is the last lane's, or the one after
+      // it when the lane had the entry's last point)
+      auto advance = [&](const Win &w_, uint32_t p0_) {
+        const uint32_t n_ = (w_.mine.y >> 8) & 31u, t_ = p0_ + lane - (w_.mine.y >> 13);
+        const uint32_t nl = (uint32_t)__popcll(__ballot(w_.pt));  // >= 1 (a prefix of the lanes)
+        const uint32_t e_last = (uint32_t)__builtin_amdgcn_readlane((int)w_.e_rel, 63);
+        const uint32_t full = (uint32_t)__builtin_amdgcn_readlane((int)(t_ + 1u == n_ ? 1u : 0u), 63);
+        eb += nl == 64u ? e_last + full : (uint32_t)kWin;  // (nl < 64: the window ended at entry eb + kWin, or it was the last)
+        return nl;
+      };
+      auto process = [&](const Win &w_, uint32_t p0_, const uint4 &rv, const uint4 &sv) {
         ++st_scan;
-        const uint2 mine = w.mine;
-        const uint32_t owner = mine.y & 0xFFu, n = (mine.y >> 8) & 31u, t = p0 + lane - (mine.y >> 13);
-        const bool pt = w.pt;
-        const uint64_t pb = __ballot(pt);  // (a prefix of the lanes)
+        const uint2 mine = w_.mine;
+        const uint32_t owner = mine.y & 0xFFu, t = p0_ + lane - (mine.y >> 13);
+        const bool pt = w_.pt;
+        const uint64_t pb = __ballot(pt);
         st_scan_lanes += (uint32_t)__popcll(pb);
-        // next window: from the end of this one (p0 + 64, or the start of entry eb + kWin if that came first);
-        // its first entry is the last lane's, or the one after it when the lane had the entry's last point
-        const uint32_t nl = (uint32_t)__popcll(pb);  // >= 1
-        {
-          const uint32_t e_last = (uint32_t)__builtin_amdgcn_readlane((int)w.e_rel, 63);
-          const uint32_t full = (uint32_t)__builtin_amdgcn_readlane((int)(t + 1u == n ? 1u : 0u), 63);
-          eb += nl == 64u ? e_last + full : (uint32_t)kWin;  // (nl < 64: the window ended at entry eb + kWin, or it was the last)
-        }
         bool hit = false;
         float res = 0.0f;
-        uint4 sv = make_uint4(0, 0, 0, 0);
         uint32_t oqi = 0, hbase = 0;
-#ifdef SMHIP_PHASE_PROF
-        const unsigned long long ptl = clock64();
-        uint4 rv_p = make_uint4(0, 0, 0, 0);
-        if (pt) {
-          const uint4 *fh = pts4 + (size_t)mine.x + t;
-          rv_p = fh[0];
-          sv = fh[(n + 7u) & ~7u];
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        pt_scan_load += clock64() - ptl;
-#endif
-        uint4 rv = make_uint4(0, 0, 0, 0);
-#ifdef SMHIP_PHASE_PROF
-        rv = rv_p;
-#else
-        if (pt) {
-          const uint4 *fh = pts4 + (size_t)mine.x + t;
-          rv = fh[0];
-          sv = fh[(n + 7u) & ~7u];
-        }
-#endif
-        // the next window's entries are looked up (LDS only) while the point loads are in flight
-        const Win w_next = lookup(eb, p0 + nl);
         if (pt) {
           const float4 oa = own_a[owner];
           const uint4 ob = own_b[owner];
@@ -381,8 +367,29 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        p0 += nl;
-        w = w_next;
+      };
+      // Two windows in flight, A and B in turn (no register copies between them): while one is processed, the
+      // other's entries have been looked up and its point loads are on their way.
+      if (n_points > 0) {
+        Win wA = lookup(0u, 0u), wB = wA;
+        uint4 rvA, svA, rvB, svB;
+        load_points(wA, 0u, rvA, svA);
+        for (;;) {
+          const uint32_t nlA = advance(wA, p0);
+          const bool moreB = p0 + nlA < n_points;
+          wB = lookup(eb, p0 + nlA);
+          load_points(wB, p0 + nlA, rvB, svB);  // (past the end: no lane has a point, all load slot 0)
+          process(wA, p0, rvA, svA);
+          p0 += nlA;
+          if (!moreB) break;
+          const uint32_t nlB = advance(wB, p0);
+          const bool moreA = p0 + nlB < n_points;
+          wA = lookup(eb, p0 + nlB);
+          load_points(wA, p0 + nlB, rvA, svA);
+          process(wB, p0, rvB, svB);
+          p0 += nlB;
+          if (!moreA) break;
+        }
       }
       if (c > 0) {
         hits = own_b[lane].w;
