@@ -123,16 +123,15 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
 // The hit slots of nq queries (fast_cap each) as segments of <= 2 GiB; the pointer table goes to the device
 // when a segment was (re)allocated.
 int ReserveRegion(smhip_ctx *ctx, uint64_t nq, uint32_t fast_cap, HitSlots *out) {
-  const size_t rec_bytes = kHitWordsMap * sizeof(uint32_t);  // 12-byte records on the mapping path
   uint32_t qshift = 0;
-  while (qshift < 31 && ((uint64_t)2 << qshift) * fast_cap * rec_bytes <= (1ull << 31)) ++qshift;
+  while (qshift < 31 && ((uint64_t)2 << qshift) * fast_cap * sizeof(Hit) <= (1ull << 31)) ++qshift;
   const uint64_t per_seg = 1ull << qshift;
   const size_t n_seg = (size_t)std::max<uint64_t>((nq + per_seg - 1) / per_seg, 1);
   if (ctx->region_segs.size() < n_seg) ctx->region_segs.resize(n_seg);
   std::vector<void *> tab(ctx->region_segs.size(), nullptr);
   for (size_t k = 0; k < n_seg; ++k) {
     const uint64_t q_here = std::min<uint64_t>(per_seg, nq - std::min<uint64_t>(nq, k * per_seg));
-    HIPCHK(ctx->region_segs[k].Reserve(std::max<uint64_t>(q_here, 1) * fast_cap * rec_bytes));
+    HIPCHK(ctx->region_segs[k].Reserve(std::max<uint64_t>(q_here, 1) * fast_cap * sizeof(Hit)));
   }
   for (size_t k = 0; k < ctx->region_segs.size(); ++k) tab[k] = ctx->region_segs[k].p;
   if (tab != ctx->h_region_tab) {
@@ -141,7 +140,7 @@ int ReserveRegion(smhip_ctx *ctx, uint64_t nq, uint32_t fast_cap, HitSlots *out)
     HIPCHK(hipMemcpyAsync(ctx->region_tab.p, ctx->h_region_tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice,
                           ctx->stream));
   }
-  *out = HitSlots{ctx->region_tab.as<uint32_t *>(), qshift, fast_cap, kHitWordsMap};
+  *out = HitSlots{ctx->region_tab.as<Hit *>(), qshift, fast_cap};
   return SMHIP_OK;
 }
 }  // namespace
@@ -760,7 +759,7 @@ int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_
     if (rc) return rc;
   }
   HIPCHK(ctx->qrec.Reserve(nq * 32));
-  HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * kHitWordsMap * sizeof(uint32_t)));
+  HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * sizeof(Hit)));
   return SMHIP_OK;
 }
 
@@ -840,12 +839,12 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
   uint64_t NA = 0;
   for (int attempt = 0;; ++attempt) {
-    HIPCHK(ctx->ovf_pool.Reserve(pool_cap * kHitWordsMap * sizeof(uint32_t)));
+    HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
     // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
     HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, hit_slots,
                             ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
-                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<uint32_t>(), ctx->q_ovf_off.as<uint32_t>(),
+                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
                             pool_cap));
     HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
                              ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(),
@@ -876,7 +875,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   sa.carried_off = ctx->carried_off.as<uint32_t>();
   sa.carried = ctx->carried.as<smhip_carried_anchor>();
   sa.region = hit_slots;
-  sa.ovf_pool = ctx->ovf_pool.as<uint32_t>();
+  sa.ovf_pool = ctx->ovf_pool.as<Hit>();
   sa.anchor_off = ctx->anchor_off.as<uint64_t>();
   sa.fast_cap = p->hits_per_query_fast;
   sa.nnp = (uint32_t)p->num_nearest_points;
@@ -1370,7 +1369,7 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (e == hipSuccess) step(hipMemcpyAsync(d_q.p, queries, (uint64_t)n_queries * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   if (e == hipSuccess) step(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   if (e == hipSuccess) {
-    step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, HitSlots{d_tab.as<uint32_t *>(), 31u, cap, 4u}, d_cnt.as<uint32_t>(),
+    step(LaunchSeedLookupRaw(ctx, *p, d_q.as<float>(), n_queries, cap, HitSlots{d_tab.as<Hit *>(), 31u, cap}, d_cnt.as<uint32_t>(),
                              d_nodes.as<uint32_t>(), d_pts.as<uint32_t>(), ctx->counters.as<uint32_t>(), d_qrec.p));
   }
   if (e == hipSuccess) {

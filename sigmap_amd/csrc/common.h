@@ -43,22 +43,14 @@ struct RawReadMeta {  // one read of smhip_reads_upload_raw (32 B)
 // 16 384 chunks, and a device allocation beyond 4 GB costs tens of ms per GB on this platform
 // (tools/micro/malloc_chunks.hip: 8 x 3.9 GB in 1.4 ms, one 27 GB block in 3 s), so it is cut into
 // segments of at most 2 GiB: queries [k << qshift, (k + 1) << qshift) live in segment k.
-// A hit record is rec_words 32-bit words {position lo, position hi, dist[, slot]}: 3 on the mapping path (the
-// slot index is only needed by the per-stage entry point smhip_seed_lookup, which uses 4 = struct Hit) - a
-// quarter less to write for the walker and to read, twice, for the sort's partition kernel.
-struct Hit3 {
-  uint32_t pos_lo, pos_hi, dist_bits;
-};
 struct HitSlots {
-  uint32_t *const *seg;  // device array of segment base pointers
-  uint32_t qshift;       // queries per segment = 1 << qshift
+  Hit *const *seg;   // device array of segment base pointers
+  uint32_t qshift;   // queries per segment = 1 << qshift
   uint32_t fast_cap;
-  uint32_t rec_words;    // 3 or 4
-  __device__ __forceinline__ uint32_t *At(uint32_t q, uint32_t ord) const {
-    return seg[q >> qshift] + ((size_t)(q & ((1u << qshift) - 1u)) * fast_cap + ord) * rec_words;
+  __device__ __forceinline__ Hit *At(uint32_t q, uint32_t ord) const {
+    return seg[q >> qshift] + ((size_t)(q & ((1u << qshift) - 1u)) * fast_cap + ord);
   }
 };
-constexpr uint32_t kHitWordsMap = 3;  // hit record of the mapping path
 
 // Resident read slots (keep floats each), cut into segments of at most 2 GiB like HitSlots.
 struct SlotView {
@@ -314,7 +306,7 @@ hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float 
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, HitSlots region, uint32_t *q_count,
-                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, uint32_t *pool,
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap);
 // explicit query list variant used by smhip_seed_lookup (queries given as n x 6 floats)
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -329,7 +321,7 @@ struct SortArgs {
   const uint32_t *q_off, *q_count, *ovf_tab, *qstart, *carried_off;
   const smhip_carried_anchor *carried;
   HitSlots region;
-  const uint32_t *ovf_pool;  // (records of region.rec_words words)
+  const Hit *ovf_pool;
   const uint64_t *anchor_off;
   uint32_t fast_cap, nnp, step, n_refs;
   const uint32_t *span_bound;  // device: largest target position of the index and of this batch's carried anchors

@@ -83,7 +83,7 @@ struct Sink {
   uint32_t *q_points;
   smhip_chunk_result *results;  // unused (per-chunk sums are formed by AnchorCountKernel)
   uint32_t *counters;   // [0] stack overflow flag, [1] #overflow queries, [3] pool full, [24..25] pool cursor (u64)
-  uint32_t *pool;       // overflow pool: hits beyond the fast slots, in geometric segments (records like the region's)
+  Hit *pool;            // overflow pool: hits beyond the fast slots, in geometric segments
   uint32_t *ovf_tab;    // [n_queries][kOvfLevels] pool offset of each segment
   uint64_t pool_cap;
 };
@@ -108,12 +108,6 @@ enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
 // go to the query's own slots): segments of the shared pool whose sizes double (fast_cap,
 // 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a query with
 // many hits never has to be searched twice.  Called for one hit at a time in ordinal order.
-// one store per hit: 12 bytes on the mapping path, 16 with the slot index for the per-stage entry point
-__device__ __forceinline__ void StoreHit(uint32_t *dst, const Hit &h, uint32_t rec_words) {
-  if (rec_words == 3) *reinterpret_cast<Hit3 *>(dst) = Hit3{(uint32_t)h.position, (uint32_t)(h.position >> 32), __float_as_uint(h.dist)};
-  else *reinterpret_cast<Hit *>(dst) = h;
-}
-
 __device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint32_t ord, const Hit &h,
                                              uint32_t &ovf_base) {
   const uint32_t k = ord - sink.fast_cap;
@@ -133,7 +127,7 @@ __device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint
     }
     if (level < (uint32_t)kOvfLevels) sink.ovf_tab[(size_t)qi * kOvfLevels + level] = ovf_base;
   }
-  if (ovf_base != 0xFFFFFFFFu) StoreHit(sink.pool + ((size_t)ovf_base + (k - first)) * sink.region.rec_words, h, sink.region.rec_words);
+  if (ovf_base != 0xFFFFFFFFu) sink.pool[(size_t)ovf_base + (k - first)] = h;
 }
 
 #ifdef SMHIP_PHASE_PROF  // tools/phase_prof.sh: shader-clock ticks per wave in the phases of the walker
@@ -355,7 +349,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         h.dist = res;
         h.slot = (mine.x >> 1) + t;
         const bool emit = hit && ord < sink.nnp;
-        if (emit && ord < sink.fast_cap) StoreHit(sink.region.At(oqi, ord), h, sink.region.rec_words);
+        if (emit && ord < sink.fast_cap) *sink.region.At(oqi, ord) = h;
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
         for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
           if (lane == (uint32_t)__builtin_ctzll(ovm)) {
@@ -940,7 +934,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
 
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,
                             uint32_t n_chunks, uint64_t n_queries_max, HitSlots region, uint32_t *q_count,
-                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, uint32_t *pool,
+                            uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap) {
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
             nullptr, counters, pool, ovf_tab, pool_cap};

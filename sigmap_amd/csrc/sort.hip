@@ -288,7 +288,7 @@ struct DecodeCtx {
   const uint32_t *qoff;  // LDS: exclusive offsets of the queries' anchor runs, [nq + 1]
   uint32_t q0, nq, ncar, n, qso;
   uint64_t car0;
-  const uint32_t *seg;  // the hit-slot segment that holds all of the chunk's queries (the rule), or null
+  const Hit *seg;  // the hit-slot segment that holds all of the chunk's queries (the rule), or null
   __device__ DecodeCtx(const SortArgs &a, const uint32_t *qoff_, uint32_t q0_, uint32_t nq_, uint32_t ncar_, uint32_t n_,
                        uint32_t c)
       : qoff(qoff_), q0(q0_), nq(nq_), ncar(ncar_), n(n_), qso(a.qstart ? a.qstart[c] : 0u),
@@ -296,16 +296,6 @@ struct DecodeCtx {
     if (nq && (q0 >> a.region.qshift) == ((q0 + nq - 1) >> a.region.qshift)) seg = a.region.seg[q0 >> a.region.qshift];
   }
 };
-// a hit record as {position lo, position hi, dist bits, -}
-__device__ __forceinline__ uint4 LoadHit(const uint32_t *p, uint32_t rec_words) {
-  if (rec_words == 3) {  // (one 12-byte load: as a struct of three words hipcc splits it into 8 + 4)
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
-    const u32x3 h = *reinterpret_cast<const u32x3_a4 *>(p);
-    return make_uint4(h.x, h.y, h.z, 0u);
-  }
-  return *reinterpret_cast<const uint4 *>(p);
-}
 struct Decoded {
   uint32_t grp, tpos, qpos;
   float dist;
@@ -402,68 +392,37 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
         const uint4 raw = *reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
         fn(Decoded{raw.x, raw.y, raw.z, __uint_as_float(raw.w)});
       }
-      // kQG queries of the wave at a time: the first 128 hits of all of them are loaded (unconditionally, from
-      // clamped addresses: a load under a condition would be waited for at the end of its branch) before any is
-      // processed -- one memory round trip per kQG queries instead of one per query (a wave's 14 queries of a
-      // 12 Mb chunk one after the other were 24 us of a 56 us chunk, per pass)
-      constexpr uint32_t kQG = 2, kWaves = kBigThreads / 64;
-      const uint32_t rw = a.region.rec_words;  // 3 words {position lo, hi, dist} on the mapping path
-      auto slots_of = [&](uint32_t qi) {
-        return dc.seg ? dc.seg + (size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap * rw : a.region.At(qi, 0);
-      };
-      auto emit = [&](const uint4 &raw, uint32_t qpos) {  // Hit {uint64 position, dist[, slot]}
-        const uint64_t position = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
-        fn(Decoded{(uint32_t)((position >> 33) << 1) | (uint32_t)(position & 1), (uint32_t)(position >> 1), qpos,
-                   __uint_as_float(raw.z)});
-      };
-      for (uint32_t kb = wave; kb < nq; kb += kQG * kWaves) {
-        uint4 raw[kQG][2];
-        uint32_t cnt[kQG];
+      for (uint32_t k = wave; k < nq; k += kBigThreads / 64) {
+        const uint32_t cnt = qoff[k + 1] - qoff[k];
+        const uint32_t qi = q0 + k;
+        const Hit *slots = dc.seg ? dc.seg + (size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap : a.region.At(qi, 0);
+        const uint32_t qpos = (k + 1) * a.step + dc.qso;  // position + query_start_offset
+        for (uint32_t h0 = 0; h0 < cnt; h0 += 128) {  // two hits per lane in flight
+          uint4 raw[2];
+          bool live[2];
 #pragma unroll
-        for (uint32_t g = 0; g < kQG; ++g) {
-          const uint32_t k = min(kb + g * kWaves, nq - 1u);  // (past the chunk's last query: that query again, ignored)
-          cnt[g] = kb + g * kWaves < nq ? qoff[k + 1] - qoff[k] : 0u;
-          const uint32_t *slots = slots_of(q0 + k);
-          const uint32_t top = min(max(cnt[g], 1u), a.fast_cap) - 1u;  // last slot that may be read
-#pragma unroll
-          for (int u = 0; u < 2; ++u) raw[g][u] = LoadHit(slots + (size_t)min(64u * u + lane, top) * rw, rw);
-        }
-#pragma unroll
-        for (uint32_t g = 0; g < kQG; ++g) {
-          const uint32_t k = kb + g * kWaves;
-          const uint32_t qpos = (k + 1) * a.step + dc.qso;  // position + query_start_offset
-          const uint32_t in_slots = min(cnt[g], a.fast_cap);
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-            if (64u * u + lane < in_slots) emit(raw[g][u], qpos);
-          // the rest of a long query: further slots, then the geometric overflow segments (seed_lookup.hip
-          // EmitOverflow; a missing segment reads as zeros)
-          for (uint32_t h = 128u + lane; h < cnt[g]; h += 64u) {
-            const uint32_t qi = q0 + k;
-            uint4 rv = make_uint4(0, 0, 0, 0);
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t h = h0 + 64 * u + lane;
+            live[u] = h < cnt;
+            raw[u] = make_uint4(0, 0, 0, 0);
+            if (!live[u]) continue;
             if (h < a.fast_cap) {
-              rv = LoadHit(slots_of(qi) + (size_t)h * rw, rw);
-            } else {
+              raw[u] = *reinterpret_cast<const uint4 *>(slots + h);
+            } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow); a missing segment reads as zeros
               const uint32_t kk = h - a.fast_cap;
               const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
               const uint32_t first = a.fast_cap * ((1u << level) - 1u);
               const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-              if (seg != 0xFFFFFFFFu) rv = LoadHit(a.ovf_pool + ((size_t)seg + (kk - first)) * rw, rw);
+              if (seg != 0xFFFFFFFFu) raw[u] = *reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
             }
-            emit(rv, qpos);
           }
-          // (a query with fewer than 128 slots and more hits than slots: the hits between the slots and 128)
-          if (a.fast_cap < 128u)
-            for (uint32_t h = a.fast_cap + lane; h < min(cnt[g], 128u); h += 64u) {
-              const uint32_t qi = q0 + k;
-              uint4 rv = make_uint4(0, 0, 0, 0);
-              const uint32_t kk = h - a.fast_cap;
-              const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
-              const uint32_t first = a.fast_cap * ((1u << level) - 1u);
-              const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-              if (seg != 0xFFFFFFFFu) rv = LoadHit(a.ovf_pool + ((size_t)seg + (kk - first)) * rw, rw);
-              emit(rv, qpos);
-            }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const uint64_t position = (uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32);  // Hit {uint64 position, dist, slot}
+            fn(Decoded{(uint32_t)((position >> 33) << 1) | (uint32_t)(position & 1), (uint32_t)(position >> 1), qpos,
+                       __uint_as_float(raw[u].z)});
+          }
         }
       }
     };
