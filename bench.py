@@ -300,7 +300,10 @@ def main():
         seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"]
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-        if os.path.exists(pmc):
+        # (the counter profile was taken on the default workload: for any other shape the kernel's own bytes)
+        default_shape = (args.reads == 10000 and args.contigs == 16 and args.contig_len == 750000 and
+                         args.walk_blocks == 0 and args.fast_cap == 0)
+        if default_shape and os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
@@ -363,7 +366,8 @@ def main():
                 "basis": ("calibrated memory-side counters (profiles/r2_calibration.json: every L2 read miss is a "
                           "128-byte request, writes by WRITE_SIZE), per launch, from the profile run named in "
                           "traffic_source" if traffic else
-                          "the walker's own algorithmic bytes (no counter profile found under profiles/)"),
+                          "the walker's own algorithmic bytes (no counter profile for this workload under profiles/: the committed "
+                          "one is for the default workload only)"),
                 "frac_of_measured_streaming_ceiling": round(achieved / HBM_STREAM_GBS, 4),
                 "launch_ms": round(seed_ms, 4),
                 "measured": "HIP events on the context stream around the SeedWalkKernel launch, serial pass of this run "
