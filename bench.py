@@ -57,13 +57,17 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N > 1 run: nccl = RCCL over xGMI (one rank per GPU); gloo = through host "
                          "memory, ranks may share a GPU (a way to exercise the multi-rank flow on a one-GPU box)")
+    ap.add_argument("--force-bcast", action="store_true",
+                    help="with one rank: run the index replication collectives anyway (one-rank process group over "
+                         "--backend, five dist.broadcast calls) and map the contexts beyond the first from the broadcast "
+                         "copy -- exercises the N > 1 transport on a one-GPU box")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
     return ap.parse_args()
 
 
-def cpu_baseline(ix, pa_list, n_refs, ref_lens, seconds):
+def cpu_baseline(ix, raw_reads, n_refs, ref_lens, seconds):
     """The oracle (CPU restatement of the reference path) on bounded samples of the same reads: one
     thread (BASELINE configs[0] is `-t 1`), then one thread per host core (the reference parallelises
     over reads the same way, sigmap.cc:618-630).  This is the only place bench.py touches oracle/: as
@@ -73,7 +77,9 @@ def cpu_baseline(ix, pa_list, n_refs, ref_lens, seconds):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    tree = po.OracleTree(ix.values.copy())
+    from sigmap_amd import synth
+    pa_list = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw_reads]   # A1, untimed like
+    tree = po.OracleTree(ix.values.copy())                                    # the reference's load phase
     positions = np.ascontiguousarray(ix.positions)
 
     def run(n_threads, n_sample):
@@ -117,10 +123,13 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything initialises HIP
     import torch   # first: the process ends up with ONE HIP runtime, the one torch brings (multigpu.py)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_bcast:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:   # --force-bcast outside torch.distributed.run: a one-rank group of our own
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "gloo":
             local_rank = local_rank % max(torch.cuda.device_count(), 1)   # ranks may share a GPU
             torch.cuda.set_device(local_rank)
@@ -154,9 +163,16 @@ def main():
         # (torch.distributed.run exports OMP_NUM_THREADS=1: ask for the cores explicitly)
         ix = pipeline.HostIndex.build(genome, lm, threads=max(1, (os.cpu_count() or 1) // max(world, 1)))
         t_build = time.perf_counter() - t0
+    forced = args.force_bcast and world == 1
     keepalive = replicate_index(dev, ix, rank, world, local_rank, dist,   # RCCL broadcast when world > 1
-                                via_host=(args.backend == "gloo"))
-    pool.share_index()  # the other contexts of this GPU borrow the same arrays
+                                via_host=(args.backend == "gloo"), force=forced)
+    if forced:
+        # the first context maps from the arrays it uploaded, the others from the copy that went through the
+        # collectives: `contexts_agree` below then compares the two byte for byte
+        for dv in pool.devs[1:]:
+            dv.attach_index(keepalive[1])
+    else:
+        pool.share_index()  # the other contexts of this GPU borrow the same arrays
 
     R = args.reads
     raw, _ = synth.simulate_reads(genome, lm, R, seed=1000 + rank)
@@ -334,6 +350,8 @@ def main():
                 "chunks_per_gpu_per_step": R,
                 "transport": ("rccl" if args.backend == "nccl" else "gloo (test transport; ranks may share a GPU)")
                              if world > 1 else None,
+                "forced_broadcast": ({"backend": "rccl" if args.backend == "nccl" else "gloo", "ranks": 1,
+                                      "contexts_on_broadcast_copy": len(pool.devs) - 1} if forced else None),
                 "batches_in_flight": len(pool.devs),
                 "contexts_agree": bool(contexts_agree),
                 "index_points": int(ix.n_points) if ix is not None else None,
@@ -389,8 +407,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw[:4096]]
-            out["cpu_baseline"] = cpu_baseline(ix, pa, n_refs, ref_lens, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(ix, raw[:4096], n_refs, ref_lens, args.cpu_seconds)
         print(json.dumps(out), flush=True)
         phase_prof()
     if dist is not None:

@@ -123,6 +123,12 @@ int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint
  * a single-process OpenMP program, sigmap.cc:618-632); reads then shard over the GPUs with no
  * further communication.  n_gpus == 1 is a no-op.  Errors are reported on ctxs[root]. */
 int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root);
+/* The same RCCL call sequence on ONE GPU: a one-rank communicator (ncclCommInitAll(1)) and one grouped
+ * ncclBroadcast per walker array, out of place from src's arrays into buffers dst then owns (with a single
+ * rank RCCL copies the root's send buffer into its receive buffer).  Both contexts must be on the same GPU.
+ * A self-test of the replication path for boxes with one GPU (smhip_index_bcast with n_gpus == 1 never
+ * touches RCCL); dst afterwards maps from its own copy, independent of src.  No reference counterpart. */
+int smhip_index_bcast_loopback(smhip_ctx *src, smhip_ctx *dst);
 /* GPUs visible to this process (0 when there is none / no HIP runtime). */
 int smhip_device_count(void);
 

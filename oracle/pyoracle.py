@@ -76,6 +76,8 @@ def lib():
     if _lib is None:
         L = C.CDLL(ORACLE_PATH)
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        L.so_add_signal.restype = sz
+        L.so_add_signal.argtypes = [vp, sz, C.c_float, C.c_float, C.c_float, vp]
         L.so_detect_events.restype = sz
         L.so_detect_events.argtypes = [vp, sz, vp, vp, C.POINTER(sz)]
         L.so_prefix_sums.argtypes = [vp, sz, vp, vp]
@@ -158,6 +160,14 @@ def ref():
 
 
 # ---------------------------------------------------------------- convenience wrappers
+
+def add_signal(raw, digitisation, rng, offset):
+    """SignalBatch::AddSignal (A1): int16 ADC counts -> filtered pA."""
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    out = np.empty(len(raw), dtype=np.float32)
+    n = lib().so_add_signal(_p(raw), len(raw), digitisation, rng, offset, _p(out))
+    return out[:n].copy()
+
 
 def detect_events(x):
     x = np.ascontiguousarray(x, dtype=np.float32)

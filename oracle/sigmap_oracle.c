@@ -20,6 +20,20 @@
 /* ------------------------------------------------------------------ events */
 
 /* event.h:58-68: sequential f32 prefix sums (order-sensitive). */
+/* signal_batch.cc:139-151 / :195-207 */
+size_t so_add_signal(const int16_t *raw, size_t n, float digitisation, float range, float offset, float *out) {
+  size_t valid_signal_length = 0;
+  const float scale = range / digitisation;              /* :140 / :196 (float / float) */
+  for (size_t i = 0; i < n; ++i) {
+    const float v = (float)raw[i];                       /* :137-138: file.read() into vector<float> */
+    if ((v + offset) * scale > 30 && (v + offset) * scale < 200) {  /* :142-143 / :198-199 */
+      out[valid_signal_length] = (v + offset) * scale;   /* :144 / :200 */
+      ++valid_signal_length;
+    }
+  }
+  return valid_signal_length;                            /* :148-151: the tail is erased */
+}
+
 void so_prefix_sums(const float *x, size_t n, float *ps, float *pss) {
   ps[0] = 0.0f;
   pss[0] = 0.0f;

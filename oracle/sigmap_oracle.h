@@ -12,9 +12,9 @@
  *   - so_detect_events (A2-A6), so_kdtree_build / so_radius_search (A10, N1, T9) and
  *     so_level_means (pore_model.cc) are pinned against the REAL reference code,
  *     compiled from /root/reference/src by oracle/Makefile into oracle/_ref/.
- *   - so_zscore / so_generate_events tail (A7-A8), so_generate_chains (A9, A11-A16),
+ *   - so_add_signal (A1), so_zscore / so_generate_events tail (A7-A8), so_generate_chains (A9, A11-A16),
  *     so_map_read (A17-A18) and so_sdtw (D4) restate translation units
- *     (sigmap.cc, spatial_index.cc, fast_dtw.cc) that cannot be compiled in this image
+ *     (signal_batch.cc, sigmap.cc, spatial_index.cc, fast_dtw.cc) that cannot be compiled in this image
  *     without a stand-in for <slow5/slow5.h>: PARITY UNPINNED for those functions.
  *
  * Every function cites the reference file:line it follows (paths relative to
@@ -29,6 +29,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* ---- A1: SignalBatch::AddSignal, signal_batch.cc:139-151 (FAST5; the samples were read into a float
+ * vector first, :137-138) and :195-207 (BLOW5; int16 promoted in the expression): the same loop.
+ * `scale = range / digitisation` in float; a sample survives iff 30 < (raw + offset) * scale < 200 (both
+ * strict); survivors are compacted in order.  out capacity n.  Returns the number kept.
+ * PARITY UNPINNED (signal_batch.cc includes <slow5/slow5.h> through signal_batch.h:6). ---- */
+size_t so_add_signal(const int16_t *raw, size_t n, float digitisation, float range, float offset, float *out);
 
 /* ---- event.h:16-21 ---- */
 typedef struct {

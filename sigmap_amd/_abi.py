@@ -21,7 +21,7 @@ HIP_SYMBOLS = [
     "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
-    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
+    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -211,6 +211,7 @@ def hip_lib():
         L.smhip_host_free.restype = None
         L.smhip_index_export_copy.argtypes = [vp, C.c_int, vp, u64]
         L.smhip_index_bcast.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.smhip_index_bcast_loopback.argtypes = [vp, vp]
         L.smhip_device_count.argtypes = []
         L.smhip_refine_path_run.argtypes = [vp, u32, u32]
         L.smhip_refine_path_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64]

@@ -421,6 +421,18 @@ struct Rccl {
   bool ok = false;
   std::string why;
 };
+// `p` now holds a broadcast copy of `root`'s walker arrays in its own ix_* buffers
+void AdoptReplica(smhip_ctx *p, const smhip_ctx *root) {
+  p->dim = root->dim;
+  p->index = IndexView{p->ix_nodes.as<uint4>(), p->ix_tab.as<uint32_t>(), p->ix_pts.as<float>(),
+                       p->ix_vind.as<uint32_t>(), p->ix_bbox.as<float>(), root->index.n_inner, root->index.n_leaves,
+                       root->index.m_size, root->index.root_ref};
+  p->leaf_pts_bytes = root->leaf_pts_bytes;
+  p->leaf_vind_bytes = root->leaf_vind_bytes;
+  p->have_index = true;
+  p->max_tpos_valid = false;
+  p->index_owned = true;
+}
 const Rccl &LoadRccl() {
   static Rccl r;
   static std::once_flag once;
@@ -503,19 +515,44 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
     if (c) (void)nc.CommDestroy(c);
   if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("RCCL broadcast: ") + nc.GetErrorString(nr));
   if (he != hipSuccess) return HipFail(ctx, he, "index broadcast");
-  for (int i = 0; i < n_gpus; ++i) {
-    if (i == root) continue;
-    smhip_ctx *p = ctxs[i];
-    p->dim = ctx->dim;
-    p->index = IndexView{p->ix_nodes.as<uint4>(), p->ix_tab.as<uint32_t>(), p->ix_pts.as<float>(),
-                         p->ix_vind.as<uint32_t>(), p->ix_bbox.as<float>(), ctx->index.n_inner, ctx->index.n_leaves,
-                         ctx->index.m_size, ctx->index.root_ref};
-    p->leaf_pts_bytes = ctx->leaf_pts_bytes;
-    p->leaf_vind_bytes = ctx->leaf_vind_bytes;
-    p->have_index = true;
-    p->max_tpos_valid = false;
-    p->index_owned = true;
+  for (int i = 0; i < n_gpus; ++i)
+    if (i != root) AdoptReplica(ctxs[i], ctx);
+  return SMHIP_OK;
+}
+
+int smhip_index_bcast_loopback(smhip_ctx *src, smhip_ctx *dst) {
+  if (!src || !dst || src == dst) return SMHIP_EINVAL;
+  smhip_ctx *ctx = src;  // errors are reported on the source context
+  if (!src->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_index_bcast_loopback: the source context has no index");
+  if (src->device != dst->device)
+    return Fail(ctx, SMHIP_EINVAL, "smhip_index_bcast_loopback: both contexts must be on one GPU (peers: smhip_index_bcast)");
+  const Rccl &nc = LoadRccl();
+  if (!nc.ok) return Fail(ctx, SMHIP_EHIP, nc.why);
+  smhip_index_dev d;
+  int rc = smhip_index_export(src, &d);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(src->device));
+  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
+  void *from[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
+  DevBuf *to[5] = {&dst->ix_nodes, &dst->ix_tab, &dst->ix_pts, &dst->ix_vind, &dst->ix_bbox};
+  for (int a = 0; a < 5; ++a) HIPCHK(to[a]->Reserve(bytes[a]));
+  Rccl::comm_t comm = nullptr;
+  const int dev = src->device;
+  int nr = nc.CommInitAll(&comm, 1, &dev);
+  if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll(1): ") + nc.GetErrorString(nr));
+  // the same call sequence as smhip_index_bcast: one grouped ncclBroadcast per array; with one rank and
+  // sendbuff != recvbuff RCCL copies the root's buffer into the receive buffer
+  for (int a = 0; a < 5 && nr == 0; ++a) {
+    nr = nc.GroupStart();
+    if (nr == 0) nr = nc.Broadcast(from[a], to[a]->p, bytes[a], /*ncclUint8*/ 1, 0, comm, src->stream);
+    const int ge = nc.GroupEnd();
+    if (nr == 0) nr = ge;
   }
+  const hipError_t he = hipStreamSynchronize(src->stream);
+  (void)nc.CommDestroy(comm);
+  if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("RCCL broadcast: ") + nc.GetErrorString(nr));
+  if (he != hipSuccess) return HipFail(ctx, he, "index broadcast (loopback)");
+  AdoptReplica(dst, src);
   return SMHIP_OK;
 }
 

@@ -58,18 +58,23 @@ def broadcast_host_index(ix_arrays, rank, dist):
     return out
 
 
-def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None, via_host=False):
+def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None, via_host=False, force=False):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
     uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive.
     Rank 0 copies an exported array into the broadcast tensor with smhip_index_export_copy (the
     library's own HIP runtime and stream); `device` / `copy_fn(array_id, dst_ptr, src_ptr, nbytes)` let
-    the world_size-2 gloo test run this very function with host buffers.  A failure on rank 0 before
-    the broadcasts is announced to the peers (they raise instead of waiting in a collective).
+    the world_size-2 gloo test run this very function with host buffers.  Every step that can fail on
+    rank 0 (upload, export, the five tensors and the copies into them) happens BEFORE the first
+    collective and its outcome travels in the meta broadcast: the peers raise instead of waiting in a
+    collective for a rank that has left.
     via_host=True (bench.py --backend gloo, a transport for testing the N > 1 flow where RCCL cannot run,
     e.g. several ranks on one GPU): the arrays travel as CPU tensors and every peer copies what it received
-    into device memory of its own before attaching."""
-    if world == 1:
+    into device memory of its own before attaching.
+    force=True with world == 1 (bench.py --force-bcast: a one-GPU box): the collectives run anyway on the
+    one-rank group -- the same meta + five dist.broadcast calls over the same backend -- and the call returns
+    (tensors, IndexDev of the broadcast copy) so that the caller can map from the copy and compare."""
+    if world == 1 and not force:
         dev.upload_index(ix)
         return None
     import torch
@@ -83,39 +88,45 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
     if copy_fn is None:
         copy_fn = lambda array_id, dst_ptr, src_ptr, nbytes: dev.export_copy(array_id, dst_ptr, nbytes)
     meta = [0] * (1 + len(_SCALARS) + len(_ARRAYS))   # [0]: 1 = rank 0 has its index, -1 = it failed
-    d = None
+    tensors = []
     err = None
     if rank == 0:
         try:
             dev.upload_index(ix)
             d = dev.export_index()
+            for k, a in enumerate(_ARRAYS):
+                nbytes = int(getattr(d, a + "_bytes"))
+                t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                copy_fn(k, t.data_ptr(), getattr(d, a), nbytes)
+                tensors.append(t)
             meta = [1] + [int(getattr(d, f)) for f in _SCALARS] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
         except Exception as e:   # tell the peers before raising
             err = e
             meta[0] = -1
+            tensors = []
     meta = broadcast_meta(meta, rank, dist, device)
     if meta[0] != 1:
         raise RuntimeError(f"rank {rank}: index upload failed on rank 0" + (f": {err}" if err else ""))
     meta = meta[1:]
-    tensors = []
-    for k, (a, nbytes) in enumerate(zip(_ARRAYS, meta[len(_SCALARS):])):
-        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if rank == 0:
-            copy_fn(k, t.data_ptr(), getattr(d, a), nbytes)
-        dist.broadcast(t, src=0)  # RCCL broadcast over xGMI
-        tensors.append(t)
+    sizes = meta[len(_SCALARS):]
+    for k, nbytes in enumerate(sizes):
+        if rank != 0:
+            tensors.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+        dist.broadcast(tensors[k], src=0)  # RCCL broadcast over xGMI
     if on_gpu:
         torch.cuda.synchronize()
-    if rank != 0:
+    if rank != 0 or force:
         nd = _abi.IndexDev()
         for f, v in zip(_SCALARS, meta):
             setattr(nd, f, v)
         if via_host:
             tensors = [t.to(gpu) for t in tensors]   # H2D into this rank's own device memory
             torch.cuda.synchronize()
-        for a, t, nbytes in zip(_ARRAYS, tensors, meta[len(_SCALARS):]):
+        for a, t, nbytes in zip(_ARRAYS, tensors, sizes):
             setattr(nd, a, t.data_ptr())
             setattr(nd, a + "_bytes", nbytes)
+        if rank == 0:
+            return tensors, nd   # force: rank 0 keeps its own arrays; the copy is the caller's to attach
         try:
             dev.attach_index(nd)
         except Exception as e:

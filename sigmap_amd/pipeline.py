@@ -163,6 +163,11 @@ class DeviceMapper:
         self._check(self.L.smhip_index_export_copy(self._h, array_id, C.c_void_p(dst_ptr), nbytes),
                     "smhip_index_export_copy")
 
+    def bcast_loopback_to(self, other):
+        """RCCL self-test on one GPU (smhip_index_bcast_loopback): `other` gets its own copy of this
+        context's index through a one-rank communicator and the grouped ncclBroadcast calls."""
+        self._check(self.L.smhip_index_bcast_loopback(self._h, other._h), "smhip_index_bcast_loopback")
+
     def attach_index(self, d):
         self._check(self.L.smhip_index_attach(self._h, C.byref(d)), "smhip_index_attach")
 

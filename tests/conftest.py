@@ -28,13 +28,15 @@ def bits(a):
 
 @pytest.fixture(scope="session")
 def small_world():
-    """Seeded 3-contig 300 kb genome, pore model, index (host build), 48 reads in pA."""
+    """Seeded 3-contig 300 kb genome, pore model, index (host build), 48 reads in pA (the ORACLE's
+    AddSignal conversion, so_add_signal: the checker's inputs never pass through product code)."""
+    from oracle import pyoracle as po
     from sigmap_amd import pipeline, synth
     genome = synth.make_genome(7, [150000, 100000, 50000])
     lm = synth.make_pore_model()
     raw, truth = synth.simulate_reads(genome, lm, 48, 11)
     ix = pipeline.HostIndex.build(genome, lm, threads=4)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     return dict(genome=genome, lm=lm, raw=raw, truth=truth, ix=ix, pa=pa,
                 ref_lens=np.array([len(g) for g in genome], dtype=np.uint32))
 

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from oracle import pyoracle as po
 from sigmap_amd import _abi, pipeline, synth
 
 pytestmark = pytest.mark.skipif(not _abi.host_lib().smhost_have_fast5(), reason="host library built without HDF5")
@@ -34,7 +35,7 @@ def test_fast5_roundtrip_equals_sgr(tmp_path, multi):
     assert [x[0] for x in a] == ids == [x[0] for x in b]
     for (ia, pa, dg, rg, of), (ib, pb, _, _, _), r in zip(a, b, raws):
         assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
-        exp = pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        exp = po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         assert np.array_equal(pa.view(np.uint32), exp.view(np.uint32))
         assert (dg, rg, of) == (np.float32(synth.DIGITISATION), np.float32(synth.RANGE), np.float32(synth.OFFSET))
     assert len(a[1][1]) == len(a[0][1])  # the three out-of-range samples were dropped
@@ -48,9 +49,9 @@ def test_fast5_float_attributes_keep_six_significant_digits(tmp_path):
     synth.write_fast5(p, raws, multi_read=True, digitisation=8192.0, rng=1402.882324, offset=6.0)
     got = synth.load_signals(p)     # a single file instead of a directory
     assert got[0][3] == np.float32(1402.88) and got[0][2] == np.float32(8192.0) and got[0][4] == np.float32(6.0)
-    exp = pipeline.raw_to_pa(raws[0], 8192.0, float(np.float32(1402.88)), 6.0)
+    exp = po.add_signal(raws[0], 8192.0, float(np.float32(1402.88)), 6.0)
     assert np.array_equal(got[0][1].view(np.uint32), exp.view(np.uint32))
-    other = pipeline.raw_to_pa(raws[0], 8192.0, 1402.882324, 6.0)
+    other = po.add_signal(raws[0], 8192.0, 1402.882324, 6.0)
     assert not np.array_equal(exp.view(np.uint32), other.view(np.uint32))   # the rounding is observable
 
 

@@ -76,9 +76,10 @@ def test_events_edge_cases(device):
 
 # ------------------------------------------------------------------ ADC -> pA on the device (A1)
 
-def test_raw_conversion_matches_host_addsignal(device):
+def test_raw_conversion_matches_oracle_addsignal(device):
     """SignalBatch::AddSignal (signal_batch.cc:139-151): scale, (30, 200) pA filter, in-order
-    compaction -- the device's resident-read path against the host conversion, bit for bit: reads with
+    compaction -- the device's resident-read path against the ORACLE's restatement (so_add_signal), bit
+    for bit, and the product's host loop (smhost_raw_to_pa) against the same oracle: reads with
     samples below 30 and above 200 pA, ragged lengths (0, 1, a segment boundary, several segments), a
     read longer than its slot keeps, per-read calibration constants."""
     rng = np.random.default_rng(5)
@@ -102,7 +103,9 @@ def test_raw_conversion_matches_host_addsignal(device):
     got_len = device.upload_raw(pin.array, ro, dg, rg, of, slots=slots)
     some_dropped = False
     for k, r in enumerate(raws):
-        want = pipeline.raw_to_pa(r, dg[k], rg[k], of[k])
+        want = po.add_signal(r, dg[k], rg[k], of[k])
+        host = pipeline.raw_to_pa(r, dg[k], rg[k], of[k])       # SignalBatch::AddSignal mirror of the host library
+        assert np.array_equal(bits(host), bits(want)), k
         some_dropped |= 0 < len(want) < len(r)
         assert got_len[k] == len(want), (k, got_len[k], len(want))
         pa, kept, total = device.download_pa(int(slots[k]), keep)
@@ -317,7 +320,7 @@ def test_many_contigs_more_than_128_candidate_chains():
     genome = [uniq[2 * i] + shared + uniq[2 * i + 1] for i in range(NC)]
     lm = synth.make_pore_model()
     raw, _ = synth.simulate_reads([shared], lm, 12, seed=5)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     ix = pipeline.HostIndex.build(genome, lm, threads=4)
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
@@ -351,7 +354,7 @@ def test_more_contigs_than_the_partition_kernel_counts_groups_for():
     lm = synth.make_pore_model()
     raw, _ = synth.simulate_reads([shared], lm, 6, seed=9)
     raw2, _ = synth.simulate_reads(genome, lm, 6, seed=10)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in list(raw) + list(raw2)]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in list(raw) + list(raw2)]
     ix = pipeline.HostIndex.build(genome, lm, threads=4)
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
@@ -432,6 +435,42 @@ def test_index_export_copy_attach_gives_identical_results(device, small_world):
     other.close()
 
 
+def test_index_bcast_loopback_runs_the_rccl_calls_on_one_gpu(device, small_world):
+    """smhip_index_bcast_loopback: librccl is loaded, a one-rank communicator is created
+    (ncclCommInitAll) and the five walker arrays go through one grouped ncclBroadcast each -- the call
+    sequence of smhip_index_bcast -- into buffers the second context owns.  The copy is byte-identical
+    (export_copy of both sides) and maps to identical records, also after the source context is gone."""
+    from sigmap_amd import multigpu
+    pa = small_world["pa"][:24]
+    samples, offsets = _batch(pa)
+    src = pipeline.DeviceMapper(0)
+    src.upload_index(small_world["ix"])
+    base = src.map_chunks(samples, offsets, n_refs=3)
+    assert np.array_equal(base.tobytes(), device.map_chunks(samples, offsets, n_refs=3).tobytes())
+    peer = pipeline.DeviceMapper(0)
+    src.bcast_loopback_to(peer)
+    ds, dp = src.export_index(), peer.export_index()
+    for f in multigpu._SCALARS:
+        assert getattr(ds, f) == getattr(dp, f)
+    for k, a in enumerate(multigpu._ARRAYS):
+        n = int(getattr(ds, a + "_bytes"))
+        assert int(getattr(dp, a + "_bytes")) == n and getattr(dp, a) != getattr(ds, a)
+        x, y = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        src.export_copy(k, x.ctypes.data, n)      # (hipMemcpyDefault: host destinations are fine)
+        peer.export_copy(k, y.ctypes.data, n)
+        assert np.array_equal(x, y), a
+    assert np.array_equal(peer.map_chunks(samples, offsets, n_refs=3).tobytes(), base.tobytes())
+    src.close()                                   # the peer owns its copy
+    assert np.array_equal(peer.map_chunks(samples, offsets, n_refs=3).tobytes(), base.tobytes())
+    # argument checks
+    L = _abi.hip_lib()
+    empty = pipeline.DeviceMapper(0)
+    assert L.smhip_index_bcast_loopback(empty._h, peer._h) != 0 and b"no index" in L.smhip_last_error(empty._h)
+    assert L.smhip_index_bcast_loopback(peer._h, peer._h) != 0
+    empty.close()
+    peer.close()
+
+
 def test_mapper_pool_batches_in_flight_give_serial_results(device, small_world):
     """Batches mapped concurrently on three contexts / streams that share one resident index
     (pipeline.MapperPool) give byte for byte what one context gives one batch after the other."""
@@ -467,7 +506,7 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     positions = (np.arange(len(values), dtype=np.uint64) << np.uint64(1))  # one contig, + strand
     ix = pipeline.HostIndex.from_points(positions, values, threads=2)
     raw, _ = synth.simulate_reads([unit], lm, 6, 2)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
     samples, offsets = _batch(pa)
@@ -608,7 +647,7 @@ def test_chain_anchor_carry_over_roundtrip(device, small_world, oracle_tree):
     (spatial_index.cc:303-322): two-chunk reads must equal the oracle's streaming result."""
     genome, lm = small_world["genome"], small_world["lm"]
     raw, _ = synth.simulate_reads(genome, lm, 12, 77, n_chunks=2)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     ix, ref_lens = small_world["ix"], small_world["ref_lens"]
     first = [x[:4000] for x in pa]
     samples, offsets = _batch(first)
@@ -648,7 +687,7 @@ def test_full_size_properties():
     ix = pipeline.HostIndex.build(genome, lm, threads=0)
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     samples, offsets = _batch(pa)
     a = dev.map_chunks(samples, offsets, n_refs=16)
     b = dev.map_chunks(samples, offsets, n_refs=16)
@@ -692,7 +731,7 @@ def test_band_sweep_properties():
     dev.upload_index(ix)
     ref_sig, ref_off = pipeline.reference_signals(genome, lm)
     dev.upload_reference(ref_sig, ref_off)
-    pa = [pipeline.raw_to_pa(x, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for x in raw]
+    pa = [po.add_signal(x, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for x in raw]
     samples, offsets = _batch(pa)
     dev.upload_batch(samples, offsets)
     dev.run(1); dev.sync()
@@ -837,7 +876,7 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
     ref_lens = small_world["ref_lens"]
     rows = []
     for i, rw in enumerate(raws):
-        pa = pipeline.raw_to_pa(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        pa = po.add_signal(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         m = po.map_read(tree, positions, pa, 3, ref_lens)
         rows.append((m.ref, i, po.format_paf(m, "read%d" % i, names, ref_lens).rstrip("\n")))
     rows.sort(key=lambda t: (t[0], t[1]))

@@ -102,7 +102,7 @@ def test_config3_ecoli_band_sweep_full_size():
     sample = rng.choice(n, 192, replace=False)
     refined_checked = 0
     for k, i in enumerate(sample):
-        x = pipeline.raw_to_pa(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        x = po.add_signal(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         m = po.map_read(tree, ix.positions, x, 1, ref_lens)
         assert _paf_line(res[i], "read%d" % i, len(x), names, ref_lens) == po.format_paf(m, "read%d" % i, names, ref_lens)
         assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
@@ -149,7 +149,7 @@ def test_config4_chr1_250mb_shard():
     names = ["chr1"]
     proved = 0
     for i in sample:
-        x = pipeline.raw_to_pa(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        x = po.add_signal(raw[i], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         m = po.map_read(tree, ix.positions, x, 1, ref_lens)
         assert _paf_line(res[i], "read%d" % i, len(x), names, ref_lens) == po.format_paf(m, "read%d" % i, names, ref_lens), i
         assert res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
@@ -224,7 +224,7 @@ def test_cli_streaming_600_multichunk_reads(tmp_path, small_world):
     ref_lens = small_world["ref_lens"]
     rows, used_chunks = [], []
     for i, rw in enumerate(raws):
-        pa = pipeline.raw_to_pa(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        pa = po.add_signal(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         m = po.map_read(tree, ix.positions, pa, 3, ref_lens)
         used_chunks.append(m.chunks_used)
         rows.append((m.ref, i, po.format_paf(m, "read%d" % i, names, ref_lens).rstrip("\n")))
@@ -261,3 +261,33 @@ def test_bench_two_ranks_flow_on_one_gpu():
     assert j["config"]["chunks_with_capacity_flags"] == 0 and j["config"]["mapped_fraction"] > 0.95
     assert j["pcie_inclusive"]["results_identical"]
     assert abs(j["value"] - 2 * 1500 * 2 / (j["ms_per_step"] * 2 * 1e-3)) < 1e-3 * j["value"]
+
+
+def test_bench_one_rank_over_rccl_forced_broadcast():
+    """bench.py launched like the driver launches it, with ONE rank, backend nccl (= RCCL) and
+    --force-bcast: init_process_group(backend="nccl", device_id=...), the meta + five dist.broadcast
+    calls of multigpu.replicate_index, barrier and the max-over-ranks all_reduce all run over RCCL in a
+    process that also holds libsigmap_hip.so; two of the three contexts map from the broadcast copy and
+    agree byte for byte with the one that maps from the uploaded arrays."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl",
+           "--force-bcast", "--steps", "3", "--warmup", "1", "--reads", "1500", "--contigs", "4", "--contig-len", "300000",
+           "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3
+    fb = j["config"]["forced_broadcast"]
+    assert fb == {"backend": "rccl", "ranks": 1, "contexts_on_broadcast_copy": 2}
+    assert j["config"]["contexts_agree"] and j["config"]["census_results_identical"]
+    assert j["config"]["chunks_with_capacity_flags"] == 0 and j["config"]["mapped_fraction"] > 0.95
+    assert j["pcie_inclusive"]["results_identical"]

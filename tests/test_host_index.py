@@ -152,6 +152,28 @@ def test_raw_to_pa_filter():
     assert np.array_equal(bits(out), bits(exp))
 
 
+def test_host_addsignal_matches_oracle_addsignal():
+    """A1 on the host (SignalBatch::AddSignal mirror behind smhost_raw_to_pa) against the oracle's
+    so_add_signal (signal_batch.cc:139-151): ragged lengths, both cuts hit, values at the strict
+    boundaries, per-read calibration constants incl. 6-significant-digit attribute values."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(17)
+    cal = [(8192.0, 1467.61, 10.0), (8192.0, 1400.5, -3.0), (2048.0, 748.58, 6.0), (4096.0, 1211.3, 21.0),
+           (8192.0, 1402.88, 6.0), (1.0, 1.0, 0.0)]
+    for dg, rg, of in cal:
+        for n in (0, 1, 7, 4000, 4097, 30011):
+            raw = rng.integers(-300, 1500, size=n).astype(np.int16)
+            if n >= 7:
+                raw[:4] = [32767, -32768, 0, 1]
+            if (dg, rg, of) == (1.0, 1.0, 0.0) and n >= 7:
+                raw[:7] = [29, 30, 31, 199, 200, 201, 100]      # scale 1: the strict bounds themselves
+            want = po.add_signal(raw, dg, rg, of)
+            got = pipeline.raw_to_pa(raw, dg, rg, of)
+            assert np.array_equal(bits(got), bits(want)), (dg, rg, of, n)
+            if (dg, rg, of) == (1.0, 1.0, 0.0) and n >= 7:
+                assert list(want[:3]) == [31.0, 199.0, 100.0]
+
+
 def test_paf_logic_matches_oracle(small_world, oracle_tree):
     """smhost_format_paf on records assembled from the ORACLE's chains reproduces the oracle's
     own PAF text: pins the host-side decision/format code independently of the GPU."""

@@ -156,6 +156,81 @@ def test_world2_gloo_replicate_index_hands_the_peer_identical_arrays():
     assert got[1] is not None and got[1] == got[0]
 
 
+def _forced_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import ctypes as C
+    import torch.distributed as dist
+    from sigmap_amd import multigpu
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dev = _FakeContext()
+        tensors, nd = multigpu.replicate_index(dev, None, 0, 1, 0, dist, device="cpu", force=True,
+                                               copy_fn=lambda k, dst, src, n: C.memmove(dst, src, n))
+        d = dev.exported
+        same = all(int(getattr(nd, f)) == int(getattr(d, f)) for f in multigpu._SCALARS)
+        for a in multigpu._ARRAYS:
+            n = int(getattr(d, a + "_bytes"))
+            same = same and int(getattr(nd, a + "_bytes")) == n and getattr(nd, a) != getattr(d, a)
+            same = same and bytes((C.c_uint8 * n).from_address(getattr(nd, a))) == bytes((C.c_uint8 * n).from_address(getattr(d, a)))
+        q.put(bool(same and len(tensors) == 5))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_one_rank_broadcast_returns_an_identical_copy():
+    """bench.py --force-bcast: with ONE rank replicate_index(force=True) still runs the meta + five
+    broadcasts over the group and hands back a copy of the arrays (distinct memory, same bytes)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
+def _failing_copy_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import torch.distributed as dist
+    from sigmap_amd import multigpu
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    def bad_copy(k, dst, src, n):
+        if k == 2:
+            raise RuntimeError("export copy of array 2 failed")
+
+    try:
+        multigpu.replicate_index(_FakeContext(), None, rank, world, rank, dist, device="cpu", copy_fn=bad_copy)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_rank0_failure_in_an_export_copy_reaches_the_peer():
+    """A failure on rank 0 inside the per-array copies (not only upload / export) is announced in the meta
+    broadcast: the peer raises at once instead of waiting in a collective until the group times out."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    t0 = time.time()
+    procs = [ctx.Process(target=_failing_copy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=50) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+    assert "index upload failed on rank 0" in got[0] and "array 2" in got[0]
+    assert "index upload failed on rank 0" in got[1]
+    assert time.time() - t0 < 45
+
 
 def test_shard_range_is_the_contiguous_block_partition():
     """`sigmap -m --gpus N` (host/sigmap.cc) and bench.py shard reads the same way: part r of N gets

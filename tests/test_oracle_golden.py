@@ -112,7 +112,7 @@ def test_oracle_vs_live_reference_fresh_inputs():
     ot = po.OracleTree(values)
     rt = R.ref_kdtree_build(po._p(values), None, len(values), 6, 20)
     for r in range(4):
-        pa = pipeline.raw_to_pa(raw[r], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        pa = po.add_signal(raw[r], synth.DIGITISATION, synth.RANGE, synth.OFFSET)
         em = np.zeros(len(pa) + 1, np.float32); sd = np.zeros(len(pa) + 1, np.float32)
         ne = R.ref_detect_events_entry(po._p(pa), len(pa), po._p(em), po._p(sd))
         ev, _ = po.detect_events(pa)

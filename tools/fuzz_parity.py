@@ -30,7 +30,7 @@ def main(rounds, first):
         lm = synth.make_pore_model()
         n_reads = int(rng.integers(8, 40))
         raw, _ = synth.simulate_reads(genome, lm, n_reads, seed + 1000)
-        pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+        pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
         kind = ["read"] * len(pa)
         for i in range(len(pa)):  # pure-noise reads, flat reads (few events), reads with a stuck stretch
             u = rng.random()

@@ -17,7 +17,7 @@ def main():
     dev = pipeline.DeviceMapper(0)
     dev.params.walk_blocks_per_cu = G
     dev.upload_index(ix)
-    pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
     offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
     samples = np.concatenate(pa)
     # --- events

@@ -8,7 +8,7 @@ from oracle import pyoracle as po
 genome = synth.make_genome(7, [750000] * 16); lm = synth.make_pore_model()
 raw, _ = synth.simulate_reads(genome, lm, 2048, 1000)
 ix = pipeline.HostIndex.build(genome, lm, threads=0)
-pa = [pipeline.raw_to_pa(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
 tree = po.OracleTree.from_host_index(ix); rl = np.array([750000] * 16, np.uint32)
 for nt in (1, 8, 16, 32, 64, 128, 256):
     if nt > (os.cpu_count() or 1): break
