@@ -1126,24 +1126,27 @@ int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   HIPCHK(ctx->rp_lo.Reserve(nr * 4));
   HIPCHK(ctx->rp_hi.Reserve(nr * 4));
   HIPCHK(ctx->rp_width.Reserve((nr + 1) * 4));
-  HIPCHK(ctx->rp_celloff.Reserve((nr + 1) * 4));
+  HIPCHK(ctx->rp_celloff.Reserve((nr + 1) * 8));
   HIPCHK(ctx->rp_path.Reserve(std::max<uint64_t>(n_path, 1)));
   HIPCHK(LaunchChainWindowFill(ctx, results, ctx->qstart.as<uint32_t>(), kFeatStride, R, ctx->ref_off.as<uint64_t>(),
                                ctx->ref_n, band, pad, ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
                                ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(), ctx->rp_lo.as<uint32_t>(),
                                ctx->rp_hi.as<uint32_t>(), ctx->rp_width.as<uint32_t>()));
-  uint32_t n_cells = 0;
+  // cell offsets in 64 bits: up to 8192 rows of min(band + 1, features) cells per chunk pass 2^32 cells
+  // in one batch with long carried chains or a wide band
+  uint64_t n_cells = 0;
   if (n_rows > 0) {
-    HIPCHK(LaunchScanU32(ctx, ctx->rp_width.as<uint32_t>(), (uint32_t)n_rows, ctx->rp_celloff.as<uint32_t>()));
-    HIPCHK(hipMemcpyAsync(&n_cells, ctx->rp_celloff.as<uint32_t>() + n_rows, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(LaunchScanU32ToU64(ctx, ctx->rp_width.as<uint32_t>(), (uint32_t)n_rows, ctx->rp_celloff.as<uint64_t>()));
+    HIPCHK(hipMemcpyAsync(&n_cells, ctx->rp_celloff.as<uint64_t>() + n_rows, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // (a 32-bit scan: more than 4 G cells in one batch would have wrapped)
-    if ((uint64_t)n_cells + band > 0xFFFFFFFFull) return Fail(ctx, SMHIP_ECAP, "too many window cells in one batch");
+    if (n_cells > (1ull << 36))
+      return Fail(ctx, SMHIP_ECAP, "more than 64 Gi window cells (one path-code byte each) in one batch: map fewer chunks "
+                                   "per batch or narrow the band");
   }
   HIPCHK(ctx->rp_codes.Reserve(std::max<uint64_t>(n_cells, 1)));
   HIPCHK(LaunchDtwPathChains(ctx, ctx->ref_sig.as<float>(), ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
                              ctx->feat.as<float>(), ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(),
-                             ctx->rp_lo.as<uint32_t>(), ctx->rp_hi.as<uint32_t>(), ctx->rp_celloff.as<uint32_t>(),
+                             ctx->rp_lo.as<uint32_t>(), ctx->rp_hi.as<uint32_t>(), ctx->rp_celloff.as<uint64_t>(),
                              ctx->rp_codes.as<uint8_t>(), R, ctx->rp_dist.as<float>(), ctx->rp_end.as<int64_t>(),
                              ctx->rp_path.as<uint8_t>(), ctx->rp_poff.as<uint64_t>(), ctx->rp_plen.as<uint32_t>(),
                              ctx->rp_start.as<int64_t>()));
@@ -1160,14 +1163,16 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
   const uint32_t R = ctx->n_chunks;
   path_off[0] = 0;
   if (R == 0) return SMHIP_OK;
-  if (path_codes && path_cap < ctx->rp_path_total) return Fail(ctx, SMHIP_ECAP, "path_cap too small");
+  // (everything but the codes is delivered also when path_cap is too small: the caller sizes its retry
+  // from path_off[n_chunks], as the header says)
+  const bool codes_fit = !path_codes || path_cap >= ctx->rp_path_total;
   std::vector<uint64_t> tgt((size_t)R), toff((size_t)R + 1);
   HIPCHK(hipMemcpyAsync(dist, ctx->rp_dist.p, (uint64_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(end_pos, ctx->rp_end.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(start_pos, ctx->rp_start.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(path_len, ctx->rp_plen.p, (uint64_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(path_off, ctx->rp_poff.p, ((uint64_t)R + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (path_codes && ctx->rp_path_total)
+  if (path_codes && codes_fit && ctx->rp_path_total)
     HIPCHK(hipMemcpyAsync(path_codes, ctx->rp_path.p, ctx->rp_path_total, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ResolveTimers(ctx);
@@ -1187,8 +1192,9 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
     const int64_t t0 = (int64_t)(tgt[c] - so);
     end_pos[c] += t0;
     if (start_pos[c] >= 0) start_pos[c] += t0;
-    if (path_codes) std::reverse(path_codes + path_off[c], path_codes + path_off[c] + path_len[c]);
+    if (path_codes && codes_fit) std::reverse(path_codes + path_off[c], path_codes + path_off[c] + path_len[c]);
   }
+  if (!codes_fit) return Fail(ctx, SMHIP_ECAP, "path_cap too small (path_off[n_chunks] codes are needed)");
   return SMHIP_OK;
 }
 

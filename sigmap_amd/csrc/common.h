@@ -378,7 +378,7 @@ hipError_t LaunchChainWindowFill(smhip_ctx *ctx, const smhip_chunk_result *resul
                                  uint32_t *q_len, uint32_t *lo, uint32_t *hi, uint32_t *width);
 hipError_t LaunchDtwPathChains(smhip_ctx *ctx, const float *ref_sig, const uint64_t *t_off, const uint64_t *tgt_off,
                                const float *feat, const uint64_t *q_off, const uint32_t *q_len, const uint32_t *lo,
-                               const uint32_t *hi, const uint32_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
+                               const uint32_t *hi, const uint64_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
                                int64_t *end, uint8_t *path, const uint64_t *path_off, uint32_t *path_len,
                                int64_t *start_t);
 hipError_t LaunchSdtw(smhip_ctx *ctx, const float *target, const uint64_t *t_off, const float *query,

@@ -416,8 +416,8 @@ __global__ __launch_bounds__(64) void FeatureKernel(uint32_t n_chunks, const uin
 }
 
 // Exclusive scan of n uint32 values by one workgroup (n is a chunk count: small).
-template <typename OutT>
-__global__ __launch_bounds__(1024) void ScanKernel(const uint32_t *__restrict__ in, uint32_t n,
+template <typename OutT, typename InT = uint32_t>
+__global__ __launch_bounds__(1024) void ScanKernel(const InT *__restrict__ in, uint32_t n,
                                                    OutT *__restrict__ out) {
   __shared__ uint64_t part[1024];
   const uint32_t tid = threadIdx.x;
@@ -443,11 +443,12 @@ __global__ __launch_bounds__(1024) void ScanKernel(const uint32_t *__restrict__ 
 // Large inputs (the walker's query-order histogram: ~0.5 M bins): three coalesced launches --
 // per-block sums, scan of the sums, per-block rescan with the block's offset.
 constexpr uint32_t kScanTile = 4096;  // elements per 256-thread block
+template <typename SumT>
 __global__ __launch_bounds__(256) void ScanReduceKernel(const uint32_t *__restrict__ in, uint32_t n,
-                                                        uint32_t *__restrict__ sums) {
-  __shared__ uint32_t red[256];
+                                                        SumT *__restrict__ sums) {
+  __shared__ SumT red[256];
   const uint32_t base = blockIdx.x * kScanTile, tid = threadIdx.x;
-  uint32_t s = 0;
+  SumT s = 0;
   for (uint32_t i = base + tid; i < min(n, base + kScanTile); i += 256) s += in[i];
   red[tid] = s;
   __syncthreads();
@@ -458,12 +459,14 @@ __global__ __launch_bounds__(256) void ScanReduceKernel(const uint32_t *__restri
   if (tid == 0) sums[blockIdx.x] = red[0];
 }
 
+// (OutT = uint64_t: 64-bit offsets; the partial sums inside 256 consecutive inputs stay 32-bit)
+template <typename OutT>
 __global__ __launch_bounds__(256) void ScanApplyKernel(const uint32_t *__restrict__ in, uint32_t n,
-                                                       const uint32_t *__restrict__ block_excl,
-                                                       uint32_t *__restrict__ out) {
+                                                       const OutT *__restrict__ block_excl,
+                                                       OutT *__restrict__ out) {
   __shared__ uint32_t part[256];
   const uint32_t base = blockIdx.x * kScanTile, tid = threadIdx.x;
-  uint32_t carry = block_excl[blockIdx.x];
+  OutT carry = block_excl[blockIdx.x];
   for (uint32_t t0 = base; t0 < min(n, base + kScanTile); t0 += 256) {  // 256 elements at a time, coalesced
     const uint32_t i = t0 + tid;
     const uint32_t v = i < n ? in[i] : 0;
@@ -475,8 +478,8 @@ __global__ __launch_bounds__(256) void ScanApplyKernel(const uint32_t *__restric
       part[tid] += o;
       __syncthreads();
     }
-    if (i < n) out[i] = carry + part[tid] - v;
-    carry += part[255];
+    if (i < n) out[i] = carry + (OutT)(part[tid] - v);
+    carry += (OutT)part[255];  // (256 inputs: below 2^32 for every caller -- per-chunk anchor counts, window widths)
     __syncthreads();
   }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) out[n] = carry;
@@ -530,18 +533,29 @@ hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_
   hipError_t e = ctx->scan_tmp.Reserve(((size_t)blocks * 2 + 2) * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   uint32_t *sums = ctx->scan_tmp.as<uint32_t>(), *excl = sums + blocks;
-  hipLaunchKernelGGL(ScanReduceKernel, dim3(blocks), dim3(256), 0, ctx->stream, in, n, sums);
+  hipLaunchKernelGGL(ScanReduceKernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, in, n, sums);
   if (blocks <= 16384) {
     hipLaunchKernelGGL(ScanKernel<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, sums, blocks, excl);
   } else {
     return hipErrorInvalidValue;  // > 64 M elements: not a size this path produces
   }
-  hipLaunchKernelGGL(ScanApplyKernel, dim3(blocks), dim3(256), 0, ctx->stream, in, n, excl, out_excl);
+  hipLaunchKernelGGL(ScanApplyKernel<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, in, n, excl, out_excl);
   return hipGetLastError();
 }
 
 hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint64_t *out_excl) {
-  hipLaunchKernelGGL(ScanKernel<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, in, n, out_excl);
+  if (n <= 16384) {
+    hipLaunchKernelGGL(ScanKernel<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, in, n, out_excl);
+    return hipGetLastError();
+  }
+  // per-block sums (64-bit), their scan, per-block rescan with a 64-bit offset
+  const uint32_t blocks = (n + kScanTile - 1) / kScanTile;
+  hipError_t e = ctx->scan_tmp.Reserve(((size_t)blocks * 2 + 2) * sizeof(uint64_t));
+  if (e != hipSuccess) return e;
+  uint64_t *sums = ctx->scan_tmp.as<uint64_t>(), *excl = sums + blocks;
+  hipLaunchKernelGGL(ScanReduceKernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, in, n, sums);
+  hipLaunchKernelGGL((ScanKernel<uint64_t, uint64_t>), dim3(1), dim3(1024), 0, ctx->stream, sums, blocks, excl);
+  hipLaunchKernelGGL(ScanApplyKernel<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, in, n, excl, out_excl);
   return hipGetLastError();
 }
 }  // namespace smhip

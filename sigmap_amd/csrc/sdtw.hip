@@ -591,9 +591,6 @@ hipError_t InitSdtwAttributes() {  // per device (smhip_init)
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(DtwPathKernel<uint64_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(DtwPathKernel<uint32_t>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(kSdtwMaxT + 1) * sizeof(float)));
-  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void *>(SdtwChainKernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -716,12 +713,12 @@ hipError_t LaunchChainWindowFill(smhip_ctx *ctx, const smhip_chunk_result *resul
 
 hipError_t LaunchDtwPathChains(smhip_ctx *ctx, const float *ref_sig, const uint64_t *t_off, const uint64_t *tgt_off,
                                const float *feat, const uint64_t *q_off, const uint32_t *q_len, const uint32_t *lo,
-                               const uint32_t *hi, const uint32_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
+                               const uint32_t *hi, const uint64_t *cell_off, uint8_t *codes, uint32_t n, float *dist,
                                int64_t *end, uint8_t *path, const uint64_t *path_off, uint32_t *path_len,
                                int64_t *start_t) {
   if (n == 0) return hipSuccess;
   const size_t lds = 3 * (size_t)(kSdtwMaxT + 1) * sizeof(float);
-  hipLaunchKernelGGL(DtwPathKernel<uint32_t>, dim3(n), dim3(64), lds, ctx->stream, ref_sig, t_off, tgt_off, feat, q_off,
+  hipLaunchKernelGGL(DtwPathKernel<uint64_t>, dim3(n), dim3(64), lds, ctx->stream, ref_sig, t_off, tgt_off, feat, q_off,
                      q_len, lo, hi, cell_off, codes, dist, end, path, path_off, path_len, start_t);
   return hipGetLastError();
 }

@@ -977,11 +977,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
 #pragma unroll
     for (int t = 0; t < KPL; ++t) {
       const uint32_t i = lane + 64 * t;
-#ifdef EXP_NOSTORE
-      if (i < m && col_t[Pad(i)] == 0xFFFFFFF3u) {
-#else
       if (i < m) {
-#endif
         s_tpos[i] = col_t[Pad(i)];
         s_grp[i] = col_g[Pad(i)];
         s_qpos[i] = col_q[Pad(i)];

@@ -432,6 +432,13 @@ void ParseArgsAndRun(int argc, char *argv[]) {
       {"i", "build-index"}, {"d", "dimension"}, {"l", "max-leaf"}, {"m", "map"}, {"t", "num-threads"},
       {"r", "ref"}, {"p", "pore-model"}, {"x", "ref-index"}, {"s", "sig-dir"}, {"o", "output"}, {"h", "help"}};
   static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar", "gpus-share-device"};
+  // every option this program knows: anything else is an error, like the reference's cxxopts parser
+  // (sigmap.cc:1378 `options.parse` throws on an unknown option)
+  static const std::vector<std::string> valued = {
+      "dimension", "max-leaf", "step-size", "num-threads", "ref", "pore-model", "ref-index", "sig-dir", "output",
+      "search-radius", "max-num-chunks", "min-num-anchors", "min-num-anchors-output", "stop-mapping",
+      "stop-mapping-output", "stop-mapping-mean", "stop-mapping-mean-output", "sdtw-band", "device", "gpus",
+      "batch-chunks", "streams"};
   Args a;
   for (int i = 1; i < argc; ++i) {
     std::string k = argv[i];
@@ -443,8 +450,12 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     if (eq != std::string::npos) {
       v = k.substr(eq + 1);
       k = k.substr(0, eq);
-    } else if (std::find(flags.begin(), flags.end(), k) == flags.end()) {
-      if (i + 1 >= argc) ExitWithMessage("Missing value for --" + k);
+    }
+    const bool is_flag = std::find(flags.begin(), flags.end(), k) != flags.end();
+    if (!is_flag && std::find(valued.begin(), valued.end(), k) == valued.end())
+      ExitWithMessage("Option '" + std::string(argv[i]) + "' does not exist");
+    if (!is_flag && eq == std::string::npos) {
+      if (i + 1 >= argc) ExitWithMessage("Option '" + k + "' is missing an argument");
       v = argv[++i];
     }
     a.kv[k] = v;

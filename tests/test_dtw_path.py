@@ -289,3 +289,62 @@ def test_gpu_refine_path_matches_oracle(device, small_world, band):
         assert pipeline.print_alignment(paths[i]) == po.print_alignment(opath)
         checked += 1
     assert checked >= (12 if band >= 32 else 1)
+
+
+@pytest.mark.gpu
+def test_gpu_refine_path_beyond_2_32_window_cells(device, small_world):
+    """One batch whose windows hold more than 2^32 cells (1 250 chunks x ~8 000 rows x ~450 columns: a
+    large pad and a band wider than the query, i.e. what long carried chains or --sdtw-band 512 reach at
+    the CLI's batch sizes).  The per-row cell offsets are 64-bit: the chunks whose cells lie beyond the
+    4 GiB mark -- where 32-bit offsets would alias the first chunks' cells -- give the oracle's distance,
+    end, start and path like the first ones."""
+    from sigmap_amd import pipeline
+    genome, lm = small_world["genome"], small_world["lm"]
+    base = small_world["pa"][:25]
+    reps = 50
+    pa = base * reps
+    sig, offs = pipeline.reference_signals(genome, lm)
+    device.upload_reference(sig, offs)
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
+    samples = np.concatenate(pa)
+    device.upload_batch(samples, offsets)
+    device.run(3); device.sync()
+    res = device.download()
+    pad, band = 3800, 20000
+    device.refine_path(band=band, pad=pad)
+    dist, end, start, paths = device.refine_path_download()
+    feat, _, nf, _, _ = device.events(samples[:offsets[len(base)]], offsets[:len(base) + 1])
+
+    def window(i):
+        r = res[i]
+        c0 = r["chains"][0]
+        strand = 0 if c0["direction"] == 1 else 1
+        so, se = int(offs[2 * c0["ref"] + strand]), int(offs[2 * c0["ref"] + strand + 1])
+        t0 = max(0, int(c0["start"]) - pad); t1 = min(se - so, int(c0["end"]) + 6 + pad)
+        return so, t0, t1
+
+    cells, cells_before = 0, {}
+    for i in range(len(pa)):
+        cells_before[i] = cells
+        if res[i]["n_chains"] and end[i] != -1:
+            so, t0, t1 = window(i)
+            cells += (t1 - t0) * int(nf[i % len(base)])
+    assert cells > 2 ** 32, cells
+    beyond = [i for i in range(len(pa)) if cells_before[i] > 2 ** 32 and res[i]["n_chains"] and end[i] >= 0]
+    assert len(beyond) >= 3
+    for i in [0, 1, len(pa) // 2] + beyond[:2] + beyond[-2:]:
+        if res[i]["n_chains"] == 0:
+            continue
+        so, t0, t1 = window(i)
+        if t1 - t0 > 8192:
+            assert end[i] == -1
+            continue
+        q = feat[i % len(base), :nf[i % len(base)]]
+        T = t1 - t0
+        d, e, opath, ost = po.dtw_window(sig[so + t0:so + t1], q, np.ones(T, np.uint32), np.full(T, len(q), np.uint32))
+        assert bits(np.float32(dist[i])) == bits(np.float32(d)), (i, dist[i], d)
+        assert end[i] == t0 + e and start[i] == t0 + ost and np.array_equal(paths[i], opath), i
+    # replicas of one read give one answer wherever their cells lie
+    for i in range(len(base), len(pa)):
+        assert bits(np.float32(dist[i])) == bits(np.float32(dist[i % len(base)])) and end[i] == end[i % len(base)]
+        assert np.array_equal(paths[i], paths[i % len(base)])
