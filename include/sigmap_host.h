@@ -60,8 +60,9 @@ uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation
                           float offset, float *out);
 
 /* SignalBatch::LoadAllReadSignals, signal_batch.cc:24-67: every FAST5 file (single- or multi-read,
- * signal_batch.cc:69-151) and every .sgr file under `path` (sub-directories included; or the one
- * file), already converted to pA and filtered.  FAST5 needs a build with HDF5
+ * signal_batch.cc:69-151), every BLOW5 file (signal_batch.cc:153-210; the binary SLOW5 layout parsed
+ * directly -- record compression none / zlib / zstd, no signal compression) and every .sgr file under
+ * `path` (sub-directories included; or the one file), already converted to pA and filtered.  FAST5 needs a build with HDF5
  * (smhost_have_fast5() == 1); without it a .fast5 file terminates the process like the reference's
  * ExitWithMessage. */
 typedef struct smhost_signals smhost_signals;
@@ -79,6 +80,14 @@ int smhost_signals_get(const smhost_signals *s, uint64_t i, const char **id, con
 int smhost_write_fast5(const char *path, int multi_read, uint32_t n_reads, const char *const *ids,
                        const int16_t *const *raws, const uint32_t *raw_lens, float digitisation,
                        float range, float offset);
+
+/* Test / generator support: one BLOW5 file (file version 0.2.0, one read group, primary fields only).
+ * record_press: 0 none, 1 zlib, 2 zstd (-1 is returned when this build has no zstd:
+ * smhost_have_zstd() == 0).  The calibration constants are doubles in the file, like slow5_rec_t's. */
+int smhost_write_blow5(const char *path, int record_press, uint32_t n_reads, const char *const *ids,
+                       const int16_t *const *raws, const uint32_t *raw_lens, double digitisation, double range,
+                       double offset);
+int smhost_have_zstd(void);
 
 typedef struct {
   float search_radius;

@@ -28,7 +28,7 @@ HOST_SYMBOLS = [
     "smhost_index_free", "smhost_index_get", "smhost_reference_signal", "smhost_level_means",
     "smhost_raw_to_pa", "smhost_default_map_params", "smhost_should_stop", "smhost_format_paf",
     "smhost_have_fast5", "smhost_signals_load", "smhost_signals_free", "smhost_signals_count",
-    "smhost_signals_get", "smhost_write_fast5", "smhost_shard_range", "smhost_print_alignment",
+    "smhost_signals_get", "smhost_write_fast5", "smhost_write_blow5", "smhost_have_zstd", "smhost_shard_range", "smhost_print_alignment",
 ]
 
 
@@ -151,6 +151,8 @@ def host_lib():
                                          C.POINTER(C.c_float)]
         L.smhost_write_fast5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_void_p), C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.smhost_write_blow5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
+                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.smhost_print_alignment.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
         L.smhost_print_alignment.restype = C.c_int64
         L.smhost_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -8,8 +8,8 @@
 // (sigmap.cc:549-880) with the per-read taskloop turned into chunk rounds: round c sends chunk c
 // of every still-active read to the GPU in one batch (include/sigmap_hip.h), then the unchanged
 // early-stop / output rules run on the host (mapping_logic.cc).  Reads come from FAST5 files (single-
-// and multi-read, through the HDF5 C API, fast5_reader.cc) or from this build's .sgr container
-// (signal_batch.h); BLOW5 needs slow5lib, which is not vendored, and is rejected loudly.
+// and multi-read, through the HDF5 C API, fast5_reader.cc), BLOW5 files (blow5_reader.cc: the binary
+// SLOW5 layout parsed directly, slow5lib is not vendored) or this build's .sgr container (signal_batch.h).
 #include <omp.h>
 
 #include <algorithm>
@@ -407,7 +407,7 @@ const char *kHelp =
     "  -l, --max-leaf INT   Max leaf of spatial index [20]\n\n Mapping options:\n  -m, --map              Map signal data\n"
     "      --step-size INT    Seeding step size in reads [2]\n  -t, --num-threads INT  # threads for mapping [1] (host side)\n\n"
     " Input options:\n  -r, --ref FILE         Reference file\n  -p, --pore-model FILE  Pore model file\n"
-    "  -x, --ref-index FILE   Reference index file\n  -s, --sig-dir DIR      Signal data directory (.sgr files)\n\n"
+    "  -x, --ref-index FILE   Reference index file\n  -s, --sig-dir DIR      Signal data directory (FAST5 / BLOW5 / .sgr files)\n\n"
     " Output options:\n  -o, --output arg  Output file\n\n Development options:\n"
     "      --search-radius FLT         Search radius for each seed [0.08]\n"
     "      --max-num-chunks INT        Max # chunks before stop trying to map a read [30]\n"

@@ -99,10 +99,11 @@ bool SignalBatch::WriteSGR(const std::string &path, const std::vector<std::strin
 }
 
 // signal_batch.cc:24-67: every file under the directory (sub-directories included) whose path
-// contains ".fast5" is read as FAST5; ".sgr" files are this build's own container.  Files are taken
-// in sorted path order (the reference follows readdir order).
+// contains ".fast5" is read as FAST5, else one whose path contains ".blow5" as BLOW5 (:46-55);
+// ".sgr" files are this build's own container.  Files are taken in sorted path order (the reference
+// follows readdir order).
 static void CollectSignalFiles(const std::string &dir_path, std::vector<std::string> *fast5,
-                               std::vector<std::string> *sgr, int depth) {
+                               std::vector<std::string> *blow5, std::vector<std::string> *sgr, int depth) {
   DIR *dir = opendir(dir_path.c_str());
   if (!dir) return;
   struct dirent *ent;
@@ -117,32 +118,36 @@ static void CollectSignalFiles(const std::string &dir_path, std::vector<std::str
       subdirs.push_back(path);
     } else if (path.find(".fast5") != std::string::npos) {
       fast5->push_back(path);
+    } else if (path.find(".blow5") != std::string::npos) {
+      blow5->push_back(path);
     } else if (name.size() > 4 && name.compare(name.size() - 4, 4, ".sgr") == 0) {
       sgr->push_back(path);
-    } else if (path.find(".blow5") != std::string::npos || path.find(".slow5") != std::string::npos) {
-      std::cerr << "Skipping " << path << ": BLOW5 ingestion needs slow5lib, which this build does not have.\n";
     }
   }
   closedir(dir);
   if (depth < 8)
-    for (const auto &p : subdirs) CollectSignalFiles(p, fast5, sgr, depth + 1);
+    for (const auto &p : subdirs) CollectSignalFiles(p, fast5, blow5, sgr, depth + 1);
 }
 
 size_t SignalBatch::LoadAllReadSignals() {
   const double t0 = GetRealTime();
-  std::vector<std::string> fast5, sgr;
+  std::vector<std::string> fast5, blow5, sgr;
   DIR *dir = opendir(signal_directory_.c_str());
   if (dir) {
     closedir(dir);
-    CollectSignalFiles(signal_directory_, &fast5, &sgr, 0);
+    CollectSignalFiles(signal_directory_, &fast5, &blow5, &sgr, 0);
     std::sort(fast5.begin(), fast5.end());
+    std::sort(blow5.begin(), blow5.end());
     std::sort(sgr.begin(), sgr.end());
   } else if (signal_directory_.find(".fast5") != std::string::npos) {
     fast5.push_back(signal_directory_);  // a single file
+  } else if (signal_directory_.find(".blow5") != std::string::npos) {
+    blow5.push_back(signal_directory_);
   } else {
     sgr.push_back(signal_directory_);
   }
-  for (const auto &p : fast5) AddSignalsFromFAST5(p);
+  for (const auto &p : fast5) AddSignalsFromFAST5(p);  // signal_batch.cc:61-66: FAST5 files first, then BLOW5
+  for (const auto &p : blow5) AddSignalsFromBLOW5(p);
   for (const auto &p : sgr) AddSignalsFromSGR(p);
   std::cerr << "Loaded " << signals_.size() << " reads in " << GetRealTime() - t0 << "s.\n";
   return signals_.size();

@@ -3,9 +3,9 @@
 // GetSignalNameAt, GetSignalLengthAt, FinalizeLoading, ConvertSequencesToSignals).
 //
 // On-disk read containers: FAST5 (single- and multi-read, fast5_reader.cc, when HDF5 is present
-// at build time) and this build's own flat format (".sgr", below).  BLOW5 needs slow5lib, which
-// is not vendored.  The pA conversion and (30,200) pA filter that define what
-// the hot path sees are implemented here.
+// at build time), BLOW5 (blow5_reader.cc: the binary SLOW5 layout parsed directly, slow5lib is not
+// vendored) and this build's own flat format (".sgr", below).  The pA conversion and (30,200) pA
+// filter that define what the hot path sees are implemented here.
 //
 //   .sgr : "SGR1" | u32 n_reads | n_reads x { u32 id_len | id bytes | f32 digitisation |
 //          f32 range | f32 offset | u32 n_raw | i16 raw[n_raw] }       (little endian)
@@ -44,7 +44,13 @@ class SignalBatch {
                  const int16_t *raw, size_t n_raw);
   void AddSignalsFromSGR(const std::string &path);
   void AddSignalsFromFAST5(const std::string &path);  // signal_batch.cc:69-151
+  void AddSignalsFromBLOW5(const std::string &path);  // signal_batch.cc:156-210 (blow5_reader.cc)
   static bool HaveFAST5();
+  static bool HaveZstd();
+  // record_press: 0 none, 1 zlib, 2 zstd (tests / generator)
+  static bool WriteBLOW5(const std::string &path, int record_press, const std::vector<std::string> &ids,
+                         double digitisation, double range, double offset,
+                         const std::vector<std::vector<int16_t>> &raws);
   static bool WriteFAST5(const std::string &path, bool multi_read, const std::vector<std::string> &ids,
                          float digitisation, float range, float offset,
                          const std::vector<std::vector<int16_t>> &raws);

@@ -895,6 +895,17 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
         got5 = [strip(l) for l in open(tmp_path / "out5.paf").read().splitlines()]
         rename = lambda l: "\t".join(["read%d" % int(l.split("\t")[0][4:])] + l.split("\t")[1:])
         assert [rename(l) for l in got5] == exp
+    # the same reads as BLOW5 files (signal_batch.cc:153-210; one plain, one with zlib records): identical PAF
+    os.makedirs(tmp_path / "readsb")
+    half = len(raws) // 2
+    synth.write_blow5(str(tmp_path / "readsb" / "a.blow5"), raws[:half], ["read%d" % i for i in range(half)])
+    synth.write_blow5(str(tmp_path / "readsb" / "b.blow5"), raws[half:], ["read%d" % i for i in range(half, len(raws))],
+                      record_press=1)
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "readsb"), "-o", str(tmp_path / "outb.paf")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [strip(l) for l in open(tmp_path / "outb.paf").read().splitlines()] == exp
     # --sdtw-band adds a dt:f: tag to rows that have a chain and changes nothing else
     r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
                         "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out2.paf"),
