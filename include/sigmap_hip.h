@@ -220,10 +220,16 @@ int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_
 int smhip_host_alloc(void **out, size_t bytes);
 void smhip_host_free(void *p);
 
-/* Launch events -> seeds -> radius search -> sort -> chain on the context stream.  The kernels are
- * enqueued; the call itself waits twice for a scalar it sizes the next stage's buffers with (the
- * number of queries after event detection, the number of anchors after the search), so it returns
- * when the search has finished and sort + chain are still running.  smhip_map_sync waits for the rest. */
+/* Launch events -> seeds -> radius search -> sort -> chain on the context stream.  Two totals size the
+ * later stages' buffers and only the device knows them: the number of queries (after event detection)
+ * and the number of anchors (after the search).  The first batch of a context (and any batch while the
+ * environment sets SMHIP_SYNC_RUN=1) reads them back: the call then waits twice and returns when the
+ * search has finished, sort + chain still running.  Later batches SPECULATE: buffers are sized from the
+ * per-chunk totals of the largest batch so far (+ 25 % + slack), a guard kernel on the device empties a
+ * batch that outgrows them and raises a flag, and the call returns with every kernel enqueued and
+ * nothing waited for.  smhip_map_sync / the download calls wait for the stream, find the flag and repeat
+ * such a batch on the reading route (together with a smhip_refine_run enqueued behind it): the records
+ * never depend on the route.  Input slots named by smhip_batch_select must stay untouched until then. */
 int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs);
 int smhip_map_sync(smhip_ctx *ctx);
 /* results: n_chunks records. chain_anchors (nullable): anchors of ALL primary chains,
@@ -272,7 +278,8 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
                                uint32_t *path_len, uint64_t *path_off, uint8_t *path_codes, uint64_t path_cap);
 
 /* Diagnostic counters of the last smhip_map_run: [0] stack-overflow flag, [1] queries that needed
- * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag. */
+ * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag; of the context: [4] batches
+ * that were repeated after a speculative run outgrew its buffers, [5] speculative runs so far. */
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
 int smhip_timing_enable(smhip_ctx *ctx, int on);
 int smhip_timing_reset(smhip_ctx *ctx);

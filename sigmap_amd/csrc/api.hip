@@ -31,12 +31,14 @@ const EnvKnobs &Knobs() {
     k.classes = geti("SMHIP_CLASSES", 0);
     k.bucket_bits = geti("SMHIP_BUCKET_BITS", 0);
     k.sdtw_ring = getenv("SMHIP_SDTW_RING") ? 1 : 0;
+    k.sync_run = geti("SMHIP_SYNC_RUN", 0);
   });
   return k;
 }
 }  // namespace smhip
 
 namespace {
+int FinishRun(smhip_ctx *ctx);  // (defined with smhip_map_run: settles a speculative batch)
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
   return code;
@@ -208,6 +210,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
   if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+  if (ctx->h_run_info) (void)hipHostFree(ctx->h_run_info);
   for (DevBuf &b : ctx->pa_segs) b.Free();
   DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->pa_tab,
                     &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
@@ -592,6 +595,10 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   if ((carried == nullptr) != (carried_offsets == nullptr))
     return Fail(ctx, SMHIP_EINVAL, "carried and carried_offsets must be given together");
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->spec_pending) {  // a batch nobody collected: settle it before its inputs are replaced
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
   for (uint32_t c = 0; c < n_chunks; ++c) {
     if (sample_offsets[c + 1] < sample_offsets[c]) return Fail(ctx, SMHIP_EINVAL, "sample offsets must be non-decreasing");
     if (sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kMaxSamples)
@@ -749,6 +756,10 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
       return Fail(ctx, SMHIP_EINVAL, "chunk beyond the samples a slot keeps (keep_samples of smhip_reads_configure)");
   }
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->spec_pending) {  // a batch nobody collected: settle it before its inputs are replaced
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
   const uint64_t nb = std::max<uint64_t>(n_chunks, 1);
   HIPCHK(ctx->sel_slots.Reserve(nb * sizeof(uint32_t)));
   HIPCHK(ctx->sel_chunk.Reserve(nb * sizeof(uint32_t)));
@@ -818,21 +829,40 @@ int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t c
   return SMHIP_OK;
 }
 
-int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
-  if (!ctx || !p) return Fail(ctx, SMHIP_EINVAL, "null argument");
-  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before an index is resident");
-  if (!ctx->batch_ready) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before smhip_batch_upload");
-  if (n_refs == 0 || p->step_size < 1 || p->hits_per_query_fast == 0 || p->num_nearest_points < 1 ||
-      p->num_best_chains > 3)
-    return Fail(ctx, SMHIP_EINVAL, "bad parameter");
-  if (p->walk_blocks_per_cu > 8) return Fail(ctx, SMHIP_EINVAL, "walk_blocks_per_cu must be 0..8");
-  HIPCHK(hipSetDevice(ctx->device));
-  const uint32_t R = ctx->n_chunks;
-  ctx->run_done = false;
-  if (R == 0) {
-    ctx->run_done = true;
-    return SMHIP_OK;
+}  // extern "C"
+namespace {
+// ---- the stages of one batch, as enqueued on the context stream ----
+
+// A step's kernels are sized by two totals only the device knows: the number of queries (after event
+// detection) and the number of anchors (after the search).  smhip_map_run either reads them back
+// (two stream synchronisations; the first batches of a context) or SPECULATES: the buffers get the
+// capacities recent batches suggest, a guard kernel compares the real total with the capacity where
+// it becomes known and -- beyond it -- empties the batch for the kernels downstream (which then touch
+// nothing) and raises a flag; the whole chain is enqueued without the host ever waiting.  The flag,
+// the totals and the pool state travel to pinned host memory behind the last kernel; whoever next
+// needs the results (smhip_map_sync, the downloads) finds an overflow there and repeats the batch the
+// synchronous way.  Results never depend on the route.
+struct RunInfo {  // pinned host mirror, written by the stream
+  uint32_t nq_total, guard_q, guard_a, pad;
+  uint64_t na_total;
+  uint32_t counters[26];
+};
+
+template <typename OffT>
+__global__ void GuardTotalKernel(uint32_t *__restrict__ counts, OffT *__restrict__ offsets, uint32_t n, OffT cap,
+                                 uint32_t *__restrict__ flag, OffT *__restrict__ total_out) {
+  const OffT total = offsets[n];
+  if (threadIdx.x == 0) *total_out = total;  // the real total, also when the batch is emptied below
+  if (total <= cap) return;
+  __syncthreads();  // (one workgroup: every thread has read the total before anyone clears it)
+  for (uint32_t i = threadIdx.x; i <= n; i += blockDim.x) {
+    if (i < n) counts[i] = 0;
+    offsets[i] = 0;
   }
+  if (threadIdx.x == 0) *flag = 1u;
+}
+
+int EnqueueFront(smhip_ctx *ctx, const smhip_params *p, uint32_t R) {
   HIPCHK(ctx->feat.Reserve((uint64_t)R * kFeatStride * sizeof(float)));
   HIPCHK(ctx->results.Reserve((uint64_t)R * sizeof(smhip_chunk_result)));
   HIPCHK(ctx->nq.Reserve((uint64_t)R * sizeof(uint32_t)));
@@ -841,63 +871,50 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   HIPCHK(ctx->anchor_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t)));
   HIPCHK(ctx->n_groups.Reserve((uint64_t)R * sizeof(uint32_t)));
   HIPCHK(ctx->out_anchor_cnt.Reserve((uint64_t)R * sizeof(uint32_t)));
-  HIPCHK(ctx->counters.Reserve(32 * sizeof(uint32_t)));
-  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+  // counters: [0..31] the search's (zeroed before every walker launch); [32] / [33] guard flags of the
+  // speculative route, [34] queries, [36..37] anchors as counted on the device
+  HIPCHK(ctx->counters.Reserve(40 * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(ctx->counters.as<uint32_t>() + 32, 0, 8 * sizeof(uint32_t), ctx->stream));
   {
     ScopedTimer t(ctx, T_EVENTS);
     HIPCHK(LaunchEvents(ctx, *p, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), R, kFeatStride,
-                        ctx->feat.as<float>(), nullptr, results, ctx->nq.as<uint32_t>()));
+                        ctx->feat.as<float>(), nullptr, ctx->results.as<smhip_chunk_result>(), ctx->nq.as<uint32_t>()));
   }
   HIPCHK(LaunchScanU32(ctx, ctx->nq.as<uint32_t>(), R, ctx->q_off.as<uint32_t>()));
-  uint32_t NQ = 0;
-  HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
+  return SMHIP_OK;
+}
+
+// per-query buffers for up to nq_cap queries, the query records, the search, the chunks' anchor counts
+int EnqueueSearch(smhip_ctx *ctx, const smhip_params *p, uint32_t R, uint64_t nq_cap, uint64_t pool_cap, HitSlots *hit_slots) {
+  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
   HIPCHK(ctx->q_count.Reserve(nq_cap * sizeof(uint32_t)));
-  HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->q_nodes.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->q_points.Reserve(nq_cap * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_list.Reserve(nq_cap * sizeof(uint32_t)));
-  HitSlots hit_slots;
   {
-    int rc = ReserveRegion(ctx, nq_cap, p->hits_per_query_fast, &hit_slots);
+    int rc = ReserveRegion(ctx, nq_cap, p->hits_per_query_fast, hit_slots);
     if (rc) return rc;
   }
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
-  HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
-  // Overflow pool (hits beyond a query's fast slots).  The walker keeps adding the sizes of the
-  // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
-  // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
-  // the size is remembered for the following batches).
-  // (SMHIP_POOL_MIN: test knob that makes the first size too small; read per call, nothing cached)
-  const char *pool_env = getenv("SMHIP_POOL_MIN");
-  const uint64_t pool_first = pool_env ? (uint64_t)strtoull(pool_env, nullptr, 10) : nq_cap * 64 + (1u << 22);
-  uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
-  uint64_t NA = 0;
-  for (int attempt = 0;; ++attempt) {
-    HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
-    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
-    // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
-    HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, hit_slots,
-                            ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
-                            ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(),
-                            pool_cap));
-    HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(),
-                             ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(),
-                             R, ctx->chunk_anchor_cnt.as<uint32_t>(), results));
-    HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
-    uint32_t hc[26] = {0};
-    HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
-    const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
-    if (demand <= pool_cap || demand > 0xFFFF0000ull) break;  // level limit / beyond 32-bit offsets: report the flag
-    pool_cap = demand;
-    ctx->pool_hint = pool_cap;
-  }
-  const uint64_t na = std::max<uint64_t>(NA, 1);
+  HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
+  HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
+  HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+  // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
+  HIPCHK(LaunchSeedLookup(ctx, *p, ctx->qrec.p, ctx->q_off.as<uint32_t>(), R, nq_cap, *hit_slots,
+                          ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
+                          ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(), pool_cap));
+  HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(),
+                           ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(), R,
+                           ctx->chunk_anchor_cnt.as<uint32_t>(), results));
+  HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
+  return SMHIP_OK;
+}
+
+// per-anchor buffers for up to na_cap anchors, sort, chaining
+int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t R, uint64_t na_cap, const HitSlots &hit_slots) {
+  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+  const uint64_t na = std::max<uint64_t>(na_cap, 1);
   DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
                   &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};
   for (DevBuf *b : b4) HIPCHK(b->Reserve(na * 4));
@@ -940,7 +957,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   sa.results = results;
   {
     ScopedTimer t(ctx, T_SORT);
-    HIPCHK(LaunchSort(ctx, sa, R, NA));
+    HIPCHK(LaunchSort(ctx, sa, R, na_cap));
   }
   ChainArgs ca;
   ca.anchor_off = sa.anchor_off;
@@ -963,10 +980,146 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();
   {
     ScopedTimer t(ctx, T_CHAIN);
-    HIPCHK(LaunchChain(ctx, *p, ca, R, NA, n_refs));
+    HIPCHK(LaunchChain(ctx, *p, ca, R, na_cap, n_refs));
   }
   hipLaunchKernelGGL(OrStatusKernel, dim3(64), dim3(256), 0, ctx->stream, results, R, ctx->counters.as<uint32_t>());
   HIPCHK(hipGetLastError());
+  return SMHIP_OK;
+}
+
+uint64_t FirstPoolCap(smhip_ctx *ctx, uint64_t nq_cap) {
+  // Overflow pool (hits beyond a query's fast slots).  The walker keeps adding the sizes of the
+  // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
+  // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
+  // the size is remembered for the following batches).
+  // (SMHIP_POOL_MIN: test knob that makes the first size too small; read per call, nothing cached)
+  const char *pool_env = getenv("SMHIP_POOL_MIN");
+  const uint64_t pool_first = pool_env ? (uint64_t)strtoull(pool_env, nullptr, 10) : nq_cap * 64 + (1u << 22);
+  return std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
+}
+
+void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
+  const uint64_t non_carried = NA > ctx->n_carried ? NA - ctx->n_carried : 0;
+  ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, (NQ + R - 1) / R);
+  ctx->hint_a_per_chunk = std::max<uint64_t>(ctx->hint_a_per_chunk, (non_carried + R - 1) / R);
+  ctx->hint_valid = true;
+}
+
+// the synchronous route: both totals are read back and the buffers sized exactly
+int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
+  const uint32_t R = ctx->n_chunks;
+  int rc = EnqueueFront(ctx, p, R);
+  if (rc) return rc;
+  uint32_t NQ = 0;
+  HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
+  uint64_t pool_cap = FirstPoolCap(ctx, nq_cap);
+  uint64_t NA = 0;
+  HitSlots hit_slots;
+  for (int attempt = 0;; ++attempt) {
+    rc = EnqueueSearch(ctx, p, R, nq_cap, pool_cap, &hit_slots);
+    if (rc) return rc;
+    uint32_t hc[26] = {0};
+    HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
+    const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
+    if (demand <= pool_cap || demand > 0xFFFF0000ull) break;  // level limit / beyond 32-bit offsets: report the flag
+    pool_cap = demand;
+    ctx->pool_hint = pool_cap;
+  }
+  LearnTotals(ctx, R, NQ, NA);
+  return EnqueueBack(ctx, p, n_refs, R, NA, hit_slots);
+}
+
+// the speculative route: nothing is read back; capacities from the totals of earlier batches
+int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
+  const uint32_t R = ctx->n_chunks;
+  uint64_t nq_cap = std::min<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk * 5 / 4 + 32768, 0xFFFFFFF0ull);
+  uint64_t na_cap = (uint64_t)R * ctx->hint_a_per_chunk * 5 / 4 + ctx->n_carried + (1u << 20);
+  // (SMHIP_SPEC_TIGHT: test knob, read per call -- 1 halves the query capacity, 2 the anchor capacity, so that
+  // the guards fire and the batch is repeated on the synchronous route)
+  if (const char *tight = getenv("SMHIP_SPEC_TIGHT")) {
+    if (atoi(tight) == 1) nq_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk / 2, 1);
+    if (atoi(tight) == 2) na_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_a_per_chunk / 2, 1);
+  }
+  if (!ctx->h_run_info) HIPCHK(hipHostMalloc(&ctx->h_run_info, sizeof(RunInfo), hipHostMallocDefault));
+  int rc = EnqueueFront(ctx, p, R);
+  if (rc) return rc;
+  uint32_t *flags = ctx->counters.as<uint32_t>() + 32;  // [0] guard_q, [1] guard_a, [2] queries, [4..5] anchors
+  // beyond the capacity: no queries for anybody downstream (the chunks then hold their carried anchors only)
+  hipLaunchKernelGGL(GuardTotalKernel<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, ctx->nq.as<uint32_t>(),
+                     ctx->q_off.as<uint32_t>(), R, (uint32_t)nq_cap, flags + 0, flags + 2);
+  HIPCHK(hipGetLastError());
+  HitSlots hit_slots;
+  rc = EnqueueSearch(ctx, p, R, nq_cap, FirstPoolCap(ctx, nq_cap), &hit_slots);
+  if (rc) return rc;
+  hipLaunchKernelGGL(GuardTotalKernel<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, ctx->chunk_anchor_cnt.as<uint32_t>(),
+                     ctx->anchor_off.as<uint64_t>(), R, na_cap, flags + 1, reinterpret_cast<uint64_t *>(flags + 4));
+  HIPCHK(hipGetLastError());
+  rc = EnqueueBack(ctx, p, n_refs, R, na_cap, hit_slots);
+  if (rc) return rc;
+  RunInfo *info = static_cast<RunInfo *>(ctx->h_run_info);
+  HIPCHK(hipMemcpyAsync(&info->counters[0], ctx->counters.p, 26 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&info->guard_q, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&info->nq_total, flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&info->na_total, flags + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->spec_pending = true;
+  ++ctx->spec_runs;
+  ctx->spec_params = *p;
+  ctx->spec_n_refs = n_refs;
+  return SMHIP_OK;
+}
+
+// Called by everything that hands results to the host: waits for the stream and, when a speculative batch
+// outgrew a capacity (or the hit pool), maps the batch again the synchronous way -- and repeats the sDTW
+// refinement that was enqueued behind it.
+int FinishRun(smhip_ctx *ctx) {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!ctx->spec_pending) return SMHIP_OK;
+  ctx->spec_pending = false;
+  const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);
+  const bool overflow = info->guard_q || info->guard_a || info->counters[3];
+  if (!overflow) {
+    LearnTotals(ctx, std::max(ctx->n_chunks, 1u), info->nq_total, info->na_total);
+    return SMHIP_OK;
+  }
+  ++ctx->spec_reruns;
+  int rc = RunBatchSync(ctx, &ctx->spec_params, ctx->spec_n_refs);
+  if (rc) return rc;
+  if (ctx->refine_done) rc = smhip_refine_run(ctx, ctx->refine_band, ctx->refine_pad);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SMHIP_OK;
+}
+}  // namespace
+extern "C" {
+
+int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
+  if (!ctx || !p) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before an index is resident");
+  if (!ctx->batch_ready) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before smhip_batch_upload");
+  if (n_refs == 0 || p->step_size < 1 || p->hits_per_query_fast == 0 || p->num_nearest_points < 1 ||
+      p->num_best_chains > 3)
+    return Fail(ctx, SMHIP_EINVAL, "bad parameter");
+  if (p->walk_blocks_per_cu > 8) return Fail(ctx, SMHIP_EINVAL, "walk_blocks_per_cu must be 0..8");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->spec_pending) {  // the previous batch was never collected: settle it first
+    int rc = FinishRun(ctx);
+    if (rc) return rc;
+  }
+  const uint32_t R = ctx->n_chunks;
+  ctx->run_done = false;
+  if (R == 0) {
+    ctx->run_done = true;
+    return SMHIP_OK;
+  }
+  // (SMHIP_SYNC_RUN=1: always the synchronous route -- an A/B switch; results are the same)
+  const bool speculate = ctx->hint_valid && !Knobs().sync_run && !getenv("SMHIP_POOL_MIN");
+  const int rc = speculate ? RunBatchSpeculative(ctx, p, n_refs) : RunBatchSync(ctx, p, n_refs);
+  if (rc) return rc;
   ctx->run_done = true;
   return SMHIP_OK;
 }
@@ -974,7 +1127,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
 int smhip_map_sync(smhip_ctx *ctx) {
   if (!ctx) return SMHIP_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc = FinishRun(ctx);
+  if (rc) return rc;
   ResolveTimers(ctx);
   return SMHIP_OK;
 }
@@ -988,6 +1142,10 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
   if (R == 0) {
     if (chain_anchor_offsets) chain_anchor_offsets[0] = 0;
     return SMHIP_OK;
+  }
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
   }
   HIPCHK(hipMemcpyAsync(results, ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,
                         ctx->stream));
@@ -1055,6 +1213,8 @@ int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t R = ctx->n_chunks;
   ctx->refine_done = false;
+  ctx->refine_band = band;  // (FinishRun repeats the refinement behind a batch it had to map again)
+  ctx->refine_pad = pad;
   if (R == 0) {
     ctx->refine_done = true;
     return SMHIP_OK;
@@ -1077,6 +1237,10 @@ int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos) {
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t R = ctx->n_chunks;
   if (R == 0) return SMHIP_OK;
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
   HIPCHK(hipMemcpyAsync(dist, ctx->refine_dist.p, (uint64_t)R * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(end_pos, ctx->refine_end.p, (uint64_t)R * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1096,6 +1260,10 @@ int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   if (R == 0) {
     ctx->refine_path_done = true;
     return SMHIP_OK;
+  }
+  {  // (this call sizes its scratch from the batch's results: they must be final)
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
   }
   const smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
   const uint64_t r1 = (uint64_t)R + 1;
@@ -1203,8 +1371,14 @@ int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]) {
   memset(out, 0, 16 * sizeof(uint32_t));
   if (!ctx->counters.p) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
   HIPCHK(hipMemcpyAsync(out, ctx->counters.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  out[4] = ctx->spec_reruns;
+  out[5] = ctx->spec_runs;
   return SMHIP_OK;
 }
 
@@ -1281,6 +1455,10 @@ int smhip_events_raw(smhip_ctx *ctx, uint32_t n_chunks, uint32_t feat_stride, ui
   if ((ps || pss || t1 || t2) && row_stride < (uint32_t)kMaxSamples + 1)
     return Fail(ctx, SMHIP_EINVAL, "row_stride must be >= 4097");
   HIPCHK(hipSetDevice(ctx->device));
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
   const uint64_t evn = (uint64_t)n_chunks * feat_stride;
   DevBuf d_start, d_len;
   std::vector<uint16_t> h_peaks;

@@ -213,6 +213,14 @@ struct smhip_ctx {
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact, sort_tmp;
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
+  // speculative batches (api.hip RunBatchSpeculative): queries / non-carried anchors per chunk of the largest
+  // batch so far, the pinned record the stream reports a batch's totals and flags in, what a repeat needs
+  uint64_t hint_q_per_chunk = 0, hint_a_per_chunk = 0;
+  bool hint_valid = false, spec_pending = false;
+  void *h_run_info = nullptr;
+  smhip_params spec_params{};
+  uint32_t spec_n_refs = 0, spec_reruns = 0, spec_runs = 0;
+  uint32_t refine_band = 0, refine_pad = 0;
   // sDTW refinement
   smhip::DevBuf ref_sig, ref_off, refine_dist, refine_end;
   // DTW-with-path refinement (smhip_refine_path_run): per-chunk / per-row window arrays and results
@@ -273,6 +281,7 @@ struct EnvKnobs {
   int classes = 0;             // SMHIP_CLASSES
   int bucket_bits = 0;         // SMHIP_BUCKET_BITS
   int sdtw_ring = 0;           // SMHIP_SDTW_RING
+  int sync_run = 0;            // SMHIP_SYNC_RUN: smhip_map_run always reads its two totals back
 };
 const EnvKnobs &Knobs();
 // Per-device kernel attributes (dynamic LDS opt-ins): called by smhip_init for the context's device.

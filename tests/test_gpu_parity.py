@@ -634,6 +634,76 @@ def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tr
     dev.close()
 
 
+def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
+    """smhip_map_run sizes its later stages from two totals only the device knows.  The first batch of a
+    context reads them back (two stream synchronisations); later batches are enqueued whole against
+    capacities learnt from earlier ones, with guard kernels on the device.  Same records either way --
+    also when a guard fires (SMHIP_SPEC_TIGHT halves a capacity: the batch is emptied on the device,
+    flagged, and repeated on the reading route by the next call that collects results, sDTW refinement
+    included) and when a batch is several times larger per chunk than anything seen before."""
+    pa, ix, ref_lens = small_world["pa"], small_world["ix"], small_world["ref_lens"]
+    genome, lm = small_world["genome"], small_world["lm"]
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    sig, offs = pipeline.reference_signals(genome, lm)
+    dev.upload_reference(sig, offs)
+    samples, offsets = _batch(pa[:24])
+
+    def run(with_refine=True):
+        dev.upload_batch(samples, offsets)
+        dev.run(3)
+        if with_refine:
+            dev.refine(band=64, pad=32)
+        dev.sync()
+        res = dev.download()
+        return res.tobytes(), (tuple(x.tobytes() for x in dev.refine_download()) if with_refine else None)
+
+    base = run()                                         # reading route: learns the totals
+    c = dev.debug_counters()
+    assert c[5] == 0 and c[4] == 0
+    assert run() == base                                 # speculative, capacities hold
+    c = dev.debug_counters()
+    assert c[5] == 1 and c[4] == 0
+    for k, tight in enumerate(("1", "2")):               # query guard, then anchor guard: repeated, identical
+        os.environ["SMHIP_SPEC_TIGHT"] = tight
+        try:
+            assert run() == base
+        finally:
+            del os.environ["SMHIP_SPEC_TIGHT"]
+        c = dev.debug_counters()
+        assert c[5] == 2 + k and c[4] == 1 + k, (tight, c[:8])
+    assert run(with_refine=False)[0] == base[0]
+    # a batch with ~20 x the anchors per chunk of anything seen so far (wide radius): the anchor guard fires by
+    # itself; the result is the oracle's
+    dev.params.search_radius = 0.5
+    s2, o2 = _batch(pa)                                  # 48 chunks x > 16 384 anchors: beyond the 2^20 slack
+    dev.upload_batch(s2, o2)
+    dev.run(3)
+    dev.sync()
+    res = dev.download()
+    c = dev.debug_counters()
+    assert c[4] == 3 and (res["status"] == 0).all() and int(res["n_anchors"].sum()) > (1 << 20) + 48 * 2000
+    names = ["contig0", "contig1", "contig2"]
+    lines = _paf_lines(res, pa, names, ref_lens)
+    for i, x in enumerate(pa[:6]):
+        m = po.map_read(oracle_tree, ix.positions, x, 3, ref_lens, params={"search_radius": 0.5})
+        assert res[i]["n_anchors"] == m.stats.anchors and lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
+    # ... and the next wide batch fits what was learnt from it
+    dev.upload_batch(s2, o2)
+    dev.run(3)
+    dev.sync()
+    assert dev.download().tobytes() == res.tobytes() and dev.debug_counters()[4] == 3
+    # a collected-by-nobody batch is settled by the next upload (no stale flag, no hang)
+    dev.params.search_radius = pipeline.default_params().search_radius
+    dev.upload_batch(samples, offsets)
+    dev.run(3)
+    dev.upload_batch(samples, offsets)
+    dev.run(3)
+    dev.sync()
+    assert dev.download().tobytes() == base[0]
+    dev.close()
+
+
 def test_pipeline_empty_and_degenerate_batches(device):
     res = device.map_chunks(np.zeros(0, np.float32), np.array([0], np.uint32), n_refs=3)
     assert len(res) == 0
