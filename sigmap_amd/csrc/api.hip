@@ -193,6 +193,11 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
     smhip_destroy(ctx);
     return SMHIP_EHIP;
   }
+  if (hipHostMalloc(&ctx->h_run_info, 256, hipHostMallocDefault) != hipSuccess) {  // RunInfo of the speculative batches
+    ctx->h_run_info = nullptr;
+    smhip_destroy(ctx);
+    return SMHIP_EHIP;
+  }
   ctx->timers.resize(T_COUNT);
   for (int i = 0; i < T_COUNT; ++i) ctx->timers[i].name = kTimerNames[i];
   *out = ctx;
@@ -842,11 +847,14 @@ namespace {
 // the totals and the pool state travel to pinned host memory behind the last kernel; whoever next
 // needs the results (smhip_map_sync, the downloads) finds an overflow there and repeats the batch the
 // synchronous way.  Results never depend on the route.
-struct RunInfo {  // pinned host mirror, written by the stream
-  uint32_t nq_total, guard_q, guard_a, pad;
-  uint64_t na_total;
-  uint32_t counters[26];
+// pinned host mirror of the context's 40 counter words, copied behind the last kernel of a speculative batch:
+// [0..25] the search's counters ([3] pool exhausted), [32] / [33] the guards' flags, [34] queries and
+// [36..37] anchors as counted on the device
+struct RunInfo {
+  uint32_t w[40];
+  uint64_t anchors() const { return (uint64_t)w[36] | ((uint64_t)w[37] << 32); }
 };
+static_assert(sizeof(RunInfo) <= 256, "smhip_init allocates 256 bytes for it");
 
 template <typename OffT>
 __global__ void GuardTotalKernel(uint32_t *__restrict__ counts, OffT *__restrict__ offsets, uint32_t n, OffT cap,
@@ -998,6 +1006,14 @@ uint64_t FirstPoolCap(smhip_ctx *ctx, uint64_t nq_cap) {
   return std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
 }
 
+// capacities of a speculative batch of R chunks: 25 % above the largest per-chunk totals seen, plus slack
+uint64_t SpecCapQueries(const smhip_ctx *ctx, uint32_t R) {
+  return std::min<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk * 5 / 4 + 32768, 0xFFFFFFF0ull);
+}
+uint64_t SpecCapAnchors(const smhip_ctx *ctx, uint32_t R) {
+  return (uint64_t)R * ctx->hint_a_per_chunk * 5 / 4 + ctx->n_carried + (1u << 20);
+}
+
 void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
   const uint64_t non_carried = NA > ctx->n_carried ? NA - ctx->n_carried : 0;
   ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, (NQ + R - 1) / R);
@@ -1013,7 +1029,10 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   uint32_t NQ = 0;
   HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
+  // (buffers are reserved at the capacity a speculative batch of this size would ask for next, so that the
+  // switch to that route does not reallocate -- a hipFree synchronises the whole device)
+  ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, ((uint64_t)NQ + R - 1) / R);
+  const uint64_t nq_cap = std::max<uint64_t>(std::max<uint64_t>(NQ, 1), SpecCapQueries(ctx, R));
   uint64_t pool_cap = FirstPoolCap(ctx, nq_cap);
   uint64_t NA = 0;
   HitSlots hit_slots;
@@ -1031,21 +1050,20 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     ctx->pool_hint = pool_cap;
   }
   LearnTotals(ctx, R, NQ, NA);
-  return EnqueueBack(ctx, p, n_refs, R, NA, hit_slots);
+  return EnqueueBack(ctx, p, n_refs, R, std::max<uint64_t>(NA, SpecCapAnchors(ctx, R)), hit_slots);
 }
 
 // the speculative route: nothing is read back; capacities from the totals of earlier batches
 int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   const uint32_t R = ctx->n_chunks;
-  uint64_t nq_cap = std::min<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk * 5 / 4 + 32768, 0xFFFFFFF0ull);
-  uint64_t na_cap = (uint64_t)R * ctx->hint_a_per_chunk * 5 / 4 + ctx->n_carried + (1u << 20);
+  uint64_t nq_cap = SpecCapQueries(ctx, R), na_cap = SpecCapAnchors(ctx, R);
   // (SMHIP_SPEC_TIGHT: test knob, read per call -- 1 halves the query capacity, 2 the anchor capacity, so that
   // the guards fire and the batch is repeated on the synchronous route)
   if (const char *tight = getenv("SMHIP_SPEC_TIGHT")) {
     if (atoi(tight) == 1) nq_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk / 2, 1);
     if (atoi(tight) == 2) na_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_a_per_chunk / 2, 1);
   }
-  if (!ctx->h_run_info) HIPCHK(hipHostMalloc(&ctx->h_run_info, sizeof(RunInfo), hipHostMallocDefault));
+  if (!ctx->h_run_info) HIPCHK(hipHostMalloc(&ctx->h_run_info, 256, hipHostMallocDefault));  // (smhip_init allocates it)
   int rc = EnqueueFront(ctx, p, R);
   if (rc) return rc;
   uint32_t *flags = ctx->counters.as<uint32_t>() + 32;  // [0] guard_q, [1] guard_a, [2] queries, [4..5] anchors
@@ -1061,11 +1079,7 @@ int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) 
   HIPCHK(hipGetLastError());
   rc = EnqueueBack(ctx, p, n_refs, R, na_cap, hit_slots);
   if (rc) return rc;
-  RunInfo *info = static_cast<RunInfo *>(ctx->h_run_info);
-  HIPCHK(hipMemcpyAsync(&info->counters[0], ctx->counters.p, 26 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&info->guard_q, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&info->nq_total, flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&info->na_total, flags + 4, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_run_info, ctx->counters.p, sizeof(RunInfo), hipMemcpyDeviceToHost, ctx->stream));
   ctx->spec_pending = true;
   ++ctx->spec_runs;
   ctx->spec_params = *p;
@@ -1081,9 +1095,9 @@ int FinishRun(smhip_ctx *ctx) {
   if (!ctx->spec_pending) return SMHIP_OK;
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);
-  const bool overflow = info->guard_q || info->guard_a || info->counters[3];
+  const bool overflow = info->w[32] || info->w[33] || info->w[3];
   if (!overflow) {
-    LearnTotals(ctx, std::max(ctx->n_chunks, 1u), info->nq_total, info->na_total);
+    LearnTotals(ctx, std::max(ctx->n_chunks, 1u), info->w[34], info->anchors());
     return SMHIP_OK;
   }
   ++ctx->spec_reruns;

@@ -12,6 +12,7 @@
 // as chain ends, so it is re-applied after the DP as (prefix max over earlier buckets) +
 // (running max inside the bucket), which is the same sequence of values.
 #include <float.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -87,6 +88,24 @@ __global__ __launch_bounds__(256) void ChainTileCountKernel(ChainArgs a, uint32_
 __device__ unsigned long long g_phase_prof[32];  // (the PHASE_* macros of common.h)
 #endif
 
+// The gap tests of a predecessor that lies within max_target_gap_length on the target (spatial_index.cc:483-497):
+// gap_length < max_gap_length && 0.75 < gap_scale < 5 with gap_scale = (float)qd / (float)td.  For
+// 0 < td < 2^21 and 0 <= qd the two float comparisons are EXACTLY the integer ones, 4 qd > 3 td and qd < 5 td:
+// near either bound qd < 2^24, so both operands convert exactly, and their correctly rounded quotient can
+// only reach 5 (or 0.75) from the other side when it lies within half an ulp of it, i.e. when 1 / td < 2^-22
+// (resp. 1 / (4 td) < 2^-25); a qd beyond 2^24 gives a quotient above 8 either way.  Checked against the float
+// form for every td < 2^21 at and around both bounds, and for every (td, qd) with td <= 6000.  td is at most
+// max_target_gap_length where this is called; kIntGap = false keeps the division for parameters beyond 2^21.
+template <bool kIntGap>
+__device__ __forceinline__ bool GapTestsPass(int32_t td, int32_t qd, int max_gap_length) {
+  const int gap_length = abs(td - qd);
+  // (0 < td < 2^21: 5 td and 3 td fit 32 bits; 4 qd > 3 td  <=>  qd > floor(3 td / 4))
+  if (kIntGap) return gap_length < max_gap_length && qd < 5 * td && qd > ((3 * td) >> 2);
+  const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
+  return gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f;
+}
+
+template <bool kIntGap>
 __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t n_chunks,
                                                            const uint32_t *__restrict__ tile_off, float radius, int dim,
                                                            int max_gap_length, int max_target_gap_length,
@@ -94,12 +113,10 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   // Every WAVE works on its own: no workgroup barrier anywhere (the 256-anchor tiles of the first version spent a
   // fifth of their time waiting at the barrier behind the wave with the longest backward scan).
   __shared__ uint32_t s_gmax_all[4][kTile + 2];  // maxima of the buckets the tile touches, relative to its first bucket
-  __shared__ int32_t s_t_all[4][kRing], s_q_all[4][kRing];
-  __shared__ uint32_t s_g_all[4][kRing];
+  __shared__ uint4 s_ring_all[4][kRing];         // {target, query, bucket, -}: one 16-byte LDS read per scan step
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *s_gmax = s_gmax_all[wave];
-  int32_t *s_t = s_t_all[wave], *s_q = s_q_all[wave];
-  uint32_t *s_g = s_g_all[wave];
+  uint4 *s_ring = s_ring_all[wave];
   // Every wave takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1, ...): one
   // search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p in slot p & 127)
   // already holds the previous tile, so a tile loads only its own 64 records.
@@ -146,11 +163,10 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         nx_g = grp[ai];
         nx_d = dist[ai];
       }
-      s_t[ai & (kRing - 1)] = (int32_t)nx_t;
-      s_q[ai & (kRing - 1)] = (int32_t)nx_q;
-      s_g[ai & (kRing - 1)] = nx_g;
+      s_ring[ai & (kRing - 1)] = make_uint4(nx_t, nx_q, nx_g, 0u);
       my_dist = nx_d;
     }
+    const uint32_t my_t = nx_t, my_q = nx_q, my_g = nx_g;
     have_nx = tile + 1 < tile_end && tile + 1 < tile_off[c + 1];
     if (have_nx) {
       const uint32_t gi = ai + kTile;
@@ -163,9 +179,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     }
     if (!ring_valid && t0 > 0) {  // first tile of this wave in the middle of a chunk
       const uint32_t p = w0 + lane;
-      s_t[p & (kRing - 1)] = (int32_t)tpos[p];
-      s_q[p & (kRing - 1)] = (int32_t)qpos[p];
-      s_g[p & (kRing - 1)] = grp[p];
+      s_ring[p & (kRing - 1)] = make_uint4(tpos[p], qpos[p], grp[p], 0u);
     }
     s_gmax[lane] = 0;
     if (lane < 2) s_gmax[kTile + lane] = 0;
@@ -187,54 +201,68 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     uint32_t ord = 0, ord_last = 0;
     {
       // (with a valid ring the anchor before the tile is in LDS too: its bucket starts the count)
-      const bool change = ai < n && (ai > t0 || ring_valid) && s_g[ai & (kRing - 1)] != s_g[(ai - 1) & (kRing - 1)];
+      const bool change = ai < n && (ai > t0 || ring_valid) && my_g != s_ring[(ai - 1) & (kRing - 1)].z;
       const unsigned long long m = __ballot(change);
       ord = first_ord + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));  // changes up to and including ai
       ord_last = first_ord + (uint32_t)__popcll(m);                       // ordinal of the tile's last anchor
       first_ord += (uint32_t)(m & 1ull);                                  // ordinal of the tile's first anchor
     }
     PHASE_MARK(1);
-    if (ai < n) {
-      const uint32_t g = s_g[ai & (kRing - 1)];
-      const int32_t ct = s_t[ai & (kRing - 1)], cq = s_q[ai & (kRing - 1)];
-      bool isolated = true;
-      int32_t skips = 0;
-      uint32_t steps = 0;
-      // the predecessor's record (bucket, target, query) is read one step ahead of its use, all
-      // three words together, so that a step of the scan does not wait for LDS
-      auto rec = [&](uint32_t pj, uint32_t &rg, int32_t &rt, int32_t &rq) {
-        if (pj >= w0) {
-          rg = s_g[pj & (kRing - 1)];
-          rt = s_t[pj & (kRing - 1)];
-          rq = s_q[pj & (kRing - 1)];
-        } else {
-          rg = grp[pj];
-          rt = (int32_t)tpos[pj];
-          rq = (int32_t)qpos[pj];
-        }
-      };
-      uint32_t ng = ~g;
-      int32_t nt = 0, nq = 0;
-      if (ai > 0) rec(ai - 1, ng, nt, nq);
-      for (uint32_t pj = ai; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-        const uint32_t pg = ng;
-        const int32_t pt = nt, pq = nq;
-        if (pj > 0) rec(pj - 1, ng, nt, nq);
-        if (pg != g) break;  // bucket start
+    // ---- the backward scans of the tile's 64 anchors, in lockstep and WITHOUT BRANCHES while the predecessors
+    // are in the ring: a step is one 16-byte LDS read and ~25 predicated VALU operations for all lanes (the
+    // per-lane branches of the sequential form cost three times that per step).  `found`: a predecessor passed
+    // the gap tests (the anchor is not isolated); `active` ends at a bucket start, beyond the target gap, after
+    // max_num_skips + 1 failed candidates, with `found`, or when the band is used up.
+    const int32_t ct = (int32_t)my_t, cq = (int32_t)my_q;
+    bool found = false;
+    bool active = ai < n && ai > 0;
+    uint32_t pj = ai;  // the next predecessor is pj - 1
+    int32_t skips = 0;
+    uint32_t steps = 0;
+    for (;;) {
+      const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
+      if (!__ballot(go)) break;
+      const uint4 r = s_ring[(pj - 1u) & (kRing - 1)];
+      const int32_t pt = (int32_t)r.x, pq = (int32_t)r.y;
+      const bool other_bucket = r.z != my_g;
+      const bool same_pos = pq == cq || pt == ct;                     // `continue`: not evaluated, no skip counted
+      const bool far = pt + max_target_gap_length < ct;               // `break`
+      const int32_t td = ct - pt, qd = cq - pq;
+      const bool evaluated = !other_bucket && !same_pos && !far && qd >= 0;
+      const bool pass = evaluated && GapTestsPass<kIntGap>(td, qd, max_gap_length);
+      const bool fail = evaluated && !pass;
+      if (go) {
+        found = pass;
+        skips += fail ? 1 : 0;
+        // (a far predecessor ends the scan also when it shares the query position: every older predecessor of
+        // the bucket is farther still, so the reference's loop `continue`s or `break`s its way out of the bucket
+        // without evaluating anything)
+        active = !(other_bucket || far || pass || skips > max_num_skips);
+        --pj;
+        ++steps;
+      }
+    }
+    // lanes whose scan leaves the ring (64+ predecessors back: dense true-locus regions): the sequential form,
+    // predecessors from memory
+    if (active && pj > 0 && pj <= w0 && steps < (uint32_t)chaining_band_length) {
+      for (; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
+        const uint32_t pg = grp[pj];
+        const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
+        if (pg != my_g) break;  // bucket start
         if (pq == cq || pt == ct) continue;
         if (pt + max_target_gap_length < ct) break;
         const int32_t td = ct - pt, qd = cq - pq;
         if (qd < 0) continue;
-        const int gap_length = abs(td - qd);
-        const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-        if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) {
-          isolated = false;
+        if (GapTestsPass<kIntGap>(td, qd, max_gap_length)) {
+          found = true;
           break;
         }
         if (++skips > max_num_skips) break;
       }
-      PHASE_MARK(2);
-      if (isolated) {
+    }
+    PHASE_MARK(2);
+    if (ai < n) {
+      if (!found) {
         const float coef = (float)(1 - 0.2 * (double)my_dist / (double)radius);
         const float sc = coef * (float)dim;
         score[ai] = sc;
@@ -369,6 +397,7 @@ __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_t
 // ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER ITEM, flattened over the whole batch.
 // Predecessor records are fetched kPf at a time so the dependent chain sees one memory latency
 // per block instead of one per predecessor.
+template <bool kIntGap>
 __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
                                                     float radius, int dim, int max_gap_length,
                                                     int max_target_gap_length, int chaining_band_length,
@@ -529,9 +558,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
         {
           const int32_t m = min(min(td, qd), dim);
           const float matching = (float)m * coef;
-          const int gap_length = abs(td - qd);
-          const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-          if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f) curv = ps[kk] + matching;
+          if (GapTestsPass<kIntGap>(td, qd, max_gap_length)) curv = ps[kk] + matching;
         }
         if (curv > best) {
           best = curv;
@@ -567,7 +594,7 @@ __global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t 
 // target (spatial_index.cc:461-540) -- are reproduced with an exclusive prefix max (running
 // best), a prefix sum (num_skips) and ballots (first exit), which yields exactly the state the
 // sequential loop would have at its exit.
-template <bool kLds>
+template <bool kLds, bool kIntGap>
 __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t s, const uint32_t *__restrict__ pend,
                                             uint32_t npend, int32_t *l_t, int32_t *l_q, float *l_s, float *l_d,
                                             const uint32_t *tpos, const uint32_t *qpos, const float *dist,
@@ -627,10 +654,7 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
             cls = 3;
             const int32_t m = min(min(td, qd), dim);
             const float matching = (float)m * coef;
-            const int gap_length = abs(td - qd);
-            const float gap_scale = td > 0 ? (float)qd / (float)td : 1.0f;
-            if (gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f)
-              cur = (in_ring ? l_s[pm] : score[pj]) + matching;
+            if (GapTestsPass<kIntGap>(td, qd, max_gap_length)) cur = (in_ring ? l_s[pm] : score[pj]) + matching;
           }
         }
       }
@@ -679,6 +703,7 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
   if (lane == 0) atomicMax(gmax_slot, __float_as_uint(gm));  // (other items of the bucket run at the same time)
 }
 
+template <bool kIntGap>
 __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ ioff,
                                                        uint32_t n_chunks, float radius, int dim, int max_gap_length,
                                                        int max_target_gap_length, int chaining_band_length,
@@ -722,10 +747,10 @@ __global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32
       }
     __syncthreads();
     if (in_lds)
-      DpBigBucket<true>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
+      DpBigBucket<true, kIntGap>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
                         &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
     else
-      DpBigBucket<false>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
+      DpBigBucket<false, kIntGap>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
                          &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length,
                          max_num_skips);
   }
@@ -1329,20 +1354,39 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   if ((e = LaunchScanU32(ctx, tiles, n_chunks, tile_off)) != hipSuccess) return e;
   const uint64_t max_tiles = n_anchors_total / kTile + n_chunks;
   const uint32_t tile_blocks = (uint32_t)std::min<uint64_t>((max_tiles + 3) / 4, 256u * 8u * 2u);  // four waves (tile ranges) each
-  hipLaunchKernelGGL(ChainClassifyKernel, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
-                     p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
-                     p.max_num_skips);
+  // (integer form of the gap-scale tests: exact for target gaps below 2^21, see GapTestsPass)
+  // (SMHIP_FLOAT_GAP: test knob, read per call -- the float form also where the integer one is valid)
+  const bool int_gap = p.max_target_gap_length >= 0 && p.max_target_gap_length < (1 << 21) && !getenv("SMHIP_FLOAT_GAP");
+  if (int_gap)
+    hipLaunchKernelGGL(ChainClassifyKernel<true>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
+                       p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
+                       p.max_num_skips);
+  else
+    hipLaunchKernelGGL(ChainClassifyKernel<false>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
+                       p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
+                       p.max_num_skips);
   hipLaunchKernelGGL(ChainPendingKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.max_target_gap_length, n_pending,
                      n_items);
   if ((e = LaunchScanU32(ctx, n_items, n_chunks, ioff)) != hipSuccess) return e;
   const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((n_anchors_total + 63) / 64, 16384);
-  if (dp_blocks > 0)
-    hipLaunchKernelGGL(ChainDpKernel, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+  if (dp_blocks > 0) {
+    if (int_gap)
+      hipLaunchKernelGGL(ChainDpKernel<true>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+                         kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
+                         big_list, big_count, n_pending);
+    else
+      hipLaunchKernelGGL(ChainDpKernel<false>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+                         kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
+                         big_list, big_count, n_pending);
+  }
+  if (int_gap)
+    hipLaunchKernelGGL(ChainDpBigKernel<true>, dim3(8192), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
                        kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
                        big_list, big_count, n_pending);
-  hipLaunchKernelGGL(ChainDpBigKernel, dim3(8192), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
-                     kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
-                     big_list, big_count, n_pending);
+  else
+    hipLaunchKernelGGL(ChainDpBigKernel<false>, dim3(8192), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+                       kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips,
+                       big_list, big_count, n_pending);
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
                      p.num_best_chains, p.min_chaining_score, n_chains, n_pending, kMaxDim);
   hipLaunchKernelGGL(ChainFinalizeKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);

@@ -704,6 +704,20 @@ def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
     dev.close()
 
 
+def test_integer_gap_tests_equal_the_float_form(device, small_world):
+    """The chaining kernels evaluate `0.75 < (float)qd / (float)td < 5` (spatial_index.cc:489-497) as
+    4 qd > 3 td and qd < 5 td, exact for target gaps below 2^21 (chain.hip GapTestsPass; exhaustive host
+    check: tools/micro/gap_tests.c).  SMHIP_FLOAT_GAP selects the division form: identical records."""
+    samples, offsets = _batch(small_world["pa"])
+    base = device.map_chunks(samples, offsets, n_refs=3)
+    os.environ["SMHIP_FLOAT_GAP"] = "1"
+    try:
+        flt = device.map_chunks(samples, offsets, n_refs=3)
+    finally:
+        del os.environ["SMHIP_FLOAT_GAP"]
+    assert base.tobytes() == flt.tobytes() and (base["n_chains"] > 0).sum() > 40
+
+
 def test_pipeline_empty_and_degenerate_batches(device):
     res = device.map_chunks(np.zeros(0, np.float32), np.array([0], np.uint32), n_refs=3)
     assert len(res) == 0
