@@ -17,8 +17,9 @@ Two timed regions of EXACTLY K steps each, both fenced by barrier + synchronize:
                    resident in host RAM").
 
 Prints ONE JSON line on rank 0, including
-  roofline     : HBM traffic of the dominant kernel (seed_lookup) from calibrated counters / its launch
-                 duration, next to the kernel's own algorithmic bytes and the reference algorithm's
+  roofline     : fabric (L2-miss) traffic of the dominant kernel (seed_lookup) from the committed counter profile of
+                 this workload shape / its launch duration measured live, next to the random-line ceiling, the
+                 useful bytes by SURVEY 8(d)'s weights, the kernel's own bytes and the reference algorithm's
   cpu_baseline : the CPU restatement (oracle/, "port") timed on bounded samples, rank 0, N=1
 """
 import argparse
@@ -36,6 +37,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_STREAM_GBS = 6290.0    # same guide: measured streaming ceiling (float4 copy)
+RANDOM_LINES_PER_S = 52e9  # tools/micro/random_lines.hip: random 128-byte lines per second beyond L2
 CHUNK = 4000
 REF_CHUNKS_PER_S_PER_CORE = 19.6  # unmodified reference, -t 1, 12 Mb (survey probe)
 
@@ -314,20 +316,27 @@ def main():
         # written, the query records -- i.e. what a perfect memory system would have to move for it
         own_bytes = 64 * w_nodes + 32 * w_points + 16 * int(res["hits_total"].sum()) + 64 * queries
         seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"]
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-        # (the counter profile was taken on the default workload: for any other shape the kernel's own bytes)
-        default_shape = (args.reads == 10000 and args.contigs == 16 and args.contig_len == 750000 and
-                         args.walk_blocks == 0 and args.fast_cap == 0)
-        if default_shape and os.path.exists(pmc):
+        # SURVEY 8(d) weights on the WALKER'S OWN visits (16 B per node record it needs, 28 B per point it tests, 24 B
+        # per anchor, the raw samples and the result record): the bytes a perfect layout would have to move
+        useful_bytes = 2 * CHUNK * R + 16 * w_nodes + 28 * w_points + 24 * anchors + 64 * R
+        traffic, traffic_src, prof_ms = None, None, None
+        # a committed counter profile whose workload has this run's shape (tools/collect_profiles.sh)
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_pmc_traffic.json"))):
             try:
                 j = json.load(open(pmc))
-                traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
-                traffic_src = j.get("source")
+                sh = j.get("shape") or {}
+                if (sh.get("reads"), sh.get("contigs"), sh.get("contig_len")) == (args.reads, args.contigs, args.contig_len) \
+                        and args.walk_blocks == 0 and args.fast_cap == 0:
+                    traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
+                    traffic_src = j.get("source")
+                    prof_ms = (j.get("launch_avg_ns_kernel_trace_serial") or 0) * 1e-6 or None
+                    break
             except Exception:
                 traffic = None
         basis = traffic if traffic else own_bytes
         achieved = basis / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+        lines_per_s = (traffic / 128.0) / (seed_ms * 1e-3) if traffic and seed_ms > 0 else None
         total_chunks = R * world * args.steps
         out = {
             "metric": "signal chunks/sec (4k-sample reads) mapped to yeast ref",
@@ -381,11 +390,17 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "basis": ("calibrated memory-side counters (profiles/r2_calibration.json: every L2 read miss is a "
-                          "128-byte request, writes by WRITE_SIZE), per launch, from the profile run named in "
-                          "traffic_source" if traffic else
-                          "the walker's own algorithmic bytes (no counter profile for this workload under profiles/: the committed "
-                          "one is for the default workload only)"),
+                "basis": ("L2-miss (fabric) bytes of the committed counter profile named in traffic_source -- 128 B x "
+                          "TCC_EA0_RDREQ + WRITE_SIZE per launch (profiles/r3_calibration.json); they INCLUDE Infinity-Cache "
+                          "hits, so frac is an upper bound on HBM utilisation -- divided by THIS run's launch duration "
+                          "(the profile's own: profile_launch_ms)" if traffic else
+                          "the walker's own algorithmic bytes (no counter profile of this workload shape under profiles/)"),
+                "profile_launch_ms": round(prof_ms, 4) if prof_ms else None,
+                # 128-byte lines per second against the 52 G random lines / s tools/micro/random_lines.hip measures beyond L2
+                "frac_of_random_line_ceiling": round(lines_per_s / RANDOM_LINES_PER_S, 4) if lines_per_s else None,
+                # SURVEY 8(d) weights on the walker's own node visits and point tests: what a perfect layout would move
+                "useful_bytes_per_launch": useful_bytes,
+                "useful_bytes_frac": round(useful_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seed_ms > 0 else None,
                 "frac_of_measured_streaming_ceiling": round(achieved / HBM_STREAM_GBS, 4),
                 "launch_ms": round(seed_ms, 4),
                 "measured": "HIP events on the context stream around the SeedWalkKernel launch, serial pass of this run "

@@ -1,7 +1,7 @@
 """Reduces the raw rocprofv3 counter CSVs of tools/calibrate_traffic.sh (gpurun_out/calib/) to
 per-kernel, per-dispatch counter means and compares the calibration kernels with their known byte
 counts.  Writes gpurun_out/calib/summary.json on the GPU box; `python tools/calib_summarize.py commit`
-copies the result to profiles/r2_calibration.json."""
+copies the result to profiles/r3_calibration.json."""
 import collections
 import csv
 import glob
@@ -93,6 +93,6 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "commit":
-        shutil.copy(os.path.join(SRC, "summary.json"), os.path.join(ROOT, "profiles", "r2_calibration.json"))
+        shutil.copy(os.path.join(SRC, "summary.json"), os.path.join(ROOT, "profiles", "r3_calibration.json"))
     else:
         main()

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): PMC passes (one counter set each, never with sys/hip/hsa tracing)
 # over tools/micro/calib_traffic (known byte counts, walker access shapes) and over the bench's
 # walker, raw output under gpurun_out/calib/.  tools/calib_summarize.py writes the committed
-# profiles/r2_calibration.json from it.
+# profiles/r3_calibration.json from it.
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -19,7 +19,8 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_
   i=$((i+1))
   echo "$c" > $OUT/pass_$i.counters
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/micro_$i -- $OUT/calib_traffic > /dev/null 2> $OUT/micro_${i}_err.log
-  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu --depth 1 > $OUT/bench_$i.json 2> $OUT/bench_${i}_err.log
+  # (MICRO_ONLY=1: only the calibration kernels -- the bench's walker counters come from tools/collect_profiles.sh)
+  [ "${MICRO_ONLY:-0}" = 1 ] || timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu --depth 1 > $OUT/bench_$i.json 2> $OUT/bench_${i}_err.log
 done
 du -sh $OUT
 python3 tools/calib_summarize.py > $OUT/summary_print.txt 2>&1

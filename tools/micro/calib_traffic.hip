@@ -46,6 +46,17 @@ __global__ __launch_bounds__(256) void CalibStreamRead(const uint4 *__restrict__
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the same stream under another name: the eviction pass of (4), so that the per-kernel counter means of
+// CalibStreamRead are those of the 2 GiB pass alone
+__global__ __launch_bounds__(256) void CalibEvictRead(const uint4 *__restrict__ t, uint64_t n16, uint32_t *sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const uint4 v = t[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // (2) the walker's node fetch: the four lanes of a quad fetch the four 16-byte parts of one random
 // 64-byte record with global_load_lds_dwordx4 (16 records per instruction), records never repeated.
 __global__ __launch_bounds__(256) void CalibQuadRecord64(const uint4 *__restrict__ t, uint32_t mask, uint32_t per_quad,
@@ -194,7 +205,7 @@ int main() {
     hipLaunchKernelGGL(CalibSpillWrite, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<float4 *>(table), entries, sink);
     CHK(hipDeviceSynchronize());
     // evict: stream over the other 3 GiB
-    hipLaunchKernelGGL(CalibStreamRead, dim3(blocks), dim3(256), 0, 0, table + (1ull << 30) / 16, (3ull << 30) / 16, sink);
+    hipLaunchKernelGGL(CalibEvictRead, dim3(blocks), dim3(256), 0, 0, table + (1ull << 30) / 16, (3ull << 30) / 16, sink);
     hipLaunchKernelGGL(CalibSpillRead, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const float4 *>(table), entries, sink);
     CHK(hipDeviceSynchronize());
     const uint64_t b = (uint64_t)blocks * 256 * entries * 32;

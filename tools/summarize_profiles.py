@@ -1,6 +1,11 @@
-"""Turns gpurun_out/prof/ (raw rocprofv3 output of tools/collect_profiles.sh) into the small
-committed files under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_per_launch.csv,
-<tag>_bench.json and <tag>_pmc_traffic.json (read by bench.py for roofline.traffic)."""
+"""Turns gpurun_out/prof_<tag>/ (raw rocprofv3 output of tools/collect_profiles.sh) into the small
+committed files under profiles/: <tag>_kernel_stats[_serial].csv, <tag>_pmc_per_launch.csv, <tag>_*bench.json
+and <tag>_pmc_traffic.json (read by bench.py for roofline.traffic when its workload has the shape recorded there).
+
+  on the GPU box : python3 tools/summarize_profiles.py <tag> --reduce-only   (writes gpurun_out/prof_<tag>/reduced/;
+                   the raw per-dispatch CSVs are then deleted so that the merge-back stays small)
+  here           : python3 tools/summarize_profiles.py <tag>                 (copies reduced/ into profiles/)
+"""
 import collections
 import csv
 import glob
@@ -10,7 +15,6 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -19,29 +23,40 @@ def short(name):
     return n.split("(")[0]
 
 
-def main(tag):
-    os.makedirs(DST, exist_ok=True)
+def parse_shape(text):
+    """bench.py shape arguments -> the dict bench.py compares its own arguments with."""
+    shape = {"reads": 10000, "contigs": 16, "contig_len": 750000}
+    t = text.split()
+    for k, name in (("--reads", "reads"), ("--contigs", "contigs"), ("--contig-len", "contig_len")):
+        if k in t:
+            shape[name] = int(t[t.index(k) + 1])
+    return shape
+
+
+def reduce(tag):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    red = os.path.join(src, "reduced")
+    os.makedirs(red, exist_ok=True)
     for sub, suffix in (("kt", ""), ("kt_serial", "_serial")):
-        ks = sorted(glob.glob(os.path.join(SRC, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
+        ks = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
         if not ks:
             continue
         rows = list(csv.DictReader(open(ks[-1])))  # newest run
-        with open(os.path.join(DST, f"{tag}_kernel_stats{suffix}.csv"), "w", newline="") as f:
+        with open(os.path.join(red, f"{tag}_kernel_stats{suffix}.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     per = collections.defaultdict(dict)
-    for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
             continue
         cc = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
         if not cc:
             continue
-        cc = cc[-1:]
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(set)
-        for r in csv.DictReader(open(cc[0])):
+        for r in csv.DictReader(open(cc[-1])):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
@@ -49,40 +64,64 @@ def main(tag):
             for c, val in v.items():
                 per[k][c] = val / max(1, len(disp[k]))
     counters = sorted({c for v in per.values() for c in v})
-    with open(os.path.join(DST, f"{tag}_pmc_per_launch.csv"), "w", newline="") as f:
+    with open(os.path.join(red, f"{tag}_pmc_per_launch.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel"] + counters)
-        for k in sorted(per, key=lambda k: -per[k].get("SQ_WAVE_CYCLES", 0)):
+        for k in sorted(per, key=lambda k: -per[k].get("FETCH_SIZE", 0)):
             w.writerow([k] + ["%.6g" % per[k].get(c, float("nan")) for c in counters])
+    shape_txt = open(os.path.join(src, "shape.txt")).read().strip() if os.path.exists(os.path.join(src, "shape.txt")) else ""
     seed = next((k for k in per if k.startswith("SeedWalkKernel<false>")), None)
     out = {}
     if seed and "TCC_EA0_RDREQ_sum" in per[seed]:
-        # profiles/r2_calibration.json: on gfx950 EVERY L2 read miss goes to the fabric as one 128-byte
+        # profiles/r3_calibration.json: on gfx950 EVERY L2 read miss goes to the fabric as one 128-byte
         # request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for 64-byte records, 32-byte records, leaf lines
         # and streams alike), and FETCH_SIZE tallies it at 64 bytes; WRITE_SIZE counts 32-byte write
-        # requests exactly.  HBM-side bytes = 128 * read requests + WRITE_SIZE.
+        # requests exactly.  Fabric-side bytes = 128 * read requests + WRITE_SIZE.
         rd = per[seed]["TCC_EA0_RDREQ_sum"]
         write_kb = per[seed].get("WRITE_SIZE", 0.0)
+        ks = os.path.join(red, f"{tag}_kernel_stats_serial.csv")
+        avg_ns = None
+        if os.path.exists(ks):
+            for r in csv.DictReader(open(ks)):
+                if r["kernel"].startswith("SeedWalkKernel<false>"):
+                    avg_ns = float(r["avg_ns"])
         out = {
             "kernel": seed,
+            "shape": parse_shape(shape_txt), "bench_shape_args": shape_txt,
             "seed_lookup_hbm_bytes_per_launch": int(rd * 128 + write_kb * 1024),
             "read_requests_128B": rd, "read_bytes": int(rd * 128),
             "fetch_size_kb_as_reported": per[seed].get("FETCH_SIZE"), "write_size_kb": write_kb,
             "rdreq_128B": per[seed].get("TCC_EA0_RDREQ_128B_sum"), "rdreq_64B": per[seed].get("TCC_EA0_RDREQ_64B_sum"),
             "l2_hit_rate": (per[seed]["TCC_HIT_sum"] / (per[seed]["TCC_HIT_sum"] + per[seed]["TCC_MISS_sum"])
                             if "TCC_HIT_sum" in per[seed] else None),
+            "launch_avg_ns_kernel_trace_serial": avg_ns,
+            "what": "L2-miss (fabric) bytes: 128 B x TCC_EA0_RDREQ + WRITE_SIZE.  Infinity-Cache (MALL) hits are counted in "
+                    "these requests, so this is an UPPER bound on HBM traffic",
             "source": f"profiles/{tag}_pmc_per_launch.csv: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) "
-                      f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1; mean per launch of {seed}; "
-                      "calibration profiles/r2_calibration.json",
+                      f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1 {shape_txt}; mean per launch of "
+                      f"{seed}; calibration profiles/r3_calibration.json",
         }
-        json.dump(out, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(red, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_default.json", "kt_bench.json", "kt_serial_bench.json"):
-        p = os.path.join(SRC, name)
+        p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
-            shutil.copy(p, os.path.join(DST, f"{tag}_{name}"))
-    print("profiles written:", sorted(os.listdir(DST)))
-    print(json.dumps(out, indent=1)[:600])
+            shutil.copy(p, os.path.join(red, f"{tag}_{name}"))
+    print(json.dumps(out, indent=1)[:900])
+
+
+def commit(tag):
+    red = os.path.join(ROOT, "gpurun_out", "prof_" + tag, "reduced")
+    os.makedirs(DST, exist_ok=True)
+    for f in sorted(os.listdir(red)):
+        shutil.copy(os.path.join(red, f), os.path.join(DST, f))
+    print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(tag)))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r2")
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r3_yeast"
+    if "--reduce-only" in sys.argv:
+        reduce(tag)
+    else:
+        if not os.path.isdir(os.path.join(ROOT, "gpurun_out", "prof_" + tag, "reduced")):
+            reduce(tag)
+        commit(tag)
