@@ -53,6 +53,20 @@ int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
     if (_e != hipSuccess) return HipFail(ctx, _e, #expr); \
   } while (0)
 
+// Pinned host staging of the context (grow-only): small transfers to and from caller-owned pageable memory go
+// through it as ONE DMA each -- a hipMemcpyAsync on pageable memory is cut into many staged pieces, ~19 us of
+// blit kernel apiece on the stream (a 1.8 MB result download: a dozen of them).
+hipError_t StageReserve(smhip_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->h_stage_cap) return hipSuccess;
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  ctx->h_stage = nullptr;
+  ctx->h_stage_cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault);
+  if (e == hipSuccess) ctx->h_stage_cap = want;
+  return e;
+}
+
 void ResolveTimers(smhip_ctx *ctx) {
   for (auto &p : ctx->pending) {
     float ms = 0;
@@ -106,13 +120,19 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
   HIPCHK(ctx->qstart.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
   HIPCHK(ctx->carried_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
   HIPCHK(ctx->carried.Reserve(std::max<uint64_t>(n_carried, 1) * sizeof(smhip_carried_anchor)));
-  if (query_start_offsets)
-    HIPCHK(hipMemcpyAsync(ctx->qstart.p, query_start_offsets, (uint64_t)n_chunks * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
-  else
+  // small arrays through the pinned staging (words [2 n, 4 n + 2) of it: smhip_batch_select keeps its own two
+  // arrays in front); the anchors themselves -- large, and only present in later chunk rounds -- directly
+  HIPCHK(StageReserve(ctx, (4 * (size_t)n_chunks + 8) * sizeof(uint32_t)));
+  uint32_t *st = static_cast<uint32_t *>(ctx->h_stage) + 2 * (size_t)n_chunks;
+  if (query_start_offsets) {
+    memcpy(st, query_start_offsets, (size_t)n_chunks * sizeof(uint32_t));
+    HIPCHK(hipMemcpyAsync(ctx->qstart.p, st, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  } else {
     HIPCHK(hipMemsetAsync(ctx->qstart.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
+  }
   if (carried) {
-    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, carried_offsets, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
+    memcpy(st + n_chunks, carried_offsets, ((size_t)n_chunks + 1) * sizeof(uint32_t));
+    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, st + n_chunks, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
                           hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->carried.p, carried, n_carried * sizeof(smhip_carried_anchor), hipMemcpyHostToDevice,
                           ctx->stream));
@@ -216,6 +236,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   if (ctx->h_run_info) (void)hipHostFree(ctx->h_run_info);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (DevBuf &b : ctx->pa_segs) b.Free();
   DevBuf *bufs[] = {&ctx->reads_raw, &ctx->reads_meta, &ctx->reads_segstart, &ctx->reads_seg, &ctx->pa_tab,
                     &ctx->slot_len, &ctx->reads_len, &ctx->sel_slots, &ctx->sel_chunk, &ctx->chunk_begin, &ctx->chunk_len,
@@ -770,9 +791,16 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   HIPCHK(ctx->sel_chunk.Reserve(nb * sizeof(uint32_t)));
   HIPCHK(ctx->chunk_begin.Reserve((nb + 1) * sizeof(uint64_t)));
   HIPCHK(ctx->chunk_len.Reserve((nb + 1) * sizeof(uint32_t)));
-  HIPCHK(hipMemcpyAsync(ctx->sel_slots.p, slots, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->sel_chunk.p, chunk_index, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice,
-                        ctx->stream));
+  // (through the pinned staging: [slots][chunk_index], and in UploadBatchSideInputs [qstart][carried_off] behind them)
+  HIPCHK(StageReserve(ctx, (4 * (size_t)n_chunks + 8) * sizeof(uint32_t)));
+  {
+    uint32_t *st = static_cast<uint32_t *>(ctx->h_stage);
+    memcpy(st, slots, (size_t)n_chunks * sizeof(uint32_t));
+    memcpy(st + n_chunks, chunk_index, (size_t)n_chunks * sizeof(uint32_t));
+    HIPCHK(hipMemcpyAsync(ctx->sel_slots.p, st, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->sel_chunk.p, st + n_chunks, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice,
+                          ctx->stream));
+  }
   HIPCHK(LaunchSelectChunks(ctx, ctx->sel_slots.as<uint32_t>(), ctx->sel_chunk.as<uint32_t>(), n_chunks, chunk_size,
                             SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
                             ctx->slot_len.as<uint32_t>(), ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>()));
@@ -1161,9 +1189,11 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
     int rc0 = FinishRun(ctx);
     if (rc0) return rc0;
   }
-  HIPCHK(hipMemcpyAsync(results, ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,
+  HIPCHK(StageReserve(ctx, (size_t)R * sizeof(smhip_chunk_result)));
+  HIPCHK(hipMemcpyAsync(ctx->h_stage, ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,
                         ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(results, ctx->h_stage, (size_t)R * sizeof(smhip_chunk_result));
   ResolveTimers(ctx);
   if (chain_anchors && chain_anchor_offsets) {
     // (context-owned scratch: a hipFree here would synchronise the whole device, i.e. stall the other
@@ -1255,9 +1285,14 @@ int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos) {
     int rc0 = FinishRun(ctx);
     if (rc0) return rc0;
   }
-  HIPCHK(hipMemcpyAsync(dist, ctx->refine_dist.p, (uint64_t)R * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(end_pos, ctx->refine_end.p, (uint64_t)R * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(StageReserve(ctx, (size_t)R * (sizeof(float) + sizeof(int64_t))));
+  int64_t *st_end = static_cast<int64_t *>(ctx->h_stage);
+  float *st_dist = reinterpret_cast<float *>(st_end + R);
+  HIPCHK(hipMemcpyAsync(st_dist, ctx->refine_dist.p, (uint64_t)R * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(st_end, ctx->refine_end.p, (uint64_t)R * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(dist, st_dist, (size_t)R * sizeof(float));
+  memcpy(end_pos, st_end, (size_t)R * sizeof(int64_t));
   ResolveTimers(ctx);
   return SMHIP_OK;
 }

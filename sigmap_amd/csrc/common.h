@@ -218,6 +218,8 @@ struct smhip_ctx {
   uint64_t hint_q_per_chunk = 0, hint_a_per_chunk = 0;
   bool hint_valid = false, spec_pending = false;
   void *h_run_info = nullptr;
+  void *h_stage = nullptr;   // pinned staging of small transfers to / from pageable caller memory (api.hip StageReserve)
+  size_t h_stage_cap = 0;
   smhip_params spec_params{};
   uint32_t spec_n_refs = 0, spec_reruns = 0, spec_runs = 0;
   uint32_t refine_band = 0, refine_pad = 0;

@@ -387,6 +387,66 @@ class Sigmap {
       for (size_t k = ctxs[g].size(); k-- > 0;) smhip_destroy(ctxs[g][k]);  // borrowers first
   }
 
+  // Development mode `--features events|cwt -s DIR -o OUT` (no index, no reference): the feature signal the
+  // mapping path (events: Sigmap::GenerateEvents, sigmap.cc:1048-1083) or the reference's dormant CWT path
+  // (cwt: Sigmap::GenerateFeatureSignalUsingCWT, sigmap.cc:1085-1098, scale0 = 8 as for reads, :947) derives from
+  // every 4000-sample chunk of every read, computed on the GPU, as text: `read<TAB>chunk<TAB>k<TAB>position<TAB>value`
+  // with %f values like the reference's disabled debugging dumps (EventsToText, sigmap.cc:1198-1235, which writes
+  // the z-scored event means of whole reads, one `%f` per line).  position = sample index of a CWT peak / valley
+  // inside its chunk; 0 for events (the compression drops the spans).
+  static void DumpFeatures(const std::string &kind, int device, const std::string &signal_directory,
+                           const std::string &output_file_path) {
+    if (kind != "events" && kind != "cwt") ExitWithMessage("--features takes `events` or `cwt`");
+    SignalBatch reads;
+    reads.InitializeLoading(signal_directory);
+    const size_t num_reads = reads.LoadAllReadSignals();  // host conversion: pA, (30, 200) filter
+    smhip_ctx *ctx = nullptr;
+    if (smhip_init(device, &ctx) != SMHIP_OK) ExitWithMessage("No usable GPU (smhip_init failed).");
+    smhip_params dp;
+    smhip_default_params(&dp);
+    FILE *out = fopen(output_file_path.c_str(), "w");
+    if (!out) ExitWithMessage("Cannot open output file " + output_file_path);
+    const uint32_t chunk_size = 4000, stride = 2736, batch_chunks = 4096;
+    std::vector<float> samples, feat((size_t)batch_chunks * stride), stdv;
+    std::vector<uint32_t> offsets(1, 0), pos((size_t)batch_chunks * stride), nf(batch_chunks), owner, chunk_of;
+    auto flush = [&]() {
+      const uint32_t n = (uint32_t)owner.size();
+      if (n == 0) return;
+      int rc;
+      if (kind == "cwt") {
+        rc = smhip_cwt_features(ctx, samples.data(), offsets.data(), n, 8.0f, stride, feat.data(), pos.data(), nf.data(),
+                                nullptr);
+      } else {
+        stdv.resize((size_t)n * stride);
+        rc = smhip_events(ctx, &dp, samples.data(), offsets.data(), n, stride, feat.data(), stdv.data(), nf.data(), nullptr,
+                          nullptr);
+      }
+      if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU feature extraction failed: ") + smhip_last_error(ctx));
+      for (uint32_t c = 0; c < n; ++c)
+        for (uint32_t k = 0; k < std::min(nf[c], stride); ++k)
+          fprintf(out, "%s\t%u\t%u\t%u\t%f\n", reads.GetSignalNameAt(owner[c]), chunk_of[c], k,
+                  kind == "cwt" ? pos[(size_t)c * stride + k] : 0u, feat[(size_t)c * stride + k]);
+      samples.clear();
+      offsets.assign(1, 0);
+      owner.clear();
+      chunk_of.clear();
+    };
+    for (size_t r = 0; r < num_reads; ++r) {
+      const std::vector<float> &v = reads.GetSignalAt(r).signal_values;
+      for (uint32_t c = 0; (size_t)(c + 1) * chunk_size <= v.size(); ++c) {  // whole chunks only (sigmap.cc:643)
+        samples.insert(samples.end(), v.begin() + (size_t)c * chunk_size, v.begin() + (size_t)(c + 1) * chunk_size);
+        offsets.push_back((uint32_t)samples.size());
+        owner.push_back((uint32_t)r);
+        chunk_of.push_back(c);
+        if (owner.size() == batch_chunks) flush();
+      }
+    }
+    flush();
+    fclose(out);
+    smhip_destroy(ctx);
+    std::cerr << "Wrote the " << kind << " features of " << num_reads << " reads.\n";
+  }
+
  protected:
   int dimension_ = 6, max_leaf_ = 20;
   MappingParams params_;
@@ -424,6 +484,7 @@ const char *kHelp =
     "      --gpus-share-device         (development) the --gpus are all GPU --device and share one index\n"
     "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
     "      --streams INT               device contexts / HIP streams that share the index and the chunk budget [2]\n"
+    "      --features events|cwt       (development) with -s DIR -o FILE: dump every chunk's feature signal as text\n"
     "  -h, --help  Print help\n";
 }  // namespace
 
@@ -438,7 +499,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
       "dimension", "max-leaf", "step-size", "num-threads", "ref", "pore-model", "ref-index", "sig-dir", "output",
       "search-radius", "max-num-chunks", "min-num-anchors", "min-num-anchors-output", "stop-mapping",
       "stop-mapping-output", "stop-mapping-mean", "stop-mapping-mean-output", "sdtw-band", "device", "gpus",
-      "batch-chunks", "streams"};
+      "batch-chunks", "streams", "features"};
   Args a;
   for (int i = 1; i < argc; ++i) {
     std::string k = argv[i];
@@ -475,7 +536,11 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     if (!a.Has(k)) ExitWithMessage(msg);
     return a.Str(k);
   };
-  if (a.Has("build-index")) {
+  if (a.Has("features")) {
+    const std::string dir = need("sig-dir", "No signal data directory specified!");
+    const std::string out = need("output", "No output file specified!");
+    Sigmap::DumpFeatures(a.Str("features"), a.Has("device") ? std::stoi(a.Str("device")) : 0, dir, out);
+  } else if (a.Has("build-index")) {
     const int dimension = a.Has("dimension") ? std::stoi(a.Str("dimension")) : 6;
     const int max_leaf = a.Has("max-leaf") ? std::stoi(a.Str("max-leaf")) : 20;
     std::cerr << "Dimension: " << dimension << ", max leaf: " << max_leaf << "\n";

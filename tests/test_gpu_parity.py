@@ -872,6 +872,46 @@ def test_cwt_features_match_oracle_and_reference(device, small_world, scale0):
     assert total > 2000 and same >= 0.995 * total
 
 
+def test_cli_features_mode_dumps_device_features(tmp_path, small_world, device):
+    """`sigmap --features events|cwt -s DIR -o FILE` (development mode; the reachable form of the reference's
+    disabled EventsToText dump and of its dormant CWT feature path): every whole 4000-sample chunk's feature
+    signal as text.  events == the oracle's GenerateEvents (exact, printed %f); cwt == what smhip_cwt_features
+    returns for the same chunks (that stage's own parity: test_cwt_features_match_oracle_and_reference)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "sigmap_amd", "bin", "sigmap")
+    genome, lm = small_world["genome"], small_world["lm"]
+    raw2, _ = synth.simulate_reads(genome, lm, 3, 21, n_chunks=2)
+    raw1, _ = synth.simulate_reads(genome, lm, 2, 22, n_chunks=1)
+    raws = [r for r in raw2] + [r for r in raw1] + [np.asarray(raw1[0][:3000])]     # (the last: no whole chunk)
+    os.makedirs(tmp_path / "reads")
+    synth.write_sgr(str(tmp_path / "reads" / "a.sgr"), raws)
+    chunks = []   # (read name, chunk, pA samples)
+    for i, rw in enumerate(raws):
+        x = po.add_signal(rw, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+        for c in range(len(x) // 4000):
+            chunks.append(("read%d" % i, c, x[c * 4000:(c + 1) * 4000]))
+    assert len(chunks) == 8
+    for kind in ("events", "cwt"):
+        out = tmp_path / (kind + ".txt")
+        r = subprocess.run([exe, "--features", kind, "-s", str(tmp_path / "reads"), "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = [l.split("\t") for l in open(out).read().splitlines()]
+        want = []
+        if kind == "events":
+            for name, c, x in chunks:
+                f, _ = po.generate_events(x)
+                want += [[name, str(c), str(k), "0", "%f" % v] for k, v in enumerate(f)]
+        else:
+            samples, offsets = _batch([x for _, _, x in chunks])
+            feat, pos, cnt, _ = device.cwt_features(samples, offsets, scale0=8.0)
+            for j, (name, c, _) in enumerate(chunks):
+                want += [[name, str(c), str(k), str(int(pos[j, k])), "%f" % feat[j, k]] for k in range(int(cnt[j]))]
+        assert got == want and len(got) > 1000
+    r = subprocess.run([exe, "--features", "mad", "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "x")], capture_output=True, text=True)
+    assert r.returncode != 0 and "events" in r.stderr
+
+
 def _oracle_sd(x):
     """SD exactly as GenerateZscoreNormalizedSignal accumulates it (sequential f64), narrowed to f32."""
     mean = 0.0
