@@ -193,7 +193,9 @@ def main():
     assert all(int(l.min()) == CHUNK for l in lens), "the generator's reads lose no sample to the (30,200) pA filter"
     if args.sdtw_band > 0:
         ref_sig, ref_off = pipeline.reference_signals(genome, lm)
-        pool.for_each(lambda dv: dv.upload_reference(ref_sig, ref_off))
+        pool.first.upload_reference(ref_sig, ref_off)     # one copy per GPU: the other contexts borrow it
+        for dv in pool.devs[1:]:
+            dv.share_reference(pool.first)
 
     prefetched = {}  # context -> the reads of its next step are already on their way (pcie_inclusive region)
 

@@ -255,6 +255,11 @@ int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
  * signals: concatenated float arrays in the order contig0 +, contig0 -, contig1 +, ...;
  * offsets[2*n_refs + 1] in elements. */
 int smhip_reference_upload(smhip_ctx *ctx, const float *signals, const uint64_t *offsets, uint32_t n_refs);
+/* Borrow the reference signal `owner` uploaded (another context of the SAME GPU, which must outlive this
+ * one's use of it): the contexts of a GPU share one copy, like the index (smhip_index_export / _attach). */
+int smhip_reference_share(smhip_ctx *ctx, smhip_ctx *owner);
+/* Free and total device memory of the context's GPU (hipMemGetInfo): callers size their batches from it. */
+int smhip_mem_info(smhip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* For chunk c with >= 1 chain: target = strand signal[t0, t1) with t0 = max(0, start - pad),
  * t1 = min(len, end + dim + pad); query = the chunk's feature signal (F values); row t (1-based,
  * absolute index ta = t0 + t - 1) may use the 1-based columns [centre - band/2, centre + band/2]

@@ -18,7 +18,7 @@ HIP_SYMBOLS = [
     "smhip_default_params", "smhip_init", "smhip_destroy", "smhip_last_error", "smhip_stream",
     "smhip_index_upload", "smhip_index_export", "smhip_index_attach", "smhip_batch_upload",
     "smhip_map_run", "smhip_map_sync", "smhip_map_download", "smhip_map_chunks",
-    "smhip_reference_upload", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
+    "smhip_reference_upload", "smhip_reference_share", "smhip_mem_info", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
     "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
@@ -194,6 +194,8 @@ def hip_lib():
         L.smhip_map_download.argtypes = [vp, vp, vp, u64, vp]
         L.smhip_map_chunks.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp, vp, vp, vp]
         L.smhip_reference_upload.argtypes = [vp, vp, vp, u32]
+        L.smhip_reference_share.argtypes = [vp, vp]
+        L.smhip_mem_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.smhip_refine_run.argtypes = [vp, u32, u32]
         L.smhip_refine_download.argtypes = [vp, vp, vp]
         L.smhip_debug_counters.argtypes = [vp, vp]

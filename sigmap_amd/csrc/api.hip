@@ -1246,6 +1246,29 @@ int smhip_reference_upload(smhip_ctx *ctx, const float *signals, const uint64_t 
                         ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->ref_n = n_refs;
+  ctx->d_ref_sig = ctx->ref_sig.as<float>();
+  ctx->d_ref_off = ctx->ref_off.as<uint64_t>();
+  return SMHIP_OK;
+}
+
+int smhip_reference_share(smhip_ctx *ctx, smhip_ctx *owner) {
+  if (!ctx || !owner || ctx == owner) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (owner->ref_n == 0 || owner->d_ref_sig != owner->ref_sig.as<float>())
+    return Fail(ctx, SMHIP_ESTATE, "smhip_reference_share: the owner holds no reference signal of its own");
+  if (owner->device != ctx->device) return Fail(ctx, SMHIP_EINVAL, "smhip_reference_share: contexts of one GPU only");
+  ctx->ref_n = owner->ref_n;
+  ctx->d_ref_sig = owner->d_ref_sig;
+  ctx->d_ref_off = owner->d_ref_off;
+  return SMHIP_OK;
+}
+
+int smhip_mem_info(smhip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (!ctx) return SMHIP_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
   return SMHIP_OK;
 }
 
@@ -1268,7 +1291,7 @@ int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   {
     ScopedTimer t(ctx, T_SDTW);
     HIPCHK(LaunchSdtwChains(ctx, ctx->results.as<smhip_chunk_result>(), ctx->feat.as<float>(), kFeatStride,
-                            ctx->qstart.as<uint32_t>(), R, ctx->ref_sig.as<float>(), ctx->ref_off.as<uint64_t>(),
+                            ctx->qstart.as<uint32_t>(), R, ctx->d_ref_sig, ctx->d_ref_off,
                             ctx->ref_n, band, pad, ctx->refine_dist.as<float>(), ctx->refine_end.as<int64_t>()));
   }
   ctx->refine_done = true;
@@ -1329,7 +1352,7 @@ int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   HIPCHK(ctx->rp_start.Reserve(r1 * 8));
   ScopedTimer t(ctx, T_SDTW);
   // rows and path capacity (T + Q) of every chunk's window, their prefix sums, the totals
-  HIPCHK(LaunchChainWindowRows(ctx, results, ctx->qstart.as<uint32_t>(), R, ctx->ref_off.as<uint64_t>(), ctx->ref_n, pad,
+  HIPCHK(LaunchChainWindowRows(ctx, results, ctx->qstart.as<uint32_t>(), R, ctx->d_ref_off, ctx->ref_n, pad,
                                ctx->rp_rows.as<uint32_t>(), ctx->rp_cap.as<uint32_t>()));
   HIPCHK(LaunchScanU32ToU64(ctx, ctx->rp_rows.as<uint32_t>(), R, ctx->rp_toff.as<uint64_t>()));
   HIPCHK(LaunchScanU32ToU64(ctx, ctx->rp_cap.as<uint32_t>(), R, ctx->rp_poff.as<uint64_t>()));
@@ -1345,7 +1368,7 @@ int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   HIPCHK(ctx->rp_width.Reserve((nr + 1) * 4));
   HIPCHK(ctx->rp_celloff.Reserve((nr + 1) * 8));
   HIPCHK(ctx->rp_path.Reserve(std::max<uint64_t>(n_path, 1)));
-  HIPCHK(LaunchChainWindowFill(ctx, results, ctx->qstart.as<uint32_t>(), kFeatStride, R, ctx->ref_off.as<uint64_t>(),
+  HIPCHK(LaunchChainWindowFill(ctx, results, ctx->qstart.as<uint32_t>(), kFeatStride, R, ctx->d_ref_off,
                                ctx->ref_n, band, pad, ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
                                ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(), ctx->rp_lo.as<uint32_t>(),
                                ctx->rp_hi.as<uint32_t>(), ctx->rp_width.as<uint32_t>()));
@@ -1361,7 +1384,7 @@ int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
                                    "per batch or narrow the band");
   }
   HIPCHK(ctx->rp_codes.Reserve(std::max<uint64_t>(n_cells, 1)));
-  HIPCHK(LaunchDtwPathChains(ctx, ctx->ref_sig.as<float>(), ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
+  HIPCHK(LaunchDtwPathChains(ctx, ctx->d_ref_sig, ctx->rp_toff.as<uint64_t>(), ctx->rp_tgt.as<uint64_t>(),
                              ctx->feat.as<float>(), ctx->rp_qoff.as<uint64_t>(), ctx->rp_qlen.as<uint32_t>(),
                              ctx->rp_lo.as<uint32_t>(), ctx->rp_hi.as<uint32_t>(), ctx->rp_celloff.as<uint64_t>(),
                              ctx->rp_codes.as<uint8_t>(), R, ctx->rp_dist.as<float>(), ctx->rp_end.as<int64_t>(),
@@ -1396,7 +1419,7 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
   // window-relative rows -> absolute positions on the strand's signal, like smhip_refine_download:
   // row r of chunk c is target index t0 + r, t0 = max(0, start - pad) = (window offset) - (strand offset)
   std::vector<uint64_t> ref_off((size_t)2 * ctx->ref_n + 1);
-  HIPCHK(hipMemcpyAsync(ref_off.data(), ctx->ref_off.p, ref_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ref_off.data(), ctx->d_ref_off, ref_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(tgt.data(), ctx->rp_tgt.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<smhip_chunk_result> res((size_t)R);
   HIPCHK(hipMemcpyAsync(res.data(), ctx->results.p, (uint64_t)R * sizeof(smhip_chunk_result), hipMemcpyDeviceToHost,

@@ -225,6 +225,8 @@ struct smhip_ctx {
   uint32_t refine_band = 0, refine_pad = 0;
   // sDTW refinement
   smhip::DevBuf ref_sig, ref_off, refine_dist, refine_end;
+  const float *d_ref_sig = nullptr;     // the reference signal in use: this context's (ref_sig) or one borrowed
+  const uint64_t *d_ref_off = nullptr;  // from another context of the GPU (smhip_reference_share)
   // DTW-with-path refinement (smhip_refine_path_run): per-chunk / per-row window arrays and results
   smhip::DevBuf rp_rows, rp_cap, rp_toff, rp_poff, rp_tgt, rp_qoff, rp_qlen, rp_lo, rp_hi, rp_width, rp_celloff, rp_codes,
       rp_dist, rp_end, rp_path, rp_plen, rp_start;

@@ -153,10 +153,15 @@ class Sigmap {
         ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
         off.push_back(sig.size());
       }
-      for (auto &gpu : ctxs)
-        for (smhip_ctx *c : gpu)
-          if (smhip_reference_upload(c, sig.data(), off.data(), num_refs) != SMHIP_OK)
-            ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
+      // one copy per GPU: its first context uploads, the others borrow (like the index)
+      for (int g = 0; g < num_gpus; ++g) {
+        smhip_ctx *owner = share_device ? ctxs[0][0] : ctxs[g][0];
+        for (smhip_ctx *c : ctxs[g]) {
+          const int rc = c == owner ? smhip_reference_upload(c, sig.data(), off.data(), num_refs)
+                                    : smhip_reference_share(c, owner);
+          if (rc != SMHIP_OK) ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
+        }
+      }
     }
     smhip_params dp;
     smhip_default_params(&dp);
@@ -185,12 +190,32 @@ class Sigmap {
     const uint32_t keep = std::max<uint32_t>(1, std::min<uint32_t>(max_chunks, 1u << 16)) * chunk_size;
     size_t lane_budget = std::max<size_t>(1, max_batch_chunks / (size_t)num_streams);
     lane_budget = std::max<size_t>(1, std::min<size_t>(lane_budget, ((size_t)8 << 30) / ((size_t)keep * sizeof(float))));
+    {
+      // ... and within the memory the GPU has left: per chunk in flight a context needs its read slot, ~288 queries x
+      // (8 KB of hit slots + ~1.4 KB of per-query records and overflow pool) and ~60 bytes per anchor (estimated
+      // from the index size); half of the free memory is left to the anchor-sized buffers of large references and
+      // to growth.  (A default budget that an MI355X takes in its stride fails on a smaller device otherwise.)
+      uint64_t free_b = 0, total_b = 0;
+      if (smhip_mem_info(ctxs[0][0], &free_b, &total_b) == SMHIP_OK && free_b > 0) {
+        const double hits_per_query = 1.7e-6 * (double)index.tree().m_size;  // measured: 41 at 12 Mb, 850 at 250 Mb
+        const double per_chunk = (double)keep * sizeof(float) + 288.0 * (8192.0 + 1400.0) +
+                                 288.0 * std::min(hits_per_query, 5000.0) * 60.0 + 120000.0;
+        const size_t contexts_here = (size_t)num_streams * (share_device ? (size_t)num_gpus : 1u);
+        const size_t fit = (size_t)((double)free_b * 0.5 / per_chunk / (double)contexts_here);
+        if (fit < lane_budget) {
+          std::cerr << "Chunks in flight per context limited to " << std::max<size_t>(fit, 1) << " of " << lane_budget
+                    << " by the device's free memory (" << (free_b >> 20) << " MiB).\n";
+          lane_budget = std::max<size_t>(fit, 1);
+        }
+      }
+    }
     // read slots of every context: set-up like the index, before the mapping span
     for (auto &gpu : ctxs)
       for (smhip_ctx *c : gpu)
         if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
             smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
-          ExitWithMessage(std::string("Read slots: ") + smhip_last_error(c));
+          ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
+                          " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
     phase("Reserved read slots and batch buffers");
     const double t_map = GetRealTime();
     // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted

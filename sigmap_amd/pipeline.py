@@ -254,6 +254,15 @@ class DeviceMapper:
         self._check(self.L.smhip_reference_upload(self._h, ptr(signals), ptr(offsets), (len(offsets) - 1) // 2),
                     "smhip_reference_upload")
 
+    def share_reference(self, owner):
+        """Borrow the reference signal another context of this GPU uploaded (smhip_reference_share)."""
+        self._check(self.L.smhip_reference_share(self._h, owner._h), "smhip_reference_share")
+
+    def mem_info(self):
+        free, total = C.c_uint64(), C.c_uint64()
+        self._check(self.L.smhip_mem_info(self._h, C.byref(free), C.byref(total)), "smhip_mem_info")
+        return free.value, total.value
+
     def refine(self, band=64, pad=32):
         self._check(self.L.smhip_refine_run(self._h, band, pad), "smhip_refine_run")
 

@@ -704,6 +704,38 @@ def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
     dev.close()
 
 
+def test_contexts_of_a_gpu_share_one_reference_signal(device, small_world):
+    """smhip_reference_share: a second context refines against the reference signal the first one uploaded
+    (one copy per GPU, like the index) and gets the same distances; smhip_mem_info reports the device's memory."""
+    genome, lm = small_world["genome"], small_world["lm"]
+    sig, offs = pipeline.reference_signals(genome, lm)
+    device.upload_reference(sig, offs)
+    samples, offsets = _batch(small_world["pa"][:16])
+
+    def refined(dv):
+        dv.upload_batch(samples, offsets)
+        dv.run(3)
+        dv.refine(band=64, pad=32)
+        dv.sync()
+        return dv.download().tobytes(), tuple(x.tobytes() for x in dv.refine_download())
+
+    want = refined(device)
+    peer = pipeline.DeviceMapper(0)
+    peer.attach_index(device.export_index())
+    with pytest.raises(RuntimeError):
+        peer.refine(band=64, pad=32)              # no batch, no reference yet
+    empty = pipeline.DeviceMapper(0)
+    with pytest.raises(RuntimeError):
+        peer.share_reference(empty)               # the owner holds none
+    empty.close()
+    peer.share_reference(device)
+    assert refined(peer) == want
+    free, total = peer.mem_info()
+    assert 0 < free <= total and total > (64 << 30)
+    peer.close()
+    assert refined(device) == want                # the owner is unaffected by the borrower's end
+
+
 def test_integer_gap_tests_equal_the_float_form(device, small_world):
     """The chaining kernels evaluate `0.75 < (float)qd / (float)td < 5` (spatial_index.cc:489-497) as
     4 qd > 3 td and qd < 5 td, exact for target gaps below 2^21 (chain.hip GapTestsPass; exhaustive host
