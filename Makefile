@@ -41,7 +41,15 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sigmap_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libsigmap_hip.so: $(HIP_OBJS)
+# sort.hip prefetches with inline-assembly loads the compiler does not track: the device assembly of the same
+# flags is checked for any use of a load's destination registers before the matching wait (tools/check_asm_prefetch.py)
+build/sort.asmcheck: $(CSRC)/sort.hip $(CSRC)/common.h include/sigmap_hip.h tools/check_asm_prefetch.py
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S $(CSRC)/sort.hip -o build/sort.device.s
+	python3 tools/check_asm_prefetch.py build/sort.device.s
+	@touch $@
+
+$(LIBDIR)/libsigmap_hip.so: $(HIP_OBJS) build/sort.asmcheck
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
