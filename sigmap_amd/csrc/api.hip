@@ -1011,6 +1011,10 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   ca.scratch = ctx->keys.as<uint64_t>();
   ca.pending = ctx->a_tpos.as<uint32_t>();  // the unsorted SoA is dead after the sort
   ca.lists = ctx->a_qpos.as<uint32_t>();
+  ca.item_lo = ctx->a_dist.as<uint64_t>();
+  ca.item_hi = ctx->a_grp.as<uint64_t>();
+  ca.item_counts = nullptr;  // (set by LaunchChain)
+  ca.item_cap = 0;
   ca.results = results;
   ca.out_anchors = ctx->out_anchors.as<smhip_carried_anchor>();
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();
@@ -1042,6 +1046,21 @@ uint64_t SpecCapAnchors(const smhip_ctx *ctx, uint32_t R) {
   return (uint64_t)R * ctx->hint_a_per_chunk * 5 / 4 + ctx->n_carried + (1u << 20);
 }
 
+// Can the per-query / per-anchor buffers grow to these capacities?  (Their headroom above the exact totals is a
+// convenience of the speculative route; a batch sized for the whole device -- the 250 Mb shard: 2.3 G anchors --
+// must not fail for it.)  Bytes per query: hit slots, overflow table, records, keys, counters; per anchor: the
+// unsorted and sorted columns, score, predecessor, group starts, sort records, flags, chain anchors.
+bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap, uint64_t na_cap) {
+  const uint64_t per_query = (uint64_t)p->hits_per_query_fast * sizeof(Hit) + kOvfLevels * 4 + 32 * 2 + 4 * 6 + 64 * sizeof(Hit);
+  const uint64_t per_anchor = 11 * 4 + 2 * sizeof(uint64_t) + 1 + sizeof(smhip_carried_anchor);
+  uint64_t have_q = ctx->q_count.cap / 4, have_a = ctx->score.cap / 4;  // what these buffers hold already
+  const uint64_t grow = (nq_cap > have_q ? (nq_cap - have_q) * per_query : 0) + (na_cap > have_a ? (na_cap - have_a) * per_anchor : 0);
+  if (grow == 0) return true;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  return grow + grow / 8 + (1ull << 30) < free_b;
+}
+
 void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
   const uint64_t non_carried = NA > ctx->n_carried ? NA - ctx->n_carried : 0;
   ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, (NQ + R - 1) / R);
@@ -1060,7 +1079,8 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   // (buffers are reserved at the capacity a speculative batch of this size would ask for next, so that the
   // switch to that route does not reallocate -- a hipFree synchronises the whole device)
   ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, ((uint64_t)NQ + R - 1) / R);
-  const uint64_t nq_cap = std::max<uint64_t>(std::max<uint64_t>(NQ, 1), SpecCapQueries(ctx, R));
+  uint64_t nq_cap = std::max<uint64_t>(NQ, 1);
+  if (CapacitiesAffordable(ctx, p, SpecCapQueries(ctx, R), 0)) nq_cap = std::max(nq_cap, SpecCapQueries(ctx, R));
   uint64_t pool_cap = FirstPoolCap(ctx, nq_cap);
   uint64_t NA = 0;
   HitSlots hit_slots;
@@ -1078,7 +1098,9 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     ctx->pool_hint = pool_cap;
   }
   LearnTotals(ctx, R, NQ, NA);
-  return EnqueueBack(ctx, p, n_refs, R, std::max<uint64_t>(NA, SpecCapAnchors(ctx, R)), hit_slots);
+  uint64_t na_cap = NA;
+  if (CapacitiesAffordable(ctx, p, 0, SpecCapAnchors(ctx, R))) na_cap = std::max(na_cap, SpecCapAnchors(ctx, R));
+  return EnqueueBack(ctx, p, n_refs, R, na_cap, hit_slots);
 }
 
 // the speculative route: nothing is read back; capacities from the totals of earlier batches
@@ -1159,7 +1181,8 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     return SMHIP_OK;
   }
   // (SMHIP_SYNC_RUN=1: always the synchronous route -- an A/B switch; results are the same)
-  const bool speculate = ctx->hint_valid && !Knobs().sync_run && !getenv("SMHIP_POOL_MIN");
+  const bool speculate = ctx->hint_valid && !Knobs().sync_run && !getenv("SMHIP_POOL_MIN") &&
+                         CapacitiesAffordable(ctx, p, SpecCapQueries(ctx, R), SpecCapAnchors(ctx, R));
   const int rc = speculate ? RunBatchSpeculative(ctx, p, n_refs) : RunBatchSync(ctx, p, n_refs);
   if (rc) return rc;
   ctx->run_done = true;

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -133,7 +134,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
+    size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20) + 256;  // (head room, bounded: buffers reach 40 GB)
     const bool trace = TraceAlloc();
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
@@ -364,6 +365,9 @@ struct ChainArgs {
   uint64_t *scratch;  // the sort's key buffer (2 keys per anchor), dead by now
   uint32_t *pending;  // per chunk: anchors that need the sequential DP, in index order (dead a_tpos)
   uint32_t *lists;    // per chunk: anchor index lists of the traced chains (dead a_qpos)
+  uint64_t *item_lo, *item_hi;  // batch-wide descriptors of the DP's items (dead a_dist / a_grp): short items from the
+  uint32_t *item_counts;        // front ([0] of them), long items from the back ([1]); item_cap entries each
+  uint32_t item_cap;
   smhip_chunk_result *results;
   smhip_carried_anchor *out_anchors;
   uint32_t *out_anchor_cnt;

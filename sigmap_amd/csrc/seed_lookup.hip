@@ -805,14 +805,27 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     const QueryRec r = qrec[q];
-    uint32_t node = ix.root_ref;
-    while (!(node & kLeafTag)) {
+    // The descent stops as soon as the bucket is decided: the leaves below a node are the ordinals [lo, hi) --
+    // leaves are numbered in tree order and inner records in pre-order, so the first child's subtree holds
+    // (second child's inner index - this index) leaves, or (second child's leaf ordinal - lo) -- and once lo and
+    // hi - 1 share a bucket the remaining ~6 of ~25 dependent record reads are not needed (same keys as a full
+    // descent).
+    uint32_t node = ix.root_ref, lo = 0, hi = (uint32_t)ix.n_leaves;
+    while (!(node & kLeafTag) && (lo >> shift) != ((hi - 1u) >> shift)) {
       const uint4 rec = ix.inner[(size_t)node * 4];
       const float val = r.q[(rec.z >> 28) & 7u];
       const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
-      node = ((diff1 + diff2) < 0 ? rec.z : rec.w) & (kLeafTag | kIdxMask);
+      const uint32_t ref2 = rec.w & (kLeafTag | kIdxMask);
+      const uint32_t n1 = (ref2 & kLeafTag) ? (ref2 & kIdxMask) - lo : ref2 - node;  // leaves below the first child
+      if ((diff1 + diff2) < 0) {
+        hi = lo + n1;
+        node = rec.z & (kLeafTag | kIdxMask);
+      } else {
+        lo += n1;
+        node = ref2;
+      }
     }
-    const uint32_t lb = (node & kIdxMask) >> shift, range = lb / per_range;
+    const uint32_t lb = ((node & kLeafTag) ? (node & kIdxMask) : lo) >> shift, range = lb / per_range;
     const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
                      r.q[5] * r.q[5];
     uint32_t cls = 0;  // number of thresholds <= r2 (binary search over 15 sorted values)

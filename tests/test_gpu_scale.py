@@ -132,7 +132,7 @@ def test_config4_chr1_250mb_shard():
     assert ix.n_points > 4.9e8
     dev = pipeline.DeviceMapper(0)
     dev.upload_index(ix)
-    res, _ = _map_all(dev, raw, 1, 12500)          # two batches of 12 500 (<= 20 000 chunks each)
+    res, _ = _map_all(dev, raw, 1, 10000)          # batches of 10 000 chunks: 1.8 G anchors, ~170 GB of device buffers each
     assert (res["status"] == 0).all()               # no capacity flag: nothing was truncated on the device
     c0 = res["chains"][:, 0]
     ok = (res["n_chains"] > 0) & ((c0["direction"] == 1) == (truth["strand"] == 0)) & \
@@ -156,9 +156,9 @@ def test_config4_chr1_250mb_shard():
         proved += int(m.stats.hits > m.stats.anchors)   # the oracle, too, cut a query at 5000 hits
     assert proved >= 16
     # idempotence / order independence at full size: the second batch again, in reverse read order
-    back = np.ascontiguousarray(raw[12500:][::-1])
-    again, _ = _map_all(dev, back, 1, 12500)
-    assert again[::-1].tobytes() == res[12500:].tobytes()
+    back = np.ascontiguousarray(raw[15000:][::-1])
+    again, _ = _map_all(dev, back, 1, 10000)
+    assert again[::-1].tobytes() == res[15000:].tobytes()
     # the census walk (exactly nanoflann's node set) returns the same records on 2 000 chunks
     dev.params.reference_walk = 1
     try:
