@@ -207,7 +207,10 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
     delete ctx;
     return SMHIP_EHIP;
   }
-  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->convert_done, hipEventDisableTiming) != hipSuccess) {
     smhip_destroy(ctx);
@@ -232,6 +235,12 @@ void smhip_destroy(smhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
   if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
@@ -1013,8 +1022,6 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   ca.lists = ctx->a_qpos.as<uint32_t>();
   ca.item_lo = ctx->a_dist.as<uint64_t>();
   ca.item_hi = ctx->a_grp.as<uint64_t>();
-  ca.item_counts = nullptr;  // (set by LaunchChain)
-  ca.item_cap = 0;
   ca.results = results;
   ca.out_anchors = ctx->out_anchors.as<smhip_carried_anchor>();
   ca.out_anchor_cnt = ctx->out_anchor_cnt.as<uint32_t>();

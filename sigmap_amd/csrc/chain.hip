@@ -298,10 +298,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
 // three anchors; the true locus of a read is one long item.
 __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_target_gap_length,
                                                           uint32_t *__restrict__ n_pending,
-                                                          uint32_t *__restrict__ item_counts, uint32_t item_cap) {
+                                                          uint32_t *__restrict__ n_items) {
   __shared__ uint32_t s_wave[4], s_wave8[8][4];
   __shared__ uint32_t s_run;
-  __shared__ uint32_t s_base[1];
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
   const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
@@ -392,50 +391,52 @@ __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_t
     if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
   }
-  // ---- one DESCRIPTOR per item in a batch-wide list, so that the DP kernel finds everything about an item with
-  // one load instead of a chain of dependent ones (chunk search, item bounds, first anchor, its bucket):
-  // lo = chunk | first pending index << 32, hi = pending anchors | bucket ordinal << 32.  The chunk's items take
-  // consecutive entries from the front of the arrays (one atomic per chunk); an item with more than
-  // kBigPendingMin anchors (wave per item; about one per chunk: the read's true locus) is listed a second time
-  // from the back.  An item's first listed anchor has an unlisted predecessor that no other item shares, so
-  // short items + 13 x long items <= anchors / 2: the two ends never meet in arrays of anchors / 2 entries.
+  // ---- one DESCRIPTOR per item, so that the DP kernel finds everything about an item with one load instead of
+  // a chain of dependent ones (item bounds, first anchor, its bucket): lo = chunk | first pending index << 32,
+  // hi = pending anchors | bucket ordinal << 32.  An item's first listed anchor has an unlisted predecessor that
+  // no other item shares, so a chunk of n anchors has at most n / 2 items: chunk c owns the entries
+  // [anchor_off[c] / 2, anchor_off[c + 1] / 2) of the descriptor arrays (one 8-byte word per two anchors each) --
+  // no atomics (one atomic per workgroup on a common counter cost 0.13 ms: 2 048 workgroups arrive together).
   const uint32_t n_it = s_run;
   const uint32_t *pred = a.pred + base;
+  uint64_t *d_lo = a.item_lo + base / 2, *d_hi = a.item_hi + base / 2;
   __syncthreads();
-  if (tid == 0) s_base[0] = n_it ? atomicAdd(&item_counts[0], n_it) : 0u;
-  __syncthreads();
-  const uint32_t first = s_base[0];
   for (uint32_t k = tid; k < n_it; k += 256) {
     const uint32_t p0 = items[k];
     const uint32_t npl = (k + 1 < n_it ? items[k + 1] : npend) - p0;
     const uint32_t g = pred[pending[p0]];  // the bucket's ordinal, left there by the classify kernel
-    const uint64_t d_lo = (uint64_t)c | ((uint64_t)p0 << 32), d_hi = (uint64_t)npl | ((uint64_t)g << 32);
-    a.item_lo[first + k] = d_lo;
-    a.item_hi[first + k] = d_hi;
-    if (npl > (uint32_t)kBigPendingMin) {
-      const uint32_t at = item_cap - 1u - atomicAdd(&item_counts[1], 1u);
-      a.item_lo[at] = d_lo;
-      a.item_hi[at] = d_hi;
-    }
+    d_lo[k] = (uint64_t)c | ((uint64_t)p0 << 32);
+    d_hi[k] = (uint64_t)npl | ((uint64_t)g << 32);
   }
+  if (tid == 0) n_items[c] = n_it;
 }
 
 // ---- C1: chaining DP (spatial_index.cc:436-541), ONE LANE PER ITEM, flattened over the whole batch.
 // Predecessor records are fetched kPf at a time so the dependent chain sees one memory latency
 // per block instead of one per predecessor.
 template <bool kIntGap>
-__device__ __forceinline__ void DpSmallItems(const ChainArgs &a, uint32_t first_block, uint32_t n_blocks,
-                                             uint32_t (*s_ids)[64], float radius, int dim, int max_gap_length,
-                                             int max_target_gap_length, int chaining_band_length, int max_num_skips) {
-  const uint32_t total_items = a.item_counts[0];
+__device__ __forceinline__ void DpSmallItems(const ChainArgs &a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
+                                             uint32_t first_block, uint32_t n_blocks, uint32_t (*s_ids)[64], float radius,
+                                             int dim, int max_gap_length, int max_target_gap_length,
+                                             int chaining_band_length, int max_num_skips) {
+  const uint32_t total_items = ioff[n_chunks];
   PHASE_DECL();
   // grid-stride over items (their total is only known on the device)
   for (uint32_t gi = (blockIdx.x - first_block) * 64 + threadIdx.x; gi < total_items; gi += n_blocks * 64) {
   PHASE_INIT();
-  const uint64_t d_lo = a.item_lo[gi], d_hi = a.item_hi[gi];  // (ChainPendingKernel)
-  const uint32_t c = (uint32_t)d_lo, p0 = (uint32_t)(d_lo >> 32), npl = (uint32_t)d_hi, g = (uint32_t)(d_hi >> 32);
-  if (npl > (uint32_t)kBigPendingMin) continue;  // a long item (the true locus of a read): chained by a whole wave
+  // chunk of the item: chunks hold similar numbers of items, so a proportional guess and a few steps either way
+  // replace the 14 dependent loads of a binary search (which remains for a guess that is far off)
+  uint32_t c = (uint32_t)(((uint64_t)gi * n_chunks) / total_items);
+  {
+    uint32_t steps = 0;
+    while (c > 0 && ioff[c] > gi && steps < 8) { --c; ++steps; }
+    while (c + 1 < n_chunks && ioff[c + 1] <= gi && steps < 8) { ++c; ++steps; }
+    if (ioff[c] > gi || ioff[c + 1] <= gi) c = ChunkOfFlat(ioff, n_chunks, gi);
+  }
   const uint64_t base = a.anchor_off[c];
+  const uint64_t d_hi = a.item_hi[base / 2 + (gi - ioff[c])], d_lo = a.item_lo[base / 2 + (gi - ioff[c])];  // (ChainPendingKernel)
+  const uint32_t p0 = (uint32_t)(d_lo >> 32), npl = (uint32_t)d_hi, g = (uint32_t)(d_hi >> 32);
+  if (npl > (uint32_t)kBigPendingMin) continue;  // a long item (the true locus of a read): chained by a whole wave
   const uint32_t *tpos = a.s_tpos + base, *qpos = a.s_qpos + base;
   const float *dist = a.s_dist + base;
   const uint32_t *gstart = a.group_start + base;
@@ -707,15 +708,23 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
 }
 
 template <bool kIntGap>
-__device__ __forceinline__ void DpBigItems(const ChainArgs &a, uint32_t n_blocks, int32_t *l_t, int32_t *l_q, float *l_s,
-                                           float *l_d, float radius, int dim, int max_gap_length,
-                                           int max_target_gap_length, int chaining_band_length, int max_num_skips) {
+__device__ __forceinline__ void DpBigItems(const ChainArgs &a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
+                                           uint32_t n_blocks, int32_t *l_t, int32_t *l_q, float *l_s, float *l_d,
+                                           float radius, int dim, int max_gap_length, int max_target_gap_length,
+                                           int chaining_band_length, int max_num_skips) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t nbig = a.item_counts[1];
-  for (uint32_t b = blockIdx.x; b < nbig; b += n_blocks) {
-    const uint64_t d_lo = a.item_lo[a.item_cap - 1u - b], d_hi = a.item_hi[a.item_cap - 1u - b];  // (from the back)
-    const uint32_t c = (uint32_t)d_lo, p0 = (uint32_t)(d_lo >> 32), p1 = p0 + (uint32_t)d_hi, g = (uint32_t)(d_hi >> 32);
-    const uint64_t base = a.anchor_off[c];
+  // a workgroup (one wave) takes chunks in turn, looks through the chunk's item descriptors (a few hundred,
+  // coalesced) and chains the long ones -- about one per chunk
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += n_blocks) {
+   const uint32_t n_it = ioff[c + 1] - ioff[c];
+   const uint64_t base = a.anchor_off[c];
+   for (uint32_t k0 = 0; k0 < n_it; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const uint64_t my_hi = k < n_it ? a.item_hi[base / 2 + k] : 0ull;
+    for (unsigned long long mb = __ballot((uint32_t)my_hi > (uint32_t)kBigPendingMin); mb; mb &= mb - 1ull) {
+    const uint32_t kb = k0 + (uint32_t)__builtin_ctzll(mb);
+    const uint64_t d_lo = a.item_lo[base / 2 + kb], d_hi = a.item_hi[base / 2 + kb];
+    const uint32_t p0 = (uint32_t)(d_lo >> 32), p1 = p0 + (uint32_t)d_hi, g = (uint32_t)(d_hi >> 32);
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint32_t G = a.n_groups[c];
     const uint32_t *gstart = a.group_start + base;
@@ -746,28 +755,34 @@ __device__ __forceinline__ void DpBigItems(const ChainArgs &a, uint32_t n_blocks
       DpBigBucket<false, kIntGap>(lane, ng, s, pending + p0, p1 - p0, l_t, l_q, l_s, l_d, tpos, qpos, dist, score, pred, used,
                          &gmax[g], radius, dim, max_gap_length, max_target_gap_length, chaining_band_length,
                          max_num_skips);
+    }
+   }
   }
 }
 
-// ---- C1 + C1b in ONE launch: the first kDpBigBlocks workgroups (dispatched first) take the long items, a wave
-// each; the others the short items, a lane each.  The two used to be consecutive launches (0.57 + 0.40 ms at
-// 12 Mb): the long items are few and latency-bound, the short ones many -- together they fill the chip.
+// ---- C1 and C1b are independent (different items, disjoint anchors; the bucket maxima are atomics): the few long
+// items -- latency-bound, a wave each -- run on the context's auxiliary stream beside the many short ones
+// (consecutive launches: 0.57 + 0.40 ms at 12 Mb; ONE launch with both bodies, 0.78 - 0.83 ms: the lane DP then
+// runs at the wave DP's register count, five waves per SIMD instead of eight).
 constexpr uint32_t kDpBigBlocks = 8192;
 template <bool kIntGap>
-__global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, float radius, int dim, int max_gap_length,
+__global__ __launch_bounds__(64) void ChainDpKernel(ChainArgs a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
+                                                    float radius, int dim, int max_gap_length,
                                                     int max_target_gap_length, int chaining_band_length,
                                                     int max_num_skips) {
-  // long items: the bucket (or a ring over it) in LDS; short items: each lane's pending anchor ids
-  __shared__ __align__(16) uint32_t lds[4 * kBigGroupCap];
-  static_assert(4 * kBigGroupCap >= kBigPendingMin * 64, "the lane DP's id table fits the wave DP's staging room");
-  if (blockIdx.x < kDpBigBlocks) {
-    DpBigItems<kIntGap>(a, kDpBigBlocks, reinterpret_cast<int32_t *>(lds), reinterpret_cast<int32_t *>(lds + kBigGroupCap),
-                        reinterpret_cast<float *>(lds + 2 * kBigGroupCap), reinterpret_cast<float *>(lds + 3 * kBigGroupCap),
-                        radius, dim, max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
-  } else {
-    DpSmallItems<kIntGap>(a, kDpBigBlocks, gridDim.x - kDpBigBlocks, reinterpret_cast<uint32_t(*)[64]>(lds), radius, dim,
-                          max_gap_length, max_target_gap_length, chaining_band_length, max_num_skips);
-  }
+  __shared__ uint32_t s_ids[kBigPendingMin][64];  // each lane's pending anchor ids
+  DpSmallItems<kIntGap>(a, ioff, n_chunks, 0u, gridDim.x, s_ids, radius, dim, max_gap_length, max_target_gap_length,
+                        chaining_band_length, max_num_skips);
+}
+template <bool kIntGap>
+__global__ __launch_bounds__(64) void ChainDpBigKernel(ChainArgs a, const uint32_t *__restrict__ ioff, uint32_t n_chunks,
+                                                       float radius, int dim, int max_gap_length,
+                                                       int max_target_gap_length, int chaining_band_length,
+                                                       int max_num_skips) {
+  __shared__ int32_t l_t[kBigGroupCap], l_q[kBigGroupCap];
+  __shared__ float l_s[kBigGroupCap], l_d[kBigGroupCap];
+  DpBigItems<kIntGap>(a, ioff, n_chunks, gridDim.x, l_t, l_q, l_s, l_d, radius, dim, max_gap_length, max_target_gap_length,
+                      chaining_band_length, max_num_skips);
 }
 
 // ---- C2: one wave per chunk: running max_chaining_score across buckets (spatial_index.cc:420,
@@ -1353,12 +1368,9 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   uint32_t *n_chains = ctx->chain_cnt.as<uint32_t>(), *goff = n_chains + n_chunks;
   uint32_t *n_pending = goff + n_chunks + 1;
   uint32_t *tiles = n_pending + n_chunks, *tile_off = tiles + n_chunks;
-  uint32_t *item_counts = tile_off + n_chunks + 1;  // [0] short items, [1] long items (ChainPendingKernel)
-  if ((e = hipMemsetAsync(item_counts, 0, 2 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
-  // item descriptors: the unsorted SoA is dead after the sort -- a_dist / a_grp hold 4 bytes per anchor each,
-  // i.e. one 8-byte word per two anchors, and a batch has at most half as many items as anchors
-  a.item_counts = item_counts;
-  a.item_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_anchors_total, 1) / 2, 0xFFFFFFFFull);
+  uint32_t *n_items = tile_off + n_chunks + 1, *ioff = n_items + n_chunks;
+  // (item descriptors: the unsorted SoA is dead after the sort -- a_dist / a_grp hold 4 bytes per anchor each,
+  // i.e. one 8-byte word per two anchors, and a chunk has at most half as many items as anchors)
   if ((e = LaunchScanU32(ctx, a.n_groups, n_chunks, goff)) != hipSuccess) return e;
   // candidate chains: 3 per bucket, a bucket holds >= 1 anchor and there are <= 2 per contig; second
   // half = the ranked copy of the chunks with more than kChainCap candidates
@@ -1383,14 +1395,28 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
                        p.max_num_skips);
   hipLaunchKernelGGL(ChainPendingKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.max_target_gap_length, n_pending,
-                     item_counts, a.item_cap);
-  const uint32_t dp_blocks = kDpBigBlocks + (uint32_t)std::min<uint64_t>((n_anchors_total + 63) / 64 + 1, 16384);
+                     n_items);
+  if ((e = LaunchScanU32(ctx, n_items, n_chunks, ioff)) != hipSuccess) return e;
+  // fork: the wave DP of the long items on the auxiliary stream, the lane DP of the short ones here; join before C2
+  if ((e = hipEventRecord(ctx->ev_fork, ctx->stream)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0)) != hipSuccess) return e;
   if (int_gap)
-    hipLaunchKernelGGL(ChainDpKernel<true>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, p.search_radius, kMaxDim,
-                       p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+    hipLaunchKernelGGL(ChainDpBigKernel<true>, dim3(kDpBigBlocks), dim3(64), 0, ctx->aux_stream, a, ioff, n_chunks,
+                       p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
+                       p.max_num_skips);
   else
-    hipLaunchKernelGGL(ChainDpKernel<false>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, p.search_radius, kMaxDim,
-                       p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+    hipLaunchKernelGGL(ChainDpBigKernel<false>, dim3(kDpBigBlocks), dim3(64), 0, ctx->aux_stream, a, ioff, n_chunks,
+                       p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
+                       p.max_num_skips);
+  if ((e = hipEventRecord(ctx->ev_join, ctx->aux_stream)) != hipSuccess) return e;
+  const uint32_t dp_blocks = (uint32_t)std::min<uint64_t>((n_anchors_total + 63) / 64 + 1, 16384);
+  if (int_gap)
+    hipLaunchKernelGGL(ChainDpKernel<true>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+                       kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+  else
+    hipLaunchKernelGGL(ChainDpKernel<false>, dim3(dp_blocks), dim3(64), 0, ctx->stream, a, ioff, n_chunks, p.search_radius,
+                       kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length, p.max_num_skips);
+  if ((e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)) != hipSuccess) return e;
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
                      p.num_best_chains, p.min_chaining_score, n_chains, n_pending, kMaxDim);
   hipLaunchKernelGGL(ChainFinalizeKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);

@@ -188,6 +188,8 @@ struct smhip_ctx {
   std::vector<smhip::DevBuf> pa_segs;  // the slots' segments (SlotView); pa_tab = their pointers on the device
   std::vector<float *> h_pa_tab;
   uint32_t pa_sshift = 0;
+  hipStream_t aux_stream = nullptr;    // independent kernels of a step beside `stream` (chain.hip: the wave DP), fork / join
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // by these events
   hipStream_t copy_stream = nullptr;   // H2D of raw reads, overlapped with the kernels on `stream`
   hipEvent_t copy_done = nullptr, convert_done = nullptr;
   uint32_t n_slots = 0, reads_keep = 0;
@@ -365,9 +367,7 @@ struct ChainArgs {
   uint64_t *scratch;  // the sort's key buffer (2 keys per anchor), dead by now
   uint32_t *pending;  // per chunk: anchors that need the sequential DP, in index order (dead a_tpos)
   uint32_t *lists;    // per chunk: anchor index lists of the traced chains (dead a_qpos)
-  uint64_t *item_lo, *item_hi;  // batch-wide descriptors of the DP's items (dead a_dist / a_grp): short items from the
-  uint32_t *item_counts;        // front ([0] of them), long items from the back ([1]); item_cap entries each
-  uint32_t item_cap;
+  uint64_t *item_lo, *item_hi;  // descriptors of the DP's items (dead a_dist / a_grp): chunk c's at [anchor_off[c] / 2, ..)
   smhip_chunk_result *results;
   smhip_carried_anchor *out_anchors;
   uint32_t *out_anchor_cnt;
