@@ -137,15 +137,34 @@ __device__ unsigned long long g_walk_prof[8];
 #define WALK_T() 0ull
 #endif
 
-template <bool kStrict>
+// kMode: kWalkExact  -- nanoflann's traversal order and pruning rule on top of the box rule: hits in the reference's
+//                       order (the per-stage entry point, and the queries beyond the 5000-hit cap, where the order
+//                       decides which hits survive, spatial_index.cc:371-372);
+//        kWalkCensus -- exactly nanoflann's node set (reference_walk = 1: the census of its work);
+//        kWalkSet    -- the hit SET of a query in whatever order is cheapest.  Every hit of a query with at most
+//                       num_nearest_points hits becomes an anchor and the anchors are sorted afterwards
+//                       (spatial_index.cc:411-417), so for those queries -- all of them on a 12 Mb reference, 99.4 %
+//                       on a 250 Mb one -- only the set matters; the others are searched again in kWalkExact mode
+//                       (LaunchSeedLookup).  nanoflann's own rule (mindistsq + cut_dist - dists[idx] <= radius) only
+//                       ever prunes subtrees without hits -- its search is exact -- so the box rule alone finds the
+//                       same set: the walk then carries no dists[] / mindistsq state, a pending visit is a 4-byte
+//                       node reference instead of a 32-byte record (no spill traffic), and a node visit is two box
+//                       tests, no plane arithmetic.
+enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2 };
+constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area)
+
+template <int kMode>
 __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem,
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
+  constexpr bool kStrict = kMode == kWalkCensus;
+  constexpr bool kSet = kMode == kWalkSet;
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
+  uint32_t *stk32 = reinterpret_cast<uint32_t *>(stk);  // (set walk: the same area as 4-byte references)
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
@@ -175,7 +194,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   // the query on the box grid, two dimensions per word like the records: the nearest grid index
   uint32_t qc01 = 0, qc23 = 0, qc45 = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
-  __shared__ float4 tos[2][2][kSeedThreads];
+  __shared__ float4 tos[kSet ? 1 : 2][2][kSet ? 1 : kSeedThreads];
+  __shared__ uint32_t lstk[kSet ? kSetStack : 1][kSet ? kSeedThreads : 1];  // set walk: the newest pending references
   // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
   __shared__ uint32_t fifo[kFifo][kSeedThreads];
   __shared__ uint32_t ovf_lds[kSeedThreads];  // scan phase: overflow segment base of each lane's query
@@ -434,10 +454,12 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const float4 b = *(reinterpret_cast<const float4 *>(&qrec[ri]) + 1);
         qi = __float_as_uint(b.w);
         q0 = a.x; q1 = a.y; q2 = a.z; q3 = a.w; q4 = b.x; q5 = b.y;
-        d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
-        mind = 0.0f;
-        SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
-        SM_INIT_DIM(5, d5)
+        if (!kSet) {
+          d0 = d1 = d2 = d3 = d4 = d5 = 0.0f;
+          mind = 0.0f;
+          SM_INIT_DIM(0, d0) SM_INIT_DIM(1, d1) SM_INIT_DIM(2, d2) SM_INIT_DIM(3, d3) SM_INIT_DIM(4, d4)
+          SM_INIT_DIM(5, d5)
+        }
         node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
         {
           uint32_t gc[6];
@@ -472,14 +494,98 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     }
     const unsigned long long pt2 = WALK_T();
     pt_wait += pt2 - pt1;
-    if (rf_pending) {  // the refill issued by the previous pop has landed too: it is the oldest cached entry
+    if (!kSet && rf_pending) {  // the refill issued by the previous pop has landed too: it is the oldest cached entry
       const uint32_t slot = tcnt == 0 ? thead : thead ^ 1u;
       tos[slot][0][threadIdx.x] = rf_a;
       tos[slot][1][threadIdx.x] = rf_b;
       ++tcnt;
       rf_pending = false;
     }
-    if (active && mode == M_NODE) {
+    if (kSet) {
+      if (active && mode == M_NODE) {
+        // ---- set walk: test both children's boxes; the first that passes is visited next, a second one is left on
+        // the stack; leaves go to the FIFO at once.  A reference on the stack has passed its box test.
+        uint32_t cur = 0xFFFFFFFFu;  // the node to go on with (none: pop)
+        if (!(node & kLeafTag)) {
+          const uint32_t rot = (lane >> 2) & 3u;
+          const uint4 *mine = stage_w + lane * 4;
+          const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
+          ++nn;
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#define SM_GAP(qlw, hiw, low, qhw)                                                                    \
+  __builtin_elementwise_max(__builtin_elementwise_sub_sat(qlw, __builtin_bit_cast(us2, hiw)), \
+                            __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, low), qhw))
+          const us2 k3 = {3, 3};
+          const us2 ql01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc01), k3),
+                    ql23 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc23), k3),
+                    ql45 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc45), k3);
+          const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
+                    qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
+                    qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
+          float lb1, lb2;  // (the bounds of the exact walk below: same arithmetic, same margins)
+          {
+            const us2 g01 = SM_GAP(ql01, b0.w, b0.x, qh01), g23 = SM_GAP(ql23, b1.x, b0.y, qh23),
+                      g45 = SM_GAP(ql45, b1.y, b0.z, qh45);
+            const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
+                        e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
+            lb1 = e0 * e0;
+            lb1 = __fmaf_rn(e1, e1, lb1); lb1 = __fmaf_rn(e2, e2, lb1); lb1 = __fmaf_rn(e3, e3, lb1);
+            lb1 = __fmaf_rn(e4, e4, lb1); lb1 = __fmaf_rn(e5, e5, lb1);
+          }
+          {
+            const us2 g01 = SM_GAP(ql01, b2.y, b1.z, qh01), g23 = SM_GAP(ql23, b2.z, b1.w, qh23),
+                      g45 = SM_GAP(ql45, b2.w, b2.x, qh45);
+            const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
+                        e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
+            lb2 = e0 * e0;
+            lb2 = __fmaf_rn(e1, e1, lb2); lb2 = __fmaf_rn(e2, e2, lb2); lb2 = __fmaf_rn(e3, e3, lb2);
+            lb2 = __fmaf_rn(e4, e4, lb2); lb2 = __fmaf_rn(e5, e5, lb2);
+          }
+#undef SM_GAP
+          const uint32_t ref1 = hd.z & (kLeafTag | kIdxMask), ref2 = hd.w & (kLeafTag | kIdxMask);
+          const bool in1 = lb1 < radius, in2 = lb2 < radius;
+          cur = in1 ? ref1 : (in2 ? ref2 : 0xFFFFFFFFu);
+          if (in1 && in2) {  // the second child waits on the stack
+            if (sp < (uint32_t)kSetStack) {
+              lstk[sp][threadIdx.x] = ref2;
+              ++sp;
+            } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
+              stk32[sp - (uint32_t)kSetStack] = ref2;
+              ++sp;
+            } else {
+              atomicOr(&sink.counters[0], 1u);
+            }
+          }
+        } else {
+          cur = node & (kLeafTag | kIdxMask);  // a leaf left over from the previous visit (the FIFO was full)
+        }
+        // leaves go to the FIFO as they come up (until it is full: the lane then waits for the scan phase with the
+        // leaf as its current node); the next inner node is the one to fetch
+        for (;;) {
+          if (cur == 0xFFFFFFFFu) {
+            if (sp == 0) break;
+            --sp;
+            cur = sp < (uint32_t)kSetStack ? lstk[sp][threadIdx.x] : stk32[sp - (uint32_t)kSetStack];
+          }
+          if (!(cur & kLeafTag) || fifo_cnt == (uint32_t)kFifo) break;
+          ++nn;
+          fifo[fifo_cnt++][threadIdx.x] = cur & kIdxMask;
+          cur = 0xFFFFFFFFu;
+        }
+        if (cur == 0xFFFFFFFFu) {  // stack empty: traversal of this query complete
+          if (fifo_cnt > 0) {
+            mode = M_DRAIN;  // its pending leaves are scanned first
+          } else {
+            sink.q_count[qi] = hits;
+            if (sink.q_nodes) sink.q_nodes[qi] = nn;
+            if (sink.q_points) sink.q_points[qi] = np;
+            mode = M_FETCH;
+          }
+        } else {
+          node = cur;
+        }
+      }
+    } else if (active && mode == M_NODE) {
       bool pop = true;
       if (node & kLeafTag) {
         // a leaf visit of searchLevel (nanoflann.hpp:1350-1369): the root of a one-leaf tree, or a far
@@ -853,8 +959,21 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
 
-hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qrec, const uint32_t *n_queries_dev,
-                      uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride) {
+// The queries the set walk found more than num_nearest_points hits for: their records (visiting order, the
+// record's last word is the query id) are listed for a second search in the reference's traversal order.
+__global__ void OverCapCollectKernel(const QueryRec *__restrict__ order, const uint32_t *__restrict__ n_queries_dev,
+                                     const uint32_t *__restrict__ q_count, uint32_t nnp, QueryRec *__restrict__ list,
+                                     uint32_t *__restrict__ n_list) {
+  const uint32_t total = *n_queries_dev;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const QueryRec r = order[i];
+    if (q_count[r.k] > nnp) list[atomicAdd(n_list, 1u)] = r;
+  }
+}
+
+hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const QueryRec *qrec, const uint32_t *n_queries_dev,
+                      uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride,
+                      uint32_t blocks_override = 0) {
   const int env_blocks = Knobs().lane_blocks_per_cu, xcd_ranges = Knobs().xcd_ranges,
             env_thr = Knobs().scan_threshold;
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
@@ -862,18 +981,23 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, const QueryRec *qre
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
-  const uint32_t blocks = 256 * blocks_per_cu;
-  const size_t stack_bytes = (size_t)blocks * kSeedThreads * kStackDepth * 2 * sizeof(float4);
+  const uint32_t blocks = blocks_override ? blocks_override : 256 * blocks_per_cu;
+  const size_t stack_bytes = (size_t)256 * 8 * kSeedThreads * kStackDepth * 2 * sizeof(float4);  // (any grid up to 8 per CU)
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
   if (e != hipSuccess) return e;
-  if (p.reference_walk)
-    hipLaunchKernelGGL(SeedWalkKernel<true>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
-                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
-                       xcd_ranges ? range_end : nullptr, range_stride, (uint32_t)thr);
+  const uint32_t *re = xcd_ranges ? range_end : nullptr;
+  if (mode == kWalkCensus)
+    hipLaunchKernelGGL(SeedWalkKernel<kWalkCensus>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
+                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
+                       (uint32_t)thr);
+  else if (mode == kWalkSet)
+    hipLaunchKernelGGL(SeedWalkKernel<kWalkSet>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
+                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
+                       (uint32_t)thr);
   else
-    hipLaunchKernelGGL(SeedWalkKernel<false>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
-                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(),
-                       xcd_ranges ? range_end : nullptr, range_stride, (uint32_t)thr);
+    hipLaunchKernelGGL(SeedWalkKernel<kWalkExact>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
+                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
+                       (uint32_t)thr);
   return hipGetLastError();
 }
 }  // namespace
@@ -960,9 +1084,28 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
     e = BuildQueryOrder(ctx, qr, q_off + n_chunks, 0, n_queries_max, &order, &range_end, &range_stride);
   }
   if (e != hipSuccess) return e;
-  ScopedTimer t(ctx, T_SEED);  // the walker launch alone: what rocprofv3's kernel trace reports for SeedWalkKernel
-  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
-                    range_stride);
+  ScopedTimer t(ctx, T_SEED);  // the search itself (the set walk, and the second search of the queries beyond the cap)
+  if (p.reference_walk)
+    return LaunchWalk(ctx, p, kWalkCensus, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+                      range_stride);
+  // (SMHIP_EXACT_WALK: A/B switch, read per call -- every query in the reference's traversal order, as before the set walk)
+  if (getenv("SMHIP_EXACT_WALK"))
+    return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+                      range_stride);
+  e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+                 range_stride);
+  if (e != hipSuccess) return e;
+  // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal
+  // order (spatial_index.cc:371-372), so they are searched again in that order; their slots, overflow segments
+  // and counts are simply written a second time.  (None on a 12 Mb reference; 0.6 % of the queries on a 250 Mb one.)
+  // The list takes the room of the unsorted query records, which nobody reads after the visiting order is built;
+  // its length stays on the device: counters[7]; the range cursors [16..23] start again.
+  QueryRec *list = const_cast<QueryRec *>(qr);
+  if ((e = hipMemsetAsync(counters + 16, 0, 8 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(counters + 7, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(OverCapCollectKernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<const QueryRec *>(order),
+                     q_off + n_chunks, q_count, (uint32_t)p.num_nearest_points, list, counters + 7);
+  return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0, 256);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -977,8 +1120,9 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
   Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
-  ScopedTimer t(ctx, T_SEED);
-  return LaunchWalk(ctx, p, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
+  ScopedTimer t(ctx, T_SEED);  // (the per-stage entry point reports hits in the reference's traversal order)
+  return LaunchWalk(ctx, p, p.reference_walk ? kWalkCensus : kWalkExact, reinterpret_cast<const QueryRec *>(order), nullptr,
+                    n, sink, range_end, range_stride);
 }
 }  // namespace smhip
 
