@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       }
       first_ord = lo;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     PHASE_MARK(0);
     uint32_t ord = 0, ord_last = 0;
     {
@@ -275,15 +275,15 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       }
     }
     PHASE_MARK(3);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     PHASE_MARK(4);
     if (lane <= ord_last - first_ord && s_gmax[lane] != 0) atomicMax(&gmax_g[first_ord + lane], s_gmax[lane]);
     ord_carry = ord_last;
     ring_valid = true;
     PHASE_MARK(5);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();  // the ring half and the maxima are free for the next tile
   }
   PHASE_FLUSH();

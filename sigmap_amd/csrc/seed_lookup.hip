@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
   constexpr bool kSet = kMode == kWalkSet;
+  if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
   const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
   uint32_t *stk32 = reinterpret_cast<uint32_t *>(stk);  // (set walk: the same area as 4-byte references)
@@ -199,6 +200,10 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
   __shared__ uint32_t fifo[kFifo][kSeedThreads];
   __shared__ uint32_t ovf_lds[kSeedThreads];  // scan phase: overflow segment base of each lane's query
+  // address of the first hit slot of each lane's query (HitSlots::At(qi, 0): a pointer-table load), taken when the
+  // query is handed out: at emit time it is an LDS read -- a global load there made every scan iteration wait for
+  // everything in flight (the next window's point loads included)
+  __shared__ Hit *slot_base[kSeedThreads];
   // staging of the cooperative node fetch: 64 records x 64 B per wave
   __shared__ uint4 stage[kSeedThreads / 64][256];
   const uint32_t lane = threadIdx.x & 63u;
@@ -273,9 +278,9 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
         ovf_lds[threadIdx.x] = ovf_base;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       // The points of all pending leaves form one flat sequence (leaf after leaf in entry order), scanned 64
       // at a time, ONE POINT PER LANE, whatever the leaf boundaries: leaves hold 1..20 points (12.5 on average:
       // fixed groups of 21 lanes per leaf left 35 % of the lanes idle).  The window of an iteration starts in
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const uint32_t run_first = 63u - (uint32_t)__clzll((long long)((rb & lowmask) | 1ull));
         const uint32_t in_run_below = (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
         const uint32_t ord = hbase + in_run_below;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();  // every lane has read its owner's count
         // the last lane of a run adds the run's hits to the owner's count
         const uint64_t next_is_first_or_idle = (rb | ~pb) >> 1;  // bit L: lane L + 1 starts a run or has no point
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         h.dist = res;
         h.slot = (mine.x >> 1) + t;
         const bool emit = hit && ord < sink.nnp;
-        if (emit && ord < sink.fast_cap) *sink.region.At(oqi, ord) = h;
+        if (emit && ord < sink.fast_cap) slot_base[(threadIdx.x & ~63u) + owner][ord] = h;
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
         for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
           if (lane == (uint32_t)__builtin_ctzll(ovm)) {
@@ -378,9 +383,9 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
             ovf_lds[(threadIdx.x & ~63u) + owner] = ob;
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       };
       // Two windows in flight, A and B in turn (no register copies between them): while one is processed, the
       // other's entries have been looked up and its point loads are on their way.
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           SM_INIT_DIM(5, d5)
         }
         node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
+        slot_base[threadIdx.x] = sink.region.At(qi, 0);
         {
           uint32_t gc[6];
 #define SM_GRID(k) gc[k] = (uint32_t)fminf(fmaxf(rintf((q##k - box_base[k]) * box_inv[k]), 0.0f), 65535.0f);
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     }
   }
 #ifdef SMHIP_PHASE_PROF
-  if (!kStrict && lane == 0) {
+  if (kSet && lane == 0) {  // (the production walk)
     const unsigned long long pt_all = clock64() - pt_begin;
     atomicAdd(&g_walk_prof[0], pt_all);
     atomicAdd(&g_walk_prof[1], pt_scan);
@@ -959,15 +965,18 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
 
-// The queries the set walk found more than num_nearest_points hits for: their records (visiting order, the
-// record's last word is the query id) are listed for a second search in the reference's traversal order.
-__global__ void OverCapCollectKernel(const QueryRec *__restrict__ order, const uint32_t *__restrict__ n_queries_dev,
+// The queries the set walk found more than num_nearest_points hits for are listed for a second search in the
+// reference's traversal order: their records from the unsorted array (query i at [i]), the last word set to the
+// query id like QueryScatterKernel does.
+__global__ void OverCapCollectKernel(const QueryRec *__restrict__ qrec, const uint32_t *__restrict__ n_queries_dev,
                                      const uint32_t *__restrict__ q_count, uint32_t nnp, QueryRec *__restrict__ list,
                                      uint32_t *__restrict__ n_list) {
   const uint32_t total = *n_queries_dev;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const QueryRec r = order[i];
-    if (q_count[r.k] > nnp) list[atomicAdd(n_list, 1u)] = r;
+    if (q_count[i] <= nnp) continue;
+    QueryRec r = qrec[i];
+    r.k = i;
+    list[atomicAdd(n_list, 1u)] = r;
   }
 }
 
@@ -1098,13 +1107,13 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal
   // order (spatial_index.cc:371-372), so they are searched again in that order; their slots, overflow segments
   // and counts are simply written a second time.  (None on a 12 Mb reference; 0.6 % of the queries on a 250 Mb one.)
-  // The list takes the room of the unsorted query records, which nobody reads after the visiting order is built;
-  // its length stays on the device: counters[7]; the range cursors [16..23] start again.
-  QueryRec *list = const_cast<QueryRec *>(qr);
+  // The list takes the room of the visiting order, which the set walk has consumed; its length stays on the
+  // device: counters[7]; the range cursors [16..23] start again.
+  QueryRec *list = reinterpret_cast<QueryRec *>(const_cast<uint32_t *>(order));
   if ((e = hipMemsetAsync(counters + 16, 0, 8 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(counters + 7, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(OverCapCollectKernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<const QueryRec *>(order),
-                     q_off + n_chunks, q_count, (uint32_t)p.num_nearest_points, list, counters + 7);
+  hipLaunchKernelGGL(OverCapCollectKernel, dim3(1024), dim3(256), 0, ctx->stream, qr, q_off + n_chunks, q_count,
+                     (uint32_t)p.num_nearest_points, list, counters + 7);
   return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0, 256);
 }
 

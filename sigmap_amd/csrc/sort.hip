@@ -152,7 +152,7 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
 #pragma unroll
           for (int k = 0; k < 4; ++k) rank += (x + k < ms && o[k] < mine) ? 1u : 0u;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();  // all reads of the buckets precede the permuting writes
         if (gl < ms) lds_keys[b0 + rank] = mine;
       }
@@ -174,7 +174,7 @@ __device__ __forceinline__ void LdsSortKeys(uint64_t (&mykeys)[PT], uint32_t n, 
           for (int k = 0; k < 8; ++k) rank += o[k] < mine ? 1u : 0u;
         }
         for (; x < cm; ++x) rank += lds_keys[c0 + x] < mine ? 1u : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         if (lane < cm) lds_keys[c0 + rank] = mine;
       }
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
       col_q[Pad(i)] = rv.z;  // (slots beyond the part get the clamped copies: never read)
       col_d[Pad(i)] = rv.w;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     uint64_t k[KPL];
 #pragma unroll
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
       if (NARROW) k[r] = key_stage[from + from / KPL];  // the 64-bit key of that element: its target and group
       // (!NARROW: the sorted 64-bit keys are in registers; the staging room is simply overwritten below)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < KPL; ++r) {
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
       col_t[e] = (uint32_t)(k[r] >> ibits);
       col_g[e] = (uint32_t)(k[r] >> (32 + ibits));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     PHASE_MARK(2);
     // runs of equal (group, target): ordered by (query, distance) by the lane that owns the run's first element
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
         col_d[Pad(y)] = __float_as_uint(kd);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     PHASE_MARK(3);
     uint32_t *s_tpos = a.s_tpos + A, *s_qpos = a.s_qpos + A, *s_grp = a.s_grp + A;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
         s_dist[i] = col_d[Pad(i)];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();  // the columns are free for the next part
     PHASE_MARK(4);
     if (!more) break;
