@@ -1068,6 +1068,12 @@ bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap
   return grow + grow / 8 + (1ull << 30) < free_b;
 }
 
+// counters[7] of a batch = queries the set walk found beyond the hit cap (searched a second time): beyond one in
+// two thousand the context searches every query in the reference's order from the next batch on
+void LearnOverCap(smhip_ctx *ctx, uint64_t NQ, uint32_t over_cap) {
+  if ((uint64_t)over_cap * 2000 > NQ) ctx->walk_exact_only = true;
+}
+
 void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
   const uint64_t non_carried = NA > ctx->n_carried ? NA - ctx->n_carried : 0;
   ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, (NQ + R - 1) / R);
@@ -1098,6 +1104,7 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    LearnOverCap(ctx, NQ, hc[7]);
     if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
     const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
     if (demand <= pool_cap || demand > 0xFFFF0000ull) break;  // level limit / beyond 32-bit offsets: report the flag
@@ -1153,6 +1160,7 @@ int FinishRun(smhip_ctx *ctx) {
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);
   const bool overflow = info->w[32] || info->w[33] || info->w[3];
+  LearnOverCap(ctx, info->w[34], info->w[7]);
   if (!overflow) {
     LearnTotals(ctx, std::max(ctx->n_chunks, 1u), info->w[34], info->anchors());
     return SMHIP_OK;

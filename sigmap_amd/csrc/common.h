@@ -216,6 +216,7 @@ struct smhip_ctx {
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact, sort_tmp;
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
+  bool walk_exact_only = false;  // batches with many queries beyond the 5000-hit cap: no set walk (seed_lookup.hip)
   // speculative batches (api.hip RunBatchSpeculative): queries / non-carried anchors per chunk of the largest
   // batch so far, the pinned record the stream reports a batch's totals and flags in, what a repeat needs
   uint64_t hint_q_per_chunk = 0, hint_a_per_chunk = 0;

@@ -86,6 +86,8 @@ struct Sink {
   Hit *pool;            // overflow pool: hits beyond the fast slots, in geometric segments
   uint32_t *ovf_tab;    // [n_queries][kOvfLevels] pool offset of each segment
   uint64_t pool_cap;
+  uint32_t stop_at_cap;  // second search of the queries beyond the cap: a query ends with its nnp-th hit, its totals
+                         // (hits, nodes, points) stay those of the first search
 };
 
 // nanoflann.hpp:1006-1023 computeInitialDistances (low test, then high test, per dimension)
@@ -416,9 +418,17 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       }
       fifo_cnt = 0;
       if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
-        sink.q_count[qi] = hits;
-        if (sink.q_nodes) sink.q_nodes[qi] = nn;
-        if (sink.q_points) sink.q_points[qi] = np;
+        if (!sink.stop_at_cap) {
+          sink.q_count[qi] = hits;
+          if (sink.q_nodes) sink.q_nodes[qi] = nn;
+          if (sink.q_points) sink.q_points[qi] = np;
+        }
+        mode = M_FETCH;
+      } else if (!kSet && sink.stop_at_cap && mode == M_NODE && hits >= sink.nnp) {
+        // the first nnp hits in the reference's order are out: the rest of this traversal would only count
+        sp = 0;
+        tcnt = 0;
+        rf_pending = false;
         mode = M_FETCH;
       }
       pt_scan += WALK_T() - pt0;
@@ -698,9 +708,11 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           if (fifo_cnt > 0) {
             mode = M_DRAIN;  // its pending leaves are scanned first
           } else {
-            sink.q_count[qi] = hits;
-            if (sink.q_nodes) sink.q_nodes[qi] = nn;
-            if (sink.q_points) sink.q_points[qi] = np;
+            if (!sink.stop_at_cap) {
+              sink.q_count[qi] = hits;
+              if (sink.q_nodes) sink.q_nodes[qi] = nn;
+              if (sink.q_points) sink.q_points[qi] = np;
+            }
             mode = M_FETCH;
           }
         } else {  // return from searchLevel into the innermost pending visit
@@ -1083,7 +1095,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
                             uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap) {
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
-            nullptr, counters, pool, ovf_tab, pool_cap};
+            nullptr, counters, pool, ovf_tab, pool_cap, 0u};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr, *range_end = nullptr;
   uint32_t range_stride = 0;
@@ -1097,8 +1109,13 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   if (p.reference_walk)
     return LaunchWalk(ctx, p, kWalkCensus, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
-  // (SMHIP_EXACT_WALK: A/B switch, read per call -- every query in the reference's traversal order, as before the set walk)
-  if (getenv("SMHIP_EXACT_WALK"))
+  // Large references put many queries beyond the cap (0.6 % at 250 Mb, each a traversal of tens of thousands of
+  // points that the second search would run again, one lane each, after everything else has finished): there
+  // every query is searched in the reference's order at once, as before the set walk existed.  Decided from the
+  // index size at first (hits per query ~ 1.7e-6 x points: 41 at 12 Mb, 850 at 250 Mb) and from the share of
+  // such queries in the batches seen (smhip_ctx::walk_exact_only, set by smhip_map_run).
+  // (SMHIP_EXACT_WALK: A/B switch, read per call)
+  if (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 300.0 || getenv("SMHIP_EXACT_WALK"))
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
   e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
@@ -1114,7 +1131,8 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   if ((e = hipMemsetAsync(counters + 7, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(OverCapCollectKernel, dim3(1024), dim3(256), 0, ctx->stream, qr, q_off + n_chunks, q_count,
                      (uint32_t)p.num_nearest_points, list, counters + 7);
-  return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0, 256);
+  sink.stop_at_cap = 1u;
+  return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0);
 }
 
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
@@ -1128,7 +1146,7 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   uint32_t range_stride = 0;
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
-  Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0};
+  Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0, 0u};
   ScopedTimer t(ctx, T_SEED);  // (the per-stage entry point reports hits in the reference's traversal order)
   return LaunchWalk(ctx, p, p.reference_walk ? kWalkCensus : kWalkExact, reinterpret_cast<const QueryRec *>(order), nullptr,
                     n, sink, range_end, range_stride);

@@ -507,15 +507,22 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     ix = pipeline.HostIndex.from_points(positions, values, threads=2)
     raw, _ = synth.simulate_reads([unit], lm, 6, 2)
     pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
-    dev = pipeline.DeviceMapper(0)
-    dev.upload_index(ix)
     samples, offsets = _batch(pa)
     tree = po.OracleTree(ix.values.copy())
     for cap in (5, 5000):
-        dev.params.num_nearest_points = cap
         for fast in (3, 128):   # truncation inside the fast slots and inside the overflow pass
+            # (a fresh context each time: the first batch of a context searches with the order-free set walk and
+            # repeats the queries beyond the cap in the reference's order -- here, with cap 5, all of them; a context
+            # that has seen such a batch searches everything in the reference's order from then on: second call)
+            dev = pipeline.DeviceMapper(0)
+            dev.upload_index(ix)
+            dev.params.num_nearest_points = cap
             dev.params.hits_per_query_fast = fast
             res = dev.map_chunks(samples, offsets, n_refs=1)
+            again = dev.map_chunks(samples, offsets, n_refs=1)
+            same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
+            assert all(np.array_equal(res[k], again[k]) for k in same)
+            dev.close()
             assert (res["hits_total"] > res["n_queries"] * 4).sum() >= 2   # repeats: seeds with 12 hits each
             for i, x in enumerate(pa):
                 f, _ = po.generate_events(x)
@@ -526,7 +533,7 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
                     g = res[i]["chains"][k]
                     assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
                     assert g["n_anchors"] == c["n_anchors"]
-    tree.close(); dev.close()
+    tree.close()
 
 
 def test_pipeline_heavy_ties_large_chunks(small_world):
