@@ -1065,7 +1065,11 @@ bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap
   if (grow == 0) return true;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-  return grow + grow / 8 + (1ull << 30) < free_b;
+  // Head room only for contexts that stay small -- an eighth of the device with it -- and never more than a third
+  // of what is free: the other contexts of the GPU have the same appetite, and a batch sized for the device
+  // (100 Mb reference x 3 contexts: 250 GB) must still fit at its exact size.
+  const uint64_t with_room = nq_cap * per_query + na_cap * per_anchor;
+  return with_room < total_b / 8 && 3 * grow + (1ull << 30) < free_b;
 }
 
 // counters[7] of a batch = queries the set walk found beyond the hit cap (searched a second time): beyond one in

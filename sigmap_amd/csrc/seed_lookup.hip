@@ -1111,11 +1111,12 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
                       range_stride);
   // Large references put many queries beyond the cap (0.6 % at 250 Mb, each a traversal of tens of thousands of
   // points that the second search would run again, one lane each, after everything else has finished): there
-  // every query is searched in the reference's order at once, as before the set walk existed.  Decided from the
-  // index size at first (hits per query ~ 1.7e-6 x points: 41 at 12 Mb, 850 at 250 Mb) and from the share of
-  // such queries in the batches seen (smhip_ctx::walk_exact_only, set by smhip_map_run).
+  // every query is searched in the reference's order at once, as before the set walk existed (250 Mb: 35 ms per
+  // 2 000 chunks; set walk + second search: 33 + 34 ms).  Decided from the index size at first (hits per query
+  // ~ 1.7e-6 x points: 41 at 12 Mb, 340 at 100 Mb -- set walk 33 ms against 37 --, 850 at 250 Mb; the line is drawn
+  // at 600) and from the share of such queries in the batches seen (smhip_ctx::walk_exact_only, smhip_map_run).
   // (SMHIP_EXACT_WALK: A/B switch, read per call)
-  if (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 300.0 || getenv("SMHIP_EXACT_WALK"))
+  if (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK"))
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
   e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
