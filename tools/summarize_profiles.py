@@ -33,6 +33,47 @@ def parse_shape(text):
     return shape
 
 
+WALKERS = ("SeedWalkKernel<2>", "SeedWalkKernel<0>", "SeedWalkKernel<false>")
+
+
+def traffic_json(tag, red, per, shape_txt):
+    """<tag>_pmc_traffic.json from the per-launch counter means: the production search kernel of the run -- the set
+    walk (<2>) when it ran, else the walk in the reference's order (<0>: large references; "<false>" in rounds 1-2)."""
+    seed = next((w for w in WALKERS for k in per if k == w and per[k].get("TCC_EA0_RDREQ_sum", 0) > 1e6), None)
+    if not seed:
+        return {}
+    # profiles/r3_calibration.json: on gfx950 EVERY L2 read miss goes to the fabric as one 128-byte
+    # request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for 64-byte records, 32-byte records, leaf lines
+    # and streams alike), and FETCH_SIZE tallies it at 64 bytes; WRITE_SIZE counts 32-byte write
+    # requests exactly.  Fabric-side bytes = 128 * read requests + WRITE_SIZE.
+    rd = per[seed]["TCC_EA0_RDREQ_sum"]
+    write_kb = per[seed].get("WRITE_SIZE", 0.0)
+    ks = os.path.join(red, f"{tag}_kernel_stats_serial.csv")
+    avg_ns = None
+    if os.path.exists(ks):
+        for r in csv.DictReader(open(ks)):
+            if r["kernel"] == seed:
+                avg_ns = float(r["avg_ns"])
+    out = {
+        "kernel": seed,
+        "shape": parse_shape(shape_txt), "bench_shape_args": shape_txt,
+        "seed_lookup_hbm_bytes_per_launch": int(rd * 128 + write_kb * 1024),
+        "read_requests_128B": rd, "read_bytes": int(rd * 128),
+        "fetch_size_kb_as_reported": per[seed].get("FETCH_SIZE"), "write_size_kb": write_kb,
+        "rdreq_128B": per[seed].get("TCC_EA0_RDREQ_128B_sum"), "rdreq_64B": per[seed].get("TCC_EA0_RDREQ_64B_sum"),
+        "l2_hit_rate": (per[seed]["TCC_HIT_sum"] / (per[seed]["TCC_HIT_sum"] + per[seed]["TCC_MISS_sum"])
+                        if "TCC_HIT_sum" in per[seed] else None),
+        "launch_avg_ns_kernel_trace_serial": avg_ns,
+        "what": "L2-miss (fabric) bytes: 128 B x TCC_EA0_RDREQ + WRITE_SIZE.  Infinity-Cache (MALL) hits are counted in "
+                "these requests, so this is an UPPER bound on HBM traffic",
+        "source": f"profiles/{tag}_pmc_per_launch.csv: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) "
+                  f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1 {shape_txt}; mean per launch of "
+                  f"{seed}; calibration profiles/r3_calibration.json",
+    }
+    json.dump(out, open(os.path.join(red, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    return out
+
+
 def reduce(tag):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     red = os.path.join(src, "reduced")
@@ -70,39 +111,7 @@ def reduce(tag):
         for k in sorted(per, key=lambda k: -per[k].get("FETCH_SIZE", 0)):
             w.writerow([k] + ["%.6g" % per[k].get(c, float("nan")) for c in counters])
     shape_txt = open(os.path.join(src, "shape.txt")).read().strip() if os.path.exists(os.path.join(src, "shape.txt")) else ""
-    # the production search: the set walk (kWalkSet = 2; "<false>" in the profiles of rounds 1-2)
-    seed = next((k for k in per if k.startswith("SeedWalkKernel<2>") or k.startswith("SeedWalkKernel<false>")), None)
-    out = {}
-    if seed and "TCC_EA0_RDREQ_sum" in per[seed]:
-        # profiles/r3_calibration.json: on gfx950 EVERY L2 read miss goes to the fabric as one 128-byte
-        # request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for 64-byte records, 32-byte records, leaf lines
-        # and streams alike), and FETCH_SIZE tallies it at 64 bytes; WRITE_SIZE counts 32-byte write
-        # requests exactly.  Fabric-side bytes = 128 * read requests + WRITE_SIZE.
-        rd = per[seed]["TCC_EA0_RDREQ_sum"]
-        write_kb = per[seed].get("WRITE_SIZE", 0.0)
-        ks = os.path.join(red, f"{tag}_kernel_stats_serial.csv")
-        avg_ns = None
-        if os.path.exists(ks):
-            for r in csv.DictReader(open(ks)):
-                if r["kernel"].startswith("SeedWalkKernel<2>") or r["kernel"].startswith("SeedWalkKernel<false>"):
-                    avg_ns = float(r["avg_ns"])
-        out = {
-            "kernel": seed,
-            "shape": parse_shape(shape_txt), "bench_shape_args": shape_txt,
-            "seed_lookup_hbm_bytes_per_launch": int(rd * 128 + write_kb * 1024),
-            "read_requests_128B": rd, "read_bytes": int(rd * 128),
-            "fetch_size_kb_as_reported": per[seed].get("FETCH_SIZE"), "write_size_kb": write_kb,
-            "rdreq_128B": per[seed].get("TCC_EA0_RDREQ_128B_sum"), "rdreq_64B": per[seed].get("TCC_EA0_RDREQ_64B_sum"),
-            "l2_hit_rate": (per[seed]["TCC_HIT_sum"] / (per[seed]["TCC_HIT_sum"] + per[seed]["TCC_MISS_sum"])
-                            if "TCC_HIT_sum" in per[seed] else None),
-            "launch_avg_ns_kernel_trace_serial": avg_ns,
-            "what": "L2-miss (fabric) bytes: 128 B x TCC_EA0_RDREQ + WRITE_SIZE.  Infinity-Cache (MALL) hits are counted in "
-                    "these requests, so this is an UPPER bound on HBM traffic",
-            "source": f"profiles/{tag}_pmc_per_launch.csv: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) "
-                      f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1 {shape_txt}; mean per launch of "
-                      f"{seed}; calibration profiles/r3_calibration.json",
-        }
-        json.dump(out, open(os.path.join(red, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    out = traffic_json(tag, red, per, shape_txt)
     for name in ("bench_default.json", "kt_bench.json", "kt_serial_bench.json"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
@@ -112,8 +121,16 @@ def reduce(tag):
 
 
 def commit(tag):
-    red = os.path.join(ROOT, "gpurun_out", "prof_" + tag, "reduced")
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    red = os.path.join(src, "reduced")
     os.makedirs(DST, exist_ok=True)
+    pl = os.path.join(red, f"{tag}_pmc_per_launch.csv")
+    if os.path.exists(pl):  # (re)derive the traffic summary from the reduced counter table
+        per = {}
+        for r in csv.DictReader(open(pl)):
+            per[r["kernel"]] = {k: float(v) for k, v in r.items() if k != "kernel" and v not in ("", "nan")}
+        shape_txt = open(os.path.join(src, "shape.txt")).read().strip() if os.path.exists(os.path.join(src, "shape.txt")) else ""
+        traffic_json(tag, red, per, shape_txt)
     for f in sorted(os.listdir(red)):
         shutil.copy(os.path.join(red, f), os.path.join(DST, f))
     print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(tag)))
