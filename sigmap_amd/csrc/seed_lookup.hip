@@ -1116,7 +1116,8 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   // ~ 1.7e-6 x points: 41 at 12 Mb, 340 at 100 Mb -- set walk 33 ms against 37 --, 850 at 250 Mb; the line is drawn
   // at 600) and from the share of such queries in the batches seen (smhip_ctx::walk_exact_only, smhip_map_run).
   // (SMHIP_EXACT_WALK: A/B switch, read per call)
-  if (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK"))
+  const bool force_set = getenv("SMHIP_SET_WALK") != nullptr;  // (A/B switch: the set walk whatever the index and history)
+  if (!force_set && (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK")))
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
   e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
