@@ -321,7 +321,7 @@ def main():
         # SURVEY 8(d) weights on the WALKER'S OWN visits (16 B per node record it needs, 28 B per point it tests, 24 B
         # per anchor, the raw samples and the result record): the bytes a perfect layout would have to move
         useful_bytes = 2 * CHUNK * R + 16 * w_nodes + 28 * w_points + 24 * anchors + 64 * R
-        traffic, traffic_src, prof_ms = None, None, None
+        traffic, traffic_src, prof_ms, read_lines = None, None, None, None
         # a committed counter profile whose workload has this run's shape (tools/collect_profiles.sh)
         import glob
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_pmc_traffic.json"))):
@@ -331,6 +331,7 @@ def main():
                 if (sh.get("reads"), sh.get("contigs"), sh.get("contig_len")) == (args.reads, args.contigs, args.contig_len) \
                         and args.walk_blocks == 0 and args.fast_cap == 0:
                     traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
+                    read_lines = float(j.get("read_requests_128B") or 0) or None
                     traffic_src = j.get("source")
                     prof_ms = (j.get("launch_avg_ns_kernel_trace_serial") or 0) * 1e-6 or None
                     break
@@ -338,7 +339,8 @@ def main():
                 traffic = None
         basis = traffic if traffic else own_bytes
         achieved = basis / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-        lines_per_s = (traffic / 128.0) / (seed_ms * 1e-3) if traffic and seed_ms > 0 else None
+        # (128-byte READ requests of the profile: the random-line ceiling is a read ceiling)
+        lines_per_s = (read_lines or traffic / 128.0) / (seed_ms * 1e-3) if traffic and seed_ms > 0 else None
         total_chunks = R * world * args.steps
         out = {
             "metric": "signal chunks/sec (4k-sample reads) mapped to yeast ref",
