@@ -52,15 +52,48 @@ def main(rounds, first):
         dev.params.walk_blocks_per_cu = int(rng.choice([0, 1, 2, 8]))
         dev.params.reference_walk = int(rng.integers(0, 2))
         dev.params.hits_per_query_fast = int(rng.choice([512, 64, 4]))
+        # the hit cap: lowered caps put (nearly) every query beyond it -- the set walk's second search in the
+        # reference's order, or, once the context has seen such a batch, the exact walk for everything
+        nnp = int(rng.choice([5000, 5000, 40, 7]))
+        dev.params.num_nearest_points = nnp
+        radius = float(rng.choice([0.08, 0.08, 0.15]))
+        dev.params.search_radius = radius
         dev.upload_index(ix)
         samples = np.concatenate(pa)
         offsets = np.concatenate([[0], np.cumsum([len(x) for x in pa])]).astype(np.uint32)
         res = dev.map_chunks(samples, offsets, n_refs=n_contigs)
+        # the same batch again: the speculative route of smhip_map_run (no read-backs), then with one of its
+        # capacities halved (guard kernel fires, batch repeated) -- identical records whatever the route
+        same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
+        mism = 0
+        for tight in (None, str(int(rng.integers(1, 3)))):
+            if tight:
+                os.environ["SMHIP_SPEC_TIGHT"] = tight
+            try:
+                again = dev.map_chunks(samples, offsets, n_refs=n_contigs)
+            finally:
+                os.environ.pop("SMHIP_SPEC_TIGHT", None)
+            if not all(np.array_equal(res[k], again[k]) for k in same):
+                mism += 1
+                print("   ROUTE MISMATCH (SMHIP_SPEC_TIGHT=%s)" % tight)
         names = ["contig%d" % i for i in range(n_contigs)]
         lines = _paf_lines(res, pa, names, ref_lens)
-        mism = 0
         for i, x in enumerate(pa):
-            m = po.map_read(tree, ix.positions, x, n_contigs, ref_lens)
+            if nnp != 5000:  # the oracle's map_read has the reference's constant: compare chunk-level chains
+                f, _ = po.generate_events(x)
+                if len(f) <= 50:
+                    continue
+                chains, st = po.generate_chains(tree, ix.positions, f, n_contigs, radius=radius, num_nearest_points=nnp)
+                ok = res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits and res[i]["n_chains"] == len(chains)
+                for k, c in enumerate(chains[:4]):
+                    g = res[i]["chains"][k]
+                    ok = ok and g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"] \
+                        and g["n_anchors"] == c["n_anchors"]
+                if not ok:
+                    mism += 1
+                    print("   MISMATCH read %d (%s) with cap %d" % (i, kind[i], nnp))
+                continue
+            m = po.map_read(tree, ix.positions, x, n_contigs, ref_lens, params={"search_radius": radius})
             ok = lines[i] == po.format_paf(m, "read%d" % i, names, ref_lens)
             ok = ok and res[i]["n_anchors"] == m.stats.anchors and res[i]["hits_total"] == m.stats.hits
             if dev.params.reference_walk:
@@ -102,9 +135,9 @@ def main(rounds, first):
                 print("   REFINE MISMATCH read %d (%s): band %d pad %d gpu (%r, %d) oracle (%r, %d)" % (
                     i, kind[i], band, pad, dist[i], end[i], d, t0 + e if e >= 0 else -1))
         mism += rmis
-        print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d cap=%d): %d mismatches, %d mapped"
+        print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d fast=%d cap=%d r=%.2f): %d mismatches, %d mapped"
               % (seed, n_contigs, lens, n_reads, dev.params.walk_blocks_per_cu, dev.params.reference_walk,
-                 dev.params.hits_per_query_fast, mism, int((res["n_chains"] > 0).sum())), flush=True)
+                 dev.params.hits_per_query_fast, nnp, radius, mism, int((res["n_chains"] > 0).sum())), flush=True)
         bad += mism
         dev.close(); tree.close(); ix.close()
     print("TOTAL mismatches:", bad)
