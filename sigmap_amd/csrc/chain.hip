@@ -1,12 +1,17 @@
-// chain.hip -- chaining DP, traceback, primary-chain selection and MAPQ (three kernels: DP one
-// lane per bucket, chain ends one wave per chunk, finalisation one lane per chunk).
+// chain.hip -- chaining DP, traceback, primary-chain selection and MAPQ.  Kernels: C0 classify (a wave per
+// 64-anchor tile: which anchors are settled without the sequential DP), C0b pending (a workgroup per chunk:
+// the unsettled anchors listed and cut into independent items, one descriptor each), C1 lane DP (a lane per
+// short item) beside C1b wave DP (a wave per long item, on the context's auxiliary stream), C2 ends (a wave
+// per chunk: chain ends, traceback), C3 finalize (a wave per chunk: primary chains, MAPQ, statistics).
 //
 // Replaces spatial_index.cc:419-576 (+ TracebackChains :165-220, GeneratePrimaryChains
 // :222-253, ComputeMAPQ :255-274) and the chain-0 statistics of sigmap.cc:714-729.
 //
 // The DP of one (reference, strand) bucket is sequential (score[i] depends on earlier
-// scores and on the order-dependent num_skips early exit, spatial_index.cc:461-540), but
-// buckets are independent, so the 64 lanes of the wave take buckets round-robin.  The only
+// scores and on the order-dependent num_skips early exit, spatial_index.cc:461-540), but an anchor whose
+// predecessor scan meets no predecessor that passes the gap tests keeps its own start score whatever the
+// others do (C0), and runs of unsettled anchors farther apart than max_target_gap_length never read each
+// other's scores (C0b): the sequential part shrinks to short independent items.  The only
 // cross-bucket coupling in the reference is the running `max_chaining_score`
 // (spatial_index.cc:420,542-549): it never influences scores, only which anchors qualify
 // as chain ends, so it is re-applied after the DP as (prefix max over earlier buckets) +

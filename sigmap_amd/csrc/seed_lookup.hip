@@ -52,6 +52,10 @@
 //          lanes drain their FIFOs, four points of a leaf per iteration.
 // Leaves of a query are scanned in the order they were reached, so hits keep traversal order.
 // The two newest stack entries of a lane live in LDS, older ones spill to HBM ([lane][64] x 32 B).
+// The mapping path does not need the order (the anchors are sorted afterwards) except for queries beyond
+// the reference's 5000-hit cap: it searches with the kernel's order-free SET mode (no dists[] / mindistsq
+// state, 4-byte pending visits, box rule only: the kWalk* modes at the kernel) and repeats those queries
+// in the reference's order (LaunchSeedLookup).
 // Queries are visited in the order of the leaf that contains them (QueryKey/QueryScatter: a
 // stackless descent + a counting sort that permutes the query records), each XCD taking one
 // contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the same
