@@ -61,7 +61,7 @@ def parse():
                          "memory, ranks may share a GPU (a way to exercise the multi-rank flow on a one-GPU box)")
     ap.add_argument("--force-bcast", action="store_true",
                     help="with one rank: run the index replication collectives anyway (one-rank process group over "
-                         "--backend, five dist.broadcast calls) and map the contexts beyond the first from the broadcast "
+                         "--backend, six dist.broadcast calls) and map the contexts beyond the first from the broadcast "
                          "copy -- exercises the N > 1 transport on a one-GPU box")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "

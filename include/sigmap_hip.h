@@ -108,12 +108,17 @@ typedef struct {
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[slots / 2]: original point index of the
                                                   point in first-half slot boff + t at (boff >> 1) + t */
   void *bbox;       uint64_t bbox_bytes;       /* float[4*dim]: root box {low0, high0, ...}, then
-                                                  base[dim], step[dim] of the box grid */
+                                                  base[dim], step[dim] of the box grid (one step for
+                                                  all dimensions) */
+  void *quads;      uint64_t quads_bytes;      /* 128 B per quad record (the order-free search's node array: the
+                                                  boxes and references of a node's four grandchildren, derived from
+                                                  `nodes` at upload); null / 0 for an index without them */
+  uint64_t n_quads;
 } smhip_index_dev;
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
 /* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */
 int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in);
-/* Copy exported array `array_id` (0 nodes, 1 leaf_tab, 2 leaf_pts, 3 leaf_vind, 4 bbox) into memory
+/* Copy exported array `array_id` (0 nodes, 1 leaf_tab, 2 leaf_pts, 3 leaf_vind, 4 bbox, 5 quads) into memory
  * the caller owns (device memory of the same GPU, or host memory) -- e.g. a torch tensor that torch.distributed then broadcasts
  * (the copy runs on this library's HIP runtime and stream, not through a second runtime handle). */
 int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint64_t dst_bytes);

@@ -95,7 +95,8 @@ class IndexDev(C.Structure):
                 ("leaf_tab", C.c_void_p), ("leaf_tab_bytes", C.c_uint64),
                 ("leaf_pts", C.c_void_p), ("leaf_pts_bytes", C.c_uint64),
                 ("leaf_vind", C.c_void_p), ("leaf_vind_bytes", C.c_uint64),
-                ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64)]
+                ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64),
+                ("quads", C.c_void_p), ("quads_bytes", C.c_uint64), ("n_quads", C.c_uint64)]
 
 
 class IndexView(C.Structure):

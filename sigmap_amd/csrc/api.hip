@@ -252,7 +252,7 @@ void smhip_destroy(smhip_ctx *ctx) {
                     &ctx->dl_off, &ctx->dl_compact, &ctx->sort_tmp, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
                     &ctx->rp_qoff, &ctx->rp_qlen, &ctx->rp_lo, &ctx->rp_hi, &ctx->rp_width, &ctx->rp_celloff, &ctx->rp_codes,
                     &ctx->rp_dist, &ctx->rp_end, &ctx->rp_path, &ctx->rp_plen, &ctx->rp_start,
-                    &ctx->scan_tmp, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+                    &ctx->scan_tmp, &ctx->ix_quads, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region_tab, &ctx->ovf_list,
@@ -403,6 +403,13 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   ctx->have_index = true;
   ctx->max_tpos_valid = false;
   ctx->index_owned = true;
+  {
+    const hipError_t qe = BuildQuads(ctx);  // the set walk's node array (seed_lookup.hip)
+    if (qe != hipSuccess) {
+      ctx->have_index = false;
+      return HipFail(ctx, qe, "quad records");
+    }
+  }
   return SMHIP_OK;
 }
 
@@ -425,6 +432,9 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->leaf_vind_bytes = ctx->leaf_vind_bytes;
   out->bbox = (void *)ctx->index.bbox;
   out->bbox_bytes = 4 * ctx->dim * sizeof(float);
+  out->quads = (void *)ctx->index.quads;
+  out->quads_bytes = ctx->index.n_quads * 128;
+  out->n_quads = ctx->index.n_quads;
   return SMHIP_OK;
 }
 
@@ -433,10 +443,11 @@ int smhip_index_export_copy(smhip_ctx *ctx, int array_id, void *dst_device, uint
   smhip_index_dev d;
   int rc = smhip_index_export(ctx, &d);
   if (rc) return rc;
-  const void *src[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
-  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
-  if (array_id < 0 || array_id > 4) return Fail(ctx, SMHIP_EINVAL, "array_id must be 0..4");
+  const void *src[6] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox, d.quads};
+  const uint64_t bytes[6] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes, d.quads_bytes};
+  if (array_id < 0 || array_id > 5) return Fail(ctx, SMHIP_EINVAL, "array_id must be 0..5");
   if (dst_bytes < bytes[array_id]) return Fail(ctx, SMHIP_EINVAL, "destination smaller than the array");
+  if (bytes[array_id] == 0) return SMHIP_OK;  // (an index without quad records)
   HIPCHK(hipSetDevice(ctx->device));
   // (hipMemcpyDefault: the destination may also be host memory -- the gloo test transport of bench.py)
   HIPCHK(hipMemcpyAsync(dst_device, src[array_id], bytes[array_id], hipMemcpyDefault, ctx->stream));
@@ -464,7 +475,8 @@ void AdoptReplica(smhip_ctx *p, const smhip_ctx *root) {
   p->dim = root->dim;
   p->index = IndexView{p->ix_nodes.as<uint4>(), p->ix_tab.as<uint32_t>(), p->ix_pts.as<float>(),
                        p->ix_vind.as<uint32_t>(), p->ix_bbox.as<float>(), root->index.n_inner, root->index.n_leaves,
-                       root->index.m_size, root->index.root_ref};
+                       root->index.m_size, root->index.root_ref,
+                       root->index.n_quads ? p->ix_quads.as<uint4>() : nullptr, root->index.n_quads};
   p->leaf_pts_bytes = root->leaf_pts_bytes;
   p->leaf_vind_bytes = root->leaf_vind_bytes;
   p->have_index = true;
@@ -512,15 +524,15 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
   smhip_index_dev d;
   int rc = smhip_index_export(ctx, &d);
   if (rc) return rc;
-  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
-  void *root_ptr[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
-  // peers: their own buffers for the five walker arrays
+  const uint64_t bytes[6] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes, d.quads_bytes};
+  void *root_ptr[6] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox, d.quads};
+  // peers: their own buffers for the six walker arrays
   for (int i = 0; i < n_gpus; ++i) {
     if (i == root) continue;
     smhip_ctx *p = ctxs[i];
     if (hipSetDevice(p->device) != hipSuccess) return Fail(ctx, SMHIP_EHIP, "hipSetDevice(peer)");
-    DevBuf *b[5] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox};
-    for (int a = 0; a < 5; ++a) {
+    DevBuf *b[6] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox, &p->ix_quads};
+    for (int a = 0; a < 6; ++a) {
       hipError_t e = b[a]->Reserve(bytes[a]);
       if (e != hipSuccess) return HipFail(ctx, e, "peer index allocation");
     }
@@ -531,11 +543,12 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
   int nr = nc.CommInitAll(comms.data(), n_gpus, devs.data());
   if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(nr));
   // ONE broadcast per array, all ranks of this process inside one group call
-  for (int a = 0; a < 5 && nr == 0; ++a) {
+  for (int a = 0; a < 6 && nr == 0; ++a) {
+    if (bytes[a] == 0) continue;  // (an index without quad records)
     nr = nc.GroupStart();
     for (int i = 0; i < n_gpus && nr == 0; ++i) {
       smhip_ctx *p = ctxs[i];
-      DevBuf *b[5] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox};
+      DevBuf *b[6] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox, &p->ix_quads};
       void *recv = i == root ? root_ptr[a] : b[a]->p;
       if (hipSetDevice(p->device) != hipSuccess) nr = 1;
       if (nr == 0) nr = nc.Broadcast(root_ptr[a], recv, bytes[a], /*ncclUint8*/ 1, root, comms[i], p->stream);
@@ -570,17 +583,18 @@ int smhip_index_bcast_loopback(smhip_ctx *src, smhip_ctx *dst) {
   int rc = smhip_index_export(src, &d);
   if (rc) return rc;
   HIPCHK(hipSetDevice(src->device));
-  const uint64_t bytes[5] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes};
-  void *from[5] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox};
-  DevBuf *to[5] = {&dst->ix_nodes, &dst->ix_tab, &dst->ix_pts, &dst->ix_vind, &dst->ix_bbox};
-  for (int a = 0; a < 5; ++a) HIPCHK(to[a]->Reserve(bytes[a]));
+  const uint64_t bytes[6] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes, d.quads_bytes};
+  void *from[6] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox, d.quads};
+  DevBuf *to[6] = {&dst->ix_nodes, &dst->ix_tab, &dst->ix_pts, &dst->ix_vind, &dst->ix_bbox, &dst->ix_quads};
+  for (int a = 0; a < 6; ++a) HIPCHK(to[a]->Reserve(bytes[a]));
   Rccl::comm_t comm = nullptr;
   const int dev = src->device;
   int nr = nc.CommInitAll(&comm, 1, &dev);
   if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll(1): ") + nc.GetErrorString(nr));
   // the same call sequence as smhip_index_bcast: one grouped ncclBroadcast per array; with one rank and
   // sendbuff != recvbuff RCCL copies the root's buffer into the receive buffer
-  for (int a = 0; a < 5 && nr == 0; ++a) {
+  for (int a = 0; a < 6 && nr == 0; ++a) {
+    if (bytes[a] == 0) continue;
     nr = nc.GroupStart();
     if (nr == 0) nr = nc.Broadcast(from[a], to[a]->p, bytes[a], /*ncclUint8*/ 1, 0, comm, src->stream);
     const int ge = nc.GroupEnd();
@@ -611,10 +625,12 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   if (in->n_nodes + 1 != in->n_leaves || (in->n_nodes == 0) != (in->root_ref == kLeafTag) ||
       (in->n_nodes != 0 && in->root_ref != 0))
     return Fail(ctx, SMHIP_EINVAL, "inconsistent node counts / root reference");
+  if ((in->quads == nullptr) != (in->n_quads == 0) || in->quads_bytes < in->n_quads * 128 || in->n_quads > in->n_nodes)
+    return Fail(ctx, SMHIP_EINVAL, "inconsistent quad records");
   ctx->dim = in->dim;
   ctx->index = IndexView{(const uint4 *)in->nodes, (const uint32_t *)in->leaf_tab, (const float *)in->leaf_pts,
                          (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->n_leaves,
-                         in->m_size, in->root_ref};
+                         in->m_size, in->root_ref, (const uint4 *)in->quads, in->n_quads};
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->leaf_vind_bytes = in->leaf_vind_bytes;
   ctx->have_index = true;

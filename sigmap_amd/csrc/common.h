@@ -83,6 +83,8 @@ struct IndexView {
                               // grid the children's boxes are quantised on
   uint64_t n_inner, n_leaves, m_size;
   uint32_t root_ref;          // 0 (inner record 0), or kLeafTag for a tree that is a single leaf
+  const uint4 *quads;         // 8 x uint4 per quad record (seed_lookup.hip: BuildQuads), null: none (no inner node,
+  uint64_t n_quads;           // or an index too large for them); the root's quad is number 0
 };
 
 inline bool TraceAlloc() {
@@ -169,7 +171,7 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, scan_tmp;
+  smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, ix_quads, scan_tmp;
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   smhip::DevBuf max_tpos;       // [0] largest target position of the resident index, [1] ... and of the batch's carried anchors
   bool max_tpos_valid = false;  // [0] computed for the index that is resident now
@@ -319,6 +321,7 @@ hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint3
                               uint32_t chunk_size, SlotView pa, const uint32_t *slot_len, uint64_t *cbegin,
                               uint32_t *clen);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
+hipError_t BuildQuads(smhip_ctx *ctx);  // seed_lookup.hip: ctx->index.quads from ctx->index.inner
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,

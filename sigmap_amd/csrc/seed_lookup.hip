@@ -8,8 +8,8 @@
 // Data layout in HBM (built once per index from the pre-order smhip_node array + point cloud):
 //   inner    : one 64-byte record (one sector) per INNER node, numbered in pre-order among the inner
 //              nodes: {divlow, divhigh, ref1 | feat << 28, ref2} and the TIGHT bounding boxes of
-//              BOTH CHILDREN, 24 x u16: child1 lo[6], hi[6], child2 lo[6], hi[6], quantised on the
-//              root box per dimension (value = root_lo + q * (root_hi - root_lo) / 65534) and
+//              BOTH CHILDREN, 24 x u16: child1 lo[6], hi[6], child2 lo[6], hi[6], quantised on a grid over
+//              the root box (value = root_lo[d] + q * step, step = widest root extent / 65534) and
 //              rounded OUTWARDS, so a quantised box contains the exact one.  A ref is an inner
 //              index, or kLeafTag | leaf ordinal (tree order): leaves have no record of their own.
 //   leaf_tab : uint32 per leaf: (first 16-byte slot of its point block / 16) | n << 27
@@ -110,6 +110,11 @@ struct Sink {
 
 enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
 
+// Sum over the six dimensions of (gap in grid steps)^2, three packed pairs, saturating at 2^32 - 1
+// (v_dot2_u32_u16 ... clamp): compared with radius / step^2 as an integer, no conversion to float.
+#define SM_BOXSUM(g01, g23, g45) \
+  __builtin_amdgcn_udot2(g45, g45, __builtin_amdgcn_udot2(g23, g23, __builtin_amdgcn_udot2(g01, g01, 0u, true), true), true)
+
 // Hit number `ord` >= fast_cap of query `qi` (0-based, in traversal order; the first fast_cap hits
 // go to the query's own slots): segments of the shared pool whose sizes double (fast_cap,
 // 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a query with
@@ -156,20 +161,25 @@ __device__ unsigned long long g_walk_prof[8];
 //                       same set: the walk then carries no dists[] / mindistsq state, a pending visit is a 4-byte
 //                       node reference instead of a 32-byte record (no spill traffic), and a node visit is two box
 //                       tests, no plane arithmetic.
-enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2 };
+//        kWalkQuad   -- the set walk over QUAD records (layout: BuildQuads below): one 128-byte record -- one whole
+//                       fabric request -- holds the boxes of a node's four GRANDCHILDREN, so a visit descends two
+//                       levels of the tree for the one line the binary record cost per level.
+enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2, kWalkQuad = 3 };
+constexpr int kQuadThreads = 128;  // workgroup of the quad walk: 11 KB of LDS per wave, seven workgroups per CU
 constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area)
 
-template <int kMode>
-__global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
+template <int kMode, int kThreads>
+__global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
                                                                float4 *__restrict__ stack_mem,
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
-  constexpr bool kSet = kMode == kWalkSet;
+  constexpr bool kQuad = kMode == kWalkQuad;
+  constexpr bool kSet = kMode == kWalkSet || kQuad;
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
-  const uint32_t gl = blockIdx.x * kSeedThreads + threadIdx.x;
+  const uint32_t gl = blockIdx.x * kThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
   uint32_t *stk32 = reinterpret_cast<uint32_t *>(stk);  // (set walk: the same area as 4-byte references)
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
@@ -185,14 +195,21 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
 #pragma unroll
   for (int k = 0; k < 12; ++k)
     root_box[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[k])));
-  float box_base[6], box_step[6], box_inv[6];  // grid of the children's quantised boxes (wave-uniform too)
+  // grid of the children's quantised boxes (wave-uniform too): a base per dimension, ONE step for all of them
+  float box_base[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 6; ++k)
     box_base[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[12 + k])));
-    box_step[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[18 + k])));
-    const float inv = box_step[k] > 0.0f ? 1.0f / box_step[k] : 0.0f;
-    box_inv[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv)));
+  const float box_step = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ix.bbox[18])));
+  const float box_inv =
+      __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(box_step > 0.0f ? 1.0f / box_step : 0.0f)));
+  // a box is entered iff the sum of its squared per-dimension gaps, in grid steps, is <= box_limit (SM_BOXSUM)
+  uint32_t box_limit = 0xFFFFFFFFu;
+  if (box_step > 0.0f) {
+    const double lim = floor((double)radius / ((double)box_step * (double)box_step)) + 1.0;
+    if (lim < 4294967295.0) box_limit = (uint32_t)lim;
   }
+  box_limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)box_limit);
   uint32_t mode = M_FETCH;
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
   float d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
@@ -201,19 +218,25 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
   // the query on the box grid, two dimensions per word like the records: the nearest grid index
   uint32_t qc01 = 0, qc23 = 0, qc45 = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
-  __shared__ float4 tos[kSet ? 1 : 2][2][kSet ? 1 : kSeedThreads];
-  __shared__ uint32_t lstk[kSet ? kSetStack : 1][kSet ? kSeedThreads : 1];  // set walk: the newest pending references
+  __shared__ float4 tos[kSet ? 1 : 2][2][kSet ? 1 : kThreads];
+  __shared__ uint32_t lstk[kSet ? kSetStack : 1][kSet ? kThreads : 1];  // set walk: the newest pending references
   // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
-  __shared__ uint32_t fifo[kFifo][kSeedThreads];
-  __shared__ uint32_t ovf_lds[kSeedThreads];  // scan phase: overflow segment base of each lane's query
+  __shared__ uint32_t fifo[kFifo][kThreads];
+  __shared__ uint32_t ovf_lds[kQuad ? 1 : kThreads];  // scan phase: overflow segment base of each lane's query
   // address of the first hit slot of each lane's query (HitSlots::At(qi, 0): a pointer-table load), taken when the
   // query is handed out: at emit time it is an LDS read -- a global load there made every scan iteration wait for
   // everything in flight (the next window's point loads included)
-  __shared__ Hit *slot_base[kSeedThreads];
-  // staging of the cooperative node fetch: 64 records x 64 B per wave
-  __shared__ uint4 stage[kSeedThreads / 64][256];
+  __shared__ Hit *slot_base[kQuad ? 1 : kThreads];
+  // staging of the cooperative node fetch: 64 records x 64 B (quad walk: x 128 B) per wave
+  __shared__ uint4 stage[kThreads / 64][kQuad ? 512 : 256];
   const uint32_t lane = threadIdx.x & 63u;
   uint4 *stage_w = stage[threadIdx.x >> 6];
+  // the wave's [64] slices of the two scan-phase tables above; the quad walk keeps them in the upper half of its
+  // staging area (free during a scan phase: the scan's own tables take the lower 4 KB) and a lane's slot address
+  // in registers between the phases
+  uint32_t *ovf_w = kQuad ? reinterpret_cast<uint32_t *>(stage_w + 288) : &ovf_lds[kQuad ? 0u : (threadIdx.x & ~63u)];
+  Hit **sbase_w = kQuad ? reinterpret_cast<Hit **>(stage_w + 256) : &slot_base[kQuad ? 0u : (threadIdx.x & ~63u)];
+  Hit *my_slots = nullptr;
   uint32_t tcnt = 0, thead = 0;
   uint32_t fifo_cnt = 0;
   uint32_t ovf_base = 0;  // pool offset of the current overflow segment of this lane's query
@@ -282,7 +305,8 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       if (c > 0) {
         own_a[lane] = make_float4(q0, q1, q2, q3);
         own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
-        ovf_lds[threadIdx.x] = ovf_base;
+        ovf_w[lane] = ovf_base;
+        if (kQuad) sbase_w[lane] = my_slots;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
@@ -380,13 +404,13 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         h.dist = res;
         h.slot = (mine.x >> 1) + t;
         const bool emit = hit && ord < sink.nnp;
-        if (emit && ord < sink.fast_cap) slot_base[(threadIdx.x & ~63u) + owner][ord] = h;
+        if (emit && ord < sink.fast_cap) sbase_w[owner][ord] = h;
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
         for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
           if (lane == (uint32_t)__builtin_ctzll(ovm)) {
-            uint32_t ob = ovf_lds[(threadIdx.x & ~63u) + owner];
+            uint32_t ob = ovf_w[owner];
             EmitOverflow(sink, oqi, ord, h, ob);
-            ovf_lds[(threadIdx.x & ~63u) + owner] = ob;
+            ovf_w[owner] = ob;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
       }
       if (c > 0) {
         hits = own_b[lane].w;
-        ovf_base = ovf_lds[threadIdx.x];
+        ovf_base = ovf_w[lane];
       }
       fifo_cnt = 0;
       if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
@@ -480,10 +504,11 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           SM_INIT_DIM(5, d5)
         }
         node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
-        slot_base[threadIdx.x] = sink.region.At(qi, 0);
+        if (kQuad) my_slots = sink.region.At(qi, 0);
+        else sbase_w[lane] = sink.region.At(qi, 0);
         {
           uint32_t gc[6];
-#define SM_GRID(k) gc[k] = (uint32_t)fminf(fmaxf(rintf((q##k - box_base[k]) * box_inv[k]), 0.0f), 65535.0f);
+#define SM_GRID(k) gc[k] = (uint32_t)fminf(fmaxf(rintf((q##k - box_base[k]) * box_inv), 0.0f), 65535.0f);
           SM_GRID(0) SM_GRID(1) SM_GRID(2) SM_GRID(3) SM_GRID(4) SM_GRID(5)
 #undef SM_GRID
           qc01 = gc[0] | (gc[1] << 16); qc23 = gc[2] | (gc[3] << 16); qc45 = gc[4] | (gc[5] << 16);
@@ -495,7 +520,25 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
     }
     const unsigned long long pt1 = WALK_T();
     pt_fetchq += pt1 - pt0;
-    {
+    if (kQuad) {
+      // quad records: eight lanes fetch the 16-byte parts of one 128-byte record (one whole line); part p of lane
+      // s's record lands at position p ^ ((s >> 1) & 7) of row s, so that the row reads below are conflict-free
+      const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
+      uint32_t nsrc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        nsrc[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)r * 8u + (lane >> 3)) * 4u), (int)want);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t src = (uint32_t)r * 8u + (lane >> 3);
+        if (nsrc[r] != 0xFFFFFFFFu) {
+          const uint4 *g = ix.quads + (size_t)nsrc[r] * 8 + ((lane & 7u) ^ ((src >> 1) & 7u));
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                           (__attribute__((address_space(3))) void *)(stage_w + r * 64), 16, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
+    } else {
       const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
       uint32_t nsrc[4];
 #pragma unroll
@@ -526,7 +569,50 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         // ---- set walk: test both children's boxes; the first that passes is visited next, a second one is left on
         // the stack; leaves go to the FIFO at once.  A reference on the stack has passed its box test.
         uint32_t cur = 0xFFFFFFFFu;  // the node to go on with (none: pop)
-        if (!(node & kLeafTag)) {
+        if (kQuad && !(node & kLeafTag)) {
+          // a quad record: {ref[4]} then four boxes of six words {lo01, lo23, lo45, hi01, hi23, hi45}; an unused
+          // slot has ref 0xFFFFFFFF (and an impossible box).  Every slot that passes is pushed, then the
+          // loop below pops the newest: leaves to the FIFO, the first inner reference is the next record.
+          const uint32_t rot = (lane >> 1) & 7u;
+          const uint4 *mine = stage_w + lane * 8;
+          const uint4 rf = mine[0 ^ rot], p1 = mine[1 ^ rot], p2 = mine[2 ^ rot], p3 = mine[3 ^ rot],
+                      p4 = mine[4 ^ rot], p5 = mine[5 ^ rot], p6 = mine[6 ^ rot];
+          ++nn;
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+          const us2 k3 = {3, 3};
+          const us2 ql01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc01), k3),
+                    ql23 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc23), k3),
+                    ql45 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc45), k3);
+          const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
+                    qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
+                    qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
+#define SM_GAP(qlw, hiw, low, qhw)                                                                    \
+  __builtin_elementwise_max(__builtin_elementwise_sub_sat(qlw, __builtin_bit_cast(us2, hiw)), \
+                            __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, low), qhw))
+#define SM_QBOX(lo01, lo23, lo45, hi01, hi23, hi45) \
+  SM_BOXSUM(SM_GAP(ql01, hi01, lo01, qh01), SM_GAP(ql23, hi23, lo23, qh23), SM_GAP(ql45, hi45, lo45, qh45))
+          const uint32_t s0 = SM_QBOX(p1.x, p1.y, p1.z, p1.w, p2.x, p2.y);
+          const uint32_t s1 = SM_QBOX(p2.z, p2.w, p3.x, p3.y, p3.z, p3.w);
+          const uint32_t s2 = SM_QBOX(p4.x, p4.y, p4.z, p4.w, p5.x, p5.y);
+          const uint32_t s3 = SM_QBOX(p5.z, p5.w, p6.x, p6.y, p6.z, p6.w);
+#undef SM_QBOX
+#undef SM_GAP
+          auto push = [&](uint32_t ref) {
+            if (sp < (uint32_t)kSetStack) {
+              lstk[sp][threadIdx.x] = ref;
+              ++sp;
+            } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
+              stk32[sp - (uint32_t)kSetStack] = ref;
+              ++sp;
+            } else {
+              atomicOr(&sink.counters[0], 1u);
+            }
+          };
+          if (s3 <= box_limit && rf.w != 0xFFFFFFFFu) push(rf.w);
+          if (s2 <= box_limit && rf.z != 0xFFFFFFFFu) push(rf.z);
+          if (s1 <= box_limit && rf.y != 0xFFFFFFFFu) push(rf.y);
+          if (s0 <= box_limit && rf.x != 0xFFFFFFFFu) push(rf.x);
+        } else if (!(node & kLeafTag)) {
           const uint32_t rot = (lane >> 2) & 3u;
           const uint4 *mine = stage_w + lane * 4;
           const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
@@ -542,28 +628,20 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
           const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
                     qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
                     qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
-          float lb1, lb2;  // (the bounds of the exact walk below: same arithmetic, same margins)
+          uint32_t s1, s2;  // sums of the squared gaps in grid steps (saturating)
           {
             const us2 g01 = SM_GAP(ql01, b0.w, b0.x, qh01), g23 = SM_GAP(ql23, b1.x, b0.y, qh23),
                       g45 = SM_GAP(ql45, b1.y, b0.z, qh45);
-            const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
-                        e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
-            lb1 = e0 * e0;
-            lb1 = __fmaf_rn(e1, e1, lb1); lb1 = __fmaf_rn(e2, e2, lb1); lb1 = __fmaf_rn(e3, e3, lb1);
-            lb1 = __fmaf_rn(e4, e4, lb1); lb1 = __fmaf_rn(e5, e5, lb1);
+            s1 = SM_BOXSUM(g01, g23, g45);
           }
           {
             const us2 g01 = SM_GAP(ql01, b2.y, b1.z, qh01), g23 = SM_GAP(ql23, b2.z, b1.w, qh23),
                       g45 = SM_GAP(ql45, b2.w, b2.x, qh45);
-            const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
-                        e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
-            lb2 = e0 * e0;
-            lb2 = __fmaf_rn(e1, e1, lb2); lb2 = __fmaf_rn(e2, e2, lb2); lb2 = __fmaf_rn(e3, e3, lb2);
-            lb2 = __fmaf_rn(e4, e4, lb2); lb2 = __fmaf_rn(e5, e5, lb2);
+            s2 = SM_BOXSUM(g01, g23, g45);
           }
 #undef SM_GAP
           const uint32_t ref1 = hd.z & (kLeafTag | kIdxMask), ref2 = hd.w & (kLeafTag | kIdxMask);
-          const bool in1 = lb1 < radius, in2 = lb2 < radius;
+          const bool in1 = s1 <= box_limit, in2 = s2 <= box_limit;
           cur = in1 ? ref1 : (in2 ? ref2 : 0xFFFFFFFFu);
           if (in1 && in2) {  // the second child waits on the stack
             if (sp < (uint32_t)kSetStack) {
@@ -621,14 +699,17 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
         ++nn;
         // Lower bounds of the squared distance from the query to the children's boxes, on the 16-bit
-        // grid the boxes are stored on (two dimensions per word, packed u16 arithmetic): per dimension
-        // the gap in grid steps, max(ql - hi, lo - qh, 0) with saturating subtractions, times the step.
-        // ql / qh = the query's nearest grid index -/+ 3 (saturating): a margin of more than two grid steps
-        // around the query, which covers the float rounding of the query's grid index, of the grid values
-        // fma(k, step, base) and of the sums below many times over
-        // (a step is 1.5e-5 of the box's extent, an f32 rounding 6e-8 of the value): the result is a lower
-        // bound of the f32 distance nanoflann computes for ANY point of the box, so a child whose bound is
-        // >= radius holds no hit.  b0 = c1.lo[0..5], c1.hi[0..1]; b1 = c1.hi[2..5], c2.lo[0..3];
+        // grid the boxes are stored on (two dimensions per word, packed u16 arithmetic; the SAME step in every
+        // dimension): per dimension the gap in grid steps, g = max(ql - hi, lo - qh, 0) with saturating
+        // subtractions; the child is entered iff sum g^2 <= box_limit = floor(radius / step^2) + 1, all in integers.
+        // ql / qh = the query's nearest grid index -/+ 3 (saturating): the real per-dimension distance from the
+        // query to any point of the box is more than (g + 1) steps when g > 0 (three steps of margin less the
+        // rounding of the query's grid index, of the outward-rounded box values fma(k, step, base) and of
+        // base itself: a step is 1.5e-5 of the widest extent, an f32 rounding 6e-8 of the value).  So a child with
+        // sum g^2 > box_limit >= radius / step^2 has every point at a real squared distance above
+        // step^2 * sum (g + 1)^2 >= radius * (1 + 2 / g_max), g_max <= sqrt(box_limit) ~ 2 000: three orders of
+        // magnitude more than the f32 rounding of nanoflann's own sum, whose result is therefore >= radius too --
+        // the child holds no hit.  b0 = c1.lo[0..5], c1.hi[0..1]; b1 = c1.hi[2..5], c2.lo[0..3];
         // b2 = c2.lo[4..5], c2.hi[0..5]
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #define SM_GAP(qlw, hiw, low, qhw)                                                                    \
@@ -641,24 +722,16 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
                   qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
                   qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
-        float lb1, lb2;
+        uint32_t s1, s2;  // sums of the squared gaps in grid steps (saturating)
         {
           const us2 g01 = SM_GAP(ql01, b0.w, b0.x, qh01), g23 = SM_GAP(ql23, b1.x, b0.y, qh23),
                     g45 = SM_GAP(ql45, b1.y, b0.z, qh45);
-          const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
-                      e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
-          lb1 = e0 * e0;
-          lb1 = __fmaf_rn(e1, e1, lb1); lb1 = __fmaf_rn(e2, e2, lb1); lb1 = __fmaf_rn(e3, e3, lb1);
-          lb1 = __fmaf_rn(e4, e4, lb1); lb1 = __fmaf_rn(e5, e5, lb1);
+          s1 = SM_BOXSUM(g01, g23, g45);
         }
         {
           const us2 g01 = SM_GAP(ql01, b2.y, b1.z, qh01), g23 = SM_GAP(ql23, b2.z, b1.w, qh23),
                     g45 = SM_GAP(ql45, b2.w, b2.x, qh45);
-          const float e0 = (float)g01.x * box_step[0], e1 = (float)g01.y * box_step[1], e2 = (float)g23.x * box_step[2],
-                      e3 = (float)g23.y * box_step[3], e4 = (float)g45.x * box_step[4], e5 = (float)g45.y * box_step[5];
-          lb2 = e0 * e0;
-          lb2 = __fmaf_rn(e1, e1, lb2); lb2 = __fmaf_rn(e2, e2, lb2); lb2 = __fmaf_rn(e3, e3, lb2);
-          lb2 = __fmaf_rn(e4, e4, lb2); lb2 = __fmaf_rn(e5, e5, lb2);
+          s2 = SM_BOXSUM(g01, g23, g45);
         }
 #undef SM_GAP
         const uint32_t idx = (hd.z >> 28) & 7u;
@@ -671,7 +744,7 @@ __global__ __launch_bounds__(kSeedThreads, 4) void SeedWalkKernel(IndexView ix, 
         const float diff1 = val - divlow, diff2 = val - divhigh;
         const bool low_side = (diff1 + diff2) < 0;
         const uint32_t next = low_side ? ref1 : ref2, other = low_side ? ref2 : ref1;
-        const bool in_next = (low_side ? lb1 : lb2) < radius, in_other = (low_side ? lb2 : lb1) < radius;
+        const bool in_next = (low_side ? s1 : s2) <= box_limit, in_other = (low_side ? s2 : s1) <= box_limit;
         const float dcut = low_side ? diff2 : diff1;
         const float cut = dcut * dcut;
         const float nm = mind + cut - dst;
@@ -865,14 +938,17 @@ __global__ void InnerBoxKernel(const uint4 *__restrict__ inner, const uint32_t *
   }
 }
 
-// grid[0..5] = base, grid[6..11] = step: the root's tight box cut into 65534 steps per dimension.
+// grid[0..5] = base, grid[6..11] = step: the root's tight box on a grid of ONE step for all dimensions (the
+// widest extent cut into 65534 steps), so that the walker can add squared gaps of different dimensions as integers.
 __global__ void BoxGridKernel(uint32_t root_ref, const float *__restrict__ leaf_box,
                               const float *__restrict__ inner_box, float *__restrict__ grid) {
   const int d = threadIdx.x;
   if (d >= 6) return;
   const float *r = BoxOf(root_ref, leaf_box, inner_box);
+  float widest = 0.0f;
+  for (int k = 0; k < 6; ++k) widest = fmaxf(widest, r[6 + k] - r[k]);
   grid[d] = r[d];
-  grid[6 + d] = (r[6 + d] - r[d]) / 65534.0f;
+  grid[6 + d] = widest / 65534.0f;
 }
 
 // The children's boxes of every inner record, on the grid, rounded outwards: the quantised lo
@@ -910,6 +986,84 @@ __global__ void PackBoxesKernel(uint4 *__restrict__ inner, uint64_t n_inner, con
     inner[i * 4 + 1] = make_uint4(w[0], w[1], w[2], w[3]);
     inner[i * 4 + 2] = make_uint4(w[4], w[5], w[6], w[7]);
     inner[i * 4 + 3] = make_uint4(w[8], w[9], w[10], w[11]);
+  }
+}
+
+// ---- quad records (the set walk's own node array, derived from `inner`).  The inner nodes at even depth -- the root,
+// and every inner grandchild of such a node -- are the HEADS; a head's record lists up to four SLOTS, the nodes two
+// levels below it (a child that is a leaf takes one slot itself), each with its tight box exactly as the parents'
+// binary records hold it and a reference: the quad number of a grandchild that is inner (a head again), or
+// kLeafTag | leaf ordinal.  Quads are numbered in pre-order of their heads.  128 bytes: {ref[4]}, 4 x {lo01, lo23,
+// lo45, hi01, hi23, hi45} (two u16 grid coordinates per word), 16 bytes unused.
+__global__ void QuadMarkKernel(const uint4 *__restrict__ inner, uint64_t n_inner, uint32_t *__restrict__ head,
+                               uint32_t round, uint32_t *__restrict__ changed) {
+  for (uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; x < n_inner; x += (uint64_t)gridDim.x * blockDim.x) {
+    if (head[x] != round) continue;
+    const uint4 hd = inner[x * 4];
+    const uint32_t c[2] = {hd.z & (kLeafTag | kIdxMask), hd.w & (kLeafTag | kIdxMask)};
+    for (int i = 0; i < 2; ++i) {
+      if (c[i] & kLeafTag) continue;
+      const uint4 hc = inner[(uint64_t)c[i] * 4];
+      const uint32_t g[2] = {hc.z & (kLeafTag | kIdxMask), hc.w & (kLeafTag | kIdxMask)};
+      for (int j = 0; j < 2; ++j)
+        if (!(g[j] & kLeafTag)) {
+          head[g[j]] = round + 1u;
+          *changed = 1u;
+        }
+    }
+  }
+}
+
+__global__ void QuadFlagKernel(const uint32_t *__restrict__ head, uint64_t n_inner, uint32_t *__restrict__ flag) {
+  for (uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; x < n_inner; x += (uint64_t)gridDim.x * blockDim.x)
+    flag[x] = head[x] ? 1u : 0u;
+}
+
+// box of child `which` (0 / 1) of a binary record as six words {lo01, lo23, lo45, hi01, hi23, hi45}
+__device__ __forceinline__ void ChildBoxWords(const uint4 *rec, int which, uint32_t *w) {
+  const uint4 b0 = rec[1], b1 = rec[2], b2 = rec[3];
+  if (which == 0) {
+    w[0] = b0.x; w[1] = b0.y; w[2] = b0.z; w[3] = b0.w; w[4] = b1.x; w[5] = b1.y;
+  } else {
+    w[0] = b1.z; w[1] = b1.w; w[2] = b2.x; w[3] = b2.y; w[4] = b2.z; w[5] = b2.w;
+  }
+}
+
+__global__ void QuadFillKernel(const uint4 *__restrict__ inner, uint64_t n_inner, const uint32_t *__restrict__ flag,
+                               const uint32_t *__restrict__ quad_of, uint4 *__restrict__ quads) {
+  for (uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; x < n_inner; x += (uint64_t)gridDim.x * blockDim.x) {
+    if (!flag[x]) continue;
+    uint32_t w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // unused slot: no reference, a box nothing is close to
+      w[k] = 0xFFFFFFFFu;
+      w[4 + 6 * k] = w[5 + 6 * k] = w[6 + 6 * k] = 0xFFFFFFFFu;
+    }
+    int slot = 0;
+    const uint4 *rx = inner + x * 4;
+    const uint4 hd = rx[0];
+    const uint32_t c[2] = {hd.z & (kLeafTag | kIdxMask), hd.w & (kLeafTag | kIdxMask)};
+    for (int i = 0; i < 2; ++i) {
+      if (c[i] & kLeafTag) {
+        w[slot] = c[i];
+        ChildBoxWords(rx, i, w + 4 + 6 * slot);
+        ++slot;
+        continue;
+      }
+      const uint4 *rc = inner + (uint64_t)c[i] * 4;
+      const uint4 hc = rc[0];
+      const uint32_t g[2] = {hc.z & (kLeafTag | kIdxMask), hc.w & (kLeafTag | kIdxMask)};
+      for (int j = 0; j < 2; ++j) {
+        w[slot] = (g[j] & kLeafTag) ? g[j] : quad_of[g[j]];
+        ChildBoxWords(rc, j, w + 4 + 6 * slot);
+        ++slot;
+      }
+    }
+    uint4 *o = quads + (uint64_t)quad_of[x] * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
   }
 }
 
@@ -980,6 +1134,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
+constexpr int kQuadBlocksPerCU = 7;  // 22 KB of LDS per 128-thread workgroup of the quad walk
 
 // The queries the set walk found more than num_nearest_points hits for are listed for a second search in the
 // reference's traversal order: their records from the unsorted array (query i at [i]), the last word set to the
@@ -1004,6 +1159,9 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
+  const char *env_quad_blocks = getenv("SMHIP_QUAD_BLOCKS_PER_CU");  // (experiment knob, read per call)
+  uint32_t quad_blocks_per_cu = env_quad_blocks ? (uint32_t)atoi(env_quad_blocks) : (uint32_t)kQuadBlocksPerCU;
+  if (quad_blocks_per_cu < 1 || quad_blocks_per_cu > 16) quad_blocks_per_cu = (uint32_t)kQuadBlocksPerCU;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
   const uint32_t blocks = blocks_override ? blocks_override : 256 * blocks_per_cu;
@@ -1011,18 +1169,15 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
   if (e != hipSuccess) return e;
   const uint32_t *re = xcd_ranges ? range_end : nullptr;
-  if (mode == kWalkCensus)
-    hipLaunchKernelGGL(SeedWalkKernel<kWalkCensus>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
-                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
-                       (uint32_t)thr);
-  else if (mode == kWalkSet)
-    hipLaunchKernelGGL(SeedWalkKernel<kWalkSet>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
-                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
-                       (uint32_t)thr);
-  else
-    hipLaunchKernelGGL(SeedWalkKernel<kWalkExact>, dim3(blocks), dim3(kSeedThreads), 0, ctx->stream, ctx->index, qrec,
-                       n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re, range_stride,
-                       (uint32_t)thr);
+#define SM_WALK(MODE, THREADS, BLOCKS)                                                                              \
+  hipLaunchKernelGGL((SeedWalkKernel<MODE, THREADS>), dim3(BLOCKS), dim3(THREADS), 0, ctx->stream, ctx->index, qrec, \
+                     n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re,         \
+                     range_stride, (uint32_t)thr)
+  if (mode == kWalkCensus) SM_WALK(kWalkCensus, kSeedThreads, blocks);
+  else if (mode == kWalkSet) SM_WALK(kWalkSet, kSeedThreads, blocks);
+  else if (mode == kWalkQuad) SM_WALK(kWalkQuad, kQuadThreads, blocks_override ? blocks_override : 256 * quad_blocks_per_cu);
+  else SM_WALK(kWalkExact, kSeedThreads, blocks);
+#undef SM_WALK
   return hipGetLastError();
 }
 }  // namespace
@@ -1052,6 +1207,55 @@ hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32
     hipLaunchKernelGGL(PackBoxesKernel, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(inner),
                        n_inner, leaf_box, inner_box, grid, error_flag);
   return hipGetLastError();
+}
+
+// Derives ctx->ix_quads from the resident binary records (on upload; replicas receive the array like the others).
+// Leaves index.quads null -- and the mapping path on the exact walk -- for an index beyond the scan's 64 M elements.
+hipError_t BuildQuads(smhip_ctx *ctx) {
+  IndexView &ix = ctx->index;
+  ix.quads = nullptr;
+  ix.n_quads = 0;
+  const uint64_t n = ix.n_inner;
+  if (n == 0 || n > (64ull << 20)) return hipSuccess;
+  DevBuf head, flag, ids, changed;
+  hipError_t e = hipSuccess;
+  auto done = [&](hipError_t r) {
+    (void)hipStreamSynchronize(ctx->stream);
+    head.Free();
+    flag.Free();
+    ids.Free();
+    changed.Free();
+    return r;
+  };
+  if ((e = head.Reserve(n * 4)) != hipSuccess || (e = flag.Reserve(n * 4)) != hipSuccess ||
+      (e = ids.Reserve((n + 1) * 4)) != hipSuccess || (e = changed.Reserve(4)) != hipSuccess)
+    return done(e);
+  if ((e = hipMemsetAsync(head.p, 0, n * 4, ctx->stream)) != hipSuccess) return done(e);
+  const uint32_t one = 1u;
+  if ((e = hipMemcpyAsync(head.p, &one, 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return done(e);
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+  for (uint32_t round = 1; round <= (uint32_t)kStackDepth; ++round) {  // two tree levels per round
+    uint32_t any = 0;
+    if ((e = hipMemsetAsync(changed.p, 0, 4, ctx->stream)) != hipSuccess) return done(e);
+    hipLaunchKernelGGL(QuadMarkKernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.inner, n, head.as<uint32_t>(), round,
+                       changed.as<uint32_t>());
+    if ((e = hipMemcpyAsync(&any, changed.p, 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return done(e);
+    if (!any) break;
+  }
+  hipLaunchKernelGGL(QuadFlagKernel, dim3(blocks), dim3(256), 0, ctx->stream, head.as<uint32_t>(), n, flag.as<uint32_t>());
+  if ((e = LaunchScanU32(ctx, flag.as<uint32_t>(), (uint32_t)n, ids.as<uint32_t>())) != hipSuccess) return done(e);
+  uint32_t n_quads = 0;
+  if ((e = hipMemcpyAsync(&n_quads, ids.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+    return done(e);
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return done(e);
+  if ((e = ctx->ix_quads.Reserve((uint64_t)n_quads * 128)) != hipSuccess) return done(e);
+  hipLaunchKernelGGL(QuadFillKernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.inner, n, flag.as<uint32_t>(),
+                     ids.as<uint32_t>(), ctx->ix_quads.as<uint4>());
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  ix.quads = ctx->ix_quads.as<uint4>();
+  ix.n_quads = n_quads;
+  return done(hipSuccess);
 }
 
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
@@ -1124,7 +1328,8 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   if (!force_set && (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK")))
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
-  e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+  const int set_mode = (ctx->index.quads && !getenv("SMHIP_BINARY_SET")) ? kWalkQuad : kWalkSet;  // (A/B switch)
+  e = LaunchWalk(ctx, p, set_mode, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                  range_stride);
   if (e != hipSuccess) return e;
   // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal

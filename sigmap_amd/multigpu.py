@@ -11,8 +11,8 @@ import numpy as np
 
 from . import _abi
 
-_ARRAYS = ["nodes", "leaf_tab", "leaf_pts", "leaf_vind", "bbox"]
-_SCALARS = ["dim", "root_ref", "n_nodes", "n_leaves", "m_size"]
+_ARRAYS = ["nodes", "leaf_tab", "leaf_pts", "leaf_vind", "bbox", "quads"]
+_SCALARS = ["dim", "root_ref", "n_nodes", "n_leaves", "m_size", "n_quads"]
 
 
 def shard_range(n_items, rank, world):
@@ -60,19 +60,19 @@ def broadcast_host_index(ix_arrays, rank, dist):
 
 def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn=None, via_host=False, force=False):
     """Make the index resident on this rank's GPU.  world == 1: plain upload.  Otherwise rank 0
-    uploads, then each of the five device arrays is sent with ONE RCCL broadcast and the peers
+    uploads, then each of the six device arrays is sent with ONE RCCL broadcast and the peers
     attach the received buffers (smhip_index_attach).  Returns objects to keep alive.
     Rank 0 copies an exported array into the broadcast tensor with smhip_index_export_copy (the
     library's own HIP runtime and stream); `device` / `copy_fn(array_id, dst_ptr, src_ptr, nbytes)` let
     the world_size-2 gloo test run this very function with host buffers.  Every step that can fail on
-    rank 0 (upload, export, the five tensors and the copies into them) happens BEFORE the first
+    rank 0 (upload, export, the six tensors and the copies into them) happens BEFORE the first
     collective and its outcome travels in the meta broadcast: the peers raise instead of waiting in a
     collective for a rank that has left.
     via_host=True (bench.py --backend gloo, a transport for testing the N > 1 flow where RCCL cannot run,
     e.g. several ranks on one GPU): the arrays travel as CPU tensors and every peer copies what it received
     into device memory of its own before attaching.
     force=True with world == 1 (bench.py --force-bcast: a one-GPU box): the collectives run anyway on the
-    one-rank group -- the same meta + five dist.broadcast calls over the same backend -- and the call returns
+    one-rank group -- the same meta + six dist.broadcast calls over the same backend -- and the call returns
     (tensors, IndexDev of the broadcast copy) so that the caller can map from the copy and compare."""
     if world == 1 and not force:
         dev.upload_index(ix)
@@ -112,7 +112,8 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
     for k, nbytes in enumerate(sizes):
         if rank != 0:
             tensors.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
-        dist.broadcast(tensors[k], src=0)  # RCCL broadcast over xGMI
+        if nbytes:   # (an index without quad records has an empty sixth array)
+            dist.broadcast(tensors[k], src=0)  # RCCL broadcast over xGMI
     if on_gpu:
         torch.cuda.synchronize()
     if rank != 0 or force:

@@ -437,7 +437,7 @@ def test_index_export_copy_attach_gives_identical_results(device, small_world):
 
 def test_index_bcast_loopback_runs_the_rccl_calls_on_one_gpu(device, small_world):
     """smhip_index_bcast_loopback: librccl is loaded, a one-rank communicator is created
-    (ncclCommInitAll) and the five walker arrays go through one grouped ncclBroadcast each -- the call
+    (ncclCommInitAll) and the six walker arrays go through one grouped ncclBroadcast each -- the call
     sequence of smhip_index_bcast -- into buffers the second context owns.  The copy is byte-identical
     (export_copy of both sides) and maps to identical records, also after the source context is gone."""
     from sigmap_amd import multigpu

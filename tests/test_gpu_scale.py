@@ -237,7 +237,7 @@ def test_cli_streaming_600_multichunk_reads(tmp_path, small_world):
 
 def test_bench_two_ranks_flow_on_one_gpu():
     """bench.py's N > 1 flow end to end with two ranks (launched like the driver launches it): rank 0
-    builds the index, the five walker arrays are broadcast, the peer attaches what it received, every
+    builds the index, the six walker arrays are broadcast, the peer attaches what it received, every
     rank maps its own shard, barrier, max-over-ranks time, one JSON line.  RCCL refuses two ranks on one
     GPU, so on a one-GPU box the arrays travel through `--backend gloo`; everything else is the N > 1
     path the driver runs."""
@@ -265,7 +265,7 @@ def test_bench_two_ranks_flow_on_one_gpu():
 
 def test_bench_one_rank_over_rccl_forced_broadcast():
     """bench.py launched like the driver launches it, with ONE rank, backend nccl (= RCCL) and
-    --force-bcast: init_process_group(backend="nccl", device_id=...), the meta + five dist.broadcast
+    --force-bcast: init_process_group(backend="nccl", device_id=...), the meta + six dist.broadcast
     calls of multigpu.replicate_index, barrier and the max-over-ranks all_reduce all run over RCCL in a
     process that also holds libsigmap_hip.so; two of the three contexts map from the broadcast copy and
     agree byte for byte with the one that maps from the uploaded arrays."""

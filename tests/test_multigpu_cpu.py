@@ -95,8 +95,9 @@ class _FakeContext:
         from sigmap_amd import _abi
         rng = np.random.default_rng(5)
         d = _abi.IndexDev()
-        d.dim, d.root_ref, d.n_nodes, d.n_leaves, d.m_size = 6, 0, 1000, 1001, 12345
-        for name, nbytes in (("nodes", 64000), ("leaf_tab", 4004), ("leaf_pts", 70000), ("leaf_vind", 9000), ("bbox", 96)):
+        d.dim, d.root_ref, d.n_nodes, d.n_leaves, d.m_size, d.n_quads = 6, 0, 1000, 1001, 12345, 400
+        for name, nbytes in (("nodes", 64000), ("leaf_tab", 4004), ("leaf_pts", 70000), ("leaf_vind", 9000), ("bbox", 96),
+                             ("quads", 51200)):
             buf = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
             self._keep.append(buf)
             setattr(d, name, buf.ctypes.data)
@@ -141,7 +142,7 @@ def _replicate_worker(rank, world, port, q):
 
 def test_world2_gloo_replicate_index_hands_the_peer_identical_arrays():
     """multigpu.replicate_index itself (the function bench.py calls for N > 1), with host buffers in
-    place of device memory: the peer attaches the scalars and byte-identical copies of all five arrays."""
+    place of device memory: the peer attaches the scalars and byte-identical copies of all six arrays."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -173,13 +174,13 @@ def _forced_worker(port, q):
             n = int(getattr(d, a + "_bytes"))
             same = same and int(getattr(nd, a + "_bytes")) == n and getattr(nd, a) != getattr(d, a)
             same = same and bytes((C.c_uint8 * n).from_address(getattr(nd, a))) == bytes((C.c_uint8 * n).from_address(getattr(d, a)))
-        q.put(bool(same and len(tensors) == 5))
+        q.put(bool(same and len(tensors) == len(multigpu._ARRAYS)))
     finally:
         dist.destroy_process_group()
 
 
 def test_forced_one_rank_broadcast_returns_an_identical_copy():
-    """bench.py --force-bcast: with ONE rank replicate_index(force=True) still runs the meta + five
+    """bench.py --force-bcast: with ONE rank replicate_index(force=True) still runs the meta + six
     broadcasts over the group and hands back a copy of the arrays (distinct memory, same bytes)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
