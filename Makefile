@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 ARCH ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
 HOSTFLAGS = -std=c++17 -O2 -ffp-contract=off -fopenmp -fPIC -Wall
 
 LIBDIR = sigmap_amd/lib

@@ -313,14 +313,17 @@ def main():
         # B_chunk = 2*S + Q*(Nn*16 + Np*28) + 24*A + 64 with the REFERENCE's node visits and
         # point tests, counted on the actual inputs (census pass)
         ref_bytes = 2 * CHUNK * R + 16 * nodes + 28 * points + 24 * anchors + 64 * R
-        # the walker's own bytes: what it reads by its own layout -- one 64-byte record per node visit
-        # (leaf visits read no record: an upper bound), 32 bytes per point tested, 16 bytes per hit
-        # written, the query records -- i.e. what a perfect memory system would have to move for it
-        own_bytes = 64 * w_nodes + 32 * w_points + 16 * int(res["hits_total"].sum()) + 64 * queries
+        # the walker's own bytes: what it reads by its own layout -- one record per node visit (order-free search:
+        # a 128-byte quad record, two tree levels; searches in the reference's order: a 64-byte binary record, leaf
+        # visits read none: an upper bound), 32 bytes per point tested, 16 bytes per hit written, the query
+        # records -- i.e. what a perfect memory system would have to move for it
+        quad_walk = int(dev.debug_counters()[6]) == 2
+        rec_bytes, levels_per_rec = (128, 2) if quad_walk else (64, 1)
+        own_bytes = rec_bytes * w_nodes + 32 * w_points + 16 * int(res["hits_total"].sum()) + 64 * queries
         seed_ms = serial["kernels"]["seed_lookup"]["mean_ms"]
-        # SURVEY 8(d) weights on the WALKER'S OWN visits (16 B per node record it needs, 28 B per point it tests, 24 B
-        # per anchor, the raw samples and the result record): the bytes a perfect layout would have to move
-        useful_bytes = 2 * CHUNK * R + 16 * w_nodes + 28 * w_points + 24 * anchors + 64 * R
+        # SURVEY 8(d) weights on the WALKER'S OWN visits (16 B per tree level of a record it reads, 28 B per point it
+        # tests, 24 B per anchor, the raw samples and the result record): the bytes a perfect layout would have to move
+        useful_bytes = 2 * CHUNK * R + 16 * levels_per_rec * w_nodes + 28 * w_points + 24 * anchors + 64 * R
         traffic, traffic_src, prof_ms, read_lines = None, None, None, None
         # a committed counter profile whose workload has this run's shape (tools/collect_profiles.sh)
         import glob
@@ -373,6 +376,8 @@ def main():
                 "nodes_per_query": round(nodes / max(queries, 1), 1),
                 "points_per_query": round(points / max(queries, 1), 1),
                 "walker_nodes_per_query": round(w_nodes / max(queries, 1), 1),
+                "walker_record": ("128-byte quad record (a node's four grandchildren: two tree levels per visit)" if quad_walk
+                                  else "64-byte binary record"),
                 "walker_points_per_query": round(w_points / max(queries, 1), 1),
                 "census_results_identical": bool(same),
                 "anchors_per_chunk": round(anchors / R, 1),

@@ -289,7 +289,9 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
 
 /* Diagnostic counters of the last smhip_map_run: [0] stack-overflow flag, [1] queries that needed
  * the overflow pass, [2] overflow pool slots used, [3] pool-exhausted flag; of the context: [4] batches
- * that were repeated after a speculative run outgrew its buffers, [5] speculative runs so far. */
+ * that were repeated after a speculative run outgrew its buffers, [5] speculative runs so far, [6] how the last
+ * smhip_map_run searched: 0 in the reference's traversal order (binary records), 1 the reference's own node set
+ * (reference_walk), 2 order-free over quad records (nodes_visited then counts 128-byte quad records). */
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
 int smhip_timing_enable(smhip_ctx *ctx, int on);
 int smhip_timing_reset(smhip_ctx *ctx);

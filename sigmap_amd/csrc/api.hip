@@ -1509,6 +1509,7 @@ int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   out[4] = ctx->spec_reruns;
   out[5] = ctx->spec_runs;
+  out[6] = (uint32_t)ctx->last_walk_mode;
   return SMHIP_OK;
 }
 

@@ -172,6 +172,7 @@ struct smhip_ctx {
   int dim = 0;
   smhip::IndexView index{};
   smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, ix_quads, scan_tmp;
+  int last_walk_mode = 0;         // search mode of the last smhip_map_run: 0 exact order, 1 census, 2 order-free (quad records)
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   smhip::DevBuf max_tpos;       // [0] largest target position of the resident index, [1] ... and of the batch's carried anchors
   bool max_tpos_valid = false;  // [0] computed for the index that is resident now

@@ -69,7 +69,10 @@ namespace smhip {
 namespace {
 
 constexpr int kSeedThreads = 256;
-constexpr int kFifo = 4;  // pending leaves per lane
+#ifndef SMHIP_FIFO
+#define SMHIP_FIFO 4
+#endif
+constexpr int kFifo = SMHIP_FIFO;  // pending leaves per lane (at most 7: the scan phase counts them in three ballots)
 constexpr uint32_t kIdxMask = 0x07FFFFFFu;  // index part of a ref (inner index or leaf ordinal)
 constexpr uint32_t kPassTag = 0x40000000u;  // stack entry / current node: the box test at the parent was passed
 
@@ -158,15 +161,14 @@ __device__ unsigned long long g_walk_prof[8];
 //                       on a 250 Mb one -- only the set matters; the others are searched again in kWalkExact mode
 //                       (LaunchSeedLookup).  nanoflann's own rule (mindistsq + cut_dist - dists[idx] <= radius) only
 //                       ever prunes subtrees without hits -- its search is exact -- so the box rule alone finds the
-//                       same set: the walk then carries no dists[] / mindistsq state, a pending visit is a 4-byte
-//                       node reference instead of a 32-byte record (no spill traffic), and a node visit is two box
-//                       tests, no plane arithmetic.
-//        kWalkQuad   -- the set walk over QUAD records (layout: BuildQuads below): one 128-byte record -- one whole
-//                       fabric request -- holds the boxes of a node's four GRANDCHILDREN, so a visit descends two
-//                       levels of the tree for the one line the binary record cost per level.
-enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2, kWalkQuad = 3 };
-constexpr int kQuadThreads = 128;  // workgroup of the quad walk: 11 KB of LDS per wave, seven workgroups per CU
-constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area)
+//                       same set: the walk carries no dists[] / mindistsq state, a pending visit is a 4-byte
+//                       reference instead of a 32-byte record, and it reads QUAD records (layout: BuildQuads below):
+//                       one 128-byte record -- one whole fabric request -- holds the boxes of a node's four
+//                       GRANDCHILDREN, so a visit is four box tests and descends two levels of the tree for the one
+//                       line a binary record costs per level (the launch is bound by the rate of line requests).
+enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2 };
+constexpr int kSetThreads = 128;  // workgroup of the set walk: 10 KB of LDS per wave, eight workgroups per CU
+constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area; 6: +7 %, 4: +14 %)
 
 template <int kMode, int kThreads>
 __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
@@ -176,12 +178,13 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
-  constexpr bool kQuad = kMode == kWalkQuad;
-  constexpr bool kSet = kMode == kWalkSet || kQuad;
+  constexpr bool kSet = kMode == kWalkSet;
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
   const uint32_t gl = blockIdx.x * kThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
-  uint32_t *stk32 = reinterpret_cast<uint32_t *>(stk);  // (set walk: the same area as 4-byte references)
+  // (set walk: the same area as 4-byte references, a row per lane: consecutive levels of a lane share a line that
+  // stays in L1 / L2; level-major rows and a block per wave were measured: no gain)
+  uint32_t *stk32 = reinterpret_cast<uint32_t *>(stk);
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
   const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD: speed only,
@@ -204,10 +207,11 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   const float box_inv =
       __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(box_step > 0.0f ? 1.0f / box_step : 0.0f)));
   // a box is entered iff the sum of its squared per-dimension gaps, in grid steps, is <= box_limit (SM_BOXSUM)
-  uint32_t box_limit = 0xFFFFFFFFu;
+  // (never 2^32 - 1: a saturated sum -- an unused slot of a quad record always is one -- fails the test)
+  uint32_t box_limit = 0xFFFFFFFEu;
   if (box_step > 0.0f) {
     const double lim = floor((double)radius / ((double)box_step * (double)box_step)) + 1.0;
-    if (lim < 4294967295.0) box_limit = (uint32_t)lim;
+    if (lim < 4294967294.0) box_limit = (uint32_t)lim;
   }
   box_limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)box_limit);
   uint32_t mode = M_FETCH;
@@ -222,20 +226,20 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   __shared__ uint32_t lstk[kSet ? kSetStack : 1][kSet ? kThreads : 1];  // set walk: the newest pending references
   // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
   __shared__ uint32_t fifo[kFifo][kThreads];
-  __shared__ uint32_t ovf_lds[kQuad ? 1 : kThreads];  // scan phase: overflow segment base of each lane's query
+  __shared__ uint32_t ovf_lds[kSet ? 1 : kThreads];  // scan phase: overflow segment base of each lane's query
   // address of the first hit slot of each lane's query (HitSlots::At(qi, 0): a pointer-table load), taken when the
   // query is handed out: at emit time it is an LDS read -- a global load there made every scan iteration wait for
   // everything in flight (the next window's point loads included)
-  __shared__ Hit *slot_base[kQuad ? 1 : kThreads];
-  // staging of the cooperative node fetch: 64 records x 64 B (quad walk: x 128 B) per wave
-  __shared__ uint4 stage[kThreads / 64][kQuad ? 512 : 256];
+  __shared__ Hit *slot_base[kSet ? 1 : kThreads];
+  // staging of the cooperative node fetch: 64 records x 64 B (quad walk: x 112 B, the used part of a record) per wave
+  __shared__ uint4 stage[kThreads / 64][kSet ? 448 : 256];
   const uint32_t lane = threadIdx.x & 63u;
   uint4 *stage_w = stage[threadIdx.x >> 6];
-  // the wave's [64] slices of the two scan-phase tables above; the quad walk keeps them in the upper half of its
+  // the wave's [64] slices of the two scan-phase tables above; the quad walk keeps them in the upper part of its
   // staging area (free during a scan phase: the scan's own tables take the lower 4 KB) and a lane's slot address
   // in registers between the phases
-  uint32_t *ovf_w = kQuad ? reinterpret_cast<uint32_t *>(stage_w + 288) : &ovf_lds[kQuad ? 0u : (threadIdx.x & ~63u)];
-  Hit **sbase_w = kQuad ? reinterpret_cast<Hit **>(stage_w + 256) : &slot_base[kQuad ? 0u : (threadIdx.x & ~63u)];
+  uint32_t *ovf_w = kSet ? reinterpret_cast<uint32_t *>(stage_w + 288) : &ovf_lds[kSet ? 0u : (threadIdx.x & ~63u)];
+  Hit **sbase_w = kSet ? reinterpret_cast<Hit **>(stage_w + 256) : &slot_base[kSet ? 0u : (threadIdx.x & ~63u)];
   Hit *my_slots = nullptr;
   uint32_t tcnt = 0, thead = 0;
   uint32_t fifo_cnt = 0;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         own_a[lane] = make_float4(q0, q1, q2, q3);
         own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
         ovf_w[lane] = ovf_base;
-        if (kQuad) sbase_w[lane] = my_slots;
+        if (kSet) sbase_w[lane] = my_slots;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           SM_INIT_DIM(5, d5)
         }
         node = ix.root_ref | kPassTag; sp = 0; tcnt = 0; hits = 0; nn = 0; np = 0;
-        if (kQuad) my_slots = sink.region.At(qi, 0);
+        if (kSet) my_slots = sink.region.At(qi, 0);
         else sbase_w[lane] = sink.region.At(qi, 0);
         {
           uint32_t gc[6];
@@ -520,21 +524,26 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     }
     const unsigned long long pt1 = WALK_T();
     pt_fetchq += pt1 - pt0;
-    if (kQuad) {
-      // quad records: eight lanes fetch the 16-byte parts of one 128-byte record (one whole line); part p of lane
-      // s's record lands at position p ^ ((s >> 1) & 7) of row s, so that the row reads below are conflict-free
+    if (kSet) {
+      // quad records: SEVEN lanes fetch the seven used 16-byte parts of one 128-byte record (one line: one request),
+      // nine records per instruction (lane 63 idles), the 64th record with an eighth instruction; instruction r
+      // writes 63 x 16 bytes from unit 63 r on, so record s = 9 r + lane / 7 lands as the 112-byte row 7 s .. 7 s + 6
+      // (a stride of 28 words: sixteen lanes reading the same part of their rows touch all 64 banks once)
       const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
+      const uint32_t grp = lane / 7u, part = lane - 7u * grp;
       uint32_t nsrc[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        nsrc[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)r * 8u + (lane >> 3)) * 4u), (int)want);
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t src = (uint32_t)r * 9u + grp;
+        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) * 4u), (int)want);
+        nsrc[r] = (lane < 63u && src < 64u) ? v : 0xFFFFFFFFu;
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const uint32_t src = (uint32_t)r * 8u + (lane >> 3);
         if (nsrc[r] != 0xFFFFFFFFu) {
-          const uint4 *g = ix.quads + (size_t)nsrc[r] * 8 + ((lane & 7u) ^ ((src >> 1) & 7u));
+          const uint4 *g = ix.quads + (size_t)nsrc[r] * 8 + part;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                           (__attribute__((address_space(3))) void *)(stage_w + r * 64), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void *)(stage_w + r * 63), 16, 0, 0);
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
@@ -569,15 +578,12 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         // ---- set walk: test both children's boxes; the first that passes is visited next, a second one is left on
         // the stack; leaves go to the FIFO at once.  A reference on the stack has passed its box test.
         uint32_t cur = 0xFFFFFFFFu;  // the node to go on with (none: pop)
-        if (kQuad && !(node & kLeafTag)) {
+        if (!(node & kLeafTag)) {
           // a quad record: {ref[4]} then four boxes of six words {lo01, lo23, lo45, hi01, hi23, hi45}; an unused
-          // slot has ref 0xFFFFFFFF (and an impossible box).  Every slot that passes is pushed, then the
-          // loop below pops the newest: leaves to the FIFO, the first inner reference is the next record.
-          const uint32_t rot = (lane >> 1) & 7u;
-          const uint4 *mine = stage_w + lane * 8;
-          const uint4 rf = mine[0 ^ rot], p1 = mine[1 ^ rot], p2 = mine[2 ^ rot], p3 = mine[3 ^ rot],
-                      p4 = mine[4 ^ rot], p5 = mine[5 ^ rot], p6 = mine[6 ^ rot];
-          ++nn;
+          // slot has a box (lo 65535, hi 0 in every dimension) whose sum saturates for any query
+          const uint4 *mine = stage_w + lane * 7;
+          const uint4 rf = mine[0], p1 = mine[1], p2 = mine[2], p3 = mine[3], p4 = mine[4], p5 = mine[5], p6 = mine[6];
+          ++nn;  // (this mode's nodes_visited: the quad records read)
           typedef unsigned short us2 __attribute__((ext_vector_type(2)));
           const us2 k3 = {3, 3};
           const us2 ql01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc01), k3),
@@ -597,8 +603,15 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           const uint32_t s3 = SM_QBOX(p5.z, p5.w, p6.x, p6.y, p6.z, p6.w);
 #undef SM_QBOX
 #undef SM_GAP
-          auto push = [&](uint32_t ref) {
-            if (sp < (uint32_t)kSetStack) {
+          // a passing slot: a leaf goes to the FIFO at once while there is room, the first inner reference is the
+          // record to go on with, everything else waits on the stack
+          auto take = [&](uint32_t sum, uint32_t ref) {
+            if (sum > box_limit) return;
+            if ((ref & kLeafTag) && fifo_cnt < (uint32_t)kFifo) {
+              fifo[fifo_cnt++][threadIdx.x] = ref & kIdxMask;
+            } else if (!(ref & kLeafTag) && cur == 0xFFFFFFFFu) {
+              cur = ref;
+            } else if (sp < (uint32_t)kSetStack) {
               lstk[sp][threadIdx.x] = ref;
               ++sp;
             } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
@@ -608,52 +621,10 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
               atomicOr(&sink.counters[0], 1u);
             }
           };
-          if (s3 <= box_limit && rf.w != 0xFFFFFFFFu) push(rf.w);
-          if (s2 <= box_limit && rf.z != 0xFFFFFFFFu) push(rf.z);
-          if (s1 <= box_limit && rf.y != 0xFFFFFFFFu) push(rf.y);
-          if (s0 <= box_limit && rf.x != 0xFFFFFFFFu) push(rf.x);
-        } else if (!(node & kLeafTag)) {
-          const uint32_t rot = (lane >> 2) & 3u;
-          const uint4 *mine = stage_w + lane * 4;
-          const uint4 hd = mine[0 ^ rot], b0 = mine[1 ^ rot], b1 = mine[2 ^ rot], b2 = mine[3 ^ rot];
-          ++nn;
-          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-#define SM_GAP(qlw, hiw, low, qhw)                                                                    \
-  __builtin_elementwise_max(__builtin_elementwise_sub_sat(qlw, __builtin_bit_cast(us2, hiw)), \
-                            __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, low), qhw))
-          const us2 k3 = {3, 3};
-          const us2 ql01 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc01), k3),
-                    ql23 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc23), k3),
-                    ql45 = __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qc45), k3);
-          const us2 qh01 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc01), k3),
-                    qh23 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc23), k3),
-                    qh45 = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qc45), k3);
-          uint32_t s1, s2;  // sums of the squared gaps in grid steps (saturating)
-          {
-            const us2 g01 = SM_GAP(ql01, b0.w, b0.x, qh01), g23 = SM_GAP(ql23, b1.x, b0.y, qh23),
-                      g45 = SM_GAP(ql45, b1.y, b0.z, qh45);
-            s1 = SM_BOXSUM(g01, g23, g45);
-          }
-          {
-            const us2 g01 = SM_GAP(ql01, b2.y, b1.z, qh01), g23 = SM_GAP(ql23, b2.z, b1.w, qh23),
-                      g45 = SM_GAP(ql45, b2.w, b2.x, qh45);
-            s2 = SM_BOXSUM(g01, g23, g45);
-          }
-#undef SM_GAP
-          const uint32_t ref1 = hd.z & (kLeafTag | kIdxMask), ref2 = hd.w & (kLeafTag | kIdxMask);
-          const bool in1 = s1 <= box_limit, in2 = s2 <= box_limit;
-          cur = in1 ? ref1 : (in2 ? ref2 : 0xFFFFFFFFu);
-          if (in1 && in2) {  // the second child waits on the stack
-            if (sp < (uint32_t)kSetStack) {
-              lstk[sp][threadIdx.x] = ref2;
-              ++sp;
-            } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
-              stk32[sp - (uint32_t)kSetStack] = ref2;
-              ++sp;
-            } else {
-              atomicOr(&sink.counters[0], 1u);
-            }
-          }
+          take(s0, rf.x);
+          take(s1, rf.y);
+          take(s2, rf.z);
+          take(s3, rf.w);
         } else {
           cur = node & (kLeafTag | kIdxMask);  // a leaf left over from the previous visit (the FIFO was full)
         }
@@ -666,7 +637,6 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
             cur = sp < (uint32_t)kSetStack ? lstk[sp][threadIdx.x] : stk32[sp - (uint32_t)kSetStack];
           }
           if (!(cur & kLeafTag) || fifo_cnt == (uint32_t)kFifo) break;
-          ++nn;
           fifo[fifo_cnt++][threadIdx.x] = cur & kIdxMask;
           cur = 0xFFFFFFFFu;
         }
@@ -1134,7 +1104,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
-constexpr int kQuadBlocksPerCU = 7;  // 22 KB of LDS per 128-thread workgroup of the quad walk
+constexpr int kSetScanThreshold = 8;  // ... of the set walk (2 / 4 / 8 / 16: 6.52 / 6.44 / 6.35 / 6.44 ms)
 
 // The queries the set walk found more than num_nearest_points hits for are listed for a second search in the
 // reference's traversal order: their records from the unsorted array (query i at [i]), the last word set to the
@@ -1159,9 +1129,9 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
-  const char *env_quad_blocks = getenv("SMHIP_QUAD_BLOCKS_PER_CU");  // (experiment knob, read per call)
-  uint32_t quad_blocks_per_cu = env_quad_blocks ? (uint32_t)atoi(env_quad_blocks) : (uint32_t)kQuadBlocksPerCU;
-  if (quad_blocks_per_cu < 1 || quad_blocks_per_cu > 16) quad_blocks_per_cu = (uint32_t)kQuadBlocksPerCU;
+  // (the set walk's workgroups are half the size: the same knob counts them in pairs)
+  const uint32_t set_blocks_per_cu = 2u * (uint32_t)blocks_per_cu;
+  if (mode == kWalkSet && env_thr <= 0) thr = kSetScanThreshold;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
   const uint32_t blocks = blocks_override ? blocks_override : 256 * blocks_per_cu;
@@ -1174,8 +1144,7 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
                      n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re,         \
                      range_stride, (uint32_t)thr)
   if (mode == kWalkCensus) SM_WALK(kWalkCensus, kSeedThreads, blocks);
-  else if (mode == kWalkSet) SM_WALK(kWalkSet, kSeedThreads, blocks);
-  else if (mode == kWalkQuad) SM_WALK(kWalkQuad, kQuadThreads, blocks_override ? blocks_override : 256 * quad_blocks_per_cu);
+  else if (mode == kWalkSet) SM_WALK(kWalkSet, kSetThreads, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
   else SM_WALK(kWalkExact, kSeedThreads, blocks);
 #undef SM_WALK
   return hipGetLastError();
@@ -1314,6 +1283,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   }
   if (e != hipSuccess) return e;
   ScopedTimer t(ctx, T_SEED);  // the search itself (the set walk, and the second search of the queries beyond the cap)
+  ctx->last_walk_mode = p.reference_walk ? kWalkCensus : kWalkExact;
   if (p.reference_walk)
     return LaunchWalk(ctx, p, kWalkCensus, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
@@ -1325,11 +1295,11 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   // at 600) and from the share of such queries in the batches seen (smhip_ctx::walk_exact_only, smhip_map_run).
   // (SMHIP_EXACT_WALK: A/B switch, read per call)
   const bool force_set = getenv("SMHIP_SET_WALK") != nullptr;  // (A/B switch: the set walk whatever the index and history)
-  if (!force_set && (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK")))
+  if (!ctx->index.quads || (!force_set && (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK"))))
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
-  const int set_mode = (ctx->index.quads && !getenv("SMHIP_BINARY_SET")) ? kWalkQuad : kWalkSet;  // (A/B switch)
-  e = LaunchWalk(ctx, p, set_mode, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
+  ctx->last_walk_mode = kWalkSet;
+  e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                  range_stride);
   if (e != hipSuccess) return e;
   // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal

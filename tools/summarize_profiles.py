@@ -33,12 +33,12 @@ def parse_shape(text):
     return shape
 
 
-WALKERS = ("SeedWalkKernel<2>", "SeedWalkKernel<0>", "SeedWalkKernel<false>")
+WALKERS = ("SeedWalkKernel<2, 128>", "SeedWalkKernel<2>", "SeedWalkKernel<0, 256>", "SeedWalkKernel<0>", "SeedWalkKernel<false>")
 
 
 def traffic_json(tag, red, per, shape_txt):
     """<tag>_pmc_traffic.json from the per-launch counter means: the production search kernel of the run -- the set
-    walk (<2>) when it ran, else the walk in the reference's order (<0>: large references; "<false>" in rounds 1-2)."""
+    walk (<2, ...>) when it ran, else the walk in the reference's order (<0, ...>: large references; "<false>" in rounds 1-2)."""
     seed = next((w for w in WALKERS for k in per if k == w and per[k].get("TCC_EA0_RDREQ_sum", 0) > 1e6), None)
     if not seed:
         return {}
