@@ -283,7 +283,7 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
   // Walker structures (layouts: seed_lookup.hip header) from the pre-order node array: one
-  // 64-byte record per INNER node, one table word and one point block of 2 * roundup(n, 8) 16-byte
+  // 64-byte record per INNER node, one table word and one point block of roundup(n, 4) 32-byte
   // slots (whole 128-byte lines) per leaf.  The boxes are computed on the device: leaves by the
   // gather, inner nodes level by level from the deepest one up, then quantised into the parents.
   std::vector<uint32_t> ref_of(n_nodes), depth(n_nodes, 0);
@@ -316,11 +316,11 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
       // the scan phase tests one point per lane, 21 lanes per leaf (the reference builds with
       // max_leaf = 20, sigmap.cc:1426)
       if (nd.b - nd.a > 21) return Fail(ctx, SMHIP_EINVAL, "leaf with more than 21 points");
-      if (n_slots >= (1ull << 31)) return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit leaf block numbers");
+      if (n_slots >= (1ull << 29)) return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit leaf block numbers");
       const uint32_t n = nd.b - nd.a, l = ref_of[i] & ~kLeafTag;
       leaf_left[l] = nd.a;
-      leaf_tab[l] = (uint32_t)(n_slots >> 4) | (n << 27);
-      n_slots += 2ull * ((n + 7u) & ~7u);
+      leaf_tab[l] = (uint32_t)(n_slots >> 2) | (n << 27);  // (32-byte slots, four to a line)
+      n_slots += (n + 3u) & ~3u;
       leaf_points += n;
     }
   }
@@ -337,12 +337,12 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
       if (nodes[i].feat >= 0) level_nodes[cur[depth[i]]++] = ref_of[i];
   }
   const uint32_t root_ref = ref_of[0];
-  ctx->leaf_pts_bytes = n_slots * 16 + 128;
+  ctx->leaf_pts_bytes = n_slots * 32 + 128;
   HIPCHK(ctx->ix_nodes.Reserve(std::max<uint64_t>(n_inner, 1) * 64));
   HIPCHK(ctx->ix_tab.Reserve(n_leaves * sizeof(uint32_t)));
   HIPCHK(ctx->ix_pts.Reserve(ctx->leaf_pts_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_pts.p, 0, ctx->leaf_pts_bytes, ctx->stream));
-  ctx->leaf_vind_bytes = (n_slots / 2 + 32) * sizeof(uint32_t);
+  ctx->leaf_vind_bytes = (n_slots + 32) * sizeof(uint32_t);
   HIPCHK(ctx->ix_vind.Reserve(ctx->leaf_vind_bytes));
   HIPCHK(hipMemsetAsync(ctx->ix_vind.p, 0, ctx->leaf_vind_bytes, ctx->stream));
   HIPCHK(ctx->ix_bbox.Reserve(4 * dim * sizeof(float)));

@@ -12,13 +12,13 @@
 //              the root box (value = root_lo[d] + q * step, step = widest root extent / 65534) and
 //              rounded OUTWARDS, so a quantised box contains the exact one.  A ref is an inner
 //              index, or kLeafTag | leaf ordinal (tree order): leaves have no record of their own.
-//   leaf_tab : uint32 per leaf: (first 16-byte slot of its point block / 16) | n << 27
-//   leaf_pts : one 128-byte-aligned block of 16-byte slots per leaf at slot offset `boff`: n "first
-//              halves" {v0,v1,v2,v3}, then (from slot boff + roundup(n, 8)) n "second halves"
-//              {v4, v5, uint64 Point.position}.  Eight first halves are exactly one 128-byte line.
-//              This replaces <= 20 scattered (vind -> 6 strided floats) gathers per leaf
+//   leaf_tab : uint32 per leaf: (first 32-byte slot of its point block / 4) | n << 27
+//   leaf_pts : one 128-byte-aligned block of 32-byte slots per leaf at slot offset `boff`: n points
+//              {v0, v1, v2, v3, v4, v5, uint64 Point.position}, four to a 128-byte line (a leaf of 10 .. 20 points
+//              is 3 .. 5 lines; the coordinates' first four and last two words in two runs of eight-point lines
+//              were 4 or 6).  This replaces <= 20 scattered (vind -> 6 strided floats) gathers per leaf
 //              (sigmap_adaptor.h:94-97), and a hit needs no second lookup for its position.
-//   leaf_vind: uint32[n_slots / 2]: original point index of first-half slot s at [(boff >> 1) + t]
+//   leaf_vind: uint32[n_slots]: original point index of slot boff + t
 //              (Hit.slot; only the per-stage test entry point reads it)
 //   qrec     : one 32-byte record per query: float q[6]; uint32 chunk; uint32 k
 //
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       const uint32_t my_first = (uint32_t)__popcll(cb0 & lt) + 2u * (uint32_t)__popcll(cb1 & lt) +
                                 4u * (uint32_t)__popcll(cb2 & lt);
       const uint32_t n_ent = (uint32_t)__popcll(cb0) + 2u * (uint32_t)__popcll(cb1) + 4u * (uint32_t)__popcll(cb2);
-      uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {boff, owner lane | n << 8}
+      uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {first 32-byte slot, owner lane | n << 8 | ...}
       float4 *own_a = reinterpret_cast<float4 *>(stage_w + 128);  // [64] q0..q3 of the owning lane
       uint4 *own_b = stage_w + 192;                                // [64] q4, q5, query id, hits so far
       uint32_t n_points;  // points of all pending leaves (wave-uniform)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           if ((uint32_t)e < c) {
             const uint32_t nleaf = tab[e] >> 27;
             // {first 16-byte slot of the leaf's block, owner lane | points << 8 | flat position << 13}
-            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 4, lane | (nleaf << 8) | (run << 13));
+            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 2, lane | (nleaf << 8) | (run << 13));
             run += nleaf;
             if (!kStrict) np += nleaf;  // (strict: counted when the leaf was visited)
           }
@@ -342,13 +342,13 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         return Win{ents[min(eb_ + e_rel, 255u)], e_rel, p < limit};  // (pt: then t < n, the next entry starts above p)
       };
       uint32_t eb = 0, p0 = 0;
-      // the window's point loads (both halves of the point: v0..v3, then v4, v5, position), from a valid address
+      // the window's point loads (the 32-byte point: v0..v3, then v4, v5, position), from a valid address
       // for the lanes without a point: no branch around a load, so nothing waits for it before its use
       auto load_points = [&](const Win &w_, uint32_t p0_, uint4 &rv_, uint4 &sv_) {
-        const uint32_t n_ = (w_.mine.y >> 8) & 31u, t_ = p0_ + lane - (w_.mine.y >> 13);
-        const uint4 *fh = pts4 + (w_.pt ? (size_t)w_.mine.x + t_ : (size_t)0);
+        const uint32_t t_ = p0_ + lane - (w_.mine.y >> 13);
+        const uint4 *fh = pts4 + (w_.pt ? 2 * ((size_t)w_.mine.x + t_) : (size_t)0);
         rv_ = fh[0];
-        sv_ = fh[w_.pt ? ((n_ + 7u) & ~7u) : 0u];
+        sv_ = fh[1];
       };
       // number of lanes with a point, and the first entry of the next window (from the end of this one: p0 + 64,
       // or the start of entry eb + kWin if that came first; its first entry is the last lane's, or the one after
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         Hit h;
         h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);
         h.dist = res;
-        h.slot = (mine.x >> 1) + t;
+        h.slot = mine.x + t;
         const bool emit = hit && ord < sink.nnp;
         if (emit && ord < sink.fast_cap) sbase_w[owner][ord] = h;
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
@@ -859,7 +859,7 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
   for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_leaves;
        k += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t tab = leaf_tab[k];
-    const uint32_t left = leaf_left[k], n = tab >> 27, boff = (tab & kIdxMask) << 4, rn = (n + 7u) & ~7u;
+    const uint32_t left = leaf_left[k], n = tab >> 27, boff = (tab & kIdxMask) << 2;  // (first 32-byte slot)
     float lo[6], hi[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
@@ -876,10 +876,10 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
         lo[d] = fminf(lo[d], p[d]);
         hi[d] = fmaxf(hi[d], p[d]);
       }
-      slot_vind[(size_t)(boff >> 1) + t] = v;  // Hit.slot -> original point index
-      o[(size_t)boff + t] = make_float4(p[0], p[1], p[2], p[3]);
-      o[(size_t)boff + rn + t] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
-                                             __uint_as_float((uint32_t)(pos >> 32)));
+      slot_vind[(size_t)boff + t] = v;  // Hit.slot -> original point index
+      o[2 * ((size_t)boff + t)] = make_float4(p[0], p[1], p[2], p[3]);
+      o[2 * ((size_t)boff + t) + 1] = make_float4(p[4], p[5], __uint_as_float((uint32_t)pos),
+                                                  __uint_as_float((uint32_t)(pos >> 32)));
     }
 #pragma unroll
     for (int d = 0; d < 6; ++d) {

@@ -564,10 +564,10 @@ __global__ void IndexMaxTargetKernel(const uint32_t *__restrict__ leaf_tab, cons
   uint32_t mx = 0;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_leaves; k += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t tab = leaf_tab[k];
-    const uint32_t n = tab >> 27, rn = (n + 7u) & ~7u;
-    const uint64_t boff = (uint64_t)(tab & 0x07FFFFFFu) << 4;
+    const uint32_t n = tab >> 27;
+    const uint64_t boff = (uint64_t)(tab & 0x07FFFFFFu) << 2;  // first 32-byte slot of the leaf's block
     for (uint32_t t = 0; t < n; ++t) {
-      const float4 v = leaf_pts[boff + rn + t];  // {v4, v5, position lo, position hi}
+      const float4 v = leaf_pts[2 * (boff + t) + 1];  // {v4, v5, position lo, position hi}
       const uint64_t pos = (uint64_t)__float_as_uint(v.z) | ((uint64_t)__float_as_uint(v.w) << 32);
       mx = max(mx, (uint32_t)(pos >> 1));
     }
