@@ -102,8 +102,8 @@ typedef struct {
                                                   tight boxes of both children as 24 x u16 on the grid
                                                   in bbox[12..23]; ref = inner index, or 0x80000000 |
                                                   leaf ordinal */
-  void *leaf_tab;   uint64_t leaf_tab_bytes;   /* uint32 per leaf: (boff / 4) | n << 27 */
-  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 128-byte-aligned blocks at 32-byte slot `boff`:
+  void *leaf_tab;   uint64_t leaf_tab_bytes;   /* uint32 per leaf: (boff / 8) | n << 27 */
+  void *leaf_pts;   uint64_t leaf_pts_bytes;   /* per-leaf 256-byte-aligned blocks at 32-byte slot `boff`:
                                                   n x {v0..v5, uint64 position} */
   void *leaf_vind;  uint64_t leaf_vind_bytes;  /* uint32[slots]: original point index of the
                                                   point in slot boff + t */

@@ -283,8 +283,8 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
     return Fail(ctx, SMHIP_EINVAL, "inconsistent index sizes");
   HIPCHK(hipSetDevice(ctx->device));
   // Walker structures (layouts: seed_lookup.hip header) from the pre-order node array: one
-  // 64-byte record per INNER node, one table word and one point block of roundup(n, 4) 32-byte
-  // slots (whole 128-byte lines) per leaf.  The boxes are computed on the device: leaves by the
+  // 64-byte record per INNER node, one table word and one point block of roundup(n, 8) 32-byte
+  // slots (pairs of 128-byte lines: the table word has 27 bits for the block number) per leaf.  The boxes are computed on the device: leaves by the
   // gather, inner nodes level by level from the deepest one up, then quantised into the parents.
   std::vector<uint32_t> ref_of(n_nodes), depth(n_nodes, 0);
   uint64_t n_inner = 0, n_leaves = 0, n_slots = 0, leaf_points = 0;
@@ -316,11 +316,11 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
       // the scan phase tests one point per lane, 21 lanes per leaf (the reference builds with
       // max_leaf = 20, sigmap.cc:1426)
       if (nd.b - nd.a > 21) return Fail(ctx, SMHIP_EINVAL, "leaf with more than 21 points");
-      if (n_slots >= (1ull << 29)) return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit leaf block numbers");
+      if (n_slots >= (1ull << 30)) return Fail(ctx, SMHIP_EINVAL, "index too large for 27-bit leaf block numbers");
       const uint32_t n = nd.b - nd.a, l = ref_of[i] & ~kLeafTag;
       leaf_left[l] = nd.a;
-      leaf_tab[l] = (uint32_t)(n_slots >> 2) | (n << 27);  // (32-byte slots, four to a line)
-      n_slots += (n + 3u) & ~3u;
+      leaf_tab[l] = (uint32_t)(n_slots >> 3) | (n << 27);  // (32-byte slots, four to a line; blocks of two lines)
+      n_slots += (n + 7u) & ~7u;
       leaf_points += n;
     }
   }

@@ -12,8 +12,8 @@
 //              the root box (value = root_lo[d] + q * step, step = widest root extent / 65534) and
 //              rounded OUTWARDS, so a quantised box contains the exact one.  A ref is an inner
 //              index, or kLeafTag | leaf ordinal (tree order): leaves have no record of their own.
-//   leaf_tab : uint32 per leaf: (first 32-byte slot of its point block / 4) | n << 27
-//   leaf_pts : one 128-byte-aligned block of 32-byte slots per leaf at slot offset `boff`: n points
+//   leaf_tab : uint32 per leaf: (first 32-byte slot of its point block / 8) | n << 27
+//   leaf_pts : one 256-byte-aligned block of 32-byte slots per leaf at slot offset `boff`: n points
 //              {v0, v1, v2, v3, v4, v5, uint64 Point.position}, four to a 128-byte line (a leaf of 10 .. 20 points
 //              is 3 .. 5 lines; the coordinates' first four and last two words in two runs of eight-point lines
 //              were 4 or 6).  This replaces <= 20 scattered (vind -> 6 strided floats) gathers per leaf
@@ -232,14 +232,14 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   // everything in flight (the next window's point loads included)
   __shared__ Hit *slot_base[kSet ? 1 : kThreads];
   // staging of the cooperative node fetch: 64 records x 64 B (quad walk: x 112 B, the used part of a record) per wave
-  __shared__ uint4 stage[kThreads / 64][kSet ? 448 : 256];
+  __shared__ uint4 stage[kThreads / 64][kSet ? 448 : 260];  // (scan phase: 4 160 bytes of tables)
   const uint32_t lane = threadIdx.x & 63u;
   uint4 *stage_w = stage[threadIdx.x >> 6];
   // the wave's [64] slices of the two scan-phase tables above; the quad walk keeps them in the upper part of its
   // staging area (free during a scan phase: the scan's own tables take the lower 4 KB) and a lane's slot address
   // in registers between the phases
-  uint32_t *ovf_w = kSet ? reinterpret_cast<uint32_t *>(stage_w + 288) : &ovf_lds[kSet ? 0u : (threadIdx.x & ~63u)];
-  Hit **sbase_w = kSet ? reinterpret_cast<Hit **>(stage_w + 256) : &slot_base[kSet ? 0u : (threadIdx.x & ~63u)];
+  uint32_t *ovf_w = kSet ? reinterpret_cast<uint32_t *>(stage_w + 292) : &ovf_lds[kSet ? 0u : (threadIdx.x & ~63u)];
+  Hit **sbase_w = kSet ? reinterpret_cast<Hit **>(stage_w + 260) : &slot_base[kSet ? 0u : (threadIdx.x & ~63u)];
   Hit *my_slots = nullptr;
   uint32_t tcnt = 0, thead = 0;
   uint32_t fifo_cnt = 0;
@@ -276,9 +276,11 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       const uint32_t my_first = (uint32_t)__popcll(cb0 & lt) + 2u * (uint32_t)__popcll(cb1 & lt) +
                                 4u * (uint32_t)__popcll(cb2 & lt);
       const uint32_t n_ent = (uint32_t)__popcll(cb0) + 2u * (uint32_t)__popcll(cb1) + 4u * (uint32_t)__popcll(cb2);
-      uint2 *ents = reinterpret_cast<uint2 *>(stage_w);      // [256] {first 32-byte slot, owner lane | n << 8 | ...}
-      float4 *own_a = reinterpret_cast<float4 *>(stage_w + 128);  // [64] q0..q3 of the owning lane
-      uint4 *own_b = stage_w + 192;                                // [64] q4, q5, query id, hits so far
+      // [256 + 8] {first 32-byte slot, owner lane | n << 8 | flat position << 13}; the eight entries after the last
+      // are sentinels (flat position: the maximum), so that a window's look-ahead needs no bounds
+      uint2 *ents = reinterpret_cast<uint2 *>(stage_w);
+      float4 *own_a = reinterpret_cast<float4 *>(stage_w + 132);  // [64] q0..q3 of the owning lane
+      uint4 *own_b = stage_w + 196;                                // [64] q4, q5, query id, hits so far
       uint32_t n_points;  // points of all pending leaves (wave-uniform)
       {
         uint32_t tab[kFifo];
@@ -301,11 +303,12 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           if ((uint32_t)e < c) {
             const uint32_t nleaf = tab[e] >> 27;
             // {first 16-byte slot of the leaf's block, owner lane | points << 8 | flat position << 13}
-            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 2, lane | (nleaf << 8) | (run << 13));
+            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 3, lane | (nleaf << 8) | (run << 13));
             run += nleaf;
             if (!kStrict) np += nleaf;  // (strict: counted when the leaf was visited)
           }
       }
+      if (lane < 8u) ents[n_ent + lane] = make_uint2(0u, 0xFFFFFFFFu);
       if (c > 0) {
         own_a[lane] = make_float4(q0, q1, q2, q3);
         own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
@@ -334,8 +337,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         uint32_t e_rel = 0, limit = n_points;
 #pragma unroll
         for (int i = 1; i <= kWin; ++i) {
-          const bool have = eb_ + (uint32_t)i < n_ent;
-          const uint32_t st_i = have ? (ents[eb_ + (uint32_t)i].y >> 13) : 0xFFFFFFFFu;  // (uniform address)
+          const uint32_t st_i = ents[eb_ + (uint32_t)i].y >> 13;  // (uniform address; past the end: a sentinel)
           if (i < kWin) e_rel += st_i <= p ? 1u : 0u;
           else limit = min(limit, st_i);
         }
@@ -408,7 +410,15 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         h.dist = res;
         h.slot = mine.x + t;
         const bool emit = hit && ord < sink.nnp;
-        if (emit && ord < sink.fast_cap) sbase_w[owner][ord] = h;
+        if (emit && ord < sink.fast_cap) {
+          // (a GLOBAL store: through the generic pointer read back from LDS it was a flat store, which the LDS
+          // accesses after it have to wait for)
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(1))) u32x4 GlobalU4;
+          GlobalU4 *dst = (GlobalU4 *)(uintptr_t)(sbase_w[owner] + ord);
+          const u32x4 bits = {(uint32_t)h.position, (uint32_t)(h.position >> 32), __float_as_uint(h.dist), h.slot};
+          *dst = bits;
+        }
         // rare: hits beyond the query's own slots, one lane at a time in ordinal order
         for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
           if (lane == (uint32_t)__builtin_ctzll(ovm)) {
@@ -859,7 +869,7 @@ __global__ void LeafGatherKernel(const float *__restrict__ values, const uint64_
   for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_leaves;
        k += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t tab = leaf_tab[k];
-    const uint32_t left = leaf_left[k], n = tab >> 27, boff = (tab & kIdxMask) << 2;  // (first 32-byte slot)
+    const uint32_t left = leaf_left[k], n = tab >> 27, boff = (tab & kIdxMask) << 3;  // (first 32-byte slot)
     float lo[6], hi[6];
 #pragma unroll
     for (int d = 0; d < 6; ++d) {

@@ -565,7 +565,7 @@ __global__ void IndexMaxTargetKernel(const uint32_t *__restrict__ leaf_tab, cons
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_leaves; k += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t tab = leaf_tab[k];
     const uint32_t n = tab >> 27;
-    const uint64_t boff = (uint64_t)(tab & 0x07FFFFFFu) << 2;  // first 32-byte slot of the leaf's block
+    const uint64_t boff = (uint64_t)(tab & 0x07FFFFFFu) << 3;  // first 32-byte slot of the leaf's block
     for (uint32_t t = 0; t < n; ++t) {
       const float4 v = leaf_pts[2 * (boff + t) + 1];  // {v4, v5, position lo, position hi}
       const uint64_t pos = (uint64_t)__float_as_uint(v.z) | ((uint64_t)__float_as_uint(v.w) << 32);
