@@ -338,13 +338,8 @@ __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_t
       cnt[p] = (uint32_t)__popc(bits);
       incl[p] = cnt[p];
     }
-    for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl[p], d, 64);
-        if ((int)lane >= d) incl[p] += o;
-      }
-    }
+    for (int p = 0; p < 8; ++p) incl[p] = (uint32_t)WaveScanAdd((int)incl[p]);
     if (lane == 63) {
 #pragma unroll
       for (int p = 0; p < 8; ++p) s_wave8[p][wave] = incl[p];
@@ -620,8 +615,25 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
   // predecessors come from memory.
   constexpr uint32_t kMask = (uint32_t)kBigGroupCap - 1u;
   uint32_t staged = 0;
+  // What an anchor needs before its scan can start -- its index, its own record, its start score (a double
+  // division) -- does not depend on the anchors before it: lane k fetches and computes it for anchor pi0 + k of
+  // the next 64, and the sequential loop takes it from there with a scalar lane select.  (One dependent global
+  // load + an LDS read + the division per anchor were half of an anchor's time on the item's critical path.)
+  uint32_t pre_ai = 0;
+  int32_t pre_t = 0, pre_q = 0;
+  float pre_coef = 0.0f;
   for (uint32_t pi = 0; pi < npend; ++pi) {
-    const uint32_t ai = pend[pi] - s;  // bucket-local index of the next unsettled anchor
+    if ((pi & 63u) == 0) {
+      const uint32_t k = pi + lane;
+      if (k < npend) {
+        pre_ai = pend[k] - s;
+        pre_t = (int32_t)tpos[pre_ai];
+        pre_q = (int32_t)qpos[pre_ai];
+        pre_coef = (float)(1 - 0.2 * (double)dist[pre_ai] / (double)radius);
+      }
+    }
+    const int sel = (int)(pi & 63u);
+    const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)pre_ai, sel);  // bucket-local index of the next unsettled anchor
     if (!kLds) {
       const uint32_t from = max(staged, ai + 1 > (uint32_t)kBigGroupCap ? ai + 1 - (uint32_t)kBigGroupCap : 0u);
       for (uint32_t i = from + lane; i <= ai; i += 64) {
@@ -635,10 +647,10 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
     }
     const uint32_t am = kLds ? ai : (ai & kMask);
     const int32_t ring_lo = kLds ? 0 : (int32_t)ai - (int32_t)kBigGroupCap + 1;  // oldest anchor still in LDS
-    const float coef = (float)(1 - 0.2 * (double)l_d[am] / (double)radius);
+    const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pre_coef), sel));
     float best = coef * (float)dim;
     uint32_t best_pred = ai;
-    const int32_t ct = l_t[am], cq = l_q[am];
+    const int32_t ct = __builtin_amdgcn_readlane(pre_t, sel), cq = __builtin_amdgcn_readlane(pre_q, sel);
     int32_t start_idx = 0;
     if (ai > (uint32_t)chaining_band_length) start_idx = (int32_t)ai - chaining_band_length;
     int32_t num_skips = 0;
@@ -668,21 +680,15 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
         }
       }
       const bool ev = cls == 3;
-      // running best before each lane: max(best, evaluated candidates of earlier lanes)
-      float v = ev ? cur : -FLT_MAX;
-      for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v = fmaxf(v, o);
-      }
-      float before = __shfl_up(v, 1, 64);
-      if (lane == 0) before = -FLT_MAX;
+      // running best before each lane: max(best, evaluated candidates of earlier lanes).  The two wave scans of a
+      // step are on the item's critical path (anchor after anchor): DPP row shifts and broadcasts, six dependent
+      // VALU operations each, where six __shfl_up were six dependent trips through the LDS crossbar
+      const float v = WaveScanMax(ev ? cur : -FLT_MAX);
+      // (wave_shr:1: lane l reads lane l - 1, lane 0 keeps the identity)
+      float before = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-FLT_MAX), __float_as_int(v), 0x138, 0xF, 0xF, false));
       before = fmaxf(before, best);
       const bool improved = ev && cur > before;
-      int delta = ev ? (improved ? -1 : 1) : 0;
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(delta, d, 64);
-        if ((int)lane >= d) delta += o;
-      }
+      const int delta = WaveScanAdd(ev ? (improved ? -1 : 1) : 0);
       const int ns_after = num_skips + delta;  // num_skips after this lane's step
       const unsigned long long m_end = __ballot(cls == 0);
       const unsigned long long m_skip = __ballot(ev && !improved && ns_after > max_num_skips);
@@ -692,12 +698,12 @@ __device__ __forceinline__ void DpBigBucket(uint32_t lane, uint32_t ng, uint32_t
       unsigned long long m_imp = __ballot(improved);
       if (last_valid < 63) m_imp &= (last_valid < 0) ? 0ull : ((2ull << last_valid) - 1ull);
       if (m_imp) {
-        const int l_last = 63 - __clzll((long long)m_imp);
-        best = __shfl(cur, l_last, 64);
+        const int l_last = 63 - __clzll((long long)m_imp);  // (wave-uniform: a scalar lane select)
+        best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), l_last));
         best_pred = (uint32_t)(pj0 - l_last);
       }
       if (l_end < 64 || l_skip < 64) break;
-      num_skips = __shfl(ns_after, 63, 64);
+      num_skips = __builtin_amdgcn_readlane(ns_after, 63);
     }
     if (lane == 0) {
       l_s[am] = best;
@@ -835,15 +841,11 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
     float carry = 0.0f;
     for (uint32_t g0 = 0; g0 < G; g0 += 64) {
       const uint32_t g = g0 + lane;
-      float v = g < G ? gmax[g] : 0.0f;
-      for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v = fmaxf(v, o);
-      }
-      float ex = __shfl_up(v, 1, 64);
-      if (lane == 0) ex = 0.0f;
+      const float v = WaveScanMax(g < G ? gmax[g] : 0.0f);
+      // (wave_shr:1: lane l reads lane l - 1, lane 0 keeps 0)
+      const float ex = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
       if (g < G) pmax[g] = fmaxf(carry, ex);
-      carry = fmaxf(carry, __shfl(v, 63, 64));
+      carry = fmaxf(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)));
     }
   }
   __syncthreads();
@@ -935,13 +937,9 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
         const bool valid = pi < b_hi;
         const uint32_t ai = valid ? pending[pi] : 0u;
         const float sc = valid ? score[ai] : 0.0f;
-        float pm = sc;  // inclusive prefix maximum (scores are >= 0)
-        for (int d = 1; d < 64; d <<= 1) {
-          const float o = __shfl_up(pm, d, 64);
-          if ((int)lane >= d) pm = fmaxf(pm, o);
-        }
+        float pm = WaveScanMax(sc);  // inclusive prefix maximum (scores are >= 0)
         pm = fmaxf(pm, carry);
-        carry = __shfl(pm, 63, 64);
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pm), 63));
         unsigned long long key = 0;
         if (valid && sc >= min_chaining_score && sc > pm / 2)  // spatial_index.cc:545-549
           key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(ai - bs);

@@ -4,6 +4,7 @@
 #ifndef SIGMAP_AMD_CSRC_COMMON_H_
 #define SIGMAP_AMD_CSRC_COMMON_H_
 
+#include <float.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -69,6 +70,25 @@ struct ChainTmp {
   uint32_t end_anchor;  // chunk-local index of the chain's last (highest target) anchor
   uint32_t list_off;    // chunk-local offset of the chain's anchor index list (end -> start)
 };
+
+#ifdef __HIPCC__
+// Inclusive scans over the 64 lanes of a wave with DPP: shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then lane
+// 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15, row mask 0xA) and lane 31 into rows 2 and 3 (row_bcast:31, row
+// mask 0xC).  A lane without a source keeps the identity (`old` operand, bound_ctrl off).
+__device__ __forceinline__ float WaveScanMax(float v) {
+#define SM_STEP(CTRL, ROWS) \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-FLT_MAX), __float_as_int(v), CTRL, ROWS, 0xF, false)))
+  SM_STEP(0x111, 0xF); SM_STEP(0x112, 0xF); SM_STEP(0x114, 0xF); SM_STEP(0x118, 0xF); SM_STEP(0x142, 0xA); SM_STEP(0x143, 0xC);
+#undef SM_STEP
+  return v;
+}
+__device__ __forceinline__ int WaveScanAdd(int v) {
+#define SM_STEP(CTRL, ROWS) v += __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xF, false)
+  SM_STEP(0x111, 0xF); SM_STEP(0x112, 0xF); SM_STEP(0x114, 0xF); SM_STEP(0x118, 0xF); SM_STEP(0x142, 0xA); SM_STEP(0x143, 0xC);
+#undef SM_STEP
+  return v;
+}
+#endif
 
 // Device view of the index (all pointers device memory; layouts: seed_lookup.hip header).
 constexpr uint32_t kLeafTag = 0x80000000u;  // a node ref with this bit names a leaf (ordinal in the low 27 bits)

@@ -290,12 +290,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         uint32_t mine_pts = 0;
 #pragma unroll
         for (int e = 0; e < kFifo; ++e) mine_pts += tab[e] >> 27;
-        uint32_t incl = mine_pts;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-          if ((int)lane >= d) incl += o;
-        }
+        const uint32_t incl = (uint32_t)WaveScanAdd((int)mine_pts);
         n_points = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         uint32_t run = incl - mine_pts;
 #pragma unroll
@@ -391,7 +386,8 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         // runs of lanes with the same owner (the entries of an owner are consecutive); ordinal = the owner's
         // hits so far + the hits in the lanes of its run below this one (earlier leaves of the owner in this
         // iteration and the lower points of this leaf)
-        const uint32_t prev_owner = (uint32_t)__shfl_up((int)owner, 1, 64);
+        // (wave_shr:1: lane l reads lane l - 1; lane 0's value is not used)
+        const uint32_t prev_owner = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)owner, 0x138, 0xF, 0xF, false);
         const uint64_t rb = __ballot(pt && (lane == 0 || owner != prev_owner));  // first lanes of the runs
         const uint64_t lowmask = (2ull << lane) - 1ull, below = (1ull << lane) - 1ull;
         const uint32_t run_first = 63u - (uint32_t)__clzll((long long)((rb & lowmask) | 1ull));

@@ -310,12 +310,8 @@ __device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0,
   const uint32_t qb = min(nq, tid * per), qe = min(nq, qb + per);
   uint32_t sum = 0;
   for (uint32_t k = qb; k < qe; ++k) sum += min(a.q_count[q0 + k], a.nnp);
-  uint32_t incl = sum;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-    if ((int)lane >= d) incl += o;
-  }
+  const uint32_t incl = (uint32_t)WaveScanAdd((int)sum);
   if (lane == 63) wtot[wave] = incl;
   __syncthreads();
   uint32_t before = 0;
