@@ -304,9 +304,11 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           }
       }
       if (lane < 8u) ents[n_ent + lane] = make_uint2(0u, 0xFFFFFFFFu);
+      // (every lane: the query's coordinates are read back from here after the scan -- they need not stay in
+      // registers through it)
+      own_a[lane] = make_float4(q0, q1, q2, q3);
+      own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
       if (c > 0) {
-        own_a[lane] = make_float4(q0, q1, q2, q3);
-        own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
         ovf_w[lane] = ovf_base;
         if (kSet) sbase_w[lane] = my_slots;
       }
@@ -341,9 +343,10 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       uint32_t eb = 0, p0 = 0;
       // the window's point loads (the 32-byte point: v0..v3, then v4, v5, position), from a valid address
       // for the lanes without a point: no branch around a load, so nothing waits for it before its use
-      auto load_points = [&](const Win &w_, uint32_t p0_, uint4 &rv_, uint4 &sv_) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a 128-bit register tuple: SM_PIN's operand type)
+      auto load_points = [&](const Win &w_, uint32_t p0_, u32x4 &rv_, u32x4 &sv_) {
         const uint32_t t_ = p0_ + lane - (w_.mine.y >> 13);
-        const uint4 *fh = pts4 + (w_.pt ? 2 * ((size_t)w_.mine.x + t_) : (size_t)0);
+        const u32x4 *fh = reinterpret_cast<const u32x4 *>(pts4 + (w_.pt ? 2 * ((size_t)w_.mine.x + t_) : (size_t)0));
         rv_ = fh[0];
         sv_ = fh[1];
       };
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         eb += nl == 64u ? e_last + full : (uint32_t)kWin;  // (nl < 64: the window ended at entry eb + kWin, or it was the last)
         return nl;
       };
-      auto process = [&](const Win &w_, uint32_t p0_, const uint4 &rv, const uint4 &sv) {
+      auto process = [&](const Win &w_, uint32_t p0_, const u32x4 &rv, const u32x4 &sv) {
         ++st_scan;
         const uint2 mine = w_.mine;
         const uint32_t owner = mine.y & 0xFFu, t = p0_ + lane - (mine.y >> 13);
@@ -429,15 +432,21 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       };
       // Two windows in flight, A and B in turn (no register copies between them): while one is processed, the
       // other's entries have been looked up and its point loads are on their way.
+      // SM_PIN: an empty statement every use of the window's loaded registers depends on, placed after the OTHER
+      // window's loads have been issued.  Without it the scheduler hoists the copy of a point's position words (into
+      // the registers of the hit store) to right behind the load's issue, where the wait for it stalls the wave before
+      // the current window's arithmetic: the two windows never overlapped.
+#define SM_PIN(rv_, sv_) asm volatile("" : "+v"(rv_), "+v"(sv_)::"memory")
       if (n_points > 0) {
         Win wA = lookup(0u, 0u), wB = wA;
-        uint4 rvA, svA, rvB, svB;
+        u32x4 rvA, svA, rvB, svB;
         load_points(wA, 0u, rvA, svA);
         for (;;) {
           const uint32_t nlA = advance(wA, p0);
           const bool moreB = p0 + nlA < n_points;
           wB = lookup(eb, p0 + nlA);
           load_points(wB, p0 + nlA, rvB, svB);  // (past the end: no lane has a point, all load slot 0)
+          SM_PIN(rvA, svA);
           process(wA, p0, rvA, svA);
           p0 += nlA;
           if (!moreB) break;
@@ -445,15 +454,21 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           const bool moreA = p0 + nlB < n_points;
           wA = lookup(eb, p0 + nlB);
           load_points(wA, p0 + nlB, rvA, svA);
+          SM_PIN(rvB, svB);
           process(wB, p0, rvB, svB);
           p0 += nlB;
           if (!moreA) break;
         }
+#undef SM_PIN
       }
-      if (c > 0) {
-        hits = own_b[lane].w;
-        ovf_base = ovf_w[lane];
+      {
+        const float4 ra = own_a[lane];
+        const uint4 rb = own_b[lane];
+        q0 = ra.x; q1 = ra.y; q2 = ra.z; q3 = ra.w;
+        q4 = __uint_as_float(rb.x); q5 = __uint_as_float(rb.y);
+        hits = rb.w;
       }
+      if (c > 0) ovf_base = ovf_w[lane];
       fifo_cnt = 0;
       if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
         if (!sink.stop_at_cap) {
