@@ -63,7 +63,7 @@ def parse():
                     help="with one rank: run the index replication collectives anyway (one-rank process group over "
                          "--backend, six dist.broadcast calls) and map the contexts beyond the first from the broadcast "
                          "copy -- exercises the N > 1 transport on a one-GPU box")
-    ap.add_argument("--depth", type=int, default=3,
+    ap.add_argument("--depth", type=int, default=4,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
     return ap.parse_args()
