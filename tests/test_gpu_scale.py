@@ -279,7 +279,7 @@ def test_bench_one_rank_over_rccl_forced_broadcast():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl",
            "--force-bcast", "--steps", "3", "--warmup", "1", "--reads", "1500", "--contigs", "4", "--contig-len", "300000",
-           "--no-cpu"]
+           "--depth", "3", "--no-cpu"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
