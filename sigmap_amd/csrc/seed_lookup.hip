@@ -178,6 +178,8 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
+  const uint32_t hand_thr = max(scan_threshold >> 16, 1u);  // (the launch packs two thresholds into the argument)
+  scan_threshold &= 0xFFFFu;
   constexpr bool kSet = kMode == kWalkSet;
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
   const uint32_t gl = blockIdx.x * kThreads + threadIdx.x;
@@ -490,7 +492,12 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     // ---- walk phase: one node visit per active lane ----
     ++st_walk;
     st_walk_lanes += (uint32_t)__popcll(act);
-    for (uint64_t need = __ballot(active && mode == M_FETCH); need;) {
+    // Queries are handed out to SEVERAL idle lanes at a time: a hand-out is two dependent global round trips (the
+    // query record, then the table entry of its hit slots) that stall the whole wave, whatever the number of lanes
+    // served; lanes that finish wait until hand_thr of them are idle -- or no lane has a node to visit.
+    uint64_t need = __ballot(active && mode == M_FETCH);
+    if ((uint32_t)__popcll(need) < hand_thr && __ballot(active && mode == M_NODE) != 0) need = 0;
+    for (; need;) {
       if (pool_next >= pool_end) {  // wave-uniform: take the next 64 queries of a range
         bool got = false;
         while (victim < n_ranges) {
@@ -1125,6 +1132,7 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
+constexpr int kHandoutLanes = 4;     // idle lanes of a wave that trigger a hand-out of queries (1 / 2 / 4 / 8 / 16: 5.68 / 5.61 / 5.57 / 5.57 / 5.59 ms)
 constexpr int kSetScanThreshold = 8;  // ... of the set walk (2 / 4 / 8 / 16: 6.52 / 6.44 / 6.35 / 6.44 ms)
 
 // The queries the set walk found more than num_nearest_points hits for are listed for a second search in the
@@ -1155,6 +1163,12 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   if (mode == kWalkSet && env_thr <= 0) thr = kSetScanThreshold;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
+  {
+    const char *env_hand = getenv("SMHIP_HANDOUT");  // (experiment knob, read per call)
+    int hand = env_hand ? atoi(env_hand) : kHandoutLanes;
+    if (hand < 1 || hand > 64) hand = kHandoutLanes;
+    thr |= hand << 16;  // (both thresholds travel in one kernel argument)
+  }
   const uint32_t blocks = blocks_override ? blocks_override : 256 * blocks_per_cu;
   const size_t stack_bytes = (size_t)256 * 8 * kSeedThreads * kStackDepth * 2 * sizeof(float4);  // (any grid up to 8 per CU)
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);

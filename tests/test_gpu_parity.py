@@ -1165,3 +1165,58 @@ def test_refine_matches_oracle(device, small_world, band):
             assert abs(int(end[i]) - (endp + 6)) < 64
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.gpu
+def test_quad_records_follow_the_binary_records(device):
+    """The order-free search's node array (seed_lookup.hip BuildQuads) against the binary records it is derived from:
+    the heads are exactly the inner nodes at even depth, numbered in pre-order; a head's slots are the nodes two levels
+    below it (a leaf child takes a slot itself) with the boxes the parents' binary records hold and references to
+    quads / leaves; unused slots carry no reference and a box nothing is close to; the box grid has one step."""
+    d = device.export_index()
+    assert d.n_quads > 0 and d.quads_bytes == d.n_quads * 128
+    nodes = np.empty(d.nodes_bytes // 4, dtype=np.uint32)
+    quads = np.empty(d.quads_bytes // 4, dtype=np.uint32)
+    bbox = np.empty(d.bbox_bytes // 4, dtype=np.float32)
+    device.export_copy(0, nodes.ctypes.data, nodes.nbytes)   # (smhip_index_export_copy also copies to host memory)
+    device.export_copy(5, quads.ctypes.data, quads.nbytes)
+    device.export_copy(4, bbox.ctypes.data, bbox.nbytes)
+    nodes = nodes.reshape(-1, 16)
+    quads = quads.reshape(-1, 32)
+    assert len(set(bbox[18:24].tolist())) == 1 and bbox[18] > 0           # one grid step for all dimensions
+    LEAF, MASK = 0x80000000, 0x87FFFFFF
+
+    def child(rec, which):   # (reference, six box words {lo01, lo23, lo45, hi01, hi23, hi45}) of child 0 / 1
+        ref = int(rec[2 + which]) & MASK
+        w = rec[4:16]
+        return ref, (w[0:6] if which == 0 else w[6:12])
+
+    # heads in pre-order = increasing inner index (inner records are numbered in pre-order)
+    depth = np.full(len(nodes), -1, dtype=np.int64)
+    depth[0] = 0
+    for x in range(len(nodes)):          # a node's children have larger indices: one forward pass
+        assert depth[x] >= 0
+        for which in (0, 1):
+            ref, _ = child(nodes[x], which)
+            if not ref & LEAF:
+                depth[ref] = depth[x] + 1
+    heads = np.flatnonzero(depth % 2 == 0)
+    assert len(heads) == d.n_quads
+    quad_of = {int(x): k for k, x in enumerate(heads)}
+    for k, x in enumerate(heads):
+        want = []
+        for which in (0, 1):
+            ref, box = child(nodes[x], which)
+            if ref & LEAF:
+                want.append((ref, box))
+            else:
+                for w2 in (0, 1):
+                    g, gbox = child(nodes[ref], w2)
+                    want.append((g if g & LEAF else quad_of[g], gbox))
+        q = quads[k]
+        for s in range(4):
+            if s < len(want):
+                assert int(q[s]) == want[s][0] and np.array_equal(q[4 + 6 * s:10 + 6 * s], want[s][1]), (k, s)
+            else:
+                assert int(q[s]) == 0xFFFFFFFF
+                assert (q[4 + 6 * s:7 + 6 * s] == 0xFFFFFFFF).all() and (q[7 + 6 * s:10 + 6 * s] == 0).all()
