@@ -118,30 +118,25 @@ enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
 #define SM_BOXSUM(g01, g23, g45) \
   __builtin_amdgcn_udot2(g45, g45, __builtin_amdgcn_udot2(g23, g23, __builtin_amdgcn_udot2(g01, g01, 0u, true), true), true)
 
-// Hit number `ord` >= fast_cap of query `qi` (0-based, in traversal order; the first fast_cap hits
-// go to the query's own slots): segments of the shared pool whose sizes double (fast_cap,
-// 2*fast_cap, ...), each allocated with one atomic when its first hit arrives, so a query with
-// many hits never has to be searched twice.  Called for one hit at a time in ordinal order.
-__device__ __forceinline__ void EmitOverflow(const Sink &sink, uint32_t qi, uint32_t ord, const Hit &h,
-                                             uint32_t &ovf_base) {
-  const uint32_t k = ord - sink.fast_cap;
-  const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
-  const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
-  if (k == first) {  // first hit of this segment: allocate it
-    const uint32_t size = sink.fast_cap << level;
-    // 64-bit cursor (counters[24..25]): it keeps counting past the end of the pool, so that the
-    // host learns the exact demand of a launch that ran out of room
-    const unsigned long long base =
-        atomicAdd(reinterpret_cast<unsigned long long *>(sink.counters + 24), (unsigned long long)size);
-    ovf_base = (uint32_t)base;
-    if (level == 0) atomicAdd(&sink.counters[1], 1u);
-    if (base + size > sink.pool_cap || level >= (uint32_t)kOvfLevels) {
-      atomicOr(&sink.counters[3], 1u);  // reported as SMHIP_ST_HIT_POOL_FULL
-      ovf_base = 0xFFFFFFFFu;
-    }
-    if (level < (uint32_t)kOvfLevels) sink.ovf_tab[(size_t)qi * kOvfLevels + level] = ovf_base;
+// Hits number fast_cap and beyond of a query (0-based, in traversal order; the first fast_cap go to the query's own
+// slots) live in segments of the shared pool whose sizes double (fast_cap, 2*fast_cap, ...), each allocated with
+// one atomic when its first hit arrives, so a query with many hits never has to be searched twice.  This is the
+// allocation of segment `level` of query `qi`, done by the lane that holds the segment's first hit; returns the
+// segment's pool offset, 0xFFFFFFFF when the pool is exhausted (reported as SMHIP_ST_HIT_POOL_FULL).
+__device__ __forceinline__ uint32_t AllocOverflowSegment(const Sink &sink, uint32_t qi, uint32_t level) {
+  const uint32_t size = sink.fast_cap << level;
+  // 64-bit cursor (counters[24..25]): it keeps counting past the end of the pool, so that the
+  // host learns the exact demand of a launch that ran out of room
+  const unsigned long long base =
+      atomicAdd(reinterpret_cast<unsigned long long *>(sink.counters + 24), (unsigned long long)size);
+  uint32_t seg = (uint32_t)base;
+  if (level == 0) atomicAdd(&sink.counters[1], 1u);
+  if (base + size > sink.pool_cap || level >= (uint32_t)kOvfLevels) {
+    atomicOr(&sink.counters[3], 1u);
+    seg = 0xFFFFFFFFu;
   }
-  if (ovf_base != 0xFFFFFFFFu) sink.pool[(size_t)ovf_base + (k - first)] = h;
+  if (level < (uint32_t)kOvfLevels) sink.ovf_tab[(size_t)qi * kOvfLevels + level] = seg;
+  return seg;
 }
 
 #ifdef SMHIP_PHASE_PROF  // tools/phase_prof.sh: shader-clock ticks per wave in the phases of the walker
@@ -420,12 +415,32 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           const u32x4 bits = {(uint32_t)h.position, (uint32_t)(h.position >> 32), __float_as_uint(h.dist), h.slot};
           *dst = bits;
         }
-        // rare: hits beyond the query's own slots, one lane at a time in ordinal order
-        for (uint64_t ovm = __ballot(emit && ord >= sink.fast_cap); ovm; ovm &= ovm - 1ull) {
-          if (lane == (uint32_t)__builtin_ctzll(ovm)) {
-            uint32_t ob = ovf_w[owner];
-            EmitOverflow(sink, oqi, ord, h, ob);
-            ovf_w[owner] = ob;
+        // Hits beyond the query's own slots (rare on a small reference; MOST hits on a 250 Mb one, where a query
+        // averages 800): all lanes of one (query, segment) group store together.  The group's first lane holds its
+        // lowest ordinal (ordinals ascend with the lanes of a query's run), so it is the one that allocates the
+        // segment when the window holds the segment's first hit; otherwise the segment is the query's current one
+        // (ovf_w).  One lane at a time, as this loop was at first, made the 250 Mb search 34 ms instead of 14.
+        const bool ov = emit && ord >= sink.fast_cap;
+        if (__ballot(ov)) {  // (wave-uniform: a window without such a hit skips all of it)
+          const uint32_t k = ord - sink.fast_cap;
+          const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
+          const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
+          for (uint64_t ovm = __ballot(ov); ovm;) {
+            const int leader = __builtin_ctzll(ovm);
+            const uint32_t l_owner = (uint32_t)__builtin_amdgcn_readlane((int)owner, leader);
+            const uint32_t l_level = (uint32_t)__builtin_amdgcn_readlane((int)level, leader);
+            const bool mine = ov && owner == l_owner && level == l_level;
+            uint32_t seg = 0;
+            if (lane == (uint32_t)leader) {
+              seg = ovf_w[owner];
+              if (k == first) {
+                seg = AllocOverflowSegment(sink, oqi, level);
+                ovf_w[owner] = seg;
+              }
+            }
+            seg = (uint32_t)__builtin_amdgcn_readlane((int)seg, leader);
+            if (mine && seg != 0xFFFFFFFFu) sink.pool[(size_t)seg + (k - first)] = h;
+            ovm &= ~__ballot(mine);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
             if (!live[u]) continue;
             if (h < a.fast_cap) {
               raw[u] = *reinterpret_cast<const uint4 *>(slots + h);
-            } else {  // geometric overflow segments (seed_lookup.hip EmitOverflow); a missing segment reads as zeros
+            } else {  // geometric overflow segments (seed_lookup.hip AllocOverflowSegment); a missing segment reads as zeros
               const uint32_t kk = h - a.fast_cap;
               const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
               const uint32_t first = a.fast_cap * ((1u << level) - 1u);

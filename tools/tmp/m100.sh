@@ -1,0 +1,3 @@
+run() { python bench.py --no-cpu --no-pcie --steps 3 --depth 1 --contig-len 6250000 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['serial_steps']; k=s['kernels']; print('$1', d['value'], d['ms_per_step'], 'seed', k['seed_lookup']['mean_ms'], 'sort', k['sort']['mean_ms'], 'chain', k['chain']['mean_ms'], d['config']['census_results_identical'], d['config']['overflow_queries'])"; }
+run set
+SMHIP_EXACT_WALK=1 run exact
