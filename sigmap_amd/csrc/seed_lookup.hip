@@ -12,6 +12,8 @@
 //              the root box (value = root_lo[d] + q * step, step = widest root extent / 65534) and
 //              rounded OUTWARDS, so a quantised box contains the exact one.  A ref is an inner
 //              index, or kLeafTag | leaf ordinal (tree order): leaves have no record of their own.
+//   quads    : one 128-byte record (one whole line) per inner node at EVEN depth: boxes and references of the up to
+//              four nodes two levels below it -- the order-free search's node array (BuildQuads, further down)
 //   leaf_tab : uint32 per leaf: (first 32-byte slot of its point block / 8) | n << 27
 //   leaf_pts : one 256-byte-aligned block of 32-byte slots per leaf at slot offset `boff`: n points
 //              {v0, v1, v2, v3, v4, v5, uint64 Point.position}, four to a 128-byte line (a leaf of 10 .. 20 points
@@ -54,8 +56,8 @@
 // The two newest stack entries of a lane live in LDS, older ones spill to HBM ([lane][64] x 32 B).
 // The mapping path does not need the order (the anchors are sorted afterwards) except for queries beyond
 // the reference's 5000-hit cap: it searches with the kernel's order-free SET mode (no dists[] / mindistsq
-// state, 4-byte pending visits, box rule only: the kWalk* modes at the kernel) and repeats those queries
-// in the reference's order (LaunchSeedLookup).
+// state, 4-byte pending visits, box rule only, quad records: the kWalk* modes at the kernel) and repeats those
+// queries in the reference's order (LaunchSeedLookup).
 // Queries are visited in the order of the leaf that contains them (QueryKey/QueryScatter: a
 // stackless descent + a counting sort that permutes the query records), each XCD taking one
 // contiguous eighth of that order, so the lanes of a wave and the waves of an XCD walk the same
