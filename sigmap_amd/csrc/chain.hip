@@ -224,10 +224,11 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     uint32_t pj = ai;  // the next predecessor is pj - 1
     int32_t skips = 0;
     uint32_t steps = 0;
-    for (;;) {
+    // (two predecessors per round: both ring reads are issued before either is looked at -- the second one's address
+    // does not depend on the first one's outcome, only whether it counts does -- so the ballot, the branch and the
+    // LDS round trip are paid once per pair)
+    auto step1 = [&](const uint4 &r) {
       const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
-      if (!__ballot(go)) break;
-      const uint4 r = s_ring[(pj - 1u) & (kRing - 1)];
       const int32_t pt = (int32_t)r.x, pq = (int32_t)r.y;
       const bool other_bucket = r.z != my_g;
       const bool same_pos = pq == cq || pt == ct;                     // `continue`: not evaluated, no skip counted
@@ -246,6 +247,14 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         --pj;
         ++steps;
       }
+    };
+    for (;;) {
+      const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
+      if (!__ballot(go)) break;
+      const uint4 r1 = s_ring[(pj - 1u) & (kRing - 1)];
+      const uint4 r2 = s_ring[(pj - 2u) & (kRing - 1)];  // (counts only if the first one leaves the lane active)
+      step1(r1);
+      step1(r2);
     }
     // lanes whose scan leaves the ring (64+ predecessors back: dense true-locus regions): the sequential form,
     // predecessors from memory
