@@ -97,7 +97,8 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
             for k, a in enumerate(_ARRAYS):
                 nbytes = int(getattr(d, a + "_bytes"))
                 t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-                copy_fn(k, t.data_ptr(), getattr(d, a), nbytes)
+                if nbytes:   # (an index without quad records: nothing to copy, nothing to send)
+                    copy_fn(k, t.data_ptr(), getattr(d, a), nbytes)
                 tensors.append(t)
             meta = [1] + [int(getattr(d, f)) for f in _SCALARS] + [int(getattr(d, a + "_bytes")) for a in _ARRAYS]
         except Exception as e:   # tell the peers before raising
@@ -124,7 +125,7 @@ def replicate_index(dev, ix, rank, world, local_rank, dist, device=None, copy_fn
             tensors = [t.to(gpu) for t in tensors]   # H2D into this rank's own device memory
             torch.cuda.synchronize()
         for a, t, nbytes in zip(_ARRAYS, tensors, sizes):
-            setattr(nd, a, t.data_ptr())
+            setattr(nd, a, t.data_ptr() if nbytes else None)
             setattr(nd, a + "_bytes", nbytes)
         if rank == 0:
             return tensors, nd   # force: rank 0 keeps its own arrays; the copy is the caller's to attach

@@ -85,19 +85,22 @@ class _FakeContext:
     """Stands in for pipeline.DeviceMapper on a machine without a GPU: "device" arrays are host
     buffers, export hands out their addresses, attach records what it was given."""
 
-    def __init__(self):
+    def __init__(self, quads=True):
         self.exported = None
         self.attached = None
         self._keep = []
+        self._quads = quads   # False: an index without quad records (a one-leaf tree, or one beyond their size limit)
 
     def upload_index(self, ix):
         import ctypes as C
         from sigmap_amd import _abi
         rng = np.random.default_rng(5)
         d = _abi.IndexDev()
-        d.dim, d.root_ref, d.n_nodes, d.n_leaves, d.m_size, d.n_quads = 6, 0, 1000, 1001, 12345, 400
+        d.dim, d.root_ref, d.n_nodes, d.n_leaves, d.m_size, d.n_quads = 6, 0, 1000, 1001, 12345, 400 if self._quads else 0
         for name, nbytes in (("nodes", 64000), ("leaf_tab", 4004), ("leaf_pts", 70000), ("leaf_vind", 9000), ("bbox", 96),
-                             ("quads", 51200)):
+                             ("quads", 51200 if self._quads else 0)):
+            if nbytes == 0:
+                continue   # (pointer and size stay null / 0)
             buf = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
             self._keep.append(buf)
             setattr(d, name, buf.ctypes.data)
@@ -113,10 +116,10 @@ class _FakeContext:
         self.attached = {f: int(getattr(nd, f)) for f in multigpu._SCALARS}
         for a in multigpu._ARRAYS:
             n = int(getattr(nd, a + "_bytes"))
-            self.attached[a] = bytes((C.c_uint8 * n).from_address(getattr(nd, a)))
+            self.attached[a] = bytes((C.c_uint8 * n).from_address(getattr(nd, a))) if n else b""
 
 
-def _replicate_worker(rank, world, port, q):
+def _replicate_worker(rank, world, port, q, quads=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import ctypes as C
@@ -124,7 +127,7 @@ def _replicate_worker(rank, world, port, q):
     from sigmap_amd import multigpu
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = _FakeContext()
+        dev = _FakeContext(quads)
         keep = multigpu.replicate_index(dev, None, rank, world, rank, dist, device="cpu",
                                         copy_fn=lambda k, dst, src, n: C.memmove(dst, src, n))
         if rank == 0:
@@ -132,7 +135,7 @@ def _replicate_worker(rank, world, port, q):
             want = {f: int(getattr(d, f)) for f in multigpu._SCALARS}
             for a in multigpu._ARRAYS:
                 n = int(getattr(d, a + "_bytes"))
-                want[a] = bytes((C.c_uint8 * n).from_address(getattr(d, a)))
+                want[a] = bytes((C.c_uint8 * n).from_address(getattr(d, a))) if n else b""
             q.put((0, want))
         else:
             q.put((rank, dev.attached if keep is not None else None))
@@ -155,6 +158,23 @@ def test_world2_gloo_replicate_index_hands_the_peer_identical_arrays():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[1] is not None and got[1] == got[0]
+
+
+def test_world2_gloo_replicate_index_without_quad_records():
+    """The sixth array is empty for an index without quad records: nothing is copied or sent for it, the peer
+    attaches a null pointer with n_quads == 0 and everything else as usual."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicate_worker, args=(r, 2, port, q, False)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is not None and got[1] == got[0] and got[1]["n_quads"] == 0 and got[1]["quads"] == b""
 
 
 def _forced_worker(port, q):
