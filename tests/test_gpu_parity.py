@@ -1220,3 +1220,40 @@ def test_quad_records_follow_the_binary_records(device):
             else:
                 assert int(q[s]) == 0xFFFFFFFF
                 assert (q[4 + 6 * s:7 + 6 * s] == 0xFFFFFFFF).all() and (q[7 + 6 * s:10 + 6 * s] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bases", [480, 700, 1500])
+def test_pipeline_small_trees_match_oracle(small_world, n_bases):
+    """Whole path on references of a few hundred bases: trees of three to seven levels, where the quad records of
+    the order-free search have leaves in their first-level slots, unused slots and heads with a single inner
+    grandchild; anchors, hit totals and chains against the oracle."""
+    lm = small_world["lm"]
+    rng = np.random.default_rng(n_bases)
+    unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_bases)])
+    host = _abi.host_lib()
+    sig = np.zeros(len(unit), np.float32)
+    m = host.smhost_reference_signal(_abi.ptr(np.ascontiguousarray(lm)), 6, unit, len(unit), 0, _abi.ptr(sig))
+    values = sig[:m].astype(np.float32)
+    positions = (np.arange(len(values), dtype=np.uint64) << np.uint64(1))  # one contig, + strand
+    ix = pipeline.HostIndex.from_points(positions, values, threads=1)
+    raw, _ = synth.simulate_reads([unit], lm, 5, 3)
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    samples, offsets = _batch(pa)
+    tree = po.OracleTree(ix.values.copy())
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    d = dev.export_index()
+    assert d.n_quads > 0
+    res = dev.map_chunks(samples, offsets, n_refs=1)
+    assert int(dev.debug_counters()[6]) == 2          # searched order-free, over the quad records
+    dev.close()
+    assert res["n_anchors"].sum() > 0
+    for i, x in enumerate(pa):
+        f, _ = po.generate_events(x)
+        chains, st = po.generate_chains(tree, ix.positions, f, 1)
+        assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits and res[i]["n_chains"] == len(chains)
+        for k, c in enumerate(chains[:4]):
+            g = res[i]["chains"][k]
+            assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
+    tree.close()
