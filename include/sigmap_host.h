@@ -115,6 +115,27 @@ int smhost_format_paf(const smhip_chunk_result *r, const char *read_name, uint32
                       const uint32_t *ref_lengths, uint32_t n_refs, const smhost_map_params *p,
                       char *buf, size_t cap, uint32_t *ref_bucket);
 
+/* One PAF row from the fields of the reference's PAFMapping record (output_tools.h:17-26): mapq <= 60 prints
+ * PAFOutputTools<PAFMapping>::AppendMapping's row (output_tools.h:336-354), anything else AppendUnmappedRead's
+ * (:200-210) -- OutputMappingsInVector's choice (sigmap.cc:205-213) at the CLI's threshold 0.  mapq / direction
+ * are taken modulo the record's 6-bit / 1-bit fields.  Returns bytes written (excluding NUL), -1 if cap is
+ * too small.  (The per-record form of smhost_format_paf: the row printer alone, pinned against the real
+ * output_tools.h in tests/test_oracle_golden.py.) */
+int smhost_format_paf_record(const char *read_name, uint32_t read_length, uint32_t read_start, uint32_t read_end,
+                             uint32_t frag_start, uint32_t frag_length, uint32_t mapq, uint32_t direction,
+                             const char *tags, const char *ref_name, uint32_t ref_length, char *buf, size_t cap);
+
+/* The reference genome as the driver loads it (sigmap.cc:559-568): SequenceBatch::InitializeLoading +
+ * LoadAllSequences (sequence_batch.cc:8-15,82-122; FASTA / FASTQ, plain or gzip) + PrepareNegativeSequenceAt
+ * per contig (sequence_batch.h:66-78).  Pointers stay valid until smhost_sequences_free. */
+typedef struct smhost_sequences smhost_sequences;
+smhost_sequences *smhost_sequences_load(const char *path);
+void smhost_sequences_free(smhost_sequences *s);
+uint32_t smhost_sequences_count(const smhost_sequences *s);
+uint64_t smhost_sequences_num_bases(const smhost_sequences *s);
+int smhost_sequences_get(const smhost_sequences *s, uint32_t i, const char **name, const char **bases,
+                         uint32_t *length, const char **negative);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,23 @@ def ref():
         L.ref_kdtree_dump.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.ref_level_means.restype = C.c_long
         L.ref_level_means.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_int)]
+        u32 = C.c_uint32
+        L.ref_fasta_load.restype = vp
+        L.ref_fasta_load.argtypes = [C.c_char_p]
+        L.ref_fasta_count.restype = u32
+        L.ref_fasta_count.argtypes = [vp]
+        L.ref_fasta_num_bases.restype = C.c_uint64
+        L.ref_fasta_num_bases.argtypes = [vp]
+        L.ref_fasta_get.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(u32),
+                                    C.POINTER(C.c_char_p)]
+        L.ref_fasta_free.argtypes = [vp]
+        L.ref_fasta_free.restype = None
+        L.ref_paf_mapped.restype = C.c_long
+        L.ref_paf_mapped.argtypes = [vp, u32, u32, C.c_char_p] + [u32] * 7 + [C.c_char_p, C.c_char_p, C.c_char_p, sz]
+        L.ref_paf_unmapped.restype = C.c_long
+        L.ref_paf_unmapped.argtypes = [vp, u32, u32, C.c_char_p, u32, u32, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+        L.ref_to_string_float.argtypes = [C.c_float, C.c_char_p, sz]
+        L.ref_to_string_double.argtypes = [C.c_double, C.c_char_p, sz]
         _ref = L
     return _ref
 

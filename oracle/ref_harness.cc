@@ -6,10 +6,13 @@
 // Output goes to oracle/_ref/libsigmap_ref.so (git-ignored, travels with gpurun).
 //
 // Only translation units that compile with the headers really present in this image are
-// used: event.h, nanoflann.hpp, sigmap_adaptor.h, pore_model.{h,cc} (+ utils.h, cwt.h,
-// and the genuine HDF5 headers under /opt/conda/include that utils.h includes).
-// spatial_index.cc / sigmap.cc / fast_dtw.cc include <slow5/slow5.h>, which does not
-// exist here, so they are NOT built (no stand-in headers are written).
+// used: event.h, nanoflann.hpp, sigmap_adaptor.h, pore_model.{h,cc}, cwt.{h,cc},
+// output_tools.h + sequence_batch.{h,cc} (+ kseq.h, utils.h, zlib, and the genuine HDF5
+// headers under /opt/conda/include that utils.h includes).
+// spatial_index.cc / sigmap.cc / signal_batch.cc / fast_dtw.cc include <slow5/slow5.h>
+// (through signal_batch.h:6), which does not exist here, so they are NOT built (no stand-in
+// headers are written).  output_tools.h only reaches sequence_batch.h (output_tools.h:12),
+// which needs no slow5: the PAF text and the FASTA loader ARE built (round 4).
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -19,7 +22,9 @@
 #include "cwt.h"
 #include "event.h"
 #include "nanoflann.hpp"
+#include "output_tools.h"
 #include "pore_model.h"
+#include "sequence_batch.h"
 #include "sigmap_adaptor.h"
 
 using sigmap::Event;
@@ -213,4 +218,72 @@ void ref_cwt_dog(const float *x, size_t n, float scale0, float *out) {
   for (size_t i = 0; i < n; ++i) out[i] = wt->output[i].re;
   sigmap::cwt_free(wt);
 }
+
+// ---- sequence_batch.{h,cc}: the reference's own FASTA / FASTQ loader (kseq over zlib) as the driver
+// uses it, sigmap.cc:559-568: InitializeLoading, LoadAllSequences, PrepareNegativeSequenceAt per contig.
+struct RefSeqs {
+  sigmap::SequenceBatch batch;
+  uint32_t n;
+};
+void *ref_fasta_load(const char *path) {
+  RefSeqs *r = new RefSeqs;
+  r->batch.InitializeLoading(path);
+  r->n = r->batch.LoadAllSequences();
+  for (uint32_t i = 0; i < r->n; ++i) r->batch.PrepareNegativeSequenceAt(i);
+  r->batch.FinalizeLoading();
+  return r;
+}
+uint32_t ref_fasta_count(void *h) { return ((RefSeqs *)h)->n; }
+uint64_t ref_fasta_num_bases(void *h) { return ((RefSeqs *)h)->batch.GetNumBases(); }
+// name / bases / reverse complement of contig i (pointers into the batch: valid until ref_fasta_free)
+int ref_fasta_get(void *h, uint32_t i, const char **name, const char **seq, uint32_t *len, const char **neg) {
+  RefSeqs *r = (RefSeqs *)h;
+  if (i >= r->n) return -1;
+  *name = r->batch.GetSequenceNameAt(i);
+  *seq = r->batch.GetSequenceAt(i);
+  *len = r->batch.GetSequenceLengthAt(i);
+  *neg = r->batch.GetNegativeSequenceAt(i).c_str();
+  return 0;
+}
+void ref_fasta_free(void *h) { delete (RefSeqs *)h; }
+
+// ---- output_tools.h: one PAFMapping (the record sigmap.cc:745-768 / :862-865 emplace) written by the real
+// PAFOutputTools<PAFMapping> into `tmp_path`, read back into out.  mapped != 0: AppendMapping
+// (output_tools.h:336-354), else AppendUnmappedRead (:200-210) -- the choice OutputMappingsInVector makes
+// (sigmap.cc:205-213) is the caller's.  mapq goes through the record's 6-bit field, direction through its 1-bit
+// field (output_tools.h:26).  Returns the line's length, or -1.
+static long paf_line(void *fasta, int mapped, uint32_t rid, uint32_t read_id, const char *read_name,
+                     uint32_t read_length, uint32_t read_start, uint32_t read_end, uint32_t frag_start,
+                     uint32_t frag_length, uint32_t mapq, uint32_t direction, const char *tags, const char *tmp_path,
+                     char *out, size_t cap) {
+  RefSeqs *r = (RefSeqs *)fasta;
+  sigmap::PAFOutputTools<sigmap::PAFMapping> tools;
+  sigmap::OutputTools<sigmap::PAFMapping> &base = tools;  // (AppendMapping is private in the specialisation, public here)
+  base.InitializeMappingOutput(tmp_path);
+  sigmap::PAFMapping m{read_id, std::string(read_name), read_length, read_start, read_end, frag_start, frag_length,
+                       (uint8_t)mapq, (uint8_t)direction, (uint8_t)1, std::string(tags)};
+  if (mapped) base.AppendMapping(rid, r->batch, m);
+  else base.AppendUnmappedRead(rid, r->batch, m);
+  base.FinalizeMappingOutput();
+  FILE *f = fopen(tmp_path, "rb");
+  if (!f) return -1;
+  const size_t n = fread(out, 1, cap - 1, f);
+  fclose(f);
+  out[n] = 0;
+  return (long)n;
+}
+long ref_paf_mapped(void *fasta, uint32_t rid, uint32_t read_id, const char *read_name, uint32_t read_length,
+                    uint32_t read_start, uint32_t read_end, uint32_t frag_start, uint32_t frag_length, uint32_t mapq,
+                    uint32_t direction, const char *tags, const char *tmp_path, char *out, size_t cap) {
+  return paf_line(fasta, 1, rid, read_id, read_name, read_length, read_start, read_end, frag_start, frag_length, mapq,
+                  direction, tags, tmp_path, out, cap);
+}
+long ref_paf_unmapped(void *fasta, uint32_t rid, uint32_t read_id, const char *read_name, uint32_t read_length,
+                      uint32_t mapq, const char *tags, const char *tmp_path, char *out, size_t cap) {
+  return paf_line(fasta, 0, rid, read_id, read_name, read_length, 0, 0, 0, 0, mapq, 0, tags, tmp_path, out, cap);
+}
+// The tag values are std::to_string(float / double / integer) in sigmap.cc:730-741: libstdc++'s own "%f"
+// (nan / inf / -nan included), exposed so that the goldens' tag strings are composed by the same function.
+int ref_to_string_float(float v, char *out, size_t cap) { return snprintf(out, cap, "%s", std::to_string(v).c_str()); }
+int ref_to_string_double(double v, char *out, size_t cap) { return snprintf(out, cap, "%s", std::to_string(v).c_str()); }
 }

@@ -29,6 +29,8 @@ HOST_SYMBOLS = [
     "smhost_raw_to_pa", "smhost_default_map_params", "smhost_should_stop", "smhost_format_paf",
     "smhost_have_fast5", "smhost_signals_load", "smhost_signals_free", "smhost_signals_count",
     "smhost_signals_get", "smhost_write_fast5", "smhost_write_blow5", "smhost_have_zstd", "smhost_shard_range", "smhost_print_alignment",
+    "smhost_format_paf_record", "smhost_sequences_load", "smhost_sequences_free", "smhost_sequences_count",
+    "smhost_sequences_num_bases", "smhost_sequences_get",
 ]
 
 
@@ -164,6 +166,18 @@ def host_lib():
                                         C.POINTER(C.c_char_p), C.c_void_p, C.c_uint32,
                                         C.POINTER(MapParams), C.c_char_p, C.c_size_t,
                                         C.POINTER(C.c_uint32)]
+        L.smhost_format_paf_record.argtypes = [C.c_char_p] + [C.c_uint32] * 7 + [C.c_char_p, C.c_char_p, C.c_uint32,
+                                                                                 C.c_char_p, C.c_size_t]
+        L.smhost_sequences_load.restype = C.c_void_p
+        L.smhost_sequences_load.argtypes = [C.c_char_p]
+        L.smhost_sequences_free.argtypes = [C.c_void_p]
+        L.smhost_sequences_free.restype = None
+        L.smhost_sequences_count.argtypes = [C.c_void_p]
+        L.smhost_sequences_count.restype = C.c_uint32
+        L.smhost_sequences_num_bases.argtypes = [C.c_void_p]
+        L.smhost_sequences_num_bases.restype = C.c_uint64
+        L.smhost_sequences_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_char_p)]
         _host = L
     return _host
 

@@ -262,4 +262,42 @@ int smhost_format_paf(const smhip_chunk_result *r, const char *read_name, uint32
   memcpy(buf, line.c_str(), line.size() + 1);
   return (int)line.size();
 }
+
+int smhost_format_paf_record(const char *read_name, uint32_t read_length, uint32_t read_start, uint32_t read_end,
+                             uint32_t frag_start, uint32_t frag_length, uint32_t mapq, uint32_t direction,
+                             const char *tags, const char *ref_name, uint32_t ref_length, char *buf, size_t cap) {
+  if (!read_name || !tags || !ref_name || !buf) return -1;
+  // (mapq and direction pass through the widths of the reference's record: 6 bits and 1 bit, output_tools.h:26)
+  const PAFMapping m{0, read_name, read_length, read_start, read_end, frag_start, frag_length,
+                     (uint8_t)(mapq & 63u), (uint8_t)(direction & 1u), 1, tags};
+  const std::string line = FormatPAF(m, ref_name, ref_length);
+  if (line.size() + 1 > cap) return -1;
+  memcpy(buf, line.c_str(), line.size() + 1);
+  return (int)line.size();
+}
+
+struct smhost_sequences {
+  SequenceBatch batch;
+};
+smhost_sequences *smhost_sequences_load(const char *path) {
+  if (!path) return nullptr;
+  smhost_sequences *s = new smhost_sequences;
+  s->batch.InitializeLoading(path);
+  const uint32_t n = s->batch.LoadAllSequences();
+  for (uint32_t i = 0; i < n; ++i) s->batch.PrepareNegativeSequenceAt(i);
+  s->batch.FinalizeLoading();
+  return s;
+}
+void smhost_sequences_free(smhost_sequences *s) { delete s; }
+uint32_t smhost_sequences_count(const smhost_sequences *s) { return s ? s->batch.GetNumSequences() : 0; }
+uint64_t smhost_sequences_num_bases(const smhost_sequences *s) { return s ? s->batch.GetNumBases() : 0; }
+int smhost_sequences_get(const smhost_sequences *s, uint32_t i, const char **name, const char **bases,
+                         uint32_t *length, const char **negative) {
+  if (!s || i >= s->batch.GetNumSequences()) return -1;
+  if (name) *name = s->batch.GetSequenceNameAt(i);
+  if (bases) *bases = s->batch.GetSequenceAt(i);
+  if (length) *length = s->batch.GetSequenceLengthAt(i);
+  if (negative) *negative = s->batch.GetNegativeSequenceAt(i).c_str();
+  return 0;
+}
 }

@@ -7,9 +7,15 @@ container only (needs /root/reference); the .npz files are committed, the refere
                + 300 queries -> hit lists in traversal order                 (nanoflann.hpp:1278-1410)
   levels.npz : pore-model table + sequences -> level means                  (pore_model.cc:57-81)
   cwt.npz    : 4 MAD-normalised signals x scales {8, 5, 2} -> DoG CWT signal (cwt.cc:1633-1841)
+  paf.json   : a FASTA text -> names / bases / reverse complements as the real SequenceBatch loads them
+               (sequence_batch.cc:8-15,82-122, sequence_batch.h:66-78); PAFMapping records -> the rows the
+               real PAFOutputTools<PAFMapping> prints (output_tools.h:200-210,336-354), tag values by the
+               real std::to_string                                    (`python make_golden.py paf` makes it alone)
 """
 import ctypes as C
+import json
 import os
+import struct
 import sys
 import tempfile
 
@@ -23,7 +29,130 @@ from sigmap_amd import pipeline, synth  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def _f32_bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def _bits_f32(b):
+    return struct.unpack("<f", struct.pack("<I", b))[0]
+
+
+FASTA_TEXT = (">chrA first contig\twith a comment\n"
+              "ACGTACGTTTGACNACGATCGATCGGGATCNNNNACGT\n"
+              "acgtnacgtRYKMacgt\n"
+              "\n"
+              "GGGTTTAAACCC\n"
+              ">chrB\r\n"
+              "TTGACCAGTNNAC\r\n"
+              "GATTACA\r\n"
+              ">chrC|x=1 \n"
+              "A\n"
+              ">chrD\n"
+              "CCCCCCCCCCGGGGGGGGGGAAAAAAAAAATTTTTTTTTTACGTACGTACGTNACGT\n")
+
+
+def paf_golden():
+    """The REAL output_tools.h / sequence_batch.cc (oracle/_ref) on a FASTA text and on PAFMapping records: those of
+    the oracle's so_map_read for 24 seeded reads (fields as sigmap.cc:745-768 / :862-865 fill them) and hand-made
+    ones (mapq 0 / 60 / 61 / 63, '-' strand, nan / inf / huge / tiny tag values, a 32-bit wrap of start + length).
+    The tag string is composed as sigmap.cc:730-741 / :830-859 composes it (minus the wall-clock mt:f: tag), every
+    float through the real std::to_string."""
+    R = po.ref()
+
+    def to_s(bits):
+        buf = C.create_string_buffer(512)
+        R.ref_to_string_float(C.c_float(_bits_f32(bits)), buf, 512)
+        return buf.value.decode()
+
+    def tags_of(ci, sl, n_chains, cm, fbits):
+        t = "ci:i:%d\tsl:i:%d" % (ci, sl)
+        if n_chains >= 1:
+            t += "\tcm:i:%d\tnc:i:%d" % (cm, n_chains)
+            for key, b in zip(("s1", "s2", "sm", "ad", "at", "aq"), fbits):
+                t += "\t%s:f:%s" % (key, to_s(b))
+        return t
+
+    gold = {"fasta": FASTA_TEXT}
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "ref.fa")
+        with open(fa, "wb") as f:
+            f.write(FASTA_TEXT.encode())
+        h = R.ref_fasta_load(fa.encode())
+        n = R.ref_fasta_count(h)
+        gold["num_bases"] = int(R.ref_fasta_num_bases(h))
+        contigs = []
+        for i in range(n):
+            name, seq, neg, ln = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_uint32()
+            assert R.ref_fasta_get(h, i, C.byref(name), C.byref(seq), C.byref(ln), C.byref(neg)) == 0
+            contigs.append(dict(name=name.value.decode(), length=int(ln.value), seq=seq.value.decode("latin1"),
+                                neg=neg.value.decode("latin1")))
+        gold["contigs"] = contigs
+        rows = []
+        # ---- records of real reads (the oracle's streaming map on the small world of tests/conftest.py)
+        genome = synth.make_genome(7, [150000, 100000, 50000])
+        lm = synth.make_pore_model()
+        raw, _ = synth.simulate_reads(genome, lm, 24, 11)
+        ix = pipeline.HostIndex.build(genome, lm, threads=4)
+        tree = po.OracleTree(ix.values.copy())
+        ref_lens = np.array([len(g) for g in genome], dtype=np.uint32)
+        rng = np.random.default_rng(3)
+        sigs = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+        sigs += [rng.normal(90, 12, size=4000).astype(np.float32), rng.normal(90, 12, size=12000).astype(np.float32)]
+        for i, x in enumerate(sigs):
+            m = po.map_read(tree, ix.positions, x, 3, ref_lens)
+            rows.append(dict(kind="oracle", read_name="read%d" % i, rid=int(m.ref) % n, mapped=int(m.mapped), read_length=int(m.read_length),
+                             read_start=int(m.read_start), read_end=int(m.read_end), frag_start=int(m.frag_start),
+                             frag_length=int(m.frag_length), mapq=int(m.mapq), direction=int(m.direction),
+                             ci=int(m.chunks_used), n_chains=int(m.n_chains), cm=int(m.cm),
+                             fbits=[_f32_bits(v) for v in (m.s1, m.s2, m.sm, m.ad, m.at, m.aq)]))
+        tree.close()
+        # ---- hand-made records
+        NAN, NNAN, INF, NINF = 0x7fc00000, 0xffc00000, 0x7f800000, 0xff800000
+        one = _f32_bits(1.0)
+        hand = [
+            dict(mapq=0, direction=1, fbits=[_f32_bits(33.25), 0, _f32_bits(33.25), _f32_bits(0.0123456), _f32_bits(7.5), _f32_bits(8.999999)]),
+            dict(mapq=60, direction=0, fbits=[_f32_bits(1e30), _f32_bits(1e-30), _f32_bits(-0.0), _f32_bits(123456.789), one, one]),
+            dict(mapq=61, direction=1, fbits=[NAN, NNAN, INF, NINF, _f32_bits(0.5), _f32_bits(2.5e-7)]),
+            dict(mapq=63, direction=0, fbits=[one] * 6),
+            dict(mapq=17, direction=0, frag_start=4294967000, frag_length=1000, fbits=[one] * 6),
+            dict(mapq=61, direction=0, n_chains=0, read_start=0, read_end=0, frag_start=0, frag_length=0, fbits=[0] * 6),
+            dict(mapq=1, direction=1, n_chains=1, cm=10, rid=2, read_length=1, fbits=[_f32_bits(10.0), 0, _f32_bits(10.0), NAN, NAN, NAN]),
+            dict(mapq=59, direction=1, rid=3, read_name="a read name with spaces", fbits=[_f32_bits(3.4028235e38)] * 6),
+        ]
+        for k, hrec in enumerate(hand):
+            rec = dict(kind="hand", read_name="hand%d" % k, rid=k % n, read_length=123456 + k, read_start=17 * k, read_end=4000 + k,
+                       frag_start=1000 * k + 1, frag_length=3999, ci=1 + k, n_chains=3, cm=11 + k)
+            rec.update(hrec)
+            rec["mapped"] = 1 if rec["mapq"] <= 60 else 0
+            rows.append(rec)
+        tmp = os.path.join(td, "row.paf").encode()
+        for rec in rows:
+            tags = tags_of(rec["ci"], rec["read_length"], rec["n_chains"], rec["cm"], rec["fbits"])
+            buf = C.create_string_buffer(4096)
+            # OutputMappingsInVector, sigmap.cc:205-213, at the CLI's mapq threshold 0
+            if rec["mapq"] <= 60:
+                k = R.ref_paf_mapped(h, rec["rid"], 0, rec["read_name"].encode(), rec["read_length"], rec["read_start"],
+                                     rec["read_end"], rec["frag_start"], rec["frag_length"], rec["mapq"], rec["direction"],
+                                     tags.encode(), tmp, buf, 4096)
+            else:
+                k = R.ref_paf_unmapped(h, rec["rid"], 0, rec["read_name"].encode(), rec["read_length"], rec["mapq"],
+                                       tags.encode(), tmp, buf, 4096)
+            assert k > 0
+            rec["tags"] = tags
+            rec["line"] = buf.value.decode()
+        gold["rows"] = rows
+        gold["to_string"] = [[b, to_s(b)] for b in (0, 0x80000000, one, NAN, NNAN, INF, NINF, _f32_bits(1e30), _f32_bits(1e-30),
+                                                     _f32_bits(0.1), _f32_bits(2.5), _f32_bits(3.4028235e38), 1, _f32_bits(16777217.0))]
+        R.ref_fasta_free(h)
+    with open(os.path.join(OUT, "paf.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+    print("paf.json:", len(gold["rows"]), "rows,", len(gold["contigs"]), "contigs")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "paf":
+        paf_golden()
+        return
     R = po.ref()
     genome = synth.make_genome(21, [25000, 15000])
     lm = synth.make_pore_model()
@@ -113,6 +242,7 @@ def main():
         for sc in (8, 5, 2):
             cw["out%d_s%d" % (r, sc)] = po.ref_cwt_dog(a, float(sc))
     np.savez_compressed(os.path.join(OUT, "cwt.npz"), **cw)
+    paf_golden()
     print("golden written:", os.listdir(OUT))
 
 

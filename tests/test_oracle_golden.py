@@ -192,3 +192,127 @@ def test_mad_and_peaks_known_answers():
     assert pos.tolist() == [1, 2, 3, 4, 7, 9] and pk.tolist() == [1, 0, 2, 0, -2, 3]
     f, p, cw = po.cwt_features(np.linspace(60, 120, 50).astype(np.float32) + np.float32(5) * np.sin(np.arange(50, dtype=np.float32)), 4.0)
     assert len(f) == len(p) and (np.diff(p.astype(np.int64)) > 0).all()
+
+
+# ------------------------------------------------------------------ A18 + reference FASTA loading, pinned to the
+# REAL output_tools.h / sequence_batch.cc (tests/golden/paf.json, made by make_golden.py from oracle/_ref)
+
+@pytest.fixture(scope="module")
+def paf_gold():
+    import json
+    with open(os.path.join(GOLDEN, "paf.json")) as f:
+        return json.load(f)
+
+
+def _bits_f32(b):
+    import struct
+    return struct.unpack("<f", struct.pack("<I", b))[0]
+
+
+def test_paf_rows_against_reference_golden(paf_gold):
+    """Every golden row -- 26 records of the oracle's streaming map, 8 hand-made ones (mapq 0 / 60 / 61 / 63, '-' strand,
+    nan / -nan / inf / huge tag values, start + length wrapping 32 bits, a row without chains) -- as printed by the real
+    PAFOutputTools<PAFMapping>::AppendMapping / AppendUnmappedRead: the oracle's so_format_paf and the product's row
+    printer (smhost_format_paf_record -> host/output_tools.h FormatPAF) give the same bytes."""
+    from sigmap_amd import _abi
+    H = _abi.host_lib()
+    contigs = paf_gold["contigs"]
+    kinds = set()
+    for rec in paf_gold["rows"]:
+        ref = contigs[rec["rid"]]
+        m = po.Mapping()
+        m.mapped, m.ref, m.read_length = rec["mapped"], rec["rid"], rec["read_length"]
+        m.read_start, m.read_end, m.frag_start, m.frag_length = rec["read_start"], rec["read_end"], rec["frag_start"], rec["frag_length"]
+        m.mapq, m.direction, m.chunks_used, m.n_chains, m.cm = rec["mapq"], rec["direction"], rec["ci"], rec["n_chains"], rec["cm"]
+        m.s1, m.s2, m.sm, m.ad, m.at, m.aq = [_bits_f32(b) for b in rec["fbits"]]
+        buf = C.create_string_buffer(4096)
+        po.lib().so_format_paf(C.byref(m), rec["read_name"].encode(), ref["name"].encode(), ref["length"], buf, 4096)
+        assert buf.value.decode() == rec["line"], rec["read_name"]
+        buf2 = C.create_string_buffer(4096)
+        k = H.smhost_format_paf_record(rec["read_name"].encode(), rec["read_length"], rec["read_start"], rec["read_end"],
+                                       rec["frag_start"], rec["frag_length"], rec["mapq"], rec["direction"],
+                                       rec["tags"].encode(), ref["name"].encode(), ref["length"], buf2, 4096)
+        assert k == len(rec["line"]) and buf2.value.decode() == rec["line"], rec["read_name"]
+        kinds.add((rec["kind"], rec["mapq"] <= 60, rec["direction"]))
+    assert {("oracle", True, 1), ("oracle", True, 0), ("oracle", False, 0), ("hand", True, 0), ("hand", False, 1)} <= kinds
+    # the tag values: std::to_string(float) of the reference == the "%f" both restatements print
+    libc = C.CDLL(None)
+    libc.snprintf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_double]
+    for b, text in paf_gold["to_string"]:
+        out = C.create_string_buffer(128)
+        libc.snprintf(out, 128, b"%f", C.c_double(_bits_f32(b)))   # a float promoted to double, as in a variadic call
+        assert out.value.decode() == text, hex(b)
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_fasta_loader_against_reference_golden(paf_gold, tmp_path, gz):
+    """host/sequence_batch.cc (own reader on zlib) against the real SequenceBatch::LoadAllSequences (kseq) +
+    PrepareNegativeSequenceAt on a FASTA text with comments, blank / CRLF lines, lower case, N and IUPAC codes."""
+    import gzip
+    from sigmap_amd import _abi
+    H = _abi.host_lib()
+    p = tmp_path / ("ref.fa.gz" if gz else "ref.fa")
+    data = paf_gold["fasta"].encode()
+    p.write_bytes(gzip.compress(data) if gz else data)
+    h = H.smhost_sequences_load(str(p).encode())
+    assert h
+    try:
+        assert H.smhost_sequences_count(h) == len(paf_gold["contigs"])
+        assert H.smhost_sequences_num_bases(h) == paf_gold["num_bases"]
+        for i, c in enumerate(paf_gold["contigs"]):
+            name, seq, neg, ln = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_uint32()
+            assert H.smhost_sequences_get(h, i, C.byref(name), C.byref(seq), C.byref(ln), C.byref(neg)) == 0
+            assert name.value.decode() == c["name"] and ln.value == c["length"]
+            assert seq.value.decode("latin1") == c["seq"] and neg.value.decode("latin1") == c["neg"]
+            # the oracle's reverse complement (sequence_batch.h:66-78)
+            out = C.create_string_buffer(c["length"] + 1)
+            po.lib().so_reverse_complement(c["seq"].encode("latin1"), c["length"], out)
+            assert out.value.decode("latin1") == c["neg"]
+    finally:
+        H.smhost_sequences_free(h)
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_paf_rows_vs_live_reference_random_records(paf_gold, tmp_path):
+    """300 random PAFMapping records (random float bit patterns in the tags, all mapq values of the 6-bit field)
+    through the real output_tools.h here and now, against both restatements."""
+    from sigmap_amd import _abi
+    H, R = _abi.host_lib(), po.ref()
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(paf_gold["fasta"].encode())
+    h = R.ref_fasta_load(str(fa).encode())
+    contigs = paf_gold["contigs"]
+    rng = np.random.default_rng(8)
+    tmp = str(tmp_path / "row.paf").encode()
+    for k in range(300):
+        rid = int(rng.integers(len(contigs)))
+        u = [int(x) for x in rng.integers(0, 2 ** 32, size=6, dtype=np.uint64)]
+        mapq, direction, n_chains = int(rng.integers(64)), int(rng.integers(2)), int(rng.integers(0, 4))
+        fb = [int(x) for x in rng.integers(0, 2 ** 32, size=6, dtype=np.uint64)]
+        m = po.Mapping()
+        m.mapped, m.ref, m.read_length, m.read_start, m.read_end, m.frag_start, m.frag_length = 1, rid, *u[:5]
+        m.mapq, m.direction, m.chunks_used, m.n_chains, m.cm = mapq, direction, 1 + k % 30, n_chains, u[5]
+        m.s1, m.s2, m.sm, m.ad, m.at, m.aq = [_bits_f32(b) for b in fb]
+        name = "r%d" % k
+        a = C.create_string_buffer(8192)
+        po.lib().so_format_paf(C.byref(m), name.encode(), contigs[rid]["name"].encode(), contigs[rid]["length"], a, 8192)
+        line = a.value.decode()
+        tags = line.rstrip("\n").split("\t", 12)[12]
+        b = C.create_string_buffer(8192)
+        if mapq <= 60:   # OutputMappingsInVector, sigmap.cc:205-213
+            n = R.ref_paf_mapped(h, rid, k, name.encode(), u[0], u[1], u[2], u[3], u[4], mapq, direction, tags.encode(), tmp, b, 8192)
+        else:
+            n = R.ref_paf_unmapped(h, rid, k, name.encode(), u[0], mapq, tags.encode(), tmp, b, 8192)
+        assert n == len(line) and b.value.decode() == line
+        # the tag values themselves through the real std::to_string
+        if n_chains >= 1:
+            vals = dict(t.split(":", 2)[::2] for t in tags.split("\t"))
+            for key, bitsv in zip(("s1", "s2", "sm", "ad", "at", "aq"), fb):
+                s = C.create_string_buffer(256)
+                R.ref_to_string_float(C.c_float(_bits_f32(bitsv)), s, 256)
+                assert vals[key] == s.value.decode()
+        c = C.create_string_buffer(8192)
+        H.smhost_format_paf_record(name.encode(), u[0], u[1], u[2], u[3], u[4], mapq, direction, tags.encode(),
+                                   contigs[rid]["name"].encode(), contigs[rid]["length"], c, 8192)
+        assert c.value.decode() == line
+    R.ref_fasta_free(h)
