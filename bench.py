@@ -383,6 +383,12 @@ def main():
                 "anchors_per_chunk": round(anchors / R, 1),
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
+                "fast_hit_slots_per_query": int(dev.resolved_params().hits_per_query_fast),
+                "search_mode": {1: "reference order (binary records)", 2: "set walk (quad records) + second search of "
+                                "over-cap queries"}.get(int(dev.resolved_params().search_mode), "?"),
+                "index_census_hits": (lambda h: {"q50": int(h[len(h) // 2]), "q75": int(h[len(h) * 3 // 4]),
+                                                 "q90": int(h[len(h) * 9 // 10]), "max": int(h[-1]), "mean": round(float(h.mean()), 1),
+                                                 "share_over_5000": round(float((h > 5000).mean()), 5)})(dev.index_census()),
                 "walker_phase_stats": walker_stats(dev),
                 "sdtw_refined_fraction": (round(float((refined[1] >= 0).mean()), 4)
                                           if args.sdtw_band > 0 else None),

@@ -64,14 +64,34 @@ typedef struct {
   float min_chaining_score;       /* 10 */
   /* device-side capacities (not reference semantics; exceeding one is reported, never
    * silently truncated) */
-  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pool (512) */
+  uint32_t hits_per_query_fast;   /* per-query slots before the overflow pool; 0 (default) = automatic: the power of
+                                     two in [512, 2048] that holds three quarters of the queries of the index census
+                                     (smhip_index_census) entirely */
   uint32_t walk_blocks_per_cu;    /* resident 256-thread workgroups per CU of the tree walker
                                      (0 = default 4; speed only) */
   uint32_t reference_walk;        /* 0: skip subtrees whose tight box is out of range (same hits,
                                      same order).  1: visit exactly nanoflann's node set, so that
                                      nodes_visited / points_tested count the reference's work
                                      (the census behind bench.py's algorithmic bytes) */
+  uint32_t search_mode;           /* how smhip_map_run and smhip_seed_lookup walk the tree (same hits, same anchors,
+                                     same PAF in every mode; speed only):
+                                       SMHIP_SEARCH_AUTO  the order-free set walk over quad records, its queries
+                                                          beyond num_nearest_points hits searched a second time in the
+                                                          reference's order -- unless the index (smhip_index_upload's
+                                                          census of its own points) or the batches seen so far say that
+                                                          more than set_walk_max_over_cap of the queries would be:
+                                                          then everything in the reference's order at once;
+                                       SMHIP_SEARCH_EXACT always the reference's traversal order (binary records);
+                                       SMHIP_SEARCH_SET   always the set walk (+ the second search).
+                                     smhip_seed_lookup: AUTO = EXACT (hits reported in nanoflann's order); SET reports
+                                     every query's hits in the set walk's own order (the same SET of hits).
+                                     An index without quad records (no inner node) is always walked in EXACT mode. */
+  float set_walk_max_over_cap;    /* AUTO: share of queries beyond the hit cap above which the set walk is not used
+                                     (0.0005) */
 } smhip_params;
+#define SMHIP_SEARCH_AUTO 0u
+#define SMHIP_SEARCH_EXACT 1u
+#define SMHIP_SEARCH_SET 2u
 
 void smhip_default_params(smhip_params *p);
 
@@ -134,6 +154,19 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root);
  * A self-test of the replication path for boxes with one GPU (smhip_index_bcast with n_gpus == 1 never
  * touches RCCL); dst afterwards maps from its own copy, independent of src.  No reference counterpart. */
 int smhip_index_bcast_loopback(smhip_ctx *src, smhip_ctx *dst);
+/* Census of the resident index: the hit counts (radius p->search_radius, no cap) of 4096 of its own points used
+ * as queries -- reads are noisy copies of such windows --, ascending.  Taken once per index and radius (the first
+ * smhip_map_run does it when a parameter is left automatic); decides SMHIP_SEARCH_AUTO and the automatic
+ * hits_per_query_fast.  hits (nullable): up to cap counts; *n_out = size of the sample.  No reference counterpart. */
+int smhip_index_census(smhip_ctx *ctx, const smhip_params *p, uint32_t *hits, uint32_t cap, uint32_t *n_out);
+/* The parameters of the last smhip_map_run with the automatic choices resolved (hits_per_query_fast, search_mode). */
+int smhip_resolved_params(smhip_ctx *ctx, smhip_params *out);
+/* Development knobs (speed experiments and test hooks; results never depend on them).  A context reads SMHIP_<NAME>
+ * from the environment ONCE, in smhip_init, and only when SMHIP_DEV=1 is set there as well; this call sets a knob of
+ * a live context and is refused (SMHIP_ESTATE) for a context created without SMHIP_DEV=1.  Names (lower case):
+ * lane_blocks_per_cu, xcd_ranges, scan_threshold, classes, bucket_bits, handout, sdtw_ring, sync_run, pool_min,
+ * spec_tight, float_gap, sort_lines. */
+int smhip_dev_knob(smhip_ctx *ctx, const char *name, long long value);
 /* GPUs visible to this process (0 when there is none / no HIP runtime). */
 int smhip_device_count(void);
 
@@ -330,7 +363,9 @@ int smhip_events_raw(smhip_ctx *ctx, uint32_t n_chunks, uint32_t feat_stride, ui
 /* nanoflann radiusSearch, nanoflann.hpp:1278-1301, for n_queries windows of `dim` floats.
  * Hits of query i in traversal order at point_idx/dist[i*cap ..], counts[i] = total hits
  * (may exceed cap).  point_idx = original point-cloud index (the pair.first nanoflann
- * returns). */
+ * returns).  With p->search_mode == SMHIP_SEARCH_SET the mapping path's order-free walk over quad records
+ * runs instead: the same set of hits per query, in that walk's order (smhip_debug_counters [6] tells which
+ * walk ran: an index without inner nodes has no quad records and is walked in the reference's order). */
 int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *queries,
                       uint32_t n_queries, uint32_t cap, uint32_t *counts, uint64_t *point_idx,
                       float *dist, uint64_t *nodes_visited, uint64_t *points_tested);

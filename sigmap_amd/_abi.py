@@ -12,6 +12,7 @@ HIP_LIB_PATH = os.environ.get("SMHIP_LIB") or os.path.join(LIB_DIR, "libsigmap_h
 HOST_LIB_PATH = os.environ.get("SMHOST_LIB") or os.path.join(LIB_DIR, "libsigmap_host.so")
 
 SMHIP_TOPK = 4
+SEARCH_AUTO, SEARCH_EXACT, SEARCH_SET = 0, 1, 2   # smhip_params.search_mode
 
 # every symbol include/sigmap_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = [
@@ -22,6 +23,7 @@ HIP_SYMBOLS = [
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
     "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
+    "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -52,7 +54,7 @@ class Params(C.Structure):
         ("min_num_anchors", C.c_int32), ("num_best_chains", C.c_int32),
         ("num_nearest_points", C.c_int32), ("min_chaining_score", C.c_float),
         ("hits_per_query_fast", C.c_uint32), ("walk_blocks_per_cu", C.c_uint32),
-        ("reference_walk", C.c_uint32),
+        ("reference_walk", C.c_uint32), ("search_mode", C.c_uint32), ("set_walk_max_over_cap", C.c_float),
     ]
 
 
@@ -232,6 +234,9 @@ def hip_lib():
         L.smhip_index_bcast.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
         L.smhip_index_bcast_loopback.argtypes = [vp, vp]
         L.smhip_device_count.argtypes = []
+        L.smhip_index_census.argtypes = [vp, C.POINTER(Params), vp, u32, C.POINTER(u32)]
+        L.smhip_dev_knob.argtypes = [vp, C.c_char_p, C.c_longlong]
+        L.smhip_resolved_params.argtypes = [vp, C.POINTER(Params)]
         L.smhip_refine_path_run.argtypes = [vp, u32, u32]
         L.smhip_refine_path_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64]
         L.smhip_dtw_path.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]

@@ -16,32 +16,51 @@
 
 using namespace smhip;
 
-namespace smhip {
-const EnvKnobs &Knobs() {
-  static EnvKnobs k;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    auto geti = [](const char *name, int dflt) {
-      const char *e = getenv(name);
-      return e ? atoi(e) : dflt;
-    };
-    k.lane_blocks_per_cu = geti("SMHIP_LANE_BLOCKS_PER_CU", 0);
-    k.xcd_ranges = geti("SMHIP_XCD_RANGES", 1);
-    k.scan_threshold = geti("SMHIP_SCAN_THRESHOLD", 0);
-    k.classes = geti("SMHIP_CLASSES", 0);
-    k.bucket_bits = geti("SMHIP_BUCKET_BITS", 0);
-    k.sdtw_ring = getenv("SMHIP_SDTW_RING") ? 1 : 0;
-    k.sync_run = geti("SMHIP_SYNC_RUN", 0);
-  });
+namespace {
+// name -> field of the development knobs (smhip_init reads SMHIP_<NAME>, smhip_dev_knob takes the lower-case name)
+struct KnobName {
+  const char *name;
+  int DevKnobs::*field;
+};
+const KnobName kKnobNames[] = {{"lane_blocks_per_cu", &DevKnobs::lane_blocks_per_cu}, {"xcd_ranges", &DevKnobs::xcd_ranges},
+                               {"scan_threshold", &DevKnobs::scan_threshold}, {"classes", &DevKnobs::classes},
+                               {"bucket_bits", &DevKnobs::bucket_bits}, {"handout", &DevKnobs::handout},
+                               {"sdtw_ring", &DevKnobs::sdtw_ring}, {"sync_run", &DevKnobs::sync_run},
+                               {"spec_tight", &DevKnobs::spec_tight}, {"float_gap", &DevKnobs::float_gap},
+                               {"sort_lines", &DevKnobs::sort_lines}};
+// the environment's knobs, honoured only behind SMHIP_DEV=1 (read once per context, in smhip_init)
+DevKnobs ReadDevKnobs() {
+  DevKnobs k;
+  const char *dev = getenv("SMHIP_DEV");
+  if (!dev || atoi(dev) != 1) return k;
+  k.enabled = true;
+  for (const KnobName &kn : kKnobNames) {
+    std::string env = "SMHIP_";
+    for (const char *c = kn.name; *c; ++c) env.push_back((char)toupper(*c));
+    if (const char *e = getenv(env.c_str())) k.*(kn.field) = atoi(e);
+  }
+  if (const char *e = getenv("SMHIP_POOL_MIN")) k.pool_min = strtoll(e, nullptr, 10);
   return k;
 }
-}  // namespace smhip
+}  // namespace
 
 namespace {
 int FinishRun(smhip_ctx *ctx);  // (defined with smhip_map_run: settles a speculative batch)
+int ResolveParams(smhip_ctx *ctx, smhip_params *rp);
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
   return code;
+}
+// What a context has learnt from the batches of the index it held (search mode, capacities of the speculative route,
+// overflow pool, the index census) does not carry over to another index.
+void ForgetIndexHistory(smhip_ctx *ctx) {
+  ctx->walk_exact_only = false;
+  ctx->seen_queries = ctx->seen_over_cap = 0;
+  ctx->hint_q_per_chunk = ctx->hint_a_per_chunk = 0;
+  ctx->hint_valid = false;
+  ctx->pool_hint = 0;
+  ctx->census_valid = false;
+  ctx->census_hits.clear();
 }
 int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
   return Fail(ctx, e == hipErrorOutOfMemory ? SMHIP_ENOMEM : SMHIP_EHIP,
@@ -188,8 +207,10 @@ void smhip_default_params(smhip_params *p) {
   p->num_best_chains = 3;
   p->num_nearest_points = 5000;
   p->min_chaining_score = 10;
-  p->hits_per_query_fast = 512;
+  p->hits_per_query_fast = 0;  // automatic: from the census of the resident index (512 .. 2048)
   p->walk_blocks_per_cu = 0;
+  p->search_mode = SMHIP_SEARCH_AUTO;
+  p->set_walk_max_over_cap = 0.0005f;
 }
 
 int smhip_init(int device_ordinal, smhip_ctx **out) {
@@ -203,6 +224,7 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
   if (InitSortAttributes() != hipSuccess || InitSdtwAttributes() != hipSuccess) return SMHIP_EHIP;
   smhip_ctx *ctx = new smhip_ctx;
   ctx->device = device_ordinal;
+  ctx->knobs = ReadDevKnobs();
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return SMHIP_EHIP;
@@ -403,6 +425,7 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
   ctx->have_index = true;
   ctx->max_tpos_valid = false;
   ctx->index_owned = true;
+  ForgetIndexHistory(ctx);
   {
     const hipError_t qe = BuildQuads(ctx);  // the set walk's node array (seed_lookup.hip)
     if (qe != hipSuccess) {
@@ -482,6 +505,7 @@ void AdoptReplica(smhip_ctx *p, const smhip_ctx *root) {
   p->have_index = true;
   p->max_tpos_valid = false;
   p->index_owned = true;
+  ForgetIndexHistory(p);
 }
 const Rccl &LoadRccl() {
   static Rccl r;
@@ -636,6 +660,7 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   ctx->have_index = true;
   ctx->max_tpos_valid = false;
   ctx->index_owned = false;
+  ForgetIndexHistory(ctx);
   return SMHIP_OK;
 }
 
@@ -849,6 +874,12 @@ int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_
   HIPCHK(hipSetDevice(ctx->device));
   smhip_params p;
   smhip_default_params(&p);
+  if (ctx->have_index) {  // (the automatic number of fast slots comes from the census of the index)
+    int rc = ResolveParams(ctx, &p);
+    if (rc) return rc;
+  } else {
+    p.hits_per_query_fast = 512;
+  }
   const uint64_t R = n_chunks, nq = R * queries_per_chunk;
   // the buffers smhip_map_run sizes from the chunk and query counts (the anchor-sized ones depend on
   // the index and stay lazy); the per-query hit slots are by far the largest
@@ -1055,9 +1086,8 @@ uint64_t FirstPoolCap(smhip_ctx *ctx, uint64_t nq_cap) {
   // segments it wants to the pool cursor even when the pool is exhausted, so a launch that ran out
   // of room reports the exact demand: the pool is then grown to it and the search repeated (once;
   // the size is remembered for the following batches).
-  // (SMHIP_POOL_MIN: test knob that makes the first size too small; read per call, nothing cached)
-  const char *pool_env = getenv("SMHIP_POOL_MIN");
-  const uint64_t pool_first = pool_env ? (uint64_t)strtoull(pool_env, nullptr, 10) : nq_cap * 64 + (1u << 22);
+  // (knob pool_min: makes the first size too small for the pool-growth test)
+  const uint64_t pool_first = ctx->knobs.pool_min >= 0 ? (uint64_t)ctx->knobs.pool_min : nq_cap * 64 + (1u << 22);
   return std::min<uint64_t>(std::max<uint64_t>(pool_first, ctx->pool_hint), 0xFFFF0000ull);
 }
 
@@ -1088,10 +1118,15 @@ bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap
   return with_room < total_b / 8 && 3 * grow + (1ull << 30) < free_b;
 }
 
-// counters[7] of a batch = queries the set walk found beyond the hit cap (searched a second time): beyond one in
-// two thousand the context searches every query in the reference's order from the next batch on
-void LearnOverCap(smhip_ctx *ctx, uint64_t NQ, uint32_t over_cap) {
-  if ((uint64_t)over_cap * 2000 > NQ) ctx->walk_exact_only = true;
+// counters[7] of a set-walk batch = queries found beyond the hit cap (searched a second time).  Their share over the
+// batches of this index so far -- at least 20 000 queries (some 90 chunks), so that one such query in a small tail
+// batch decides nothing -- beyond set_walk_max_over_cap: every query in the reference's order from the next batch on.
+void LearnOverCap(smhip_ctx *ctx, const smhip_params *p, uint64_t NQ, uint32_t over_cap) {
+  if (ctx->last_walk_mode != 2) return;
+  ctx->seen_queries += NQ;
+  ctx->seen_over_cap += over_cap;
+  if (ctx->seen_queries >= 20000 && (double)ctx->seen_over_cap > (double)p->set_walk_max_over_cap * (double)ctx->seen_queries)
+    ctx->walk_exact_only = true;
 }
 
 void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
@@ -1124,7 +1159,7 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    LearnOverCap(ctx, NQ, hc[7]);
+    LearnOverCap(ctx, p, NQ, hc[7]);
     if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
     const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
     if (demand <= pool_cap || demand > 0xFFFF0000ull) break;  // level limit / beyond 32-bit offsets: report the flag
@@ -1141,12 +1176,10 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
 int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   const uint32_t R = ctx->n_chunks;
   uint64_t nq_cap = SpecCapQueries(ctx, R), na_cap = SpecCapAnchors(ctx, R);
-  // (SMHIP_SPEC_TIGHT: test knob, read per call -- 1 halves the query capacity, 2 the anchor capacity, so that
-  // the guards fire and the batch is repeated on the synchronous route)
-  if (const char *tight = getenv("SMHIP_SPEC_TIGHT")) {
-    if (atoi(tight) == 1) nq_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk / 2, 1);
-    if (atoi(tight) == 2) na_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_a_per_chunk / 2, 1);
-  }
+  // (knob spec_tight: 1 halves the query capacity, 2 the anchor capacity, so that the guards fire and the batch is
+  // repeated on the synchronous route)
+  if (ctx->knobs.spec_tight == 1) nq_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk / 2, 1);
+  if (ctx->knobs.spec_tight == 2) na_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_a_per_chunk / 2, 1);
   if (!ctx->h_run_info) HIPCHK(hipHostMalloc(&ctx->h_run_info, 256, hipHostMallocDefault));  // (smhip_init allocates it)
   int rc = EnqueueFront(ctx, p, R);
   if (rc) return rc;
@@ -1180,7 +1213,7 @@ int FinishRun(smhip_ctx *ctx) {
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);
   const bool overflow = info->w[32] || info->w[33] || info->w[3];
-  LearnOverCap(ctx, info->w[34], info->w[7]);
+  LearnOverCap(ctx, &ctx->spec_params, info->w[34], info->w[7]);
   if (!overflow) {
     LearnTotals(ctx, std::max(ctx->n_chunks, 1u), info->w[34], info->anchors());
     return SMHIP_OK;
@@ -1193,17 +1226,102 @@ int FinishRun(smhip_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return SMHIP_OK;
 }
+
+// Share of the index census' sample with more than `cap` hits.
+double CensusShareAbove(const smhip_ctx *ctx, uint32_t cap) {
+  const auto &h = ctx->census_hits;
+  if (h.empty()) return 0.0;
+  return (double)(h.end() - std::upper_bound(h.begin(), h.end(), cap)) / (double)h.size();
+}
+
+// What the caller left automatic, decided from a census of the resident index (IndexCensus: the hit counts of 4096
+// of its own points used as queries -- reads are noisy copies of such windows).
+//  * hits_per_query_fast == 0: the power of two that holds three quarters of the sample's queries entirely, within
+//    [512, 2048] (hits beyond the fast slots go to the shared overflow pool: correct at any size, slower);
+//  * search_mode AUTO: the set walk, unless more than set_walk_max_over_cap of the sample lies beyond
+//    num_nearest_points hits (such queries are searched twice) or the batches so far said so (LearnOverCap).
+int ResolveParams(smhip_ctx *ctx, smhip_params *rp) {
+  const bool want_fast = rp->hits_per_query_fast == 0;
+  const bool want_mode = rp->search_mode == SMHIP_SEARCH_AUTO && ctx->index.quads && !ctx->walk_exact_only && !rp->reference_walk;
+  if ((want_fast || want_mode) && (!ctx->census_valid || ctx->census_radius != rp->search_radius)) {
+    HIPCHK(IndexCensus(ctx, *rp, 4096));
+    ctx->census_valid = true;
+    ctx->census_radius = rp->search_radius;
+  }
+  if (want_fast) {
+    const auto &h = ctx->census_hits;
+    const uint32_t q75 = h.empty() ? 0u : h[(h.size() * 3) / 4];
+    uint32_t fast = 512;
+    while (fast < 2048 && fast < q75) fast <<= 1;
+    // ... within a sixth of the device for the slots of this batch's queries (about 288 per chunk until batches
+    // have been seen)
+    size_t free_b = 0, total_b = 0;
+    if (fast > 512 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const uint64_t nq_est = (uint64_t)std::max(ctx->n_chunks, 1u) * (ctx->hint_q_per_chunk ? ctx->hint_q_per_chunk * 5 / 4 : 288);
+      while (fast > 512 && nq_est * fast * sizeof(Hit) > total_b / 6) fast >>= 1;
+    }
+    rp->hits_per_query_fast = fast;
+  }
+  if (rp->search_mode == SMHIP_SEARCH_AUTO) {
+    const bool exact = !ctx->index.quads || ctx->walk_exact_only ||
+                       (want_mode && CensusShareAbove(ctx, (uint32_t)rp->num_nearest_points) > (double)rp->set_walk_max_over_cap);
+    rp->search_mode = exact ? SMHIP_SEARCH_EXACT : SMHIP_SEARCH_SET;
+  }
+  return SMHIP_OK;
+}
 }  // namespace
 extern "C" {
+
+int smhip_dev_knob(smhip_ctx *ctx, const char *name, long long value) {
+  if (!ctx || !name) return SMHIP_EINVAL;
+  if (!ctx->knobs.enabled)
+    return Fail(ctx, SMHIP_ESTATE, "smhip_dev_knob: development knobs need SMHIP_DEV=1 in the environment of smhip_init");
+  if (!strcmp(name, "pool_min")) {
+    ctx->knobs.pool_min = value;
+    return SMHIP_OK;
+  }
+  for (const KnobName &kn : kKnobNames)
+    if (!strcmp(name, kn.name)) {
+      ctx->knobs.*(kn.field) = (int)value;
+      return SMHIP_OK;
+    }
+  return Fail(ctx, SMHIP_EINVAL, std::string("smhip_dev_knob: unknown knob ") + name);
+}
+
+int smhip_resolved_params(smhip_ctx *ctx, smhip_params *out) {
+  if (!ctx || !out) return SMHIP_EINVAL;
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_resolved_params before smhip_map_run");
+  *out = ctx->last_params;
+  return SMHIP_OK;
+}
+
+int smhip_index_census(smhip_ctx *ctx, const smhip_params *p, uint32_t *hits, uint32_t cap, uint32_t *n_out) {
+  if (!ctx || !p || !n_out) return SMHIP_EINVAL;
+  if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_index_census before an index is resident");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->spec_pending) {
+    int rc = FinishRun(ctx);
+    if (rc) return rc;
+  }
+  if (!ctx->census_valid || ctx->census_radius != p->search_radius) {
+    HIPCHK(IndexCensus(ctx, *p, 4096));
+    ctx->census_valid = true;
+    ctx->census_radius = p->search_radius;
+  }
+  *n_out = (uint32_t)ctx->census_hits.size();
+  if (hits) memcpy(hits, ctx->census_hits.data(), std::min<size_t>(cap, ctx->census_hits.size()) * sizeof(uint32_t));
+  return SMHIP_OK;
+}
 
 int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   if (!ctx || !p) return Fail(ctx, SMHIP_EINVAL, "null argument");
   if (!ctx->have_index) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before an index is resident");
   if (!ctx->batch_ready) return Fail(ctx, SMHIP_ESTATE, "smhip_map_run before smhip_batch_upload");
-  if (n_refs == 0 || p->step_size < 1 || p->hits_per_query_fast == 0 || p->num_nearest_points < 1 ||
-      p->num_best_chains > 3)
+  if (n_refs == 0 || p->step_size < 1 || p->num_nearest_points < 1 || p->num_best_chains > 3)
     return Fail(ctx, SMHIP_EINVAL, "bad parameter");
+  if (p->hits_per_query_fast > (1u << 20)) return Fail(ctx, SMHIP_EINVAL, "hits_per_query_fast must be 0 (automatic) .. 2^20");
   if (p->walk_blocks_per_cu > 8) return Fail(ctx, SMHIP_EINVAL, "walk_blocks_per_cu must be 0..8");
+  if (p->search_mode > SMHIP_SEARCH_SET) return Fail(ctx, SMHIP_EINVAL, "search_mode must be SMHIP_SEARCH_AUTO / _EXACT / _SET");
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->spec_pending) {  // the previous batch was never collected: settle it first
     int rc = FinishRun(ctx);
@@ -1215,8 +1333,16 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
     ctx->run_done = true;
     return SMHIP_OK;
   }
-  // (SMHIP_SYNC_RUN=1: always the synchronous route -- an A/B switch; results are the same)
-  const bool speculate = ctx->hint_valid && !Knobs().sync_run && !getenv("SMHIP_POOL_MIN") &&
+  // The index census (first batch after the index arrived) resolves what the caller left automatic.
+  smhip_params rp = *p;
+  {
+    const int rc0 = ResolveParams(ctx, &rp);
+    if (rc0) return rc0;
+  }
+  p = &rp;
+  ctx->last_params = rp;
+  // (knob sync_run: always the synchronous route -- an A/B switch; results are the same)
+  const bool speculate = ctx->hint_valid && !ctx->knobs.sync_run && ctx->knobs.pool_min < 0 &&
                          CapacitiesAffordable(ctx, p, SpecCapQueries(ctx, R), SpecCapAnchors(ctx, R));
   const int rc = speculate ? RunBatchSpeculative(ctx, p, n_refs) : RunBatchSync(ctx, p, n_refs);
   if (rc) return rc;
@@ -1697,6 +1823,7 @@ int smhip_seed_lookup(smhip_ctx *ctx, const smhip_params *p, const float *querie
   if (n_queries == 0) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
   if (p->walk_blocks_per_cu > 8) return Fail(ctx, SMHIP_EINVAL, "walk_blocks_per_cu must be 0..8");
+  if (p->search_mode > SMHIP_SEARCH_SET) return Fail(ctx, SMHIP_EINVAL, "search_mode must be SMHIP_SEARCH_AUTO / _EXACT / _SET");
   DevBuf d_q, d_region, d_cnt, d_nodes, d_pts, d_idx, d_dist, d_qrec, d_tab;
   const uint64_t total = (uint64_t)n_queries * cap;
   auto free_all = [&]() {

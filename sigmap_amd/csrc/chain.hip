@@ -1397,7 +1397,7 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   const uint32_t tile_blocks = (uint32_t)std::min<uint64_t>((max_tiles + 3) / 4, 256u * 8u * 2u);  // four waves (tile ranges) each
   // (integer form of the gap-scale tests: exact for target gaps below 2^21, see GapTestsPass)
   // (SMHIP_FLOAT_GAP: test knob, read per call -- the float form also where the integer one is valid)
-  const bool int_gap = p.max_target_gap_length >= 0 && p.max_target_gap_length < (1 << 21) && !getenv("SMHIP_FLOAT_GAP");
+  const bool int_gap = p.max_target_gap_length >= 0 && p.max_target_gap_length < (1 << 21) && !ctx->knobs.float_gap;
   if (int_gap)
     hipLaunchKernelGGL(ChainClassifyKernel<true>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,

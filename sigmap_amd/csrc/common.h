@@ -108,9 +108,30 @@ struct IndexView {
 };
 
 inline bool TraceAlloc() {
-  static const bool on = getenv("SMHIP_TRACE_ALLOC") != nullptr;  // (magic static: initialised once, thread-safe)
+  // (development aid, stderr only; like every SMHIP_* switch it needs SMHIP_DEV=1 beside it.  Magic static: thread-safe)
+  static const bool on = getenv("SMHIP_DEV") != nullptr && atoi(getenv("SMHIP_DEV")) == 1 && getenv("SMHIP_TRACE_ALLOC") != nullptr;
   return on;
 }
+
+// Development knobs (speed experiments and test hooks; never results).  A context takes them from the environment
+// ONCE, in smhip_init, and only when SMHIP_DEV=1 is set there too: a stray SMHIP_* variable in a user's environment
+// changes nothing.  A live context's knobs can be set with smhip_dev_knob (refused unless the context was created
+// under SMHIP_DEV=1): the tests' way of driving the rarely taken routes.
+struct DevKnobs {
+  bool enabled = false;        // SMHIP_DEV=1 at smhip_init
+  int lane_blocks_per_cu = 0;  // SMHIP_LANE_BLOCKS_PER_CU: walker workgroups of 256 threads per CU
+  int xcd_ranges = 1;          // SMHIP_XCD_RANGES=0: one visiting-order range instead of eight
+  int scan_threshold = 0;      // SMHIP_SCAN_THRESHOLD: blocked lanes that trigger a scan phase
+  int classes = 0;             // SMHIP_CLASSES: cost classes of the visiting order
+  int bucket_bits = 0;         // SMHIP_BUCKET_BITS: leaf-order resolution of the visiting order
+  int handout = 0;             // SMHIP_HANDOUT: idle lanes of a wave that trigger a hand-out of queries
+  int sdtw_ring = 0;           // SMHIP_SDTW_RING=1: ring sweep only
+  int sync_run = 0;            // SMHIP_SYNC_RUN=1: smhip_map_run always reads its two totals back
+  long long pool_min = -1;     // SMHIP_POOL_MIN: initial overflow-pool size (>= 0: also forces the reading route)
+  int spec_tight = 0;          // SMHIP_SPEC_TIGHT: 1 halves the query capacity of a speculative batch, 2 the anchor capacity
+  int float_gap = 0;           // SMHIP_FLOAT_GAP=1: division form of the chaining gap tests
+  int sort_lines = -1;         // SMHIP_SORT_LINES: 0 = scattered-record partition only, 1 = LDS-binned whole-line partition
+};
 
 // -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
 // the clock ticks between the marks of an instrumented kernel to its translation unit's g_phase_prof[32]
@@ -240,6 +261,14 @@ struct smhip_ctx {
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
   bool walk_exact_only = false;  // batches with many queries beyond the 5000-hit cap: no set walk (seed_lookup.hip)
+  uint64_t seen_queries = 0, seen_over_cap = 0;  // ... counted over the set-walk batches of this index
+  // Census of the resident index (seed_lookup.hip IndexCensus): hit counts of a sample of its own points used as
+  // queries at the default radius, sorted; taken on the first smhip_map_run after the index arrived (upload, attach
+  // or broadcast alike).  Decides the automatic search mode and the automatic number of fast hit slots.
+  std::vector<uint32_t> census_hits;
+  bool census_valid = false;
+  float census_radius = 0;
+  smhip::DevKnobs knobs;
   // speculative batches (api.hip RunBatchSpeculative): queries / non-carried anchors per chunk of the largest
   // batch so far, the pinned record the stream reports a batch's totals and flags in, what a repeat needs
   uint64_t hint_q_per_chunk = 0, hint_a_per_chunk = 0;
@@ -248,6 +277,7 @@ struct smhip_ctx {
   void *h_stage = nullptr;   // pinned staging of small transfers to / from pageable caller memory (api.hip StageReserve)
   size_t h_stage_cap = 0;
   smhip_params spec_params{};
+  smhip_params last_params{};  // the parameters of the last smhip_map_run with every automatic choice resolved
   uint32_t spec_n_refs = 0, spec_reruns = 0, spec_runs = 0;
   uint32_t refine_band = 0, refine_pad = 0;
   // sDTW refinement
@@ -303,18 +333,8 @@ struct ScopedTimer {
   }
 };
 
-// Experiment knobs from the environment (speed only, never results), read once per process under
-// std::call_once (api.hip) -- contexts are driven by concurrent host threads.
-struct EnvKnobs {
-  int lane_blocks_per_cu = 0;  // SMHIP_LANE_BLOCKS_PER_CU
-  int xcd_ranges = 1;          // SMHIP_XCD_RANGES
-  int scan_threshold = 0;      // SMHIP_SCAN_THRESHOLD
-  int classes = 0;             // SMHIP_CLASSES
-  int bucket_bits = 0;         // SMHIP_BUCKET_BITS
-  int sdtw_ring = 0;           // SMHIP_SDTW_RING
-  int sync_run = 0;            // SMHIP_SYNC_RUN: smhip_map_run always reads its two totals back
-};
-const EnvKnobs &Knobs();
+// seed_lookup.hip: fills ctx->census_hits (see smhip_ctx) with the hit counts of `samples` points of the index
+hipError_t IndexCensus(smhip_ctx *ctx, const smhip_params &p, uint32_t samples);
 // Per-device kernel attributes (dynamic LDS opt-ins): called by smhip_init for the context's device.
 hipError_t InitSortAttributes();
 hipError_t InitSdtwAttributes();

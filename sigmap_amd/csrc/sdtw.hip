@@ -739,7 +739,7 @@ hipError_t LaunchSdtwChains(smhip_ctx *ctx, const smhip_chunk_result *results, c
   const size_t lds_fast = (3 * (size_t)ring + fast_rows + 2) * sizeof(float);
   const size_t lds_full = (3 * (size_t)ring + kSdtwMaxT + 2) * sizeof(float);
   if (lds_full > 160 * 1024) return hipErrorInvalidValue;  // band beyond what the LDS rings hold
-  if (Knobs().sdtw_ring) {  // (experiments: skip the register kernel)
+  if (ctx->knobs.sdtw_ring) {  // (experiments: skip the register kernel)
     hipLaunchKernelGGL(SdtwChainKernel, dim3(n_chunks), dim3(64), lds_fast, ctx->stream, results, feat, feat_stride,
                        qstart, ref_sig, ref_off, n_refs, band, pad, kMaxDim, dist, end_pos, fast_rows, 0, ring);
   } else {

@@ -1170,8 +1170,8 @@ __global__ void OverCapCollectKernel(const QueryRec *__restrict__ qrec, const ui
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const QueryRec *qrec, const uint32_t *n_queries_dev,
                       uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride,
                       uint32_t blocks_override = 0) {
-  const int env_blocks = Knobs().lane_blocks_per_cu, xcd_ranges = Knobs().xcd_ranges,
-            env_thr = Knobs().scan_threshold;
+  const int env_blocks = ctx->knobs.lane_blocks_per_cu, xcd_ranges = ctx->knobs.xcd_ranges,
+            env_thr = ctx->knobs.scan_threshold;
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
@@ -1181,8 +1181,7 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
   {
-    const char *env_hand = getenv("SMHIP_HANDOUT");  // (experiment knob, read per call)
-    int hand = env_hand ? atoi(env_hand) : kHandoutLanes;
+    int hand = ctx->knobs.handout > 0 ? ctx->knobs.handout : kHandoutLanes;  // (experiment knob)
     if (hand < 1 || hand > 64) hand = kHandoutLanes;
     thr |= hand << 16;  // (both thresholds travel in one kernel argument)
   }
@@ -1255,16 +1254,21 @@ hipError_t BuildQuads(smhip_ctx *ctx) {
   const uint32_t one = 1u;
   if ((e = hipMemcpyAsync(head.p, &one, 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return done(e);
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
-  for (uint32_t round = 1; round <= (uint32_t)kStackDepth; ++round) {  // two tree levels per round
-    uint32_t any = 0;
+  uint32_t any = 1;
+  for (uint32_t round = 1; round <= 4u * (uint32_t)kStackDepth && any; ++round) {  // two tree levels per round
+    any = 0;
     if ((e = hipMemsetAsync(changed.p, 0, 4, ctx->stream)) != hipSuccess) return done(e);
     hipLaunchKernelGGL(QuadMarkKernel, dim3(blocks), dim3(256), 0, ctx->stream, ix.inner, n, head.as<uint32_t>(), round,
                        changed.as<uint32_t>());
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
     if ((e = hipMemcpyAsync(&any, changed.p, 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return done(e);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return done(e);
-    if (!any) break;
   }
+  // A tree deeper than the rounds above (nanoflann splits a span in the middle: depth is not bounded by log N) is left
+  // without quad records -- every head below an unmarked level would be missing -- and is walked in the exact mode.
+  if (any) return done(hipSuccess);
   hipLaunchKernelGGL(QuadFlagKernel, dim3(blocks), dim3(256), 0, ctx->stream, head.as<uint32_t>(), n, flag.as<uint32_t>());
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
   if ((e = LaunchScanU32(ctx, flag.as<uint32_t>(), (uint32_t)n, ids.as<uint32_t>())) != hipSuccess) return done(e);
   uint32_t n_quads = 0;
   if ((e = hipMemcpyAsync(&n_quads, ids.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
@@ -1293,7 +1297,7 @@ hipError_t BuildQueryOrder(smhip_ctx *ctx, const QueryRec *qrec, const uint32_t 
                            const uint32_t **range_end_out, uint32_t *range_stride_out) {
   uint32_t bits = 1;
   while ((1ull << bits) < ctx->index.n_leaves) ++bits;
-  const int env_cls = Knobs().classes, env_bits = Knobs().bucket_bits;
+  const int env_cls = ctx->knobs.classes, env_bits = ctx->knobs.bucket_bits;
   const uint32_t classes = (env_cls > 0 && env_cls <= (int)kCostClasses) ? (uint32_t)env_cls : kCostClasses;
   const uint32_t want_bits = env_bits > 0 ? (uint32_t)env_bits : kLeafBucketBits;
   const uint32_t shift = bits > want_bits ? bits - want_bits : 0;
@@ -1341,13 +1345,10 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
                       range_stride);
   // Large references put many queries beyond the cap (0.6 % at 250 Mb, each a traversal of tens of thousands of
   // points that the second search would run again, one lane each, after everything else has finished): there
-  // every query is searched in the reference's order at once, as before the set walk existed (250 Mb: 35 ms per
-  // 2 000 chunks; set walk + second search: 33 + 34 ms).  Decided from the index size at first (hits per query
-  // ~ 1.7e-6 x points: 41 at 12 Mb, 340 at 100 Mb -- set walk 33 ms against 37 --, 850 at 250 Mb; the line is drawn
-  // at 600) and from the share of such queries in the batches seen (smhip_ctx::walk_exact_only, smhip_map_run).
-  // (SMHIP_EXACT_WALK: A/B switch, read per call)
-  const bool force_set = getenv("SMHIP_SET_WALK") != nullptr;  // (A/B switch: the set walk whatever the index and history)
-  if (!ctx->index.quads || (!force_set && (ctx->walk_exact_only || 1.7e-6 * (double)ctx->index.m_size > 600.0 || getenv("SMHIP_EXACT_WALK"))))
+  // every query is searched in the reference's order at once, as before the set walk existed.  smhip_map_run has
+  // resolved SMHIP_SEARCH_AUTO by now (api.hip ResolveParams: the census of the index's own points, and the share of
+  // such queries in the batches seen so far); an index without quad records is always walked in the exact mode.
+  if (!ctx->index.quads || p.search_mode == SMHIP_SEARCH_EXACT)
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
   ctx->last_walk_mode = kWalkSet;
@@ -1368,6 +1369,64 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0);
 }
 
+// Census of the index: `samples` of its own points (the first point of evenly spaced leaves) as queries, hit counts
+// only (one slot per query; hits beyond it are counted, not stored), sorted into ctx->census_hits.
+namespace {
+__global__ void CensusQueryKernel(IndexView ix, uint32_t samples, QueryRec *__restrict__ qrec) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= samples) return;
+  const uint32_t leaf = (uint32_t)(((uint64_t)i * ix.n_leaves) / samples);
+  const uint32_t w = ix.leaf_tab[leaf], n = w >> 27;
+  const size_t slot = (size_t)(w & 0x7FFFFFFu) * 8u + (n ? i % n : 0u);
+  const float *pt = ix.leaf_pts + slot * 8u;  // 32-byte slots: v0..v5, position
+  QueryRec r;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) r.q[d] = pt[d];
+  r.chunk = 0;
+  r.k = i;
+  qrec[i] = r;
+}
+}  // namespace
+hipError_t IndexCensus(smhip_ctx *ctx, const smhip_params &p, uint32_t samples) {
+  ctx->census_hits.clear();
+  samples = (uint32_t)std::min<uint64_t>(samples, ctx->index.n_leaves);
+  if (samples == 0) return hipSuccess;
+  DevBuf d_qrec, d_region, d_tab, d_cnt;
+  hipError_t e = hipSuccess;
+  auto done = [&](hipError_t r) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&d_qrec, &d_region, &d_tab, &d_cnt}) b->Free();
+    return r;
+  };
+  if ((e = d_qrec.Reserve((size_t)samples * 32)) != hipSuccess || (e = d_region.Reserve((size_t)samples * sizeof(Hit))) != hipSuccess ||
+      (e = d_tab.Reserve(sizeof(void *))) != hipSuccess || (e = d_cnt.Reserve((size_t)samples * 4)) != hipSuccess ||
+      (e = ctx->counters.Reserve(40 * sizeof(uint32_t))) != hipSuccess)
+    return done(e);
+  void *h_tab[1] = {d_region.p};
+  if ((e = hipMemcpyAsync(d_tab.p, h_tab, sizeof h_tab, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return done(e);
+  if ((e = hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return done(e);
+  if ((e = hipMemsetAsync(d_cnt.p, 0, (size_t)samples * 4, ctx->stream)) != hipSuccess) return done(e);
+  QueryRec *qr = d_qrec.as<QueryRec>();
+  hipLaunchKernelGGL(CensusQueryKernel, dim3((samples + 255) / 256), dim3(256), 0, ctx->stream, ctx->index, samples, qr);
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  const uint32_t *order = nullptr, *range_end = nullptr;
+  uint32_t range_stride = 0;
+  if ((e = BuildQueryOrder(ctx, qr, nullptr, samples, samples, &order, &range_end, &range_stride)) != hipSuccess) return done(e);
+  Sink sink{HitSlots{d_tab.as<Hit *>(), 31u, 1u}, 1u, 1u, d_cnt.as<uint32_t>(), nullptr, nullptr, nullptr,
+            ctx->counters.as<uint32_t>(), nullptr, nullptr, 0, 0u};
+  const int saved_mode = ctx->last_walk_mode;
+  e = LaunchWalk(ctx, p, ctx->index.quads ? kWalkSet : kWalkExact, reinterpret_cast<const QueryRec *>(order), nullptr, samples,
+                 sink, range_end, range_stride);
+  ctx->last_walk_mode = saved_mode;
+  if (e != hipSuccess) return done(e);
+  ctx->census_hits.resize(samples);
+  if ((e = hipMemcpyAsync(ctx->census_hits.data(), d_cnt.p, (size_t)samples * 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+    return done(e);
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return done(e);
+  std::sort(ctx->census_hits.begin(), ctx->census_hits.end());
+  return done(hipSuccess);
+}
+
 hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const float *queries, uint32_t n,
                                uint32_t cap, HitSlots region, uint32_t *q_count, uint32_t *q_nodes,
                                uint32_t *q_points, uint32_t *counters, void *qrec) {
@@ -1380,9 +1439,12 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
   Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0, 0u};
-  ScopedTimer t(ctx, T_SEED);  // (the per-stage entry point reports hits in the reference's traversal order)
-  return LaunchWalk(ctx, p, p.reference_walk ? kWalkCensus : kWalkExact, reinterpret_cast<const QueryRec *>(order), nullptr,
-                    n, sink, range_end, range_stride);
+  ScopedTimer t(ctx, T_SEED);
+  // the per-stage entry point reports hits in the reference's traversal order, or -- SMHIP_SEARCH_SET -- as the
+  // mapping path's order-free walk over quad records finds them (same set; an index without quads: exact walk)
+  const int mode = p.reference_walk ? kWalkCensus : (p.search_mode == SMHIP_SEARCH_SET && ctx->index.quads ? kWalkSet : kWalkExact);
+  ctx->last_walk_mode = mode;
+  return LaunchWalk(ctx, p, mode, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
 }
 }  // namespace smhip
 

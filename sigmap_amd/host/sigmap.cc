@@ -197,8 +197,20 @@ class Sigmap {
       // to growth.  (A default budget that an MI355X takes in its stride fails on a smaller device otherwise.)
       uint64_t free_b = 0, total_b = 0;
       if (smhip_mem_info(ctxs[0][0], &free_b, &total_b) == SMHIP_OK && free_b > 0) {
-        const double hits_per_query = 1.7e-6 * (double)index.tree().m_size;  // measured: 41 at 12 Mb, 850 at 250 Mb
-        const double per_chunk = (double)keep * sizeof(float) + 288.0 * (8192.0 + 1400.0) +
+        // anchors per query = mean over the census of the index (its own points as queries) of min(hits, cap);
+        // fast hit slots as the device will choose them from the same census (sigmap_hip.h)
+        std::vector<uint32_t> census(4096);
+        uint32_t n_census = 0;
+        double hits_per_query = 1.7e-6 * (double)index.tree().m_size;  // (fallback: uniform random genome, 41 at 12 Mb, 850 at 250 Mb)
+        uint32_t fast_slots = 512;
+        if (smhip_index_census(ctxs[0][0], &dp, census.data(), (uint32_t)census.size(), &n_census) == SMHIP_OK && n_census > 0) {
+          double sum = 0;
+          for (uint32_t i = 0; i < n_census; ++i) sum += std::min<uint32_t>(census[i], (uint32_t)dp.num_nearest_points);
+          hits_per_query = sum / n_census;
+          const uint32_t q75 = census[((size_t)n_census * 3) / 4];
+          while (fast_slots < 2048 && fast_slots < q75) fast_slots <<= 1;
+        }
+        const double per_chunk = (double)keep * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
                                  288.0 * std::min(hits_per_query, 5000.0) * 60.0 + 120000.0;
         const size_t contexts_here = (size_t)num_streams * (share_device ? (size_t)num_gpus : 1u);
         const size_t fit = (size_t)((double)free_b * 0.5 / per_chunk / (double)contexts_here);

@@ -305,6 +305,24 @@ class DeviceMapper:
                                               ptr(pos), ptr(cnt), ptr(rows) if want_cwt else None), "smhip_cwt_features")
         return feat, pos, cnt, rows
 
+    def set_knob(self, name, value):
+        """A development knob of this context (smhip_dev_knob; needs SMHIP_DEV=1 when the context was created)."""
+        self._check(self.L.smhip_dev_knob(self._h, name.encode(), int(value)), "smhip_dev_knob")
+
+    def resolved_params(self):
+        """The parameters of the last run() with the automatic choices resolved (smhip_resolved_params)."""
+        out = _abi.Params()
+        self._check(self.L.smhip_resolved_params(self._h, C.byref(out)), "smhip_resolved_params")
+        return out
+
+    def index_census(self):
+        """Ascending hit counts of the index census (smhip_index_census)."""
+        n = C.c_uint32()
+        out = np.zeros(4096, np.uint32)
+        self._check(self.L.smhip_index_census(self._h, C.byref(self.params), ptr(out), len(out), C.byref(n)),
+                    "smhip_index_census")
+        return out[:n.value]
+
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint32)
         self._check(self.L.smhip_debug_counters(self._h, ptr(out)), "smhip_debug_counters")

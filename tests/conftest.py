@@ -5,6 +5,9 @@ import sys
 import numpy as np
 import pytest
 
+# the tests drive rarely taken routes through development knobs (smhip_dev_knob), which a context only accepts
+# when it was created under SMHIP_DEV=1
+os.environ["SMHIP_DEV"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

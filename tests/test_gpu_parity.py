@@ -235,6 +235,68 @@ def test_seed_lookup_matches_reference_golden():
     dev.close()
 
 
+def _hit_sets_equal(idx, dist, n, ref_idx, ref_dist):
+    """The hits of one query as a SET: (point id, distance bits) pairs, whatever the order."""
+    a = sorted(zip(idx[:n].tolist(), bits(dist[:n]).tolist()))
+    b = sorted(zip(np.asarray(ref_idx).tolist(), bits(ref_dist).tolist()))
+    return a == b
+
+
+def test_set_walk_matches_reference_golden():
+    """The PRODUCTION search of the mapping path -- the order-free set walk over quad records (integer box sums on the
+    one-step grid, four-slot visits, 4-byte stack with spill) -- through the per-stage entry point
+    (search_mode = SMHIP_SEARCH_SET): per query the same count and the same SET of (point id, distance bits) as the
+    REAL nanoflann (tests/golden/kdtree.npz, nanoflann.hpp:1278-1410), queries outside the root box and exact data
+    points included; at every walker occupancy."""
+    g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
+    ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=2)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    dev.params.search_mode = _abi.SEARCH_SET
+    off = g["hit_off"]
+    for blocks in (0, 1, 8):
+        dev.params.walk_blocks_per_cu = blocks
+        counts, idx, dist, _, _ = dev.seed_lookup(g["queries"], cap=256)
+        assert dev.debug_counters()[6] == 2          # the quad walk ran
+        for k in range(len(g["queries"])):
+            n = off[k + 1] - off[k]
+            assert counts[k] == n
+            assert _hit_sets_equal(idx[k], dist[k], n, g["hit_idx"][off[k]:off[k + 1]], g["hit_dist"][off[k]:off[k + 1]]), k
+    assert int(counts.sum()) == int(off[-1]) and int(off[-1]) > 1000
+    # a cap below a query's hit count: the count is still the total, the stored hits are a subset of the set
+    counts2, idx2, dist2, _, _ = dev.seed_lookup(g["queries"], cap=4)
+    assert np.array_equal(counts2, counts)
+    for k in range(len(g["queries"])):
+        ref = set(zip(g["hit_idx"][off[k]:off[k + 1]].tolist(), bits(g["hit_dist"][off[k]:off[k + 1]]).tolist()))
+        got = list(zip(idx2[k, :min(4, counts[k])].tolist(), bits(dist2[k, :min(4, counts[k])]).tolist()))
+        assert len(set(got)) == len(got) and set(got) <= ref
+    dev.close()
+
+
+@pytest.mark.parametrize("npts,max_leaf", [(6, 20), (21, 20), (26, 21), (45, 20), (300, 20), (2000, 21), (5000, 3)])
+def test_set_walk_small_trees_and_full_leaves(npts, max_leaf):
+    """Set walk on degenerate shapes: a tree that is one leaf (no quad records: the entry point falls back to the
+    reference's order and says so), a root with two leaves (a quad with two used slots), 21-point leaves, deep narrow
+    trees (max_leaf 3): the hit sets of the pinned oracle search, every query of the cloud plus far-away ones."""
+    rng = np.random.default_rng(npts)
+    vals = rng.normal(size=npts).astype(np.float32)
+    ix = pipeline.HostIndex.from_points(np.arange(npts, dtype=np.uint64) << 1, vals, max_leaf=max_leaf, threads=1)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    tree = po.OracleTree(ix.values.copy(), leaf_max=max_leaf)
+    qs = [vals[i:i + 6] + rng.normal(scale=0.05, size=6).astype(np.float32) for i in range(0, max(1, npts - 5), max(1, npts // 400))]
+    qs += [np.full(6, 7.0, np.float32), np.array([-9, 0, 0, 0, 0, 9], np.float32)]
+    qs = np.array(qs, np.float32)
+    dev.params.search_mode = _abi.SEARCH_SET
+    counts, idx, dist, _, _ = dev.seed_lookup(qs, cap=512)
+    assert dev.debug_counters()[6] == (2 if ix.n_nodes > 1 else 0)
+    for k in range(len(qs)):
+        n, oi, od, _ = tree.radius_search(qs[k], 0.08)
+        assert counts[k] == n and _hit_sets_equal(idx[k], dist[k], n, oi, od), k
+    assert counts.sum() >= len(qs) - 2
+    dev.close(); tree.close()
+
+
 # ------------------------------------------------------------------ whole path (A1-A18)
 
 def _paf_lines(res, pa_list, names, ref_lens):
@@ -511,15 +573,19 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     tree = po.OracleTree(ix.values.copy())
     for cap in (5, 5000):
         for fast in (3, 128):   # truncation inside the fast slots and inside the overflow pass
-            # (a fresh context each time: the first batch of a context searches with the order-free set walk and
-            # repeats the queries beyond the cap in the reference's order -- here, with cap 5, all of them; a context
-            # that has seen such a batch searches everything in the reference's order from then on: second call)
+            # SET: the order-free walk, then the queries beyond the cap -- here, with cap 5, all of them -- searched a
+            # second time in the reference's order; AUTO: the census of the index sees that every query is beyond the
+            # cap and searches everything in the reference's order at once.  Same records.
             dev = pipeline.DeviceMapper(0)
             dev.upload_index(ix)
             dev.params.num_nearest_points = cap
             dev.params.hits_per_query_fast = fast
+            dev.params.search_mode = _abi.SEARCH_SET
             res = dev.map_chunks(samples, offsets, n_refs=1)
+            assert dev.debug_counters()[6] == 2
+            dev.params.search_mode = _abi.SEARCH_AUTO
             again = dev.map_chunks(samples, offsets, n_refs=1)
+            assert dev.debug_counters()[6] == (0 if cap == 5 else 2)
             same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
             assert all(np.array_equal(res[k], again[k]) for k in same)
             dev.close()
@@ -534,6 +600,62 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
                     assert g["score"] == np.float32(c["score"]) and g["start"] == c["start"] and g["end"] == c["end"]
                     assert g["n_anchors"] == c["n_anchors"]
     tree.close()
+
+
+def test_repeat_injected_cloud_second_search_at_the_default_cap(small_world):
+    """A repeat-injected reference: one 600-base unit copied 5600 times at offsets of 1e-6, so that every seed
+    of a read of the unit has 5600 hits -- beyond the DEFAULT cap of 5000 (spatial_index.cc:371-372), with the fast
+    slots at 512: the set walk writes four levels of overflow segments per query, OverCapCollectKernel lists every
+    hitting query, and the second search (reference order, stop_at_cap) allocates and writes them again.  A fresh
+    context per route: SET (set walk + second search), EXACT, and AUTO (the index census sees the repeats and picks
+    the reference's order without paying the double search).  Chains against the oracle's so_generate_chains."""
+    lm = small_world["lm"]
+    rng = np.random.default_rng(8)
+    unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)])
+    host = _abi.host_lib()
+    sig = np.zeros(len(unit), np.float32)
+    m = host.smhost_reference_signal(_abi.ptr(np.ascontiguousarray(lm)), 6, unit, len(unit), 0, _abi.ptr(sig))
+    sig = sig[:m]
+    copies = 5600
+    values = np.concatenate([sig + np.float32(1e-6 * k) for k in range(copies)]).astype(np.float32)
+    positions = (np.arange(len(values), dtype=np.uint64) << np.uint64(1))  # one contig, + strand
+    ix = pipeline.HostIndex.from_points(positions, values, threads=4)
+    raw, _ = synth.simulate_reads([unit], lm, 8, 2)
+    pa = [po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET) for r in raw]
+    samples, offsets = _batch(pa)
+    tree = po.OracleTree(ix.values.copy())
+    want = []
+    for x in pa:
+        f, _ = po.generate_events(x)
+        want.append(po.generate_chains(tree, ix.positions, f, 1))
+    tree.close()
+    assert sum(1 for _, st in want if st.hits >= 100 * copies) >= 3     # reads of the + strand: ~100 seeds x 5600 hits
+    same = None
+    for mode, fast, walked in ((_abi.SEARCH_SET, 512, 2), (_abi.SEARCH_SET, 0, 2), (_abi.SEARCH_EXACT, 512, 0), (_abi.SEARCH_AUTO, 0, 0)):
+        dev = pipeline.DeviceMapper(0)       # fresh: nothing learnt from earlier batches
+        dev.upload_index(ix)
+        if mode == _abi.SEARCH_AUTO:
+            census = dev.index_census()
+            assert len(census) == 4096 and census[len(census) // 100] >= copies   # (nearly) every sampled point: 5600+ hits
+        dev.params.search_mode = mode
+        dev.params.hits_per_query_fast = fast
+        res = dev.map_chunks(samples, offsets, n_refs=1)
+        c = dev.debug_counters()
+        assert c[6] == walked and (res["status"] == 0).all(), (mode, c[:8])
+        if mode == _abi.SEARCH_SET:
+            assert c[7] >= 300                    # queries the set walk handed to the second search
+        for i, (chains, st) in enumerate(want):
+            assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits and res[i]["n_chains"] == len(chains)
+            for k, ch in enumerate(chains[:4]):
+                g = res[i]["chains"][k]
+                assert g["score"] == np.float32(ch["score"]) and g["start"] == ch["start"] and g["end"] == ch["end"]
+                assert g["n_anchors"] == ch["n_anchors"] and (k > 0 or g["mapq"] == ch["mapq"])
+        keep = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
+        cur = b"".join(np.ascontiguousarray(res[k]).tobytes() for k in keep)
+        assert same is None or cur == same
+        same = cur
+        dev.close()
+    ix.close()
 
 
 def test_pipeline_heavy_ties_large_chunks(small_world):
@@ -625,11 +747,9 @@ def test_pipeline_many_anchors_large_sort_and_pool_growth(small_world, oracle_tr
     radius = 0.5
     dev.params.search_radius = radius
     dev.params.hits_per_query_fast = 32
-    os.environ["SMHIP_POOL_MIN"] = "4096"   # first pool far too small: forces the grow-and-repeat path
-    try:
-        res = dev.map_chunks(samples, offsets, n_refs=3)
-    finally:
-        del os.environ["SMHIP_POOL_MIN"]
+    dev.set_knob("pool_min", 4096)   # first pool far too small: forces the grow-and-repeat path
+    res = dev.map_chunks(samples, offsets, n_refs=3)
+    dev.set_knob("pool_min", -1)
     assert (res["status"] == 0).all()
     assert res["n_anchors"].min() > 16384 and dev.debug_counters()[1] > 1000
     names = ["contig0", "contig1", "contig2"]
@@ -645,7 +765,7 @@ def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
     """smhip_map_run sizes its later stages from two totals only the device knows.  The first batch of a
     context reads them back (two stream synchronisations); later batches are enqueued whole against
     capacities learnt from earlier ones, with guard kernels on the device.  Same records either way --
-    also when a guard fires (SMHIP_SPEC_TIGHT halves a capacity: the batch is emptied on the device,
+    also when a guard fires (the spec_tight knob halves a capacity: the batch is emptied on the device,
     flagged, and repeated on the reading route by the next call that collects results, sDTW refinement
     included) and when a batch is several times larger per chunk than anything seen before."""
     pa, ix, ref_lens = small_world["pa"], small_world["ix"], small_world["ref_lens"]
@@ -672,11 +792,11 @@ def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
     c = dev.debug_counters()
     assert c[5] == 1 and c[4] == 0
     for k, tight in enumerate(("1", "2")):               # query guard, then anchor guard: repeated, identical
-        os.environ["SMHIP_SPEC_TIGHT"] = tight
+        dev.set_knob("spec_tight", int(tight))
         try:
             assert run() == base
         finally:
-            del os.environ["SMHIP_SPEC_TIGHT"]
+            dev.set_knob("spec_tight", 0)
         c = dev.debug_counters()
         assert c[5] == 2 + k and c[4] == 1 + k, (tight, c[:8])
     assert run(with_refine=False)[0] == base[0]
@@ -746,14 +866,14 @@ def test_contexts_of_a_gpu_share_one_reference_signal(device, small_world):
 def test_integer_gap_tests_equal_the_float_form(device, small_world):
     """The chaining kernels evaluate `0.75 < (float)qd / (float)td < 5` (spatial_index.cc:489-497) as
     4 qd > 3 td and qd < 5 td, exact for target gaps below 2^21 (chain.hip GapTestsPass; exhaustive host
-    check: tools/micro/gap_tests.c).  SMHIP_FLOAT_GAP selects the division form: identical records."""
+    check: tools/micro/gap_tests.c).  the float_gap knob selects the division form: identical records."""
     samples, offsets = _batch(small_world["pa"])
     base = device.map_chunks(samples, offsets, n_refs=3)
-    os.environ["SMHIP_FLOAT_GAP"] = "1"
+    device.set_knob("float_gap", 1)
     try:
         flt = device.map_chunks(samples, offsets, n_refs=3)
     finally:
-        del os.environ["SMHIP_FLOAT_GAP"]
+        device.set_knob("float_gap", 0)
     assert base.tobytes() == flt.tobytes() and (base["n_chains"] > 0).sum() > 40
 
 

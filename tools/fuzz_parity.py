@@ -51,7 +51,8 @@ def main(rounds, first):
         dev = pipeline.DeviceMapper(0)
         dev.params.walk_blocks_per_cu = int(rng.choice([0, 1, 2, 8]))
         dev.params.reference_walk = int(rng.integers(0, 2))
-        dev.params.hits_per_query_fast = int(rng.choice([512, 64, 4]))
+        dev.params.hits_per_query_fast = int(rng.choice([512, 64, 4, 0]))      # (0: sized from the index census)
+        dev.params.search_mode = int(rng.choice([_abi.SEARCH_AUTO, _abi.SEARCH_AUTO, _abi.SEARCH_EXACT, _abi.SEARCH_SET]))
         # the hit cap: lowered caps put (nearly) every query beyond it -- the set walk's second search in the
         # reference's order, or, once the context has seen such a batch, the exact walk for everything
         nnp = int(rng.choice([5000, 5000, 40, 7]))
@@ -67,15 +68,14 @@ def main(rounds, first):
         same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
         mism = 0
         for tight in (None, str(int(rng.integers(1, 3)))):
-            if tight:
-                os.environ["SMHIP_SPEC_TIGHT"] = tight
+            dev.set_knob("spec_tight", int(tight) if tight else 0)
             try:
                 again = dev.map_chunks(samples, offsets, n_refs=n_contigs)
             finally:
-                os.environ.pop("SMHIP_SPEC_TIGHT", None)
+                dev.set_knob("spec_tight", 0)
             if not all(np.array_equal(res[k], again[k]) for k in same):
                 mism += 1
-                print("   ROUTE MISMATCH (SMHIP_SPEC_TIGHT=%s)" % tight)
+                print("   ROUTE MISMATCH (spec_tight=%s)" % tight)
         names = ["contig%d" % i for i in range(n_contigs)]
         lines = _paf_lines(res, pa, names, ref_lens)
         for i, x in enumerate(pa):
@@ -135,9 +135,10 @@ def main(rounds, first):
                 print("   REFINE MISMATCH read %d (%s): band %d pad %d gpu (%r, %d) oracle (%r, %d)" % (
                     i, kind[i], band, pad, dist[i], end[i], d, t0 + e if e >= 0 else -1))
         mism += rmis
-        print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d fast=%d cap=%d r=%.2f): %d mismatches, %d mapped"
+        print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d fast=%d cap=%d r=%.2f search=%d walked=%d): %d mismatches, %d mapped"
               % (seed, n_contigs, lens, n_reads, dev.params.walk_blocks_per_cu, dev.params.reference_walk,
-                 dev.params.hits_per_query_fast, nnp, radius, mism, int((res["n_chains"] > 0).sum())), flush=True)
+                 dev.params.hits_per_query_fast, nnp, radius, dev.params.search_mode, int(dev.debug_counters()[6]), mism,
+                 int((res["n_chains"] > 0).sum())), flush=True)
         bad += mism
         dev.close(); tree.close(); ix.close()
     print("TOTAL mismatches:", bad)
