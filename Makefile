@@ -11,7 +11,8 @@ HOST = sigmap_amd/host
 HIP_SRCS = $(CSRC)/api.hip $(CSRC)/signal.hip $(CSRC)/events.hip $(CSRC)/seed_lookup.hip $(CSRC)/sort.hip $(CSRC)/chain.hip $(CSRC)/sdtw.hip $(CSRC)/cwt.hip
 HIP_OBJS = $(HIP_SRCS:$(CSRC)/%.hip=build/%.o)
 HOST_SRCS = $(HOST)/kdtree.cc $(HOST)/pore_model.cc $(HOST)/sequence_batch.cc $(HOST)/signal_batch.cc \
-            $(HOST)/fast5_reader.cc $(HOST)/blow5_reader.cc $(HOST)/spatial_index.cc $(HOST)/mapping_logic.cc $(HOST)/host_abi.cc
+            $(HOST)/fast5_reader.cc $(HOST)/blow5_reader.cc $(HOST)/spatial_index.cc $(HOST)/mapping_logic.cc $(HOST)/device_methods.cc \
+            $(HOST)/host_abi.cc
 # FAST5 input needs HDF5 (headers + libhdf5); this image ships it under /opt/conda.  Without it the
 # library still builds and a .fast5 file is a loud run-time error.
 HDF5_ROOT ?= /opt/conda
@@ -35,7 +36,7 @@ all: $(LIBDIR)/libsigmap_host.so $(LIBDIR)/libsigmap_hip.so cli oracle
 
 $(LIBDIR)/libsigmap_host.so: $(HOST_SRCS) $(wildcard $(HOST)/*.h) include/sigmap_host.h include/sigmap_hip.h
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(HOSTFLAGS) $(HDF5_FLAGS) $(ZSTD_FLAGS) -shared -o $@ $(HOST_SRCS) -lz $(HDF5_LIBS) $(ZSTD_LIBS)
+	$(CXX) $(HOSTFLAGS) $(HDF5_FLAGS) $(ZSTD_FLAGS) -shared -o $@ $(HOST_SRCS) -lz -ldl $(HDF5_LIBS) $(ZSTD_LIBS)
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sigmap_hip.h
 	@mkdir -p build

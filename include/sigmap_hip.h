@@ -221,6 +221,31 @@ typedef struct {
 int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets,
                        uint32_t n_chunks, const uint32_t *query_start_offsets,
                        const smhip_carried_anchor *carried, const uint32_t *carried_offsets);
+/* The same batch interface for chunks that are FEATURE signals already (the inputs of SpatialIndex::GenerateChains,
+ * spatial_index.h:87-92, batched): chunk c = features[feat_offsets[c] .. feat_offsets[c + 1]) (at most 2736 each)
+ * takes the place of the events a smhip_batch_upload chunk would yield; smhip_map_run then starts at the seeds
+ * (spatial_index.cc:326), and everything after it (download, chain anchors, sDTW refinement against the chunk's
+ * features) works as for a batch of samples.  GenerateChains has no minimum number of features (min_num_events is
+ * StreamingMap's test, sigmap.cc:660) and is undefined below `dim` of them (spatial_index.cc:330): such a chunk
+ * issues no query and chains its carried anchors only. */
+int smhip_features_upload(smhip_ctx *ctx, const float *features, const uint32_t *feat_offsets, uint32_t n_chunks,
+                          const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                          const uint32_t *carried_offsets);
+/* SpatialIndex::GenerateChains(query_signal, stdvs, query_start_offset, step, radius, num_target_signals, chains),
+ * spatial_index.cc:276-577, for n_chunks queries at once: smhip_features_upload + smhip_map_run + smhip_map_sync +
+ * smhip_map_download(results).  (step = p->step_size, radius = p->search_radius; `carried` = the anchors of the
+ * chains handed in, `results` + smhip_map_download's chain anchors = the chains handed back.  The stdvs argument of
+ * the reference is unused by it.) */
+int smhip_generate_chains(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, const float *features,
+                          const uint32_t *feat_offsets, uint32_t n_chunks, const uint32_t *query_start_offsets,
+                          const smhip_carried_anchor *carried, const uint32_t *carried_offsets,
+                          smhip_chunk_result *results);
+/* The chaining stage alone (spatial_index.cc:411-577: per-bucket std::sort, chaining DP, traceback, primary chains,
+ * MAPQ) on anchors the caller hands in, sorted or not: chunk c's anchors = anchors[anchor_offsets[c] ..
+ * anchor_offsets[c + 1]), each with its bucket (ref << 1 | strand).  Equivalent to GenerateChains called with an
+ * empty query and these anchors as the previous chains'.  Chain anchors: smhip_map_download afterwards. */
+int smhip_chain_anchors(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, const smhip_carried_anchor *anchors,
+                        const uint32_t *anchor_offsets, uint32_t n_chunks, smhip_chunk_result *results);
 /* ---- resident reads: SignalBatch::AddSignal's conversion on the device (signal_batch.cc:139-151;
  * the same loop for BLOW5 records at :195-207) ----
  * The host keeps a read as its raw ADC counts + (digitisation, range, offset); a read crosses PCIe
@@ -266,8 +291,10 @@ void smhip_host_free(void *p);
  * per-chunk totals of the largest batch so far (+ 25 % + slack), a guard kernel on the device empties a
  * batch that outgrows them and raises a flag, and the call returns with every kernel enqueued and
  * nothing waited for.  smhip_map_sync / the download calls wait for the stream, find the flag and repeat
- * such a batch on the reading route (together with a smhip_refine_run enqueued behind it): the records
- * never depend on the route.  Input slots named by smhip_batch_select must stay untouched until then. */
+ * such a batch on the reading route (together with a smhip_refine_run enqueued behind it), starting from the
+ * feature signals of the first pass: the records never depend on the route, and the read slots named by
+ * smhip_batch_select may be refilled (smhip_reads_upload_raw, which queues its conversion behind the batch's
+ * kernels) as soon as smhip_map_run has returned. */
 int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs);
 int smhip_map_sync(smhip_ctx *ctx);
 /* results: n_chunks records. chain_anchors (nullable): anchors of ALL primary chains,
@@ -275,6 +302,11 @@ int smhip_map_sync(smhip_ctx *ctx);
 int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results,
                        smhip_carried_anchor *chain_anchors, uint64_t chain_anchor_cap,
                        uint64_t *chain_anchor_offsets /* n_chunks+1 */);
+/* EVERY primary chain of every chunk (the std::vector<SignalAnchorChain> GenerateChains hands back,
+ * spatial_index.cc:552-576; the result record only holds the first SMHIP_TOPK), in rank order: chunk c's at
+ * chains[chain_offsets[c] .. chain_offsets[c + 1]); their anchors are smhip_map_download's chain_anchors, chain after
+ * chain (n_anchors each).  chains may be NULL (offsets only); SMHIP_ECAP when chain_cap is too small (offsets valid). */
+int smhip_map_download_chains(smhip_ctx *ctx, smhip_chain *chains, uint64_t chain_cap, uint64_t *chain_offsets /* n_chunks+1 */);
 /* upload + run + sync + download */
 int smhip_map_chunks(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs,
                      const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,

@@ -115,6 +115,25 @@ int smhost_format_paf(const smhip_chunk_result *r, const char *read_name, uint32
                       const uint32_t *ref_lengths, uint32_t n_refs, const smhost_map_params *p,
                       char *buf, size_t cap, uint32_t *ref_bucket);
 
+/* The reference's per-chunk class methods, as the host library's mirrors implement them on the device
+ * (sigmap_amd/host/device_methods.cc), behind a C face for the ctypes tests:
+ *   SpatialIndex::GenerateChains(query_signal, stdvs, query_start_offset, step, radius, num_target_signals, chains)
+ *     (spatial_index.h:87-92): prev_* = the chains handed in (their anchors chain after chain, n_anchors each),
+ *     out_* = the chains handed back; returns the number of chains, -2 when a capacity is too small (*n_out_anchors
+ *     then holds the anchors needed).  smhost_index_bind_device uploads the index to the given smhip_ctx (NULL: a
+ *     context of the index's own on GPU 0).
+ *   Sigmap::GenerateEvents(start, end, signal, feature_signal, feature_signal_stdvs) (sigmap.h:76): returns the
+ *     number of features; feat receives them, stdvs receives `stdvs_already` placeholder values (-1) followed by
+ *     the appended deviations (the method clears feature_signal but APPENDS to the deviations, sigmap.cc:1065-1079).
+ * Without a usable GPU these end the process with a message, like the reference's ExitWithMessage. */
+int smhost_index_bind_device(smhost_index *ix, void *smhip_context);
+int64_t smhost_generate_chains(smhost_index *ix, const float *query, uint32_t n_query, uint32_t query_start_offset, int step,
+                               float radius, uint32_t n_refs, const smhip_chain *prev_chains, uint32_t n_prev,
+                               const smhip_carried_anchor *prev_anchors, smhip_chain *out_chains, uint32_t chain_cap,
+                               smhip_carried_anchor *out_anchors, uint64_t anchor_cap, uint64_t *n_out_anchors);
+int64_t smhost_generate_events(void *smhip_context, const float *signal_pa, uint64_t n, uint64_t start, uint64_t end, float *feat,
+                               float *stdvs, uint32_t cap, uint32_t stdvs_already);
+
 /* One PAF row from the fields of the reference's PAFMapping record (output_tools.h:17-26): mapq <= 60 prints
  * PAFOutputTools<PAFMapping>::AppendMapping's row (output_tools.h:336-354), anything else AppendUnmappedRead's
  * (:200-210) -- OutputMappingsInVector's choice (sigmap.cc:205-213) at the CLI's threshold 0.  mapq / direction

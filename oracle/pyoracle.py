@@ -111,6 +111,7 @@ def lib():
                                          C.POINTER(Chains), C.POINTER(ChainStats)]
         L.so_generate_chains_ex.argtypes = [vp, vp, vp, sz, C.c_uint32, C.c_int, C.c_float, sz,
                                             C.POINTER(Chains), C.POINTER(ChainStats), u64]
+        L.so_chain_sorted_anchors.argtypes = [vp, vp, sz, C.c_int, C.c_float, C.POINTER(Chains)]
         L.so_seed_positions.restype = sz
         L.so_seed_positions.argtypes = [sz, C.c_int, C.c_int, vp]
         L.so_default_params.argtypes = [C.POINTER(MapParams)]
@@ -286,6 +287,30 @@ def generate_chains(tree, positions, query, n_refs, query_start_offset=0, step=2
     out = chains_to_list(ch)
     lib().so_chains_clear(C.byref(ch))
     return out, st
+
+
+def chain_anchors(ref_strand, target, query, distance, n_refs, radius=0.08, dim=6):
+    """The chaining stage alone (so_chain_sorted_anchors, spatial_index.cc:411-576) on one chunk's anchors given as
+    four parallel arrays (ref_strand = ref << 1 | strand, strand 0 = +): per-bucket sort by SignalAnchor::operator<
+    (target, query, distance; spatial_index.h:22-25), then DP, traceback, primary chains, MAPQ."""
+    ref_strand = np.asarray(ref_strand, np.uint32); target = np.asarray(target, np.uint32)
+    query = np.asarray(query, np.uint32); distance = np.asarray(distance, np.float32)
+    groups, ptrs, counts = [], (C.c_void_p * (2 * n_refs))(), (C.c_size_t * (2 * n_refs))()
+    for strand in range(2):
+        for ref in range(n_refs):
+            sel = np.flatnonzero(ref_strand == ((ref << 1) | strand))
+            order = sel[np.lexsort((distance[sel], query[sel], target[sel]))]
+            a = np.zeros(len(order), dtype=ANCHOR_DTYPE)
+            a["target_position"], a["query_position"], a["distance"] = target[order], query[order], distance[order]
+            groups.append(a)
+            g = strand * n_refs + ref
+            ptrs[g] = a.ctypes.data if len(a) else None
+            counts[g] = len(a)
+    ch = Chains()
+    lib().so_chain_sorted_anchors(ptrs, counts, n_refs, dim, radius, C.byref(ch))
+    out = chains_to_list(ch)
+    lib().so_chains_clear(C.byref(ch))
+    return out
 
 
 def map_read(tree, positions, signal_pa, n_refs, ref_lens, params=None):

@@ -23,7 +23,8 @@ HIP_SYMBOLS = [
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
     "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
-    "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params",
+    "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params", "smhip_features_upload", "smhip_generate_chains",
+    "smhip_chain_anchors", "smhip_map_download_chains",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -32,7 +33,8 @@ HOST_SYMBOLS = [
     "smhost_have_fast5", "smhost_signals_load", "smhost_signals_free", "smhost_signals_count",
     "smhost_signals_get", "smhost_write_fast5", "smhost_write_blow5", "smhost_have_zstd", "smhost_shard_range", "smhost_print_alignment",
     "smhost_format_paf_record", "smhost_sequences_load", "smhost_sequences_free", "smhost_sequences_count",
-    "smhost_sequences_num_bases", "smhost_sequences_get",
+    "smhost_sequences_num_bases", "smhost_sequences_get", "smhost_index_bind_device", "smhost_generate_chains",
+    "smhost_generate_events",
 ]
 
 
@@ -180,6 +182,14 @@ def host_lib():
         L.smhost_sequences_num_bases.restype = C.c_uint64
         L.smhost_sequences_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_char_p)]
+        L.smhost_index_bind_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.smhost_generate_chains.restype = C.c_int64
+        L.smhost_generate_chains.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_uint32,
+                                             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                             C.c_uint64, C.POINTER(C.c_uint64)]
+        L.smhost_generate_events.restype = C.c_int64
+        L.smhost_generate_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                             C.c_void_p, C.c_uint32, C.c_uint32]
         _host = L
     return _host
 
@@ -237,6 +247,10 @@ def hip_lib():
         L.smhip_index_census.argtypes = [vp, C.POINTER(Params), vp, u32, C.POINTER(u32)]
         L.smhip_dev_knob.argtypes = [vp, C.c_char_p, C.c_longlong]
         L.smhip_resolved_params.argtypes = [vp, C.POINTER(Params)]
+        L.smhip_features_upload.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+        L.smhip_generate_chains.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp, vp, vp, vp]
+        L.smhip_chain_anchors.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp]
+        L.smhip_map_download_chains.argtypes = [vp, vp, u64, vp]
         L.smhip_refine_path_run.argtypes = [vp, u32, u32]
         L.smhip_refine_path_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64]
         L.smhip_dtw_path.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]

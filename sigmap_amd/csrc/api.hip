@@ -664,9 +664,54 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   return SMHIP_OK;
 }
 
+}  // extern "C"
+namespace {
+// smhip_batch_upload (chunks of pA samples) and smhip_features_upload (chunks of features) share everything but the
+// per-chunk size limit and what EnqueueFront does with the chunks
+int UploadChunks(smhip_ctx *ctx, bool features, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                 const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                 const uint32_t *carried_offsets);
+}  // namespace
+extern "C" {
 int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
                        const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
                        const uint32_t *carried_offsets) {
+  return UploadChunks(ctx, false, samples_pa, sample_offsets, n_chunks, query_start_offsets, carried, carried_offsets);
+}
+
+int smhip_features_upload(smhip_ctx *ctx, const float *features, const uint32_t *feat_offsets, uint32_t n_chunks,
+                          const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                          const uint32_t *carried_offsets) {
+  return UploadChunks(ctx, true, features, feat_offsets, n_chunks, query_start_offsets, carried, carried_offsets);
+}
+
+int smhip_generate_chains(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, const float *features,
+                          const uint32_t *feat_offsets, uint32_t n_chunks, const uint32_t *query_start_offsets,
+                          const smhip_carried_anchor *carried, const uint32_t *carried_offsets,
+                          smhip_chunk_result *results) {
+  int rc = smhip_features_upload(ctx, features, feat_offsets, n_chunks, query_start_offsets, carried, carried_offsets);
+  if (rc) return rc;
+  rc = smhip_map_run(ctx, p, n_refs);
+  if (rc) return rc;
+  rc = smhip_map_sync(ctx);
+  if (rc) return rc;
+  return smhip_map_download(ctx, results, nullptr, 0, nullptr);
+}
+
+int smhip_chain_anchors(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, const smhip_carried_anchor *anchors,
+                        const uint32_t *anchor_offsets, uint32_t n_chunks, smhip_chunk_result *results) {
+  if (!ctx || !anchors || !anchor_offsets) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  // chunks without a feature: their only anchors are the ones handed in, which take the carried anchors' route
+  // into the sort (spatial_index.cc:303-322 puts previous chains' anchors into the buckets, :411-417 sorts them)
+  const std::vector<uint32_t> no_features((size_t)n_chunks + 1, 0u);
+  const float none = 0.0f;
+  return smhip_generate_chains(ctx, p, n_refs, &none, no_features.data(), n_chunks, nullptr, anchors, anchor_offsets, results);
+}
+}  // extern "C"
+namespace {
+int UploadChunks(smhip_ctx *ctx, bool features, const float *samples_pa, const uint32_t *sample_offsets, uint32_t n_chunks,
+                 const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
+                 const uint32_t *carried_offsets) {
   if (!ctx || !samples_pa || !sample_offsets) return Fail(ctx, SMHIP_EINVAL, "null argument");
   if ((carried == nullptr) != (carried_offsets == nullptr))
     return Fail(ctx, SMHIP_EINVAL, "carried and carried_offsets must be given together");
@@ -677,8 +722,10 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   }
   for (uint32_t c = 0; c < n_chunks; ++c) {
     if (sample_offsets[c + 1] < sample_offsets[c]) return Fail(ctx, SMHIP_EINVAL, "sample offsets must be non-decreasing");
-    if (sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kMaxSamples)
+    if (!features && sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kMaxSamples)
       return Fail(ctx, SMHIP_EINVAL, "a chunk exceeds 4096 samples (reference chunk size is 4000, sigmap.cc:639)");
+    if (features && sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kFeatStride)
+      return Fail(ctx, SMHIP_EINVAL, "a chunk exceeds 2736 features (the events of a 4096-sample chunk)");
   }
   const uint64_t n_samples = n_chunks ? sample_offsets[n_chunks] : 0;
   const uint64_t n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
@@ -703,12 +750,15 @@ int smhip_batch_upload(smhip_ctx *ctx, const float *samples_pa, const uint32_t *
   ctx->n_chunks = n_chunks;
   ctx->n_samples = n_samples;
   ctx->n_carried = n_carried;
+  ctx->batch_is_features = features;
   ctx->batch_ready = true;
   ctx->run_done = false;
   ctx->refine_done = false;
   ctx->refine_path_done = false;
   return SMHIP_OK;
 }
+}  // namespace
+extern "C" {
 
 int smhip_host_alloc(void **out, size_t bytes) {
   if (!out) return SMHIP_EINVAL;
@@ -858,6 +908,7 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   int rc = UploadBatchSideInputs(ctx, n_chunks, query_start_offsets, carried, carried_offsets);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned: safe to reuse on return
+  ctx->batch_is_features = false;
   ctx->n_chunks = n_chunks;
   ctx->n_samples = (uint64_t)n_chunks * chunk_size;
   ctx->n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
@@ -954,7 +1005,7 @@ __global__ void GuardTotalKernel(uint32_t *__restrict__ counts, OffT *__restrict
   if (threadIdx.x == 0) *flag = 1u;
 }
 
-int EnqueueFront(smhip_ctx *ctx, const smhip_params *p, uint32_t R) {
+int EnqueueFront(smhip_ctx *ctx, const smhip_params *p, uint32_t R, bool reuse_features = false) {
   HIPCHK(ctx->feat.Reserve((uint64_t)R * kFeatStride * sizeof(float)));
   HIPCHK(ctx->results.Reserve((uint64_t)R * sizeof(smhip_chunk_result)));
   HIPCHK(ctx->nq.Reserve((uint64_t)R * sizeof(uint32_t)));
@@ -967,7 +1018,12 @@ int EnqueueFront(smhip_ctx *ctx, const smhip_params *p, uint32_t R) {
   // speculative route, [34] queries, [36..37] anchors as counted on the device
   HIPCHK(ctx->counters.Reserve(40 * sizeof(uint32_t)));
   HIPCHK(hipMemsetAsync(ctx->counters.as<uint32_t>() + 32, 0, 8 * sizeof(uint32_t), ctx->stream));
-  {
+  if (reuse_features) {  // second pass over a batch: from the features of the first one (events.hip RestoreFrontKernel)
+    HIPCHK(LaunchRestoreFront(ctx, R, ctx->results.as<smhip_chunk_result>(), ctx->nq.as<uint32_t>()));
+  } else if (ctx->batch_is_features) {  // smhip_features_upload: the chunks ARE feature signals
+    HIPCHK(LaunchFeaturesIn(ctx, *p, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), R,
+                            kFeatStride, ctx->feat.as<float>(), ctx->results.as<smhip_chunk_result>(), ctx->nq.as<uint32_t>()));
+  } else {
     ScopedTimer t(ctx, T_EVENTS);
     HIPCHK(LaunchEvents(ctx, *p, ctx->chunk_src, ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>(), R, kFeatStride,
                         ctx->feat.as<float>(), nullptr, ctx->results.as<smhip_chunk_result>(), ctx->nq.as<uint32_t>()));
@@ -1137,9 +1193,9 @@ void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
 }
 
 // the synchronous route: both totals are read back and the buffers sized exactly
-int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
+int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, bool reuse_features = false) {
   const uint32_t R = ctx->n_chunks;
-  int rc = EnqueueFront(ctx, p, R);
+  int rc = EnqueueFront(ctx, p, R, reuse_features);
   if (rc) return rc;
   uint32_t NQ = 0;
   HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1219,7 +1275,8 @@ int FinishRun(smhip_ctx *ctx) {
     return SMHIP_OK;
   }
   ++ctx->spec_reruns;
-  int rc = RunBatchSync(ctx, &ctx->spec_params, ctx->spec_n_refs);
+  // (from the features of the first pass: the read slots / sample buffer may hold other reads by now)
+  int rc = RunBatchSync(ctx, &ctx->spec_params, ctx->spec_n_refs, /*reuse_features=*/true);
   if (rc) return rc;
   if (ctx->refine_done) rc = smhip_refine_run(ctx, ctx->refine_band, ctx->refine_pad);
   if (rc) return rc;
@@ -1401,6 +1458,36 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
   }
+  return SMHIP_OK;
+}
+
+int smhip_map_download_chains(smhip_ctx *ctx, smhip_chain *chains, uint64_t chain_cap, uint64_t *chain_offsets) {
+  if (!ctx || !chain_offsets) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download_chains before smhip_map_run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t R = ctx->n_chunks;
+  chain_offsets[0] = 0;
+  if (R == 0) return SMHIP_OK;
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
+  DevBuf &out_off = ctx->dl_off, &compact = ctx->dl_compact;
+  HIPCHK(out_off.Reserve(((uint64_t)R + 1) * sizeof(uint64_t) + (uint64_t)R * sizeof(uint32_t)));
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(out_off.as<uint64_t>() + R + 1);
+  HIPCHK(LaunchChainCount(ctx, ctx->results.as<smhip_chunk_result>(), R, cnt));
+  HIPCHK(LaunchScanU32ToU64(ctx, cnt, R, out_off.as<uint64_t>()));
+  HIPCHK(hipMemcpyAsync(chain_offsets, out_off.p, ((uint64_t)R + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint64_t total = chain_offsets[R];
+  if (!chains) return SMHIP_OK;  // (sizes only)
+  if (total > chain_cap) return Fail(ctx, SMHIP_ECAP, "chain_cap too small (chain_offsets[n_chunks] records are needed)");
+  if (total == 0) return SMHIP_OK;
+  if (!ctx->dl_chain_ranked) return Fail(ctx, SMHIP_ESTATE, "no chains resident");
+  HIPCHK(compact.Reserve(total * sizeof(smhip_chain)));
+  HIPCHK(LaunchChainGather(ctx, ctx->results.as<smhip_chunk_result>(), R, out_off.as<uint64_t>(), compact.as<smhip_chain>()));
+  HIPCHK(hipMemcpyAsync(chains, compact.p, total * sizeof(smhip_chain), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return SMHIP_OK;
 }
 

@@ -1280,6 +1280,13 @@ __device__ __forceinline__ void FinalizeBody(const ChainArgs &a, uint32_t c, uin
     if (lane == 0) a.out_anchor_cnt[c] = 0;
     return;
   }
+  // every primary chain's record, in rank order, at the front of the chunk's ranked slice (where the large-chunk
+  // route has them already): smhip_map_download_chains hands out the whole std::vector<SignalAnchorChain>, not only
+  // the SMHIP_TOPK chains of the result record
+  if (!kBig) {
+    ChainTmp *ranked = a.chain_sorted + 3 * (size_t)a.chain_off[c];
+    for (uint32_t i = lane; i < np; i += 64) ranked[i] = ch[i];
+  }
   // anchors of every primary chain, end -> start (the order TracebackChains pushes them), for the
   // next chunk's carry-over
   uint32_t w = 0;
@@ -1391,6 +1398,8 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   a.chain_tmp = ctx->chain_tmp.as<ChainTmp>();
   a.chain_sorted = a.chain_tmp + max_cand;
   a.chain_off = goff;
+  ctx->dl_chain_ranked = a.chain_sorted;  // (smhip_map_download_chains)
+  ctx->dl_chain_off = goff;
   hipLaunchKernelGGL(ChainTileCountKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, a, n_chunks, tiles);
   if ((e = LaunchScanU32(ctx, tiles, n_chunks, tile_off)) != hipSuccess) return e;
   const uint64_t max_tiles = n_anchors_total / kTile + n_chunks;
@@ -1432,6 +1441,44 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   hipLaunchKernelGGL(ChainEndsKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, p.min_num_anchors,
                      p.num_best_chains, p.min_chaining_score, n_chains, n_pending, kMaxDim);
   hipLaunchKernelGGL(ChainFinalizeKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, a, n_chunks, n_chains);
+  return hipGetLastError();
+}
+
+namespace {
+__global__ void ChainCountKernel(const smhip_chunk_result *__restrict__ results, uint32_t n_chunks, uint32_t *__restrict__ cnt) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_chunks) cnt[c] = results[c].n_chains;
+}
+// primary chains of every chunk, in rank order, as smhip_chain records (chain 0 carries the MAPQ)
+__global__ void ChainGatherKernel(const smhip_chunk_result *__restrict__ results, const ChainTmp *__restrict__ ranked,
+                                  const uint32_t *__restrict__ chain_off, const uint64_t *__restrict__ out_off,
+                                  smhip_chain *__restrict__ out) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t np = results[c].n_chains;
+  const ChainTmp *src = ranked + 3 * (size_t)chain_off[c];
+  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+    const ChainTmp t = src[i];
+    smhip_chain o;
+    o.score = t.score;
+    o.ref = t.ref;
+    o.start = t.start;
+    o.end = t.end;
+    o.n_anchors = t.n_anchors;
+    o.mapq = i == 0 ? results[c].chains[0].mapq : 0;
+    o.direction = t.direction;
+    o.pad = 0;
+    out[out_off[c] + i] = o;
+  }
+}
+}  // namespace
+hipError_t LaunchChainCount(smhip_ctx *ctx, const smhip_chunk_result *results, uint32_t n_chunks, uint32_t *cnt) {
+  hipLaunchKernelGGL(ChainCountKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, results, n_chunks, cnt);
+  return hipGetLastError();
+}
+hipError_t LaunchChainGather(smhip_ctx *ctx, const smhip_chunk_result *results, uint32_t n_chunks, const uint64_t *out_off,
+                             smhip_chain *out) {
+  hipLaunchKernelGGL(ChainGatherKernel, dim3(n_chunks), dim3(64), 0, ctx->stream, results,
+                     reinterpret_cast<const ChainTmp *>(ctx->dl_chain_ranked), ctx->dl_chain_off, out_off, out);
   return hipGetLastError();
 }
 }  // namespace smhip

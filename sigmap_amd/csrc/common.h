@@ -226,6 +226,7 @@ struct smhip_ctx {
   // reads in their slot segments, smhip_reads_upload_raw + smhip_batch_select)
   smhip::DevBuf samples, chunk_begin, chunk_len, qstart, carried, carried_off;
   const float *chunk_src = nullptr;
+  bool batch_is_features = false;  // the batch holds feature signals (smhip_features_upload), not samples
   // resident reads (SignalBatch::AddSignal on the device): raw ADC staging, per-read records, segment
   // counts / bases, the slots' filtered pA samples (n_slots x reads_keep floats) and their lengths
   smhip::DevBuf reads_raw, reads_meta, reads_segstart, reads_seg, slot_len, reads_len, sel_slots, sel_chunk, pa_tab;
@@ -258,6 +259,8 @@ struct smhip_ctx {
   // per-anchor
   smhip::DevBuf a_tpos, a_qpos, a_dist, a_grp, keys, s_tpos, s_qpos, s_dist, s_grp, score, pred, used,
       group_start, chain_tmp, chain_cnt, out_anchors, out_anchor_cnt, dl_off, dl_compact, sort_tmp;
+  const void *dl_chain_ranked = nullptr;     // the last batch's ranked candidate chains (chain.hip), primaries first ...
+  const uint32_t *dl_chain_off = nullptr;    // ... chunk c's at 3 * dl_chain_off[c] (smhip_map_download_chains)
   uint64_t cap_queries = 0, cap_anchors = 0;
   uint64_t pool_hint = 0;  // overflow-pool size a previous batch needed
   bool walk_exact_only = false;  // batches with many queries beyond the 5000-hit cap: no set walk (seed_lookup.hip)
@@ -351,6 +354,10 @@ hipError_t LaunchPackBoxes(smhip_ctx *ctx, void *inner, uint64_t n_inner, uint32
 hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samples, const uint64_t *cbegin,
                         const uint32_t *clen, uint32_t n_chunks, uint32_t feat_stride, float *feat, float *stdv,
                         smhip_chunk_result *results, uint32_t *nq);
+hipError_t LaunchFeaturesIn(smhip_ctx *ctx, const smhip_params &p, const float *src, const uint64_t *cbegin,
+                            const uint32_t *clen, uint32_t n_chunks, uint32_t feat_stride, float *feat,
+                            smhip_chunk_result *results, uint32_t *nq);
+hipError_t LaunchRestoreFront(smhip_ctx *ctx, uint32_t n_chunks, smhip_chunk_result *results, uint32_t *nq);
 // event spans (start, length) of the last LaunchEvents' raw events, event.h:200-224
 hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *clen, uint32_t *ev_start, uint32_t *ev_length);
 // signal.hip: raw ADC -> filtered pA of n_reads reads (n_segs segments in all) into their slots
@@ -419,6 +426,9 @@ struct ChainArgs {
 };
 hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a, uint32_t n_chunks,
                        uint64_t n_anchors_total, uint32_t n_refs);
+hipError_t LaunchChainCount(smhip_ctx *ctx, const smhip_chunk_result *results, uint32_t n_chunks, uint32_t *cnt);
+hipError_t LaunchChainGather(smhip_ctx *ctx, const smhip_chunk_result *results, uint32_t n_chunks, const uint64_t *out_off,
+                             smhip_chain *out);
 hipError_t LaunchCwtFeatures(smhip_ctx *ctx, const float *samples, const uint64_t *cbegin, const uint32_t *clen,
                              uint32_t n_chunks,
                              const double *h, uint32_t L, float *cwt_rows, uint32_t feat_stride, float *feat,

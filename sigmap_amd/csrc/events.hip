@@ -520,6 +520,67 @@ hipError_t LaunchEvents(smhip_ctx *ctx, const smhip_params &p, const float *samp
   return hipGetLastError();
 }
 
+// Features handed in by the caller (smhip_features_upload: the inputs of SpatialIndex::GenerateChains): chunk c =
+// src[cbegin[c] .. + clen[c]) goes to its row of the feature array, and its record and query count are written as
+// FeatureKernel writes them -- seeds at step, 2 * step, ... <= nwin - 1 (spatial_index.cc:326-356,403-408).
+// GenerateChains itself has no minimum number of features (that is StreamingMap's test, sigmap.cc:660), and is
+// undefined for fewer than `dim` of them (size_t underflow at :330): such a chunk issues no query here.
+__global__ void FeaturesInKernel(const float *__restrict__ src, const uint64_t *__restrict__ cbegin,
+                                 const uint32_t *__restrict__ clen, uint32_t feat_stride, int dim, int step,
+                                 float *__restrict__ feat, smhip_chunk_result *__restrict__ results,
+                                 uint32_t *__restrict__ nq) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t F = clen[c];
+  const float *in = src + cbegin[c];
+  float *out = feat + (size_t)c * feat_stride;
+  for (uint32_t i = threadIdx.x; i < F; i += blockDim.x) out[i] = in[i];
+  if (threadIdx.x == 0) {
+    uint32_t Q = 0;
+    if (F >= (uint32_t)dim) Q = (F - (uint32_t)dim) / (uint32_t)step;  // (nwin - 1) / step
+    smhip_chunk_result z;
+    memset(&z, 0, sizeof z);
+    z.n_features = F;
+    z.n_queries = Q;
+    results[c] = z;
+    nq[c] = Q;
+  }
+}
+
+hipError_t LaunchFeaturesIn(smhip_ctx *ctx, const smhip_params &p, const float *src, const uint64_t *cbegin,
+                            const uint32_t *clen, uint32_t n_chunks, uint32_t feat_stride, float *feat,
+                            smhip_chunk_result *results, uint32_t *nq) {
+  ctx->ev_rows = smhip_ctx::EvRows{};  // (no event-detection intermediates for smhip_events_raw)
+  if (n_chunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(FeaturesInKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, src, cbegin, clen, feat_stride,
+                     kMaxDim, p.step_size, feat, results, nq);
+  return hipGetLastError();
+}
+
+// A batch that is mapped a second time (a speculative batch that outgrew a buffer, api.hip FinishRun) starts from the
+// features of its first pass, not from the read slots again -- the caller may have replaced the reads by then
+// (smhip_reads_upload_raw of the next batch's reads into the same slots, queued behind this batch's kernels).  Only
+// the front stage writes the feature rows and these four fields of a record; everything else is zeroed like
+// FeatureKernel zeroes it, and the per-chunk query counts (emptied by the guard kernel) come back from the records.
+__global__ void RestoreFrontKernel(uint32_t n_chunks, smhip_chunk_result *__restrict__ results, uint32_t *__restrict__ nq) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const smhip_chunk_result r = results[c];
+  smhip_chunk_result z;
+  memset(&z, 0, sizeof z);
+  z.status = r.status & SMHIP_ST_FEW_PEAKS;
+  z.n_events = r.n_events;
+  z.n_features = r.n_features;
+  z.n_queries = r.n_queries;
+  results[c] = z;
+  nq[c] = r.n_queries;
+}
+
+hipError_t LaunchRestoreFront(smhip_ctx *ctx, uint32_t n_chunks, smhip_chunk_result *results, uint32_t *nq) {
+  if (n_chunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(RestoreFrontKernel, dim3((n_chunks + 255) / 256), dim3(256), 0, ctx->stream, n_chunks, results, nq);
+  return hipGetLastError();
+}
+
 hipError_t LaunchEventSpans(smhip_ctx *ctx, const uint32_t *clen, uint32_t *ev_start, uint32_t *ev_length) {
   const auto &r = ctx->ev_rows;
   if (r.n_chunks == 0) return hipSuccess;

@@ -9,6 +9,7 @@
 #include "mapping_logic.h"
 #include "pore_model.h"
 #include "sequence_batch.h"
+#include "sigmap.h"
 #include "signal_batch.h"
 #include "spatial_index.h"
 
@@ -299,5 +300,60 @@ int smhost_sequences_get(const smhost_sequences *s, uint32_t i, const char **nam
   if (length) *length = s->batch.GetSequenceLengthAt(i);
   if (negative) *negative = s->batch.GetNegativeSequenceAt(i).c_str();
   return 0;
+}
+
+// ---- the per-chunk class methods (device_methods.cc) behind a C face, for the ctypes tests ----
+int smhost_index_bind_device(smhost_index *ix, void *smhip_context) {
+  if (!ix) return -1;
+  ix->si->BindDevice(static_cast<smhip_ctx *>(smhip_context));
+  return 0;
+}
+
+int64_t smhost_generate_chains(smhost_index *ix, const float *query, uint32_t n_query, uint32_t query_start_offset, int step,
+                               float radius, uint32_t n_refs, const smhip_chain *prev_chains, uint32_t n_prev,
+                               const smhip_carried_anchor *prev_anchors, smhip_chain *out_chains, uint32_t chain_cap,
+                               smhip_carried_anchor *out_anchors, uint64_t anchor_cap, uint64_t *n_out_anchors) {
+  if (!ix || (n_query && !query) || !out_chains || !out_anchors || !n_out_anchors) return -1;
+  std::vector<SignalAnchorChain> chains;
+  size_t at = 0;
+  for (uint32_t i = 0; i < n_prev; ++i) {
+    const smhip_chain &c = prev_chains[i];
+    SignalAnchorChain ch{c.score, c.ref, c.start, c.end, c.n_anchors, (uint8_t)c.mapq, c.direction == 1 ? Positive : Negative, {}};
+    for (uint32_t k = 0; k < c.n_anchors; ++k, ++at)
+      ch.anchors.push_back(SignalAnchor{prev_anchors[at].target_position, prev_anchors[at].query_position, prev_anchors[at].distance});
+    chains.push_back(std::move(ch));
+  }
+  const std::vector<float> q(query, query + n_query), stdvs;
+  ix->si->GenerateChains(q, stdvs, query_start_offset, step, radius, n_refs, chains);
+  uint64_t total = 0;
+  for (const auto &c : chains) total += c.anchors.size();
+  *n_out_anchors = total;
+  if (chains.size() > chain_cap || total > anchor_cap) return -2;
+  at = 0;
+  for (size_t i = 0; i < chains.size(); ++i) {
+    const SignalAnchorChain &c = chains[i];
+    out_chains[i] = smhip_chain{c.score, c.reference_sequence_index, c.start_position, c.end_position, c.num_anchors, c.mapq,
+                                c.direction == Positive ? 1u : 0u, 0u};
+    for (const SignalAnchor &a : c.anchors)
+      out_anchors[at++] = smhip_carried_anchor{(c.reference_sequence_index << 1) | (c.direction == Positive ? 0u : 1u),
+                                               a.target_position, a.query_position, a.distance};
+  }
+  return (int64_t)chains.size();
+}
+
+int64_t smhost_generate_events(void *smhip_context, const float *signal_pa, uint64_t n, uint64_t start, uint64_t end, float *feat,
+                               float *stdvs, uint32_t cap, uint32_t stdvs_already) {
+  if (!signal_pa || !feat || !stdvs) return -1;
+  Sigmap sm(MappingParams(), 1, "", "", "", "", "");
+  if (smhip_context) sm.BindDevice(static_cast<smhip_ctx *>(smhip_context));
+  Signal sig;
+  sig.signal_values.assign(signal_pa, signal_pa + n);
+  std::vector<float> f(7, 1.0f);                       // stale content: the method clears it
+  std::vector<float> s(stdvs_already, -1.0f);          // ... and appends to this one
+  sm.GenerateEvents(start, end, sig, f, s);
+  if (f.size() > cap || s.size() > cap) return -2;
+  memcpy(feat, f.data(), f.size() * sizeof(float));
+  memcpy(stdvs, s.data(), s.size() * sizeof(float));
+  return (int64_t)f.size();
 }
 }

@@ -27,6 +27,7 @@
 #include "output_tools.h"
 #include "pore_model.h"
 #include "sequence_batch.h"
+#include "sigmap.h"
 #include "signal_batch.h"
 #include "spatial_index.h"
 #include "utils.h"
@@ -34,463 +35,441 @@
 namespace sigmap {
 void BuildIndex(SequenceBatch &ref, const PoreModel &pore_model, SpatialIndex &index);  // host_abi.cc
 
-class Sigmap {
- public:
-  // for index construction
-  Sigmap(int dimension, int max_leaf, const std::string &reference_file_path,
-         const std::string &pore_model_file_path, const std::string &output_file_path)
-      : dimension_(dimension), max_leaf_(max_leaf), reference_file_path_(reference_file_path),
-        pore_model_file_path_(pore_model_file_path), output_file_path_(output_file_path) {}
-  // for mapping
-  Sigmap(const MappingParams &p, int num_threads, const std::string &reference_file_path,
-         const std::string &pore_model_file_path, const std::string &signal_directory,
-         const std::string &reference_index_file_path, const std::string &output_file_path)
-      : params_(p), num_threads_(num_threads), reference_file_path_(reference_file_path),
-        pore_model_file_path_(pore_model_file_path), signal_directory_(signal_directory),
-        reference_index_file_path_(reference_index_file_path), output_file_path_(output_file_path) {}
+void Sigmap::ConstructIndex() {
+  PoreModel pore_model;
+  pore_model.Load(pore_model_file_path_);
+  SequenceBatch reference;
+  reference.InitializeLoading(reference_file_path_);
+  reference.LoadAllSequences();
+  SpatialIndex index(dimension_, max_leaf_, omp_get_max_threads(), output_file_path_);
+  BuildIndex(reference, pore_model, index);
+  index.Save();
+}
 
-  void ConstructIndex() {
+// Pinned arena of the raw reads (SignalBatch::KeepRaw): a run of reads is one DMA.
+void *Sigmap::PinnedAlloc(size_t bytes) {
+  void *p = nullptr;
+  return smhip_host_alloc(&p, bytes) == SMHIP_OK ? p : nullptr;
+}
+void Sigmap::PinnedFree(void *p) { smhip_host_free(p); }
+
+// share_device (development option --gpus-share-device): the N "GPUs" are all GPU `device` and borrow
+// one resident index, so that the read sharding, the per-GPU lanes and the merge of `--gpus N` can be
+// exercised on a one-GPU machine (RCCL itself refuses two ranks on one device).
+void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
+                  bool sdtw_cigar, bool share_device) {
+  num_gpus = std::max(1, num_gpus);
+  num_streams = std::max(1, num_streams);
+  if (device < 0 || device + (share_device ? 1 : num_gpus) > smhip_device_count())
+    ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
+                    std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
+                    " visible): this build has no CPU mapping path.");
+  double t_phase = GetRealTime();
+  auto phase = [&t_phase](const char *what) {  // set-up timeline on stderr, like the reference's "Loaded ... in"
+    const double now = GetRealTime();
+    std::cerr << what << " in " << now - t_phase << "s.\n";
+    t_phase = now;
+  };
+  SignalBatch reads;
+  reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree);  // ADC counts stay 2 bytes/sample; the GPU converts
+  reads.InitializeLoading(signal_directory_);
+  const size_t num_reads = reads.LoadAllReadSignals();
+  phase("Loaded read signals (first device use included)");
+  SequenceBatch reference;  // names and lengths for PAF; the pore model is only needed by -i
+  reference.InitializeLoading(reference_file_path_);
+  const uint32_t num_refs = reference.LoadAllSequences();
+  std::vector<uint32_t> ref_lengths(num_refs);
+  for (uint32_t i = 0; i < num_refs; ++i) ref_lengths[i] = reference.GetSequenceLengthAt(i);
+  SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
+  index.Load();
+  phase("Loaded reference and index");
+
+  // ctxs[g][k]: context k (one HIP stream each) of GPU device + g.  The first context of GPU 0
+  // uploads the index; the first contexts of the other GPUs receive it by one RCCL broadcast per
+  // array (smhip_index_bcast); the further contexts of a GPU borrow its arrays.
+  // Reads are independent (one taskloop over all reads, sigmap.cc:618-666): every GPU maps a
+  // contiguous block of the reads (read i -> GPU i * G / n), every context of a GPU takes batches
+  // from that block, driven by its own host thread.
+  std::vector<std::vector<smhip_ctx *>> ctxs((size_t)num_gpus, std::vector<smhip_ctx *>((size_t)num_streams, nullptr));
+  for (int g = 0; g < num_gpus; ++g)
+    for (auto &c : ctxs[g])
+      if (smhip_init(share_device ? device : device + g, &c) != SMHIP_OK)
+        ExitWithMessage("smhip_init failed for GPU " + std::to_string(device + g) +
+                        ": this build has no CPU mapping path.");
+  if (smhip_index_upload(ctxs[0][0], index.dimension(), index.values().data(), index.positions().data(),
+                         index.values().size(), index.tree().vind.data(), index.tree().m_size,
+                         index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
+    ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0][0]));
+  if (num_gpus > 1 && share_device) {
+    smhip_index_dev shared;
+    if (smhip_index_export(ctxs[0][0], &shared) != SMHIP_OK)
+      ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[0][0]));
+    for (int g = 1; g < num_gpus; ++g)
+      if (smhip_index_attach(ctxs[g][0], &shared) != SMHIP_OK)
+        ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][0]));
+  } else if (num_gpus > 1) {
+    const double t0 = GetRealTime();
+    std::vector<smhip_ctx *> firsts;
+    for (int g = 0; g < num_gpus; ++g) firsts.push_back(ctxs[g][0]);
+    if (smhip_index_bcast(firsts.data(), num_gpus, 0) != SMHIP_OK)
+      ExitWithMessage(std::string("Index broadcast failed: ") + smhip_last_error(ctxs[0][0]));
+    std::cerr << "Broadcast index to " << num_gpus << " GPUs in " << GetRealTime() - t0 << "s.\n";
+  }
+  for (int g = 0; g < num_gpus; ++g) {
+    smhip_index_dev shared;
+    if (smhip_index_export(ctxs[g][0], &shared) != SMHIP_OK)
+      ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[g][0]));
+    for (size_t k = 1; k < ctxs[g].size(); ++k)
+      if (smhip_index_attach(ctxs[g][k], &shared) != SMHIP_OK)
+        ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][k]));
+  }
+  phase("Index resident on the device(s)");
+  if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
     PoreModel pore_model;
     pore_model.Load(pore_model_file_path_);
-    SequenceBatch reference;
-    reference.InitializeLoading(reference_file_path_);
-    reference.LoadAllSequences();
-    SpatialIndex index(dimension_, max_leaf_, omp_get_max_threads(), output_file_path_);
-    BuildIndex(reference, pore_model, index);
-    index.Save();
-  }
-
-  // Pinned arena of the raw reads (SignalBatch::KeepRaw): a run of reads is one DMA.
-  static void *PinnedAlloc(size_t bytes) {
-    void *p = nullptr;
-    return smhip_host_alloc(&p, bytes) == SMHIP_OK ? p : nullptr;
-  }
-  static void PinnedFree(void *p) { smhip_host_free(p); }
-
-  // share_device (development option --gpus-share-device): the N "GPUs" are all GPU `device` and borrow
-  // one resident index, so that the read sharding, the per-GPU lanes and the merge of `--gpus N` can be
-  // exercised on a one-GPU machine (RCCL itself refuses two ranks on one device).
-  void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
-                    bool sdtw_cigar, bool share_device) {
-    num_gpus = std::max(1, num_gpus);
-    num_streams = std::max(1, num_streams);
-    if (device < 0 || device + (share_device ? 1 : num_gpus) > smhip_device_count())
-      ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
-                      std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
-                      " visible): this build has no CPU mapping path.");
-    double t_phase = GetRealTime();
-    auto phase = [&t_phase](const char *what) {  // set-up timeline on stderr, like the reference's "Loaded ... in"
-      const double now = GetRealTime();
-      std::cerr << what << " in " << now - t_phase << "s.\n";
-      t_phase = now;
-    };
-    SignalBatch reads;
-    reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree);  // ADC counts stay 2 bytes/sample; the GPU converts
-    reads.InitializeLoading(signal_directory_);
-    const size_t num_reads = reads.LoadAllReadSignals();
-    phase("Loaded read signals (first device use included)");
-    SequenceBatch reference;  // names and lengths for PAF; the pore model is only needed by -i
-    reference.InitializeLoading(reference_file_path_);
-    const uint32_t num_refs = reference.LoadAllSequences();
-    std::vector<uint32_t> ref_lengths(num_refs);
-    for (uint32_t i = 0; i < num_refs; ++i) ref_lengths[i] = reference.GetSequenceLengthAt(i);
-    SpatialIndex index(1000, std::vector<int>(1000, 5000), reference_index_file_path_);
-    index.Load();
-    phase("Loaded reference and index");
-
-    // ctxs[g][k]: context k (one HIP stream each) of GPU device + g.  The first context of GPU 0
-    // uploads the index; the first contexts of the other GPUs receive it by one RCCL broadcast per
-    // array (smhip_index_bcast); the further contexts of a GPU borrow its arrays.
-    // Reads are independent (one taskloop over all reads, sigmap.cc:618-666): every GPU maps a
-    // contiguous block of the reads (read i -> GPU i * G / n), every context of a GPU takes batches
-    // from that block, driven by its own host thread.
-    std::vector<std::vector<smhip_ctx *>> ctxs((size_t)num_gpus, std::vector<smhip_ctx *>((size_t)num_streams, nullptr));
-    for (int g = 0; g < num_gpus; ++g)
-      for (auto &c : ctxs[g])
-        if (smhip_init(share_device ? device : device + g, &c) != SMHIP_OK)
-          ExitWithMessage("smhip_init failed for GPU " + std::to_string(device + g) +
-                          ": this build has no CPU mapping path.");
-    if (smhip_index_upload(ctxs[0][0], index.dimension(), index.values().data(), index.positions().data(),
-                           index.values().size(), index.tree().vind.data(), index.tree().m_size,
-                           index.tree().nodes.data(), index.tree().nodes.size(), index.tree().bbox.data()) != SMHIP_OK)
-      ExitWithMessage(std::string("Index upload failed: ") + smhip_last_error(ctxs[0][0]));
-    if (num_gpus > 1 && share_device) {
-      smhip_index_dev shared;
-      if (smhip_index_export(ctxs[0][0], &shared) != SMHIP_OK)
-        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[0][0]));
-      for (int g = 1; g < num_gpus; ++g)
-        if (smhip_index_attach(ctxs[g][0], &shared) != SMHIP_OK)
-          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][0]));
-    } else if (num_gpus > 1) {
-      const double t0 = GetRealTime();
-      std::vector<smhip_ctx *> firsts;
-      for (int g = 0; g < num_gpus; ++g) firsts.push_back(ctxs[g][0]);
-      if (smhip_index_bcast(firsts.data(), num_gpus, 0) != SMHIP_OK)
-        ExitWithMessage(std::string("Index broadcast failed: ") + smhip_last_error(ctxs[0][0]));
-      std::cerr << "Broadcast index to " << num_gpus << " GPUs in " << GetRealTime() - t0 << "s.\n";
+    SignalBatch ref_signals;
+    for (uint32_t i = 0; i < num_refs; ++i) reference.PrepareNegativeSequenceAt(i);
+    ref_signals.ConvertSequencesToSignals(reference, pore_model, num_refs);
+    std::vector<float> sig;
+    std::vector<uint64_t> off(1, 0);
+    for (uint32_t i = 0; i < num_refs; ++i) {
+      const Signal &s = ref_signals.GetSignalAt(i);
+      ZscoreNormalize(s.signal_values.data(), s.signal_values.size(), sig);
+      off.push_back(sig.size());
+      ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
+      off.push_back(sig.size());
     }
+    // one copy per GPU: its first context uploads, the others borrow (like the index)
     for (int g = 0; g < num_gpus; ++g) {
-      smhip_index_dev shared;
-      if (smhip_index_export(ctxs[g][0], &shared) != SMHIP_OK)
-        ExitWithMessage(std::string("Index export failed: ") + smhip_last_error(ctxs[g][0]));
-      for (size_t k = 1; k < ctxs[g].size(); ++k)
-        if (smhip_index_attach(ctxs[g][k], &shared) != SMHIP_OK)
-          ExitWithMessage(std::string("Index attach failed: ") + smhip_last_error(ctxs[g][k]));
-    }
-    phase("Index resident on the device(s)");
-    if (sdtw_band > 0) {  // z-scored expected signal of every contig strand (sigmap.cc:566-591)
-      PoreModel pore_model;
-      pore_model.Load(pore_model_file_path_);
-      SignalBatch ref_signals;
-      for (uint32_t i = 0; i < num_refs; ++i) reference.PrepareNegativeSequenceAt(i);
-      ref_signals.ConvertSequencesToSignals(reference, pore_model, num_refs);
-      std::vector<float> sig;
-      std::vector<uint64_t> off(1, 0);
-      for (uint32_t i = 0; i < num_refs; ++i) {
-        const Signal &s = ref_signals.GetSignalAt(i);
-        ZscoreNormalize(s.signal_values.data(), s.signal_values.size(), sig);
-        off.push_back(sig.size());
-        ZscoreNormalize(s.negative_signal_values.data(), s.negative_signal_values.size(), sig);
-        off.push_back(sig.size());
-      }
-      // one copy per GPU: its first context uploads, the others borrow (like the index)
-      for (int g = 0; g < num_gpus; ++g) {
-        smhip_ctx *owner = share_device ? ctxs[0][0] : ctxs[g][0];
-        for (smhip_ctx *c : ctxs[g]) {
-          const int rc = c == owner ? smhip_reference_upload(c, sig.data(), off.data(), num_refs)
-                                    : smhip_reference_share(c, owner);
-          if (rc != SMHIP_OK) ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
-        }
+      smhip_ctx *owner = share_device ? ctxs[0][0] : ctxs[g][0];
+      for (smhip_ctx *c : ctxs[g]) {
+        const int rc = c == owner ? smhip_reference_upload(c, sig.data(), off.data(), num_refs)
+                                  : smhip_reference_share(c, owner);
+        if (rc != SMHIP_OK) ExitWithMessage(std::string("Reference signal upload failed: ") + smhip_last_error(c));
       }
     }
-    smhip_params dp;
-    smhip_default_params(&dp);
-    dp.search_radius = params_.search_radius;
-    dp.step_size = params_.read_seeding_step_size;
+  }
+  smhip_params dp;
+  smhip_default_params(&dp);
+  dp.search_radius = params_.search_radius;
+  dp.step_size = params_.read_seeding_step_size;
 
-    const uint32_t chunk_size = 4000;
-    struct ReadState {
-      uint32_t chunk_index = 0;  // next chunk to process
-      uint32_t num_events = 0;
-      uint32_t slot = 0;         // resident slot on the read's context while it is in flight
-      smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
-      float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
-      bool has_dt = false;
-      std::string cigar;               // per-base CIGAR of DTW()'s banded path (when --sdtw-cigar)
-      std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
-      double start_time = 0;
-    };
-    std::vector<ReadState> st(num_reads);
-    std::vector<uint32_t> num_chunks(num_reads, 0);
-    for (size_t r = 0; r < num_reads; ++r) memset(&st[r].last, 0, sizeof(smhip_chunk_result));
-    const uint32_t max_chunks = (uint32_t)std::max(0, params_.max_num_chunks);
-    // every context gets an equal share of the batch budget, so that `max_batch_chunks` bounds the
-    // chunks in flight on a GPU as it does with one context; a slot keeps the samples of the chunks
-    // a read may use (sigmap.cc:647: at most max_num_chunks), within 8 GiB of slots per context
-    const uint32_t keep = std::max<uint32_t>(1, std::min<uint32_t>(max_chunks, 1u << 16)) * chunk_size;
-    size_t lane_budget = std::max<size_t>(1, max_batch_chunks / (size_t)num_streams);
-    lane_budget = std::max<size_t>(1, std::min<size_t>(lane_budget, ((size_t)8 << 30) / ((size_t)keep * sizeof(float))));
-    {
-      // ... and within the memory the GPU has left: per chunk in flight a context needs its read slot, ~288 queries x
-      // (8 KB of hit slots + ~1.4 KB of per-query records and overflow pool) and ~60 bytes per anchor (estimated
-      // from the index size); half of the free memory is left to the anchor-sized buffers of large references and
-      // to growth.  (A default budget that an MI355X takes in its stride fails on a smaller device otherwise.)
-      uint64_t free_b = 0, total_b = 0;
-      if (smhip_mem_info(ctxs[0][0], &free_b, &total_b) == SMHIP_OK && free_b > 0) {
-        // anchors per query = mean over the census of the index (its own points as queries) of min(hits, cap);
-        // fast hit slots as the device will choose them from the same census (sigmap_hip.h)
-        std::vector<uint32_t> census(4096);
-        uint32_t n_census = 0;
-        double hits_per_query = 1.7e-6 * (double)index.tree().m_size;  // (fallback: uniform random genome, 41 at 12 Mb, 850 at 250 Mb)
-        uint32_t fast_slots = 512;
-        if (smhip_index_census(ctxs[0][0], &dp, census.data(), (uint32_t)census.size(), &n_census) == SMHIP_OK && n_census > 0) {
-          double sum = 0;
-          for (uint32_t i = 0; i < n_census; ++i) sum += std::min<uint32_t>(census[i], (uint32_t)dp.num_nearest_points);
-          hits_per_query = sum / n_census;
-          const uint32_t q75 = census[((size_t)n_census * 3) / 4];
-          while (fast_slots < 2048 && fast_slots < q75) fast_slots <<= 1;
-        }
-        const double per_chunk = (double)keep * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
-                                 288.0 * std::min(hits_per_query, 5000.0) * 60.0 + 120000.0;
-        const size_t contexts_here = (size_t)num_streams * (share_device ? (size_t)num_gpus : 1u);
-        const size_t fit = (size_t)((double)free_b * 0.5 / per_chunk / (double)contexts_here);
-        if (fit < lane_budget) {
-          std::cerr << "Chunks in flight per context limited to " << std::max<size_t>(fit, 1) << " of " << lane_budget
-                    << " by the device's free memory (" << (free_b >> 20) << " MiB).\n";
-          lane_budget = std::max<size_t>(fit, 1);
-        }
+  const uint32_t chunk_size = 4000;
+  struct ReadState {
+    uint32_t chunk_index = 0;  // next chunk to process
+    uint32_t num_events = 0;
+    uint32_t slot = 0;         // resident slot on the read's context while it is in flight
+    smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
+    float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
+    bool has_dt = false;
+    std::string cigar;               // per-base CIGAR of DTW()'s banded path (when --sdtw-cigar)
+    std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
+    double start_time = 0;
+  };
+  std::vector<ReadState> st(num_reads);
+  std::vector<uint32_t> num_chunks(num_reads, 0);
+  for (size_t r = 0; r < num_reads; ++r) memset(&st[r].last, 0, sizeof(smhip_chunk_result));
+  const uint32_t max_chunks = (uint32_t)std::max(0, params_.max_num_chunks);
+  // every context gets an equal share of the batch budget, so that `max_batch_chunks` bounds the
+  // chunks in flight on a GPU as it does with one context; a slot keeps the samples of the chunks
+  // a read may use (sigmap.cc:647: at most max_num_chunks), within 8 GiB of slots per context
+  const uint32_t keep = std::max<uint32_t>(1, std::min<uint32_t>(max_chunks, 1u << 16)) * chunk_size;
+  size_t lane_budget = std::max<size_t>(1, max_batch_chunks / (size_t)num_streams);
+  lane_budget = std::max<size_t>(1, std::min<size_t>(lane_budget, ((size_t)8 << 30) / ((size_t)keep * sizeof(float))));
+  {
+    // ... and within the memory the GPU has left: per chunk in flight a context needs its read slot, ~288 queries x
+    // (8 KB of hit slots + ~1.4 KB of per-query records and overflow pool) and ~60 bytes per anchor (estimated
+    // from the index size); half of the free memory is left to the anchor-sized buffers of large references and
+    // to growth.  (A default budget that an MI355X takes in its stride fails on a smaller device otherwise.)
+    uint64_t free_b = 0, total_b = 0;
+    if (smhip_mem_info(ctxs[0][0], &free_b, &total_b) == SMHIP_OK && free_b > 0) {
+      // anchors per query = mean over the census of the index (its own points as queries) of min(hits, cap);
+      // fast hit slots as the device will choose them from the same census (sigmap_hip.h)
+      std::vector<uint32_t> census(4096);
+      uint32_t n_census = 0;
+      double hits_per_query = 1.7e-6 * (double)index.tree().m_size;  // (fallback: uniform random genome, 41 at 12 Mb, 850 at 250 Mb)
+      uint32_t fast_slots = 512;
+      if (smhip_index_census(ctxs[0][0], &dp, census.data(), (uint32_t)census.size(), &n_census) == SMHIP_OK && n_census > 0) {
+        double sum = 0;
+        for (uint32_t i = 0; i < n_census; ++i) sum += std::min<uint32_t>(census[i], (uint32_t)dp.num_nearest_points);
+        hits_per_query = sum / n_census;
+        const uint32_t q75 = census[((size_t)n_census * 3) / 4];
+        while (fast_slots < 2048 && fast_slots < q75) fast_slots <<= 1;
+      }
+      const double per_chunk = (double)keep * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
+                               288.0 * std::min(hits_per_query, 5000.0) * 60.0 + 120000.0;
+      const size_t contexts_here = (size_t)num_streams * (share_device ? (size_t)num_gpus : 1u);
+      const size_t fit = (size_t)((double)free_b * 0.5 / per_chunk / (double)contexts_here);
+      if (fit < lane_budget) {
+        std::cerr << "Chunks in flight per context limited to " << std::max<size_t>(fit, 1) << " of " << lane_budget
+                  << " by the device's free memory (" << (free_b >> 20) << " MiB).\n";
+        lane_budget = std::max<size_t>(fit, 1);
       }
     }
-    // read slots of every context: set-up like the index, before the mapping span
-    for (auto &gpu : ctxs)
-      for (smhip_ctx *c : gpu)
-        if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
-            smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
-          ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
-                          " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
-    phase("Reserved read slots and batch buffers");
-    const double t_map = GetRealTime();
-    // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
-    // in order and stay with the context that admitted them (chain carry-over is per read)
-    std::vector<size_t> block((size_t)num_gpus + 1), cursor((size_t)num_gpus);
-    for (int g = 0; g <= num_gpus; ++g) ShardRange(num_reads, g, num_gpus, g < num_gpus ? &block[g] : nullptr, nullptr);
-    block[num_gpus] = num_reads;
-    for (int g = 0; g < num_gpus; ++g) cursor[g] = block[g];
-    std::vector<std::mutex> cursor_mutex((size_t)num_gpus);
-    auto lane = [&](int g, smhip_ctx *ctx) {
-      std::vector<uint32_t> free_slots(lane_budget);
-      for (size_t k = 0; k < lane_budget; ++k) free_slots[k] = (uint32_t)(lane_budget - 1 - k);
-      std::vector<size_t> batch, in_flight;
-      std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, up_slots, pa_len;
-      std::vector<uint64_t> raw_off;
-      std::vector<float> dig, rng, ofs;
-      std::vector<smhip_carried_anchor> carried, out_anchors;
-      std::vector<smhip_chunk_result> results;
-      std::vector<uint64_t> out_off;
-      std::vector<float> dts, pdist;
-      std::vector<int64_t> dte, pend, pstart;
-      std::vector<uint32_t> plen;
-      std::vector<uint64_t> poff;
-      std::vector<uint8_t> pcodes;
-      auto finish = [&](size_t r) {
-        ReadState &s = st[r];
-        free_slots.push_back(s.slot);
-        s.anchors.clear();
-        s.anchors.shrink_to_fit();
-        s.start_time = (GetRealTime() - s.start_time) * 1000;
-      };
-      while (true) {
-        size_t a = 0, b = 0;
-        {  // admit new reads up to the free slots of this context
-          std::lock_guard<std::mutex> lock(cursor_mutex[g]);
-          a = cursor[g];
-          b = std::min(block[g + 1], a + free_slots.size());
-          cursor[g] = b;
-        }
-        // their ADC counts go to the device, one DMA per run of reads inside one arena block
-        for (size_t r0 = a; r0 < b;) {
-          size_t r1 = r0;
-          const uint32_t blk = reads.GetSignalAt(r0).raw_block;
-          const int16_t *base = reads.RawBlockBase(blk);
-          raw_off.clear(); dig.clear(); rng.clear(); ofs.clear(); up_slots.clear();
-          const double now = GetRealTime();
-          for (; r1 < b && reads.GetSignalAt(r1).raw_block == blk; ++r1) {
-            const Signal &sig = reads.GetSignalAt(r1);
-            raw_off.push_back((uint64_t)(sig.raw - base));
-            dig.push_back(sig.digitisation);
-            rng.push_back(sig.range);
-            ofs.push_back(sig.offset);
-            st[r1].slot = free_slots.back();
-            free_slots.pop_back();
-            up_slots.push_back(st[r1].slot);
-            st[r1].start_time = now;
-          }
-          const Signal &last = reads.GetSignalAt(r1 - 1);
-          raw_off.push_back((uint64_t)(last.raw - base) + last.n_raw);
-          pa_len.resize(r1 - r0);
-          if (smhip_reads_upload_raw(ctx, base, raw_off.data(), dig.data(), rng.data(), ofs.data(), up_slots.data(),
-                                     (uint32_t)(r1 - r0), pa_len.data()) != SMHIP_OK)
-            ExitWithMessage(std::string("Read upload failed: ") + smhip_last_error(ctx));
-          for (size_t r = r0; r < r1; ++r) {
-            reads.SetFilteredLengthAt(r, pa_len[r - r0]);            // Signal::signal_values.size() of the reference
-            num_chunks[r] = (uint32_t)(pa_len[r - r0] / chunk_size);  // sigmap.cc:643
-            if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
-            else in_flight.push_back(r);
-          }
-          r0 = r1;
-        }
-        if (in_flight.empty()) {
-          if (a == b) break;  // nothing in flight, nothing left to admit
-          continue;
-        }
-        batch = in_flight;
-        slots.clear(); chunk_idx.clear(); qstart.clear(); carried.clear();
-        carried_off.assign(1, 0);
-        for (size_t r : batch) {
-          slots.push_back(st[r].slot);
-          chunk_idx.push_back(st[r].chunk_index);
-          qstart.push_back(st[r].num_events);
-          carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
-          carried_off.push_back((uint32_t)carried.size());
-        }
-        results.resize(batch.size());
-        out_off.resize(batch.size() + 1);
-        int rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)batch.size(), qstart.data(),
-                                    carried.empty() ? nullptr : carried.data(),
-                                    carried.empty() ? nullptr : carried_off.data());
-        if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
-        if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
-        if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
-        if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
-        dts.resize(batch.size());
-        dte.resize(batch.size());
-        if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
-        if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) {
-          pdist.resize(batch.size()); pend.resize(batch.size()); pstart.resize(batch.size());
-          plen.resize(batch.size()); poff.resize(batch.size() + 1);
-          rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(), nullptr, 0);
-          if (rc == SMHIP_OK) {
-            pcodes.resize(std::max<uint64_t>(poff[batch.size()], 1));
-            rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(),
-                                            pcodes.data(), pcodes.size());
-          }
-        }
-        // the result records first; the anchors of the chains (the next chunk's carry-over,
-        // spatial_index.cc:303-322) only when some read of the batch goes on to another chunk
-        if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
-        if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
-        bool any_continues = false;
-        for (size_t bi = 0; bi < batch.size() && !any_continues; ++bi) {
-          const size_t r = batch[bi];
-          const smhip_chunk_result &res = results[bi];
-          const bool stop = res.n_features > 50 && ShouldStopMapping(res, params_);
-          any_continues = !stop && st[r].chunk_index + 1 < num_chunks[r] && st[r].chunk_index + 1 < max_chunks;
-        }
-        if (any_continues) {
-          uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
-          while (rc == SMHIP_OK) {
-            out_anchors.resize(cap);
-            rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
-            if (rc != SMHIP_ECAP) break;
-            cap *= 4;
-            rc = SMHIP_OK;
-          }
-          if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
-        }
-        in_flight.clear();
-        for (size_t bi = 0; bi < batch.size(); ++bi) {
-          const size_t r = batch[bi];
-          ReadState &s = st[r];
-          const smhip_chunk_result &res = results[bi];
-          // a device-side capacity was exceeded: the records of this chunk may differ from the
-          // reference's, so nothing is written from them (the flags are not expected on any input)
-          if (res.status & ~SMHIP_ST_FEW_PEAKS)
-            ExitWithMessage(std::string("read ") + reads.GetSignalNameAt(r) + ": device capacity flag " +
-                            std::to_string(res.status) + " (include/sigmap_hip.h, SMHIP_ST_*)");
-          bool stop = false;
-          if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
-            s.last = res;
-            s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
-            s.dt = dts[bi];
-            s.cigar.clear();
-            if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen[bi]);
-            s.num_events += res.n_features;
-            stop = ShouldStopMapping(res, params_);
-            if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
-              s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
-          }
-          if (!stop) {
-            ++s.chunk_index;
-            if (s.chunk_index < num_chunks[r] && s.chunk_index < max_chunks) {
-              in_flight.push_back(r);
-              continue;
-            }
-          }
-          finish(r);
-        }
-      }
-    };
-    {
-      std::vector<std::thread> workers;
-      for (int g = 0; g < num_gpus; ++g)
-        for (size_t k = 0; k < ctxs[g].size(); ++k)
-          if (g || k) workers.emplace_back(lane, g, ctxs[g][k]);
-      lane(0, ctxs[0][0]);
-      for (auto &w : workers) w.join();
-    }
-    std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
-
-    // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
-    // (whichever GPU and context mapped a read)
-    std::vector<std::vector<std::string>> rows(std::max<uint32_t>(num_refs, 1));
-    for (size_t r = 0; r < num_reads; ++r) {
+  }
+  // read slots of every context: set-up like the index, before the mapping span
+  for (auto &gpu : ctxs)
+    for (smhip_ctx *c : gpu)
+      if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
+          smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
+        ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
+                        " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
+  phase("Reserved read slots and batch buffers");
+  const double t_map = GetRealTime();
+  // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
+  // in order and stay with the context that admitted them (chain carry-over is per read)
+  std::vector<size_t> block((size_t)num_gpus + 1), cursor((size_t)num_gpus);
+  for (int g = 0; g <= num_gpus; ++g) ShardRange(num_reads, g, num_gpus, g < num_gpus ? &block[g] : nullptr, nullptr);
+  block[num_gpus] = num_reads;
+  for (int g = 0; g < num_gpus; ++g) cursor[g] = block[g];
+  std::vector<std::mutex> cursor_mutex((size_t)num_gpus);
+  auto lane = [&](int g, smhip_ctx *ctx) {
+    std::vector<uint32_t> free_slots(lane_budget);
+    for (size_t k = 0; k < lane_budget; ++k) free_slots[k] = (uint32_t)(lane_budget - 1 - k);
+    std::vector<size_t> batch, in_flight;
+    std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, up_slots, pa_len;
+    std::vector<uint64_t> raw_off;
+    std::vector<float> dig, rng, ofs;
+    std::vector<smhip_carried_anchor> carried, out_anchors;
+    std::vector<smhip_chunk_result> results;
+    std::vector<uint64_t> out_off;
+    std::vector<float> dts, pdist;
+    std::vector<int64_t> dte, pend, pstart;
+    std::vector<uint32_t> plen;
+    std::vector<uint64_t> poff;
+    std::vector<uint8_t> pcodes;
+    auto finish = [&](size_t r) {
       ReadState &s = st[r];
-      uint32_t chunk_index = s.chunk_index;  // sigmap.cc:690-693
-      if (chunk_index > 0 && (chunk_index == num_chunks[r] || chunk_index == max_chunks)) --chunk_index;
-      uint32_t bucket = 0;
-      const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
-                                       (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
-                                       params_, true, s.start_time, &bucket, s.has_dt ? &s.dt : nullptr,
-                                       sdtw_cigar ? &s.cigar : nullptr);
-      rows[bucket].push_back(FormatPAF(m, num_refs ? reference.GetSequenceNameAt(bucket) : "*",
-                                       num_refs ? ref_lengths[bucket] : 0));
-    }
-    FILE *out = fopen(output_file_path_.c_str(), "w");
-    if (!out) ExitWithMessage("Cannot open output file " + output_file_path_);
-    for (auto &g : rows)
-      for (auto &line : g) fputs(line.c_str(), out);
-    fclose(out);
-    for (int g = num_gpus; g-- > 0;)
-      for (size_t k = ctxs[g].size(); k-- > 0;) smhip_destroy(ctxs[g][k]);  // borrowers first
-  }
-
-  // Development mode `--features events|cwt -s DIR -o OUT` (no index, no reference): the feature signal the
-  // mapping path (events: Sigmap::GenerateEvents, sigmap.cc:1048-1083) or the reference's dormant CWT path
-  // (cwt: Sigmap::GenerateFeatureSignalUsingCWT, sigmap.cc:1085-1098, scale0 = 8 as for reads, :947) derives from
-  // every 4000-sample chunk of every read, computed on the GPU, as text: `read<TAB>chunk<TAB>k<TAB>position<TAB>value`
-  // with %f values like the reference's disabled debugging dumps (EventsToText, sigmap.cc:1198-1235, which writes
-  // the z-scored event means of whole reads, one `%f` per line).  position = sample index of a CWT peak / valley
-  // inside its chunk; 0 for events (the compression drops the spans).
-  static void DumpFeatures(const std::string &kind, int device, const std::string &signal_directory,
-                           const std::string &output_file_path) {
-    if (kind != "events" && kind != "cwt") ExitWithMessage("--features takes `events` or `cwt`");
-    SignalBatch reads;
-    reads.InitializeLoading(signal_directory);
-    const size_t num_reads = reads.LoadAllReadSignals();  // host conversion: pA, (30, 200) filter
-    smhip_ctx *ctx = nullptr;
-    if (smhip_init(device, &ctx) != SMHIP_OK) ExitWithMessage("No usable GPU (smhip_init failed).");
-    smhip_params dp;
-    smhip_default_params(&dp);
-    FILE *out = fopen(output_file_path.c_str(), "w");
-    if (!out) ExitWithMessage("Cannot open output file " + output_file_path);
-    const uint32_t chunk_size = 4000, stride = 2736, batch_chunks = 4096;
-    std::vector<float> samples, feat((size_t)batch_chunks * stride), stdv;
-    std::vector<uint32_t> offsets(1, 0), pos((size_t)batch_chunks * stride), nf(batch_chunks), owner, chunk_of;
-    auto flush = [&]() {
-      const uint32_t n = (uint32_t)owner.size();
-      if (n == 0) return;
-      int rc;
-      if (kind == "cwt") {
-        rc = smhip_cwt_features(ctx, samples.data(), offsets.data(), n, 8.0f, stride, feat.data(), pos.data(), nf.data(),
-                                nullptr);
-      } else {
-        stdv.resize((size_t)n * stride);
-        rc = smhip_events(ctx, &dp, samples.data(), offsets.data(), n, stride, feat.data(), stdv.data(), nf.data(), nullptr,
-                          nullptr);
-      }
-      if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU feature extraction failed: ") + smhip_last_error(ctx));
-      for (uint32_t c = 0; c < n; ++c)
-        for (uint32_t k = 0; k < std::min(nf[c], stride); ++k)
-          fprintf(out, "%s\t%u\t%u\t%u\t%f\n", reads.GetSignalNameAt(owner[c]), chunk_of[c], k,
-                  kind == "cwt" ? pos[(size_t)c * stride + k] : 0u, feat[(size_t)c * stride + k]);
-      samples.clear();
-      offsets.assign(1, 0);
-      owner.clear();
-      chunk_of.clear();
+      free_slots.push_back(s.slot);
+      s.anchors.clear();
+      s.anchors.shrink_to_fit();
+      s.start_time = (GetRealTime() - s.start_time) * 1000;
     };
-    for (size_t r = 0; r < num_reads; ++r) {
-      const std::vector<float> &v = reads.GetSignalAt(r).signal_values;
-      for (uint32_t c = 0; (size_t)(c + 1) * chunk_size <= v.size(); ++c) {  // whole chunks only (sigmap.cc:643)
-        samples.insert(samples.end(), v.begin() + (size_t)c * chunk_size, v.begin() + (size_t)(c + 1) * chunk_size);
-        offsets.push_back((uint32_t)samples.size());
-        owner.push_back((uint32_t)r);
-        chunk_of.push_back(c);
-        if (owner.size() == batch_chunks) flush();
+    while (true) {
+      size_t a = 0, b = 0;
+      {  // admit new reads up to the free slots of this context
+        std::lock_guard<std::mutex> lock(cursor_mutex[g]);
+        a = cursor[g];
+        b = std::min(block[g + 1], a + free_slots.size());
+        cursor[g] = b;
+      }
+      // their ADC counts go to the device, one DMA per run of reads inside one arena block
+      for (size_t r0 = a; r0 < b;) {
+        size_t r1 = r0;
+        const uint32_t blk = reads.GetSignalAt(r0).raw_block;
+        const int16_t *base = reads.RawBlockBase(blk);
+        raw_off.clear(); dig.clear(); rng.clear(); ofs.clear(); up_slots.clear();
+        const double now = GetRealTime();
+        for (; r1 < b && reads.GetSignalAt(r1).raw_block == blk; ++r1) {
+          const Signal &sig = reads.GetSignalAt(r1);
+          raw_off.push_back((uint64_t)(sig.raw - base));
+          dig.push_back(sig.digitisation);
+          rng.push_back(sig.range);
+          ofs.push_back(sig.offset);
+          st[r1].slot = free_slots.back();
+          free_slots.pop_back();
+          up_slots.push_back(st[r1].slot);
+          st[r1].start_time = now;
+        }
+        const Signal &last = reads.GetSignalAt(r1 - 1);
+        raw_off.push_back((uint64_t)(last.raw - base) + last.n_raw);
+        pa_len.resize(r1 - r0);
+        if (smhip_reads_upload_raw(ctx, base, raw_off.data(), dig.data(), rng.data(), ofs.data(), up_slots.data(),
+                                   (uint32_t)(r1 - r0), pa_len.data()) != SMHIP_OK)
+          ExitWithMessage(std::string("Read upload failed: ") + smhip_last_error(ctx));
+        for (size_t r = r0; r < r1; ++r) {
+          reads.SetFilteredLengthAt(r, pa_len[r - r0]);            // Signal::signal_values.size() of the reference
+          num_chunks[r] = (uint32_t)(pa_len[r - r0] / chunk_size);  // sigmap.cc:643
+          if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
+          else in_flight.push_back(r);
+        }
+        r0 = r1;
+      }
+      if (in_flight.empty()) {
+        if (a == b) break;  // nothing in flight, nothing left to admit
+        continue;
+      }
+      batch = in_flight;
+      slots.clear(); chunk_idx.clear(); qstart.clear(); carried.clear();
+      carried_off.assign(1, 0);
+      for (size_t r : batch) {
+        slots.push_back(st[r].slot);
+        chunk_idx.push_back(st[r].chunk_index);
+        qstart.push_back(st[r].num_events);
+        carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
+        carried_off.push_back((uint32_t)carried.size());
+      }
+      results.resize(batch.size());
+      out_off.resize(batch.size() + 1);
+      int rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)batch.size(), qstart.data(),
+                                  carried.empty() ? nullptr : carried.data(),
+                                  carried.empty() ? nullptr : carried_off.data());
+      if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
+      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
+      if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
+      if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+      dts.resize(batch.size());
+      dte.resize(batch.size());
+      if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
+      if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) {
+        pdist.resize(batch.size()); pend.resize(batch.size()); pstart.resize(batch.size());
+        plen.resize(batch.size()); poff.resize(batch.size() + 1);
+        rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(), nullptr, 0);
+        if (rc == SMHIP_OK) {
+          pcodes.resize(std::max<uint64_t>(poff[batch.size()], 1));
+          rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(),
+                                          pcodes.data(), pcodes.size());
+        }
+      }
+      // the result records first; the anchors of the chains (the next chunk's carry-over,
+      // spatial_index.cc:303-322) only when some read of the batch goes on to another chunk
+      if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
+      if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+      bool any_continues = false;
+      for (size_t bi = 0; bi < batch.size() && !any_continues; ++bi) {
+        const size_t r = batch[bi];
+        const smhip_chunk_result &res = results[bi];
+        const bool stop = res.n_features > 50 && ShouldStopMapping(res, params_);
+        any_continues = !stop && st[r].chunk_index + 1 < num_chunks[r] && st[r].chunk_index + 1 < max_chunks;
+      }
+      if (any_continues) {
+        uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
+        while (rc == SMHIP_OK) {
+          out_anchors.resize(cap);
+          rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
+          if (rc != SMHIP_ECAP) break;
+          cap *= 4;
+          rc = SMHIP_OK;
+        }
+        if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+      }
+      in_flight.clear();
+      for (size_t bi = 0; bi < batch.size(); ++bi) {
+        const size_t r = batch[bi];
+        ReadState &s = st[r];
+        const smhip_chunk_result &res = results[bi];
+        // a device-side capacity was exceeded: the records of this chunk may differ from the
+        // reference's, so nothing is written from them (the flags are not expected on any input)
+        if (res.status & ~SMHIP_ST_FEW_PEAKS)
+          ExitWithMessage(std::string("read ") + reads.GetSignalNameAt(r) + ": device capacity flag " +
+                          std::to_string(res.status) + " (include/sigmap_hip.h, SMHIP_ST_*)");
+        bool stop = false;
+        if (res.n_features > 50) {  // sigmap.cc:660: GenerateChains only then; chains persist otherwise
+          s.last = res;
+          s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
+          s.dt = dts[bi];
+          s.cigar.clear();
+          if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen[bi]);
+          s.num_events += res.n_features;
+          stop = ShouldStopMapping(res, params_);
+          if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
+            s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
+        }
+        if (!stop) {
+          ++s.chunk_index;
+          if (s.chunk_index < num_chunks[r] && s.chunk_index < max_chunks) {
+            in_flight.push_back(r);
+            continue;
+          }
+        }
+        finish(r);
       }
     }
-    flush();
-    fclose(out);
-    smhip_destroy(ctx);
-    std::cerr << "Wrote the " << kind << " features of " << num_reads << " reads.\n";
+  };
+  {
+    std::vector<std::thread> workers;
+    for (int g = 0; g < num_gpus; ++g)
+      for (size_t k = 0; k < ctxs[g].size(); ++k)
+        if (g || k) workers.emplace_back(lane, g, ctxs[g][k]);
+    lane(0, ctxs[0][0]);
+    for (auto &w : workers) w.join();
   }
+  std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
 
- protected:
-  int dimension_ = 6, max_leaf_ = 20;
-  MappingParams params_;
-  int num_threads_ = 1;
-  std::string reference_file_path_, pore_model_file_path_, signal_directory_, reference_index_file_path_,
-      output_file_path_;
-};
+  // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
+  // (whichever GPU and context mapped a read)
+  std::vector<std::vector<std::string>> rows(std::max<uint32_t>(num_refs, 1));
+  for (size_t r = 0; r < num_reads; ++r) {
+    ReadState &s = st[r];
+    uint32_t chunk_index = s.chunk_index;  // sigmap.cc:690-693
+    if (chunk_index > 0 && (chunk_index == num_chunks[r] || chunk_index == max_chunks)) --chunk_index;
+    uint32_t bucket = 0;
+    const PAFMapping m = MakeMapping(s.last, (uint32_t)r, reads.GetSignalNameAt(r),
+                                     (uint32_t)reads.GetSignalLengthAt(r), chunk_index, s.num_events, ref_lengths,
+                                     params_, true, s.start_time, &bucket, s.has_dt ? &s.dt : nullptr,
+                                     sdtw_cigar ? &s.cigar : nullptr);
+    rows[bucket].push_back(FormatPAF(m, num_refs ? reference.GetSequenceNameAt(bucket) : "*",
+                                     num_refs ? ref_lengths[bucket] : 0));
+  }
+  FILE *out = fopen(output_file_path_.c_str(), "w");
+  if (!out) ExitWithMessage("Cannot open output file " + output_file_path_);
+  for (auto &g : rows)
+    for (auto &line : g) fputs(line.c_str(), out);
+  fclose(out);
+  for (int g = num_gpus; g-- > 0;)
+    for (size_t k = ctxs[g].size(); k-- > 0;) smhip_destroy(ctxs[g][k]);  // borrowers first
+}
+
+// Development mode `--features events|cwt -s DIR -o OUT` (no index, no reference): the feature signal the
+// mapping path (events: Sigmap::GenerateEvents, sigmap.cc:1048-1083) or the reference's dormant CWT path
+// (cwt: Sigmap::GenerateFeatureSignalUsingCWT, sigmap.cc:1085-1098, scale0 = 8 as for reads, :947) derives from
+// every 4000-sample chunk of every read, computed on the GPU, as text: `read<TAB>chunk<TAB>k<TAB>position<TAB>value`
+// with %f values like the reference's disabled debugging dumps (EventsToText, sigmap.cc:1198-1235, which writes
+// the z-scored event means of whole reads, one `%f` per line).  position = sample index of a CWT peak / valley
+// inside its chunk; 0 for events (the compression drops the spans).
+void Sigmap::DumpFeatures(const std::string &kind, int device, const std::string &signal_directory,
+                         const std::string &output_file_path) {
+  if (kind != "events" && kind != "cwt") ExitWithMessage("--features takes `events` or `cwt`");
+  SignalBatch reads;
+  reads.InitializeLoading(signal_directory);
+  const size_t num_reads = reads.LoadAllReadSignals();  // host conversion: pA, (30, 200) filter
+  smhip_ctx *ctx = nullptr;
+  if (smhip_init(device, &ctx) != SMHIP_OK) ExitWithMessage("No usable GPU (smhip_init failed).");
+  smhip_params dp;
+  smhip_default_params(&dp);
+  FILE *out = fopen(output_file_path.c_str(), "w");
+  if (!out) ExitWithMessage("Cannot open output file " + output_file_path);
+  const uint32_t chunk_size = 4000, stride = 2736, batch_chunks = 4096;
+  std::vector<float> samples, feat((size_t)batch_chunks * stride), stdv;
+  std::vector<uint32_t> offsets(1, 0), pos((size_t)batch_chunks * stride), nf(batch_chunks), owner, chunk_of;
+  auto flush = [&]() {
+    const uint32_t n = (uint32_t)owner.size();
+    if (n == 0) return;
+    int rc;
+    if (kind == "cwt") {
+      rc = smhip_cwt_features(ctx, samples.data(), offsets.data(), n, 8.0f, stride, feat.data(), pos.data(), nf.data(),
+                              nullptr);
+    } else {
+      stdv.resize((size_t)n * stride);
+      rc = smhip_events(ctx, &dp, samples.data(), offsets.data(), n, stride, feat.data(), stdv.data(), nf.data(), nullptr,
+                        nullptr);
+    }
+    if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU feature extraction failed: ") + smhip_last_error(ctx));
+    for (uint32_t c = 0; c < n; ++c)
+      for (uint32_t k = 0; k < std::min(nf[c], stride); ++k)
+        fprintf(out, "%s\t%u\t%u\t%u\t%f\n", reads.GetSignalNameAt(owner[c]), chunk_of[c], k,
+                kind == "cwt" ? pos[(size_t)c * stride + k] : 0u, feat[(size_t)c * stride + k]);
+    samples.clear();
+    offsets.assign(1, 0);
+    owner.clear();
+    chunk_of.clear();
+  };
+  for (size_t r = 0; r < num_reads; ++r) {
+    const std::vector<float> &v = reads.GetSignalAt(r).signal_values;
+    for (uint32_t c = 0; (size_t)(c + 1) * chunk_size <= v.size(); ++c) {  // whole chunks only (sigmap.cc:643)
+      samples.insert(samples.end(), v.begin() + (size_t)c * chunk_size, v.begin() + (size_t)(c + 1) * chunk_size);
+      offsets.push_back((uint32_t)samples.size());
+      owner.push_back((uint32_t)r);
+      chunk_of.push_back(c);
+      if (owner.size() == batch_chunks) flush();
+    }
+  }
+  flush();
+  fclose(out);
+  smhip_destroy(ctx);
+  std::cerr << "Wrote the " << kind << " features of " << num_reads << " reads.\n";
+}
+
 
 namespace {
 struct Args {

@@ -1,8 +1,9 @@
 // spatial_index.h -- host side of the reference point-cloud index (API of the reference's
 // SpatialIndex, spatial_index.h:47-117): construction, `.pt`/`.si` files, and the bridge
 // to the device-resident copy.  The query side (GenerateChains, spatial_index.cc:276-577)
-// runs on the GPU behind include/sigmap_hip.h; there is no CPU implementation of it in the
-// product.
+// runs on the GPU behind include/sigmap_hip.h -- batched in the command line (sigmap.cc), and as the
+// reference's own per-query method below (device_methods.cc: a one-chunk forward); there is no CPU
+// implementation of it in the product.
 #ifndef SIGMAP_AMD_SPATIALINDEX_H_
 #define SIGMAP_AMD_SPATIALINDEX_H_
 #include <cstdint>
@@ -10,6 +11,8 @@
 #include <vector>
 
 #include "kdtree.h"
+
+struct smhip_ctx;
 
 namespace sigmap {
 enum Direction { Negative = 0, Positive = 1 };
@@ -54,6 +57,18 @@ class SpatialIndex {
                  const std::vector<std::vector<float>> &negative_signals);
   void Save();  // PREFIX.pt + PREFIX.si, reference formats
   void Load();
+  ~SpatialIndex();
+
+  // ---- query side, the reference's signature (spatial_index.h:87-92): seeds of query_signal -> radius search ->
+  // anchors (+ the anchors of the chains handed in) -> sort -> chaining; `chains`: in = the previous chunk's chains,
+  // out = the new primary chains with their anchors (end -> start) and chain 0's MAPQ.  Runs on the GPU
+  // (smhip_generate_chains with one chunk).  BindDevice uploads this index to `ctx` (null: a context of its own on
+  // GPU 0, which the first GenerateChains also does by itself).  query_signal_stdvs is unused, as in the reference.
+  // Errors end the process with a message (utils.h:67 behaviour of the reference).
+  void BindDevice(smhip_ctx *ctx);
+  void GenerateChains(const std::vector<float> &query_signal, const std::vector<float> &query_signal_stdvs,
+                      uint32_t query_start_offset, int query_point_cloud_step_size, float search_radius,
+                      size_t num_target_signals, std::vector<SignalAnchorChain> &chains);
 
   void set_index_file_path_prefix(const std::string &p) { index_file_path_prefix_ = p; }
   int dimension() const { return dimension_; }
@@ -73,6 +88,8 @@ class SpatialIndex {
   std::vector<uint64_t> positions_;  // Point.position
   std::vector<float> values_;        // Point.value
   FlatKdTree tree_;
+  smhip_ctx *ctx_ = nullptr;         // device context the query side runs on (BindDevice)
+  bool owns_ctx_ = false;
 };
 
 // 11-mer style high-frequency mask (Sigmap::GenerateMaskedPositions, sigmap.cc:19-185):

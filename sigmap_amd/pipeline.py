@@ -181,6 +181,38 @@ class DeviceMapper:
         self._check(self.L.smhip_batch_upload(self._h, ptr(samples), ptr(offsets), self.n_chunks,
                                               ptr(qs), ptr(ca), ptr(co)), "smhip_batch_upload")
 
+    def upload_features(self, features, offsets, query_start_offsets=None, carried=None, carried_offsets=None):
+        """A batch of FEATURE signals (smhip_features_upload: GenerateChains' inputs); then run / sync / download."""
+        features = np.ascontiguousarray(features, dtype=np.float32)
+        if len(features) == 0:
+            features = np.zeros(1, np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        self.n_chunks = len(offsets) - 1
+        qs = None if query_start_offsets is None else np.ascontiguousarray(query_start_offsets, dtype=np.uint32)
+        ca = None if carried is None else np.ascontiguousarray(carried, dtype=_abi.CARRIED_DTYPE)
+        co = None if carried_offsets is None else np.ascontiguousarray(carried_offsets, dtype=np.uint32)
+        self._check(self.L.smhip_features_upload(self._h, ptr(features), ptr(offsets), self.n_chunks,
+                                                 ptr(qs), ptr(ca), ptr(co)), "smhip_features_upload")
+
+    def generate_chains(self, features, offsets, n_refs, with_anchors=False, **kw):
+        """SpatialIndex::GenerateChains for a batch of feature signals (smhip_generate_chains' steps)."""
+        self.upload_features(features, offsets, **kw)
+        self.run(n_refs)
+        self.sync()
+        return self.download(with_anchors=with_anchors)
+
+    def chain_anchors(self, anchors, anchor_offsets, n_refs, with_anchors=False):
+        """The chaining stage alone on caller-provided anchors (smhip_chain_anchors)."""
+        a = np.ascontiguousarray(anchors, dtype=_abi.CARRIED_DTYPE)
+        if len(a) == 0:
+            a = np.zeros(1, dtype=_abi.CARRIED_DTYPE)
+        ao = np.ascontiguousarray(anchor_offsets, dtype=np.uint32)
+        self.n_chunks = len(ao) - 1
+        res = np.zeros(self.n_chunks, dtype=_abi.RESULT_DTYPE)
+        self._check(self.L.smhip_chain_anchors(self._h, C.byref(self.params), n_refs, ptr(a), ptr(ao), self.n_chunks,
+                                               ptr(res)), "smhip_chain_anchors")
+        return self.download(with_anchors=True) if with_anchors else res
+
     def configure_reads(self, n_slots, keep_samples):
         """Resident read slots (SignalBatch::AddSignal on the device)."""
         self._check(self.L.smhip_reads_configure(self._h, n_slots, keep_samples), "smhip_reads_configure")
@@ -240,6 +272,14 @@ class DeviceMapper:
                 continue
             self._check(rc, "smhip_map_download")
             return res, anchors[:int(offs[-1])], offs
+
+    def download_chains(self):
+        """Every primary chain of every chunk (smhip_map_download_chains): (records, offsets)."""
+        offs = np.zeros(self.n_chunks + 1, dtype=np.uint64)
+        self._check(self.L.smhip_map_download_chains(self._h, None, 0, ptr(offs)), "smhip_map_download_chains")
+        chains = np.zeros(max(int(offs[-1]), 1), dtype=_abi.CHAIN_DTYPE)
+        self._check(self.L.smhip_map_download_chains(self._h, ptr(chains), len(chains), ptr(offs)), "smhip_map_download_chains")
+        return chains[:int(offs[-1])], offs
 
     def map_chunks(self, samples, offsets, n_refs, **kw):
         self.upload_batch(samples, offsets, **kw)

@@ -262,7 +262,7 @@ def test_set_walk_matches_reference_golden():
             n = off[k + 1] - off[k]
             assert counts[k] == n
             assert _hit_sets_equal(idx[k], dist[k], n, g["hit_idx"][off[k]:off[k + 1]], g["hit_dist"][off[k]:off[k + 1]]), k
-    assert int(counts.sum()) == int(off[-1]) and int(off[-1]) > 1000
+    assert int(counts.sum()) == int(off[-1]) and int(off[-1]) > 150 and int(counts.max()) >= 3
     # a cap below a query's hit count: the count is still the total, the stored hits are a subset of the set
     counts2, idx2, dist2, _, _ = dev.seed_lookup(g["queries"], cap=4)
     assert np.array_equal(counts2, counts)
