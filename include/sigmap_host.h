@@ -83,8 +83,9 @@ int smhost_write_fast5(const char *path, int multi_read, uint32_t n_reads, const
 
 /* Test / generator support: one BLOW5 file (file version 0.2.0, one read group, primary fields only).
  * record_press: 0 none, 1 zlib, 2 zstd (-1 is returned when this build has no zstd:
- * smhost_have_zstd() == 0).  The calibration constants are doubles in the file, like slow5_rec_t's. */
-int smhost_write_blow5(const char *path, int record_press, uint32_t n_reads, const char *const *ids,
+ * smhost_have_zstd() == 0); signal_press: 0 none, 1 svb-zd (StreamVByte over zig-zag deltas; slow5tools' default
+ * is zlib + svb-zd).  The calibration constants are doubles in the file, like slow5_rec_t's. */
+int smhost_write_blow5(const char *path, int record_press, int signal_press, uint32_t n_reads, const char *const *ids,
                        const int16_t *const *raws, const uint32_t *raw_lens, double digitisation, double range,
                        double offset);
 int smhost_have_zstd(void);

@@ -158,7 +158,7 @@ def host_lib():
                                          C.POINTER(C.c_float)]
         L.smhost_write_fast5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_void_p), C.c_void_p, C.c_float, C.c_float, C.c_float]
-        L.smhost_write_blow5.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
+        L.smhost_write_blow5.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.smhost_print_alignment.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
         L.smhost_print_alignment.restype = C.c_int64

@@ -177,7 +177,7 @@ int smhost_write_fast5(const char *path, int multi_read, uint32_t n_reads, const
   return SignalBatch::WriteFAST5(path, multi_read != 0, idv, digitisation, range, offset, rv) ? 0 : -1;
 }
 
-int smhost_write_blow5(const char *path, int record_press, uint32_t n_reads, const char *const *ids,
+int smhost_write_blow5(const char *path, int record_press, int signal_press, uint32_t n_reads, const char *const *ids,
                        const int16_t *const *raws, const uint32_t *raw_lens, double digitisation, double range,
                        double offset) {
   if (!path || !ids || !raws || !raw_lens) return -1;
@@ -187,7 +187,7 @@ int smhost_write_blow5(const char *path, int record_press, uint32_t n_reads, con
     idv[r] = ids[r];
     rv[r].assign(raws[r], raws[r] + raw_lens[r]);
   }
-  return SignalBatch::WriteBLOW5(path, record_press, idv, digitisation, range, offset, rv) ? 0 : -1;
+  return SignalBatch::WriteBLOW5(path, record_press, signal_press, idv, digitisation, range, offset, rv) ? 0 : -1;
 }
 
 int smhost_have_zstd(void) { return SignalBatch::HaveZstd() ? 1 : 0; }

@@ -47,8 +47,8 @@ class SignalBatch {
   void AddSignalsFromBLOW5(const std::string &path);  // signal_batch.cc:156-210 (blow5_reader.cc)
   static bool HaveFAST5();
   static bool HaveZstd();
-  // record_press: 0 none, 1 zlib, 2 zstd (tests / generator)
-  static bool WriteBLOW5(const std::string &path, int record_press, const std::vector<std::string> &ids,
+  // record_press: 0 none, 1 zlib, 2 zstd; signal_press: 0 none, 1 svb-zd (tests / generator)
+  static bool WriteBLOW5(const std::string &path, int record_press, int signal_press, const std::vector<std::string> &ids,
                          double digitisation, double range, double offset,
                          const std::vector<std::vector<int16_t>> &raws);
   static bool WriteFAST5(const std::string &path, bool multi_read, const std::vector<std::string> &ids,

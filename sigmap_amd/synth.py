@@ -124,9 +124,9 @@ def write_fast5(path, raw, ids=None, multi_read=True, digitisation=DIGITISATION,
         raise RuntimeError("smhost_write_fast5 failed for " + path)
 
 
-def write_blow5(path, raw, ids=None, record_press=0, digitisation=DIGITISATION, rng=RANGE, offset=OFFSET):
+def write_blow5(path, raw, ids=None, record_press=0, digitisation=DIGITISATION, rng=RANGE, offset=OFFSET, signal_press=0):
     """One BLOW5 file (binary SLOW5, file version 0.2.0, one read group, primary fields only) through the
-    host library's writer.  record_press: 0 none, 1 zlib, 2 zstd."""
+    host library's writer.  record_press: 0 none, 1 zlib, 2 zstd; signal_press: 0 none, 1 svb-zd."""
     import ctypes as C
     from . import _abi
     L = _abi.host_lib()
@@ -135,7 +135,7 @@ def write_blow5(path, raw, ids=None, record_press=0, digitisation=DIGITISATION, 
     idp = (C.c_char_p * len(raws))(*names)
     rp = (C.c_void_p * len(raws))(*[r.ctypes.data for r in raws])
     lens = np.array([len(r) for r in raws], dtype=np.uint32)
-    if L.smhost_write_blow5(path.encode(), record_press, len(raws), idp, rp, _abi.ptr(lens), digitisation, rng, offset) != 0:
+    if L.smhost_write_blow5(path.encode(), record_press, signal_press, len(raws), idp, rp, _abi.ptr(lens), digitisation, rng, offset) != 0:
         raise RuntimeError("smhost_write_blow5 failed for " + path)
 
 

@@ -25,12 +25,28 @@ def _reads(n=5, seed=3):
     return [np.ascontiguousarray(r) for r in raw]
 
 
-def _py_blow5(path, raws, ids, cal, press=0, version=(0, 2, 0), aux=b"", eof=True, nul_in_id=False):
-    """A BLOW5 file written field by field (the layout in sigmap_amd/host/blow5_reader.cc's header)."""
-    head = b"BLOW5\x01" + bytes(version) + bytes([press])
+def _py_svb_zd(r):
+    """svb-zd of one read, written independently of the host library's encoder: u32 n | control bytes | data bytes;
+    32-bit StreamVByte over the zig-zag codes of the sample differences (first against 0)."""
+    x = np.ascontiguousarray(r, np.int16).astype(np.int64)
+    d = np.diff(np.concatenate([[0], x]))
+    v = ((d << 1) ^ (d >> 63)) & 0xFFFFFFFF
+    nbytes = np.where(v < 1 << 8, 1, np.where(v < 1 << 16, 2, np.where(v < 1 << 24, 3, 4)))
+    ctrl = bytearray((len(v) + 3) // 4)
+    data = bytearray()
+    for i, (val, nb) in enumerate(zip(v.tolist(), nbytes.tolist())):
+        ctrl[i >> 2] |= (nb - 1) << (2 * (i & 3))
+        data += int(val).to_bytes(4, "little")[:nb]
+    return struct.pack("<I", len(v)) + bytes(ctrl) + bytes(data)
+
+
+def _py_blow5(path, raws, ids, cal, press=0, version=(0, 2, 0), aux=b"", eof=True, nul_in_id=False, svb=False, groups=1):
+    """A BLOW5 file written field by field (the layout in sigmap_amd/host/blow5_reader.cc's header): record
+    compression at byte 9, the number of read groups in bytes 10-13, signal compression (file version >= 0.2.0) at
+    byte 14."""
+    head = b"BLOW5\x01" + bytes(version) + bytes([press]) + struct.pack("<I", groups)
     if version >= (0, 2, 0):
-        head += b"\x00"                                   # signal compression: none
-    head += struct.pack("<I", 1)
+        head += bytes([1 if svb else 0])                  # signal compression
     head += b"\x00" * (64 - len(head))
     text = ("#slow5_version\t%d.%d.%d\n#num_read_groups\t1\n@run_id\tx\n" % version +
             "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*" + ("\tuint8_t" if aux else "") + "\n" +
@@ -40,7 +56,7 @@ def _py_blow5(path, raws, ids, cal, press=0, version=(0, 2, 0), aux=b"", eof=Tru
         for rid, r in zip(ids, raws):
             rid_b = rid.encode() + (b"\x00" if nul_in_id else b"")
             rec = struct.pack("<H", len(rid_b)) + rid_b + struct.pack("<IddddQ", 0, cal[0], cal[2], cal[1], 4000.0, len(r))
-            rec += np.ascontiguousarray(r, np.int16).tobytes() + aux
+            rec += (_py_svb_zd(r) if svb else np.ascontiguousarray(r, np.int16).tobytes()) + aux
             if press == 1:
                 rec = zlib.compress(rec)
             f.write(struct.pack("<Q", len(rec)) + rec)
@@ -48,8 +64,8 @@ def _py_blow5(path, raws, ids, cal, press=0, version=(0, 2, 0), aux=b"", eof=Tru
             f.write(b"5WOLB")
 
 
-@pytest.mark.parametrize("press", [0, 1, 2])
-def test_blow5_roundtrip_equals_sgr_and_oracle(tmp_path, press):
+@pytest.mark.parametrize("press,svb", [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (2, 1)])
+def test_blow5_roundtrip_equals_sgr_and_oracle(tmp_path, press, svb):
     if press == 2 and not _abi.host_lib().smhost_have_zstd():
         pytest.skip("host library built without zstd")
     raws = _reads()
@@ -58,7 +74,8 @@ def test_blow5_roundtrip_equals_sgr_and_oracle(tmp_path, press):
     ids = ["r%02d-%s" % (i, "abc"[i % 3]) for i in range(len(raws))]
     db, ds = tmp_path / "b5", tmp_path / "sg"
     os.makedirs(db / "sub"); os.makedirs(ds)
-    synth.write_blow5(str(db / "sub" / "batch_0.blow5"), raws, ids, record_press=press)   # found in a sub-directory
+    raws[2] = np.array([-32768, 32767, -32768, 0, 1, -1, 255, -256, 127, 128] * 50, np.int16)   # extreme deltas (3-byte codes)
+    synth.write_blow5(str(db / "sub" / "batch_0.blow5"), raws, ids, record_press=press, signal_press=svb)   # found in a sub-directory
     synth.write_sgr(str(ds / "batch_0.sgr"), raws, ids)
     a, b = synth.load_signals(str(db)), synth.load_signals(str(ds))
     assert [x[0] for x in a] == ids == [x[0] for x in b]                         # file order
@@ -68,14 +85,19 @@ def test_blow5_roundtrip_equals_sgr_and_oracle(tmp_path, press):
         assert np.array_equal(pa.view(np.uint32), exp.view(np.uint32))
         assert (dg, rg, of) == (np.float32(synth.DIGITISATION), np.float32(synth.RANGE), np.float32(synth.OFFSET))
     assert len(a[1][1]) == len(a[0][1]) and len(a[-1][1]) == 0
+    if svb and press == 0:   # the delta coding pays off on a real-looking signal: about one byte and a quarter per sample
+        assert os.path.getsize(db / "sub" / "batch_0.blow5") < 0.75 * os.path.getsize(ds / "batch_0.sgr")
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(press=1), dict(version=(0, 1, 0)), dict(aux=b"\x07"), dict(nul_in_id=True),
-                                dict(version=(1, 0, 0), press=1, aux=b"\x01\x02")])
+                                dict(version=(1, 0, 0), press=1, aux=b"\x01\x02"), dict(svb=True), dict(svb=True, press=1, aux=b"\x09\x08"),
+                                dict(groups=256), dict(groups=1, version=(0, 1, 0), press=1), dict(svb=True, groups=3)])
 def test_reader_on_files_written_field_by_field(tmp_path, kw):
     """The same reads through the independent Python writer: file versions 0.1.0 (no signal-compression
-    byte) / 0.2.0 / 1.0.0, zlib records, auxiliary fields after raw_signal (ignored, like the reference,
-    which reads only the primary fields), a read_id length that counts the NUL."""
+    byte) / 0.2.0 / 1.0.0, zlib records, svb-zd signals (slow5tools' default: zlib + svb-zd) with auxiliary fields
+    behind the compressed signal, auxiliary fields after raw_signal (ignored, like the reference,
+    which reads only the primary fields), a read_id length that counts the NUL, read-group counts whose low byte
+    is 0 or 1 (the count sits where an earlier version of this reader looked for the signal compression)."""
     raws = _reads(3)
     ids = ["a", "bb", "ccc"]
     cal = (8192.0, 1402.882324, 6.0)                    # doubles in the file; narrowed to float by the reader
@@ -90,11 +112,12 @@ def test_reader_on_files_written_field_by_field(tmp_path, kw):
         assert np.array_equal(g[1].view(np.uint32), exp.view(np.uint32))
 
 
-def test_host_writer_and_python_writer_agree_byte_for_byte(tmp_path):
+@pytest.mark.parametrize("svb", [0, 1])
+def test_host_writer_and_python_writer_agree_byte_for_byte(tmp_path, svb):
     raws = _reads(2)
     a, b = str(tmp_path / "a.blow5"), str(tmp_path / "b.blow5")
-    synth.write_blow5(a, raws, ["x", "y"], record_press=0, digitisation=8192.0, rng=1402.882324, offset=6.0)
-    _py_blow5(b, raws, ["x", "y"], (8192.0, 1402.882324, 6.0))
+    synth.write_blow5(a, raws, ["x", "y"], record_press=0, digitisation=8192.0, rng=1402.882324, offset=6.0, signal_press=svb)
+    _py_blow5(b, raws, ["x", "y"], (8192.0, 1402.882324, 6.0), svb=bool(svb))
     A, B = open(a, "rb").read(), open(b, "rb").read()
     # identical 64-byte binary header, records and end marker; only the free-text attribute lines differ
     assert A[:64] == B[:64] and A[-5:] == B[-5:] == b"5WOLB"
@@ -120,7 +143,8 @@ def test_malformed_files_fail_loudly(tmp_path):
         "noeof.blow5": (data[:-5], "end-of-file marker"),
         "trunc.blow5": (data[:-400], "Truncated"),
         "magic.blow5": (b"SLOW5\x01" + data[6:], "Not a BLOW5"),
-        "svb.blow5": (data[:10] + b"\x01" + data[11:], "signal compression"),
+        "sigpress.blow5": (data[:14] + b"\x02" + data[15:], "signal compression"),
+        "svbflag.blow5": (data[:14] + b"\x01" + data[15:], "Corrupt BLOW5 record"),   # raw samples are not an svb-zd stream
         "press9.blow5": (data[:9] + b"\x09" + data[10:], "unknown record compression"),
         "cols.blow5": (data.replace(b"digitisation\toffset", b"offset\tdigitisation"), "column line"),
     }
