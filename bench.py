@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU-baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive timed region")
+    ap.add_argument("--same-reads", action="store_true", help="one read set for every step and context (rounds 1-3)")
+    ap.add_argument("--no-same-reads", action="store_true", help="skip the comparison region that maps one set every step")
     ap.add_argument("--sdtw-band", type=int, default=64, help="band of the sDTW refinement (0 = skip it)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="transport of the N > 1 run: nccl = RCCL over xGMI (one rank per GPU); gloo = through host "
@@ -177,19 +179,30 @@ def main():
         pool.share_index()  # the other contexts of this GPU borrow the same arrays
 
     R = args.reads
-    raw, _ = synth.simulate_reads(genome, lm, R, seed=1000 + rank)
+    # Read sets: one more than there are contexts, a DIFFERENT set every step (step i maps set i mod n_sets), so that
+    # neither a context nor two contexts in flight ever walk the same queries twice in a row -- no cross-step or
+    # cross-stream cache reuse a real run would not have.  All sets are resident in every context's slots (set s in
+    # slots [s R, (s + 1) R)) when the `value` region starts; the pcie_inclusive region copies a step's set from
+    # pinned host memory first.
+    n_sets = max(2, args.depth + 1) if not args.same_reads else 1
+    raw_sets = [synth.simulate_reads(genome, lm, R, seed=1000 + 64 * rank + s)[0] for s in range(n_sets)]
+    raw = raw_sets[0]
     # the rank's reads as they sit in host RAM: int16 ADC counts in pinned memory (one DMA per batch)
-    pinned = pipeline.PinnedArray((R * CHUNK,), np.int16)
-    pinned.array[:] = raw.reshape(-1)
+    pinned = pipeline.PinnedArray((n_sets * R * CHUNK,), np.int16)
+    for s_i in range(n_sets):
+        pinned.array[s_i * R * CHUNK:(s_i + 1) * R * CHUNK] = raw_sets[s_i].reshape(-1)
     raw_off = (np.arange(R + 1, dtype=np.uint64) * CHUNK)
-    slots = np.arange(R, dtype=np.uint32)
     chunk0 = np.zeros(R, dtype=np.uint32)
 
-    def upload(dv, want_len=False):
-        return dv.upload_raw(pinned.array, raw_off, synth.DIGITISATION, synth.RANGE, synth.OFFSET, want_len=want_len)
+    def set_slots(s_i):
+        return (np.arange(R, dtype=np.uint32) + np.uint32(s_i * R))
 
-    pool.for_each(lambda dv: dv.configure_reads(R, CHUNK))
-    lens = [upload(dv, want_len=True) for dv in pool.devs]   # inputs resident in HBM from here on
+    def upload(dv, s_i, want_len=False):
+        return dv.upload_raw(pinned.array[s_i * R * CHUNK:(s_i + 1) * R * CHUNK], raw_off, synth.DIGITISATION, synth.RANGE,
+                             synth.OFFSET, slots=set_slots(s_i), want_len=want_len)
+
+    pool.for_each(lambda dv: dv.configure_reads(n_sets * R, CHUNK))
+    lens = [upload(dv, s_i, want_len=True) for dv in pool.devs for s_i in range(n_sets)]   # inputs resident in HBM from here on
     assert all(int(l.min()) == CHUNK for l in lens), "the generator's reads lose no sample to the (30,200) pA filter"
     if args.sdtw_band > 0:
         ref_sig, ref_off = pipeline.reference_signals(genome, lm)
@@ -197,20 +210,23 @@ def main():
         for dv in pool.devs[1:]:
             dv.share_reference(pool.first)
 
-    prefetched = {}  # context -> the reads of its next step are already on their way (pcie_inclusive region)
+    prefetched = {}  # context -> the read set whose copy is already on its way (pcie_inclusive region)
+    n_ctx = len(pool.devs)
 
-    def step(dv=dev, _i=0, with_upload=False, prefetch_next=False):
-        if with_upload and not prefetched.pop(id(dv), False):
-            upload(dv)                       # async: H2D on the copy stream, conversion waits for it
-        dv.select(slots, chunk0, CHUNK)
+    def step(dv=dev, i=0, with_upload=False, prefetch_next=False, fixed_set=None):
+        s_i = (i % n_sets) if fixed_set is None else fixed_set
+        if with_upload and prefetched.pop(id(dv), None) != s_i:
+            upload(dv, s_i)                  # async: H2D on the copy stream, conversion waits for it
+        dv.select(set_slots(s_i), chunk0, CHUNK)
         dv.run(n_refs)
         if args.sdtw_band > 0:
             dv.refine(band=args.sdtw_band, pad=32)
         if prefetch_next:
-            # the NEXT step's reads of this context: their DMA runs beside this step's kernels, their conversion
-            # is queued behind them (the events kernels of this step have read the slots by then)
-            upload(dv)
-            prefetched[id(dv)] = True
+            # the NEXT step of this context (static assignment: i + n_ctx) maps another set, i.e. other slots: its
+            # DMA and conversion run beside this step's kernels
+            nxt = (i + n_ctx) % n_sets
+            upload(dv, nxt)
+            prefetched[id(dv)] = nxt
         dv.sync()
         res = dv.download()
         refined = dv.refine_download() if args.sdtw_band > 0 else None
@@ -220,13 +236,16 @@ def main():
     # that nodes_visited / points_tested count the REFERENCE's work on these inputs (SURVEY 8d:
     # "counted on the actual inputs").  The timed passes skip subtrees whose tight box is out of
     # range (same hits, same order) and therefore touch fewer bytes than that figure.
+    last_set = (args.steps - 1) % n_sets      # the set of the timed region's last step: the records reported below
     dev.params.reference_walk = 1
-    census, _ = step()
+    census, _ = step(fixed_set=last_set)
     dev.params.reference_walk = 0
     # warm-up: W steps, and one on every context (each sizes its own scratch and hit pool)
     pool.for_each(lambda dv: step(dv, with_upload=True))
     if args.warmup > len(pool.devs):
         pool.run_steps(args.warmup - len(pool.devs), step)
+    # what every set maps to (untimed, one context): the timed steps are checked against these, whatever context ran them
+    expected = [step(dev, fixed_set=s_i) for s_i in range(n_sets)]
     pool.for_each(lambda dv: (dv.timing(True), dv.timing_reset()))
 
     def fence():
@@ -272,8 +291,20 @@ def main():
     fence()
     dt = max_over_ranks(time.perf_counter() - t0)
     res, refined = results[-1]
-    contexts_agree = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results)
+    contexts_agree = all(r.tobytes() == expected[i % n_sets][0].tobytes() for i, (r, _) in enumerate(results))
     kern = kernel_times(pool.devs)  # (with batches in flight: brackets include queueing behind the other stream)
+
+    # the same K steps with ONE read set mapped by every step on every context (what this file timed in rounds 1-3):
+    # reported once next to `value`, which it would overstate if walking the same leaves a quarter step apart helped
+    same_reads = None
+    if n_sets > 1 and not args.no_same_reads:
+        fence()
+        t0 = time.perf_counter()
+        pool.run_steps(args.steps, lambda dv, i: step(dv, i, fixed_set=0), stagger_s=stagger)
+        fence()
+        dt_same = max_over_ranks(time.perf_counter() - t0)
+        same_reads = {"value": round(R * world * args.steps / dt_same, 1), "ms_per_step": round(dt_same / args.steps * 1e3, 3),
+                      "vs_value": round(dt / dt_same, 4)}
 
     # ---- timed region 2 (pcie_inclusive): the same K steps, each starting with the DMA of its reads'
     # ADC counts from pinned host memory and their conversion on the device
@@ -284,21 +315,20 @@ def main():
         t0 = time.perf_counter()
         # (a step's reads are copied exactly once: by the step itself, or by the context's previous step while
         # that one's kernels ran; the last step of a context prefetches nothing)
-        n_ctx = len(pool.devs)
         results2 = pool.run_steps(args.steps, lambda dv, i: step(dv, i, with_upload=True,
                                                                  prefetch_next=i + n_ctx < args.steps),
-                                  stagger_s=stagger)
+                                  stagger_s=stagger, static=True)
         fence()
         prefetched.clear()
         dt2 = max_over_ranks(time.perf_counter() - t0)
-        same2 = all(np.array_equal(r.tobytes(), res.tobytes()) for r, _ in results2)
+        same2 = all(r.tobytes() == expected[i % n_sets][0].tobytes() for i, (r, _) in enumerate(results2))
         pcie = {"value": round(R * world * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                 "h2d_bytes_per_step": int(R * CHUNK * 2), "results_identical": bool(same2),
                 "convert_kernel_ms": kernel_times(pool.devs)["convert"]["mean_ms"],
                 "vs_resident": round(dt / dt2, 4),
                 "what": "every step's reads are copied as int16 ADC counts from pinned host memory (hipMemcpyAsync on a "
                         "copy stream) and converted on the device before mapping; a context starts the copy of its "
-                        "next step's reads while the current step's kernels run"}
+                        "next step's reads (another read set, other slots) while the current step's kernels run"}
 
     if rank == 0:
         status_bad = int((res["status"] & ~np.uint32(1)).astype(bool).sum())
@@ -325,14 +355,18 @@ def main():
         # tests, 24 B per anchor, the raw samples and the result record): the bytes a perfect layout would have to move
         useful_bytes = 2 * CHUNK * R + 16 * levels_per_rec * w_nodes + 28 * w_points + 24 * anchors + 64 * R
         traffic, traffic_src, prof_ms, read_lines = None, None, None, None
-        # a committed counter profile whose workload has this run's shape (tools/collect_profiles.sh)
+        # a committed counter profile of THIS code on THIS workload (tools/collect_profiles.sh): same shape, the same
+        # walker kernel (search mode) and the same walker sources (a hash of seed_lookup.hip + common.h recorded with
+        # the profile) -- bytes counted for another kernel version are never paired with this run's duration
         import glob
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_pmc_traffic.json"))):
+        walker_kernel = "SeedWalkKernel<2, 128>" if quad_walk else "SeedWalkKernel<0, 256>"
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 j = json.load(open(pmc))
                 sh = j.get("shape") or {}
                 if (sh.get("reads"), sh.get("contigs"), sh.get("contig_len")) == (args.reads, args.contigs, args.contig_len) \
-                        and args.walk_blocks == 0 and args.fast_cap == 0:
+                        and args.walk_blocks == 0 and args.fast_cap == 0 and j.get("kernel") == walker_kernel \
+                        and j.get("source_sha16") == walker_source_sha():
                     traffic = int(j["seed_lookup_hbm_bytes_per_launch"])
                     read_lines = float(j.get("read_requests_128B") or 0) or None
                     traffic_src = j.get("source")
@@ -369,6 +403,10 @@ def main():
                 "forced_broadcast": ({"backend": "rccl" if args.backend == "nccl" else "gloo", "ranks": 1,
                                       "contexts_on_broadcast_copy": len(pool.devs) - 1} if forced else None),
                 "batches_in_flight": len(pool.devs),
+                "read_sets": n_sets,
+                "read_sets_note": "step i maps read set i mod read_sets (R distinct synthetic reads each, all resident): no "
+                                  "step repeats the previous step's queries, contexts in flight walk different queries",
+                "same_reads_every_step": same_reads,
                 "contexts_agree": bool(contexts_agree),
                 "index_points": int(ix.n_points) if ix is not None else None,
                 "mapped_fraction": round(float((res["n_chains"] > 0).mean()), 4),
@@ -404,6 +442,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_is_from_stored_profile": bool(traffic),
                 "traffic_source": traffic_src,
                 "basis": ("L2-miss (fabric) bytes of the committed counter profile named in traffic_source -- 128 B x "
                           "TCC_EA0_RDREQ + WRITE_SIZE per launch (profiles/r3_calibration.json); they INCLUDE Infinity-Cache "
@@ -445,6 +484,17 @@ def main():
         dist.destroy_process_group()
     del keepalive
     pinned.close()
+
+
+def walker_source_sha():
+    """First 16 hex digits of sha256 over the walker's sources: a counter profile is only paired with a run of the
+    same code (tools/summarize_profiles.py records the same value)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sigmap_amd/csrc/seed_lookup.hip", "sigmap_amd/csrc/common.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def phase_prof():

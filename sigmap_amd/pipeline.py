@@ -497,11 +497,12 @@ class MapperPool:
         for dv in self.devs:
             fn(dv)
 
-    def run_steps(self, n_steps, step_fn, stagger_s=0.0):
+    def run_steps(self, n_steps, step_fn, stagger_s=0.0, static=False):
         """step_fn(dev, step_index) is called once for every step 0..n_steps-1: each context's thread
-        takes the next step not yet started when it has finished its previous one.  Returns the list
-        of results in step order.  `stagger_s`: context k starts k * stagger_s late, so that the contexts
-        do not all begin with the same (longest) kernel and then share the GPU for it."""
+        takes the next step not yet started when it has finished its previous one (static=True: context k
+        takes steps k, k + depth, ... -- a context then knows its next step, e.g. to prefetch its inputs).
+        Returns the list of results in step order.  `stagger_s`: context k starts k * stagger_s late, so that the
+        contexts do not all begin with the same (longest) kernel and then share the GPU for it."""
         import threading
         import time
         out = [None] * n_steps
@@ -513,10 +514,15 @@ class MapperPool:
             try:
                 if stagger_s > 0 and k > 0:
                     time.sleep(k * stagger_s)
+                mine = k
                 while not err:
-                    with lock:
-                        i = nxt[0]
-                        nxt[0] += 1
+                    if static:
+                        i = mine
+                        mine += len(self.devs)
+                    else:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
                     if i >= n_steps:
                         break
                     out[i] = step_fn(self.devs[k], i)

@@ -54,8 +54,21 @@ def traffic_json(tag, red, per, shape_txt):
         for r in csv.DictReader(open(ks)):
             if r["kernel"] == seed:
                 avg_ns = float(r["avg_ns"])
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sigmap_amd/csrc/seed_lookup.hip", "sigmap_amd/csrc/common.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    prev = os.path.join(red, f"{tag}_pmc_traffic.json")
+    sha = h.hexdigest()[:16]
+    if os.path.exists(prev):  # (re-derived here from the reduced table: keep the hash of the sources that were profiled)
+        try:
+            sha = json.load(open(prev)).get("source_sha16") or sha
+        except Exception:
+            pass
     out = {
         "kernel": seed,
+        "source_sha16": sha,
         "shape": parse_shape(shape_txt), "bench_shape_args": shape_txt,
         "seed_lookup_hbm_bytes_per_launch": int(rd * 128 + write_kb * 1024),
         "read_requests_128B": rd, "read_bytes": int(rd * 128),
