@@ -1066,7 +1066,7 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
                   &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};
   for (DevBuf *b : b4) HIPCHK(b->Reserve(na * 4));
-  HIPCHK(ctx->keys.Reserve(na * 2 * sizeof(uint64_t)));
+  HIPCHK(ctx->keys.Reserve(std::max<uint64_t>(SortRecordRoom(na, R), na) * 2 * sizeof(uint64_t)));  // the sort's records (4/3 per anchor)
   HIPCHK(ctx->used.Reserve(na));
   HIPCHK(ctx->out_anchors.Reserve(na * sizeof(smhip_carried_anchor)));
   SortArgs sa;
@@ -1161,7 +1161,7 @@ uint64_t SpecCapAnchors(const smhip_ctx *ctx, uint32_t R) {
 // unsorted and sorted columns, score, predecessor, group starts, sort records, flags, chain anchors.
 bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap, uint64_t na_cap) {
   const uint64_t per_query = (uint64_t)p->hits_per_query_fast * sizeof(Hit) + kOvfLevels * 4 + 32 * 2 + 4 * 6 + 64 * sizeof(Hit);
-  const uint64_t per_anchor = 11 * 4 + 2 * sizeof(uint64_t) + 1 + sizeof(smhip_carried_anchor);
+  const uint64_t per_anchor = 11 * 4 + 2 * sizeof(uint64_t) * 4 / 3 + 6 + 1 + sizeof(smhip_carried_anchor);
   uint64_t have_q = ctx->q_count.cap / 4, have_a = ctx->score.cap / 4;  // what these buffers hold already
   const uint64_t grow = (nq_cap > have_q ? (nq_cap - have_q) * per_query : 0) + (na_cap > have_a ? (na_cap - have_a) * per_anchor : 0);
   if (grow == 0) return true;

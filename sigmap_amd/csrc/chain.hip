@@ -118,10 +118,15 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   // Every WAVE works on its own: no workgroup barrier anywhere (the 256-anchor tiles of the first version spent a
   // fifth of their time waiting at the barrier behind the wave with the longest backward scan).
   __shared__ uint32_t s_gmax_all[4][kTile + 2];  // maxima of the buckets the tile touches, relative to its first bucket
-  __shared__ uint4 s_ring_all[4][kRing];         // {target, query, bucket, -}: one 16-byte LDS read per scan step
+  // The ring as three 4-byte COLUMNS (target, query, bucket): a scan step reads target and query only -- whether a
+  // predecessor lies in another bucket is an index comparison with the start of the anchor's own bucket -- i.e. two
+  // ds_read_b32 whose lanes hit 64 different banks while they run in step, where the packed {target, query, bucket, -}
+  // record of round 3 was one ds_read_b128: four passes through the banks, entries 16 apart on the same banks
+  // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.53).
+  __shared__ uint32_t s_ring_t_all[4][kRing], s_ring_q_all[4][kRing], s_ring_g_all[4][kRing];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *s_gmax = s_gmax_all[wave];
-  uint4 *s_ring = s_ring_all[wave];
+  uint32_t *s_ring_t = s_ring_t_all[wave], *s_ring_q = s_ring_q_all[wave], *s_ring_g = s_ring_g_all[wave];
   // Every wave takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1, ...): one
   // search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p in slot p & 127)
   // already holds the previous tile, so a tile loads only its own 64 records.
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   uint32_t c = ChunkOfFlat(tile_off, n_chunks, tile);
   bool ring_valid = false;  // the ring holds [t0 - 64, t0) of chunk c
   uint32_t ord_carry = 0;   // bucket ordinal of the last anchor of the previous tile (ring_valid)
+  uint32_t bstart_carry = 0;  // ... and the index of that bucket's first anchor
   // the records (and distance) of the next tile of the same chunk are fetched into registers while the
   // current one is processed
   bool have_nx = false;
@@ -168,7 +174,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         nx_g = grp[ai];
         nx_d = dist[ai];
       }
-      s_ring[ai & (kRing - 1)] = make_uint4(nx_t, nx_q, nx_g, 0u);
+      s_ring_t[ai & (kRing - 1)] = nx_t;
+      s_ring_q[ai & (kRing - 1)] = nx_q;
+      s_ring_g[ai & (kRing - 1)] = nx_g;
       my_dist = nx_d;
     }
     const uint32_t my_t = nx_t, my_q = nx_q, my_g = nx_g;
@@ -184,7 +192,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     }
     if (!ring_valid && t0 > 0) {  // first tile of this wave in the middle of a chunk
       const uint32_t p = w0 + lane;
-      s_ring[p & (kRing - 1)] = make_uint4(tpos[p], qpos[p], grp[p], 0u);
+      s_ring_t[p & (kRing - 1)] = tpos[p];
+      s_ring_q[p & (kRing - 1)] = qpos[p];
+      s_ring_g[p & (kRing - 1)] = grp[p];
     }
     s_gmax[lane] = 0;
     if (lane < 2) s_gmax[kTile + lane] = 0;
@@ -198,19 +208,24 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         if (gstart[mid] <= t0) lo = mid; else hi = mid;
       }
       first_ord = lo;
+      bstart_carry = G ? gstart[lo] : 0u;  // the bucket that holds anchor t0 starts there
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     PHASE_MARK(0);
     uint32_t ord = 0, ord_last = 0;
+    uint32_t bstart = 0;  // index of the first anchor of this anchor's bucket: a predecessor below it is another bucket's
     {
       // (with a valid ring the anchor before the tile is in LDS too: its bucket starts the count)
-      const bool change = ai < n && (ai > t0 || ring_valid) && my_g != s_ring[(ai - 1) & (kRing - 1)].z;
+      const bool change = ai < n && (ai > t0 || ring_valid) && my_g != s_ring_g[(ai - 1) & (kRing - 1)];
       const unsigned long long m = __ballot(change);
-      ord = first_ord + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));  // changes up to and including ai
+      const unsigned long long upto = m & ((2ull << lane) - 1ull);        // changes up to and including ai
+      ord = first_ord + (uint32_t)__popcll(upto);
       ord_last = first_ord + (uint32_t)__popcll(m);                       // ordinal of the tile's last anchor
       first_ord += (uint32_t)(m & 1ull);                                  // ordinal of the tile's first anchor
+      bstart = upto ? t0 + (63u - (uint32_t)__clzll((long long)upto)) : bstart_carry;
+      if (m) bstart_carry = t0 + (63u - (uint32_t)__clzll((long long)m));  // the bucket of the tile's last anchor
     }
     PHASE_MARK(1);
     // ---- the backward scans of the tile's 64 anchors, in lockstep and WITHOUT BRANCHES while the predecessors
@@ -227,10 +242,10 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     // (two predecessors per round: both ring reads are issued before either is looked at -- the second one's address
     // does not depend on the first one's outcome, only whether it counts does -- so the ballot, the branch and the
     // LDS round trip are paid once per pair)
-    auto step1 = [&](const uint4 &r) {
+    auto step1 = [&](uint32_t r_t, uint32_t r_q) {
       const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
-      const int32_t pt = (int32_t)r.x, pq = (int32_t)r.y;
-      const bool other_bucket = r.z != my_g;
+      const int32_t pt = (int32_t)r_t, pq = (int32_t)r_q;
+      const bool other_bucket = pj - 1u < bstart;  // (go: pj > w0 >= 0)
       const bool same_pos = pq == cq || pt == ct;                     // `continue`: not evaluated, no skip counted
       const bool far = pt + max_target_gap_length < ct;               // `break`
       const int32_t td = ct - pt, qd = cq - pq;
@@ -251,18 +266,17 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     for (;;) {
       const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
       if (!__ballot(go)) break;
-      const uint4 r1 = s_ring[(pj - 1u) & (kRing - 1)];
-      const uint4 r2 = s_ring[(pj - 2u) & (kRing - 1)];  // (counts only if the first one leaves the lane active)
-      step1(r1);
-      step1(r2);
+      const uint32_t t1 = s_ring_t[(pj - 1u) & (kRing - 1)], q1 = s_ring_q[(pj - 1u) & (kRing - 1)];
+      const uint32_t t2 = s_ring_t[(pj - 2u) & (kRing - 1)], q2 = s_ring_q[(pj - 2u) & (kRing - 1)];  // (counts only if the
+      step1(t1, q1);                                                                                 // first one leaves the
+      step1(t2, q2);                                                                                 // lane active)
     }
     // lanes whose scan leaves the ring (64+ predecessors back: dense true-locus regions): the sequential form,
     // predecessors from memory
     if (active && pj > 0 && pj <= w0 && steps < (uint32_t)chaining_band_length) {
       for (; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-        const uint32_t pg = grp[pj];
+        if (pj < bstart) break;  // bucket start
         const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
-        if (pg != my_g) break;  // bucket start
         if (pq == cq || pt == ct) continue;
         if (pt + max_target_gap_length < ct) break;
         const int32_t td = ct - pt, qd = cq - pq;

@@ -402,6 +402,7 @@ struct SortArgs {
   smhip_chunk_result *results;
 };
 hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint64_t n_anchors_total);
+uint64_t SortRecordRoom(uint64_t n_anchors_total, uint32_t n_chunks);  // 16-byte records of SortArgs::keys
 hipError_t LaunchIndexMaxTarget(smhip_ctx *ctx, uint32_t *out);
 hipError_t LaunchCarriedMaxTarget(smhip_ctx *ctx, const smhip_carried_anchor *carried, uint64_t n_carried,
                                   const uint32_t *index_max, uint32_t *out);

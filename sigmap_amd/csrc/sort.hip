@@ -277,11 +277,22 @@ __device__ __forceinline__ void EmitSorted(KeyPtr keys, uint32_t n, uint32_t ibi
 struct BigSortWork {   // global scratch of the large-chunk path (LaunchSort)
   uint32_t *part_tab;  // [n_chunks][kPartTab]
   uint4 *recs[2];      // parts of the two wave classes: {A lo, A hi | m << 16, dlo lo, dlo hi}, A = first element of the
-                       // part (m elements) in the anchor columns and in the chunk's {key, qpos, dist} records, dlo =
-                       // smallest dense key group * span + target the part can hold
+                       // part (m elements) in the sorted anchor columns, dlo = smallest dense key
+                       // group * span + target the part can hold
+  uint64_t *rin[2];    // ... and where the part's m records {key, qpos, dist} lie in the record scratch (a.keys)
   uint32_t *items;     // parts of the workgroup class: (chunk << kPartBits) | part
-  uint32_t *counters;  // [0..2] items per class
+  uint32_t *redo;      // chunks the whole-line route gave up on (a part beyond its slice): [n_chunks]
+  uint32_t *counters;  // [0..2] items per class, [3] chunks in redo
 };
+
+// The record scratch (a.keys as 16-byte records) of chunk c starts at RecOff(anchor_off[c], c).  The whole-line
+// route gives every part a fixed slice of kSlice records (parts aim at kPartTarget = 3/4 of it), so a chunk of n
+// anchors may need (n / kPartTarget + 3) * kSlice = 4 n / 3 + 1536 records: consecutive chunks' regions differ by
+// at least 4 (n / 3 - 2 / 3) + 4 + 2048.  (LaunchSort sizes a.keys for RecOff(total anchors, n_chunks).)
+constexpr uint32_t kSlice = 512;
+__host__ __device__ __forceinline__ uint64_t RecOff(uint64_t anchor_off, uint64_t c) {
+  return 4ull * (anchor_off / 3ull + c) + 2048ull * c;
+}
 
 // ---- decode: anchor i of a chunk = carried anchor i, or hit (i - ncar - qoff[k]) of the chunk's query k
 struct DecodeCtx {
@@ -328,23 +339,45 @@ __device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0,
 
 // ---- every chunk is cut into PARTS by ranges of the dense key group * span + target, span = *a.span_bound
 // (largest target of the index or of a carried anchor, + 1: known before the decode, so that an anchor's part is
-// known the moment it is decoded).  Two passes over the hits, nothing written in between: count the parts' sizes;
-// then decode again and write key, query position and distance straight into the part's slice (the hit records
-// of a chunk - a few hundred KB - are still in the caches).  The key's index field becomes the position INSIDE
-// the part, and the payload travels with the key in one 16-byte record: a part's sorter reads its own slice
-// once.  Work items for the part sorters: one record per part, by size class.  One workgroup per chunk at a
-// time, two per CU.
+// known the moment it is decoded); the key's index field becomes the position INSIDE the part, and the payload
+// travels with the key in one 16-byte record {key, query position, distance}: a part's sorter reads its own slice
+// once.  Work items for the part sorters: one record per part, by size class.  One workgroup per chunk at a time,
+// two per CU.  Two routes:
+//
+//  * kLines (the rule): ONE pass over the hits.  A part gets a fixed slice of kSlice records in the chunk's region
+//    of the record scratch; the workgroup takes the hits in TILES of up to 2048 -- a wave step is 64 hits of each of
+//    two queries --, bins the tile's records by part in LDS (count, scan, place) and copies the binned tile out:
+//    the records of one part are consecutive in the tile AND in memory, so the stores of neighbouring lanes fall
+//    into the same 128-byte lines.  The scattered 16-byte store per anchor of the exact route costs a 32-byte
+//    write request each (profiles/r3_calibration.json), and with its separate counting pass the kernel moved 64
+//    bytes per anchor at the rate of fabric REQUESTS (0.9e8 reads + 3.6e8 writes per 3.6e8 anchors); this route
+//    reads the hits once and writes whole runs.  A chunk in which a part outgrows its slice (a skewed target
+//    distribution: repeats) is listed (w.redo) and mapped by a launch of the exact route.
+//  * exact (kLines == false; the fallback, for the chunks of redo_list; knob sort_lines = 0: for every chunk): count
+//    the parts' sizes in a pass over the hits of its own, then decode again and write every record into its part's
+//    exact slice, one scattered store per anchor.
 constexpr uint32_t kBigThreads = 1024;  // (256 / 512: 4.2 / 4.4 ms against 3.6 ms at 32 Mb)
 constexpr uint32_t kGroupsLds = 1024;  // (reference, strand) groups counted in LDS by the partition kernel; more: GroupStartKernel
+constexpr uint32_t kTile = 2 * kBigThreads;  // records per tile of the whole-line route
+constexpr size_t kTileLdsBytes = (size_t)kTile * (sizeof(uint4) + sizeof(uint32_t));  // the tile's records + destinations
+template <bool kLines>
 __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a, uint32_t n_chunks, uint32_t gbits,
-                                                                       uint32_t ibits, BigSortWork w) {
+                                                                       uint32_t ibits, BigSortWork w,
+                                                                       const uint32_t *__restrict__ redo_list) {
   __shared__ uint32_t qoff[kMaxQueriesPerChunk + 2];
   __shared__ uint32_t part[kBigThreads / 64];
-  __shared__ uint32_t pcount[kMaxParts], pstart[kMaxParts + 1];
+  __shared__ uint32_t pcount[kMaxParts + 64], pstart[kMaxParts + 1];
   __shared__ uint32_t cls_n[4], cls_base[4];
   // anchors per group: whole parts are added part by part, the anchors of the few parts that straddle a group
-  // boundary one by one (second pass); the group boundaries of the sorted chunk are the prefix sums
+  // boundary (strad: one bit per part) one by one; the group boundaries of the sorted chunk are the prefix sums
   __shared__ uint32_t gcnt[kGroupsLds];
+  __shared__ uint32_t strad[kMaxParts / 32];
+  // whole-line route: per-tile counts / starts / running positions of the parts, the query hand-out, the verdict
+  __shared__ uint32_t tcount[kLines ? kMaxParts + 64 : 1], tstart[kLines ? kMaxParts + 64 : 1], tgpos[kLines ? kMaxParts + 64 : 1];
+  __shared__ uint32_t s_overflow;
+  extern __shared__ __align__(16) unsigned char tile_mem[];  // kLines: uint4 tile_rec[kTile], uint32_t tile_dst[kTile]
+  uint4 *tile_rec = reinterpret_cast<uint4 *>(tile_mem);
+  uint32_t *tile_dst = reinterpret_cast<uint32_t *>(tile_mem + (size_t)kTile * sizeof(uint4));
   const bool fold_groups = (1u << gbits) <= kGroupsLds;
   const uint32_t tid = threadIdx.x;
   const uint64_t span = (uint64_t)*a.span_bound + 1ull;
@@ -352,7 +385,10 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
   const uint32_t rbits = 64u - (uint32_t)__clzll((long long)(range - 1ull) | 1ll);
   const uint64_t idx_mask = (1ull << ibits) - 1ull;
   PHASE_DECL();
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+  // (redo_list: the exact route for the chunks the whole-line launch gave up on, w.counters[3] of them)
+  const uint32_t n_todo = redo_list ? w.counters[3] : n_chunks;
+  for (uint32_t ci = blockIdx.x; ci < n_todo; ci += gridDim.x) {
+    const uint32_t c = redo_list ? redo_list[ci] : ci;
     PHASE_INIT();
     const uint64_t base = a.anchor_off[c];
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
@@ -367,8 +403,13 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
     }
     if (n == 0 || cap) continue;  // (uniform)
     __syncthreads();  // the previous chunk is done with the shared arrays
-    for (uint32_t k = tid; k < kMaxParts; k += kBigThreads) pcount[k] = 0;
+    for (uint32_t k = tid; k < kMaxParts + 64; k += kBigThreads) {
+      pcount[k] = 0;
+      if (kLines) tcount[k] = 0;
+    }
     for (uint32_t k = tid; k < kGroupsLds; k += kBigThreads) gcnt[k] = 0;
+    if (tid < kMaxParts / 32) strad[tid] = 0;
+    if (tid == 0) s_overflow = 0;
     ScanQueryOffsets<kBigThreads>(a, q0, nq, qoff, part, tid);
     const DecodeCtx dc(a, qoff, q0, nq, ncar, n, c);
     PHASE_MARK(8);
@@ -379,11 +420,44 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
       const uint64_t dense = (uint64_t)dv.grp * span + min((uint64_t)dv.tpos, span - 1ull);
       return min((uint32_t)((dense * P) >> rbits), P - 1u);  // (the clamps only ever act on invalid carried anchors)
     };
-    // Both passes visit the anchors QUERY BY QUERY, a wave per query, its lanes over the query's hits (a large
+    // parts whose key range holds a group boundary: their anchors are counted into the groups one by one
+    constexpr uint32_t kPartsPerThread = kMaxParts / kBigThreads;
+    if (fold_groups) {
+#pragma unroll
+      for (uint32_t j = 0; j < kPartsPerThread; ++j) {
+        const uint32_t pi = tid + j * kBigThreads;
+        if (pi < P) {
+          const uint64_t lo = (((uint64_t)pi << rbits) + P - 1) / P;  // dense keys of the part: [lo, hi)
+          const uint64_t hi = min<uint64_t>(((((uint64_t)pi + 1) << rbits) + P - 1) / P, range);
+          if (lo < hi && (uint32_t)(lo / span) != (uint32_t)((hi - 1) / span)) atomicOr(&strad[pi >> 5], 1u << (pi & 31u));
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // one hit of query k (cnt anchors, slot address and query position wave-uniform): fast slots or the geometric
+    // overflow segments (seed_lookup.hip AllocOverflowSegment; a missing segment reads as zeros)
+    auto load_hit = [&](uint32_t qi, const Hit *slots, uint32_t h) {
+      if (h < a.fast_cap) return *reinterpret_cast<const uint4 *>(slots + h);
+      const uint32_t kk = h - a.fast_cap;
+      const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+      const uint32_t first = a.fast_cap * ((1u << level) - 1u);
+      const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
+      return seg != 0xFFFFFFFFu ? *reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first)) : make_uint4(0, 0, 0, 0);
+    };
+    auto decode_hit = [&](const uint4 &raw, uint32_t qpos) {  // Hit {uint64 position, dist, slot}
+      const uint64_t position = (uint64_t)raw.x | ((uint64_t)raw.y << 32);
+      return Decoded{(uint32_t)((position >> 33) << 1) | (uint32_t)(position & 1), (uint32_t)(position >> 1), qpos,
+                     __uint_as_float(raw.z)};
+    };
+    auto slots_of = [&](uint32_t qi) {
+      return dc.seg ? dc.seg + (size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap : a.region.At(qi, 0);
+    };
+    // The exact route visits the anchors QUERY BY QUERY, a wave per query, its lanes over the query's hits (a large
     // chunk has ~100 hits per query): no search for the query of an anchor, slot addresses and query position
     // are wave-uniform, the hit records of a query are read by consecutive lanes.  fn(decoded anchor).
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
     auto for_each_anchor = [&](auto &&fn) {
+      if constexpr (kLines) return;  // (the whole-line launch leaves the exact route to a launch of its own)
       for (uint32_t i = tid; i < ncar; i += kBigThreads) {  // smhip_carried_anchor {ref_strand, target, query, distance}
         const uint4 raw = *reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
         fn(Decoded{raw.x, raw.y, raw.z, __uint_as_float(raw.w)});
@@ -391,7 +465,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
       for (uint32_t k = wave; k < nq; k += kBigThreads / 64) {
         const uint32_t cnt = qoff[k + 1] - qoff[k];
         const uint32_t qi = q0 + k;
-        const Hit *slots = dc.seg ? dc.seg + (size_t)(qi & ((1u << a.region.qshift) - 1u)) * a.fast_cap : a.region.At(qi, 0);
+        const Hit *slots = slots_of(qi);
         const uint32_t qpos = (k + 1) * a.step + dc.qso;  // position + query_start_offset
         for (uint32_t h0 = 0; h0 < cnt; h0 += 128) {  // two hits per lane in flight
           uint4 raw[2];
@@ -401,30 +475,116 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
             const uint32_t h = h0 + 64 * u + lane;
             live[u] = h < cnt;
             raw[u] = make_uint4(0, 0, 0, 0);
-            if (!live[u]) continue;
-            if (h < a.fast_cap) {
-              raw[u] = *reinterpret_cast<const uint4 *>(slots + h);
-            } else {  // geometric overflow segments (seed_lookup.hip AllocOverflowSegment); a missing segment reads as zeros
-              const uint32_t kk = h - a.fast_cap;
-              const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
-              const uint32_t first = a.fast_cap * ((1u << level) - 1u);
-              const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
-              if (seg != 0xFFFFFFFFu) raw[u] = *reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first));
-            }
+            if (live[u]) raw[u] = load_hit(qi, slots, h);
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (!live[u]) continue;
-            const uint64_t position = (uint64_t)raw[u].x | ((uint64_t)raw[u].y << 32);  // Hit {uint64 position, dist, slot}
-            fn(Decoded{(uint32_t)((position >> 33) << 1) | (uint32_t)(position & 1), (uint32_t)(position >> 1), qpos,
-                       __uint_as_float(raw[u].z)});
-          }
+          for (int u = 0; u < 2; ++u)
+            if (live[u]) fn(decode_hit(raw[u], qpos));
         }
       }
     };
-    // ---- pass 1: part sizes
-    for_each_anchor([&](const Decoded &dv) { atomicAdd(&pcount[part_of(dv)], 1u); });
-    __syncthreads();
+    const uint64_t rec0 = RecOff(base, c);
+    uint4 *recs_out = reinterpret_cast<uint4 *>(a.keys) + rec0;
+    if constexpr (kLines) {
+      // ---- the whole-line pass: the chunk's anchors in their decode order (carried anchors, then the hits query by
+      // query) are cut into tiles of 2048, two per thread (anchor T * 2048 + 1024 u + tid: neighbouring lanes read
+      // neighbouring hits of a query).  The query of an anchor is found in the LDS offsets (the previous tile's
+      // answer bounds the search from below).  A tile's records are fetched while the tile before it is binned.
+      const uint32_t n_tiles = (n + kTile - 1u) / kTile;
+      const uint32_t scan_per = (P + 63u) / 64u;  // parts per lane of the tile scan (one wave)
+      uint32_t k_hint[2] = {0u, 0u};
+      uint4 raw_nx[2];
+      uint32_t qpos_nx[2];  // query position of a hit; ~0: a carried anchor (the record holds its own)
+      auto fetch = [&](uint32_t T) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t i = T * kTile + (uint32_t)u * kBigThreads + tid;
+          raw_nx[u] = make_uint4(0, 0, 0, 0);
+          qpos_nx[u] = 0xFFFFFFFFu;
+          if (i >= n) continue;
+          if (i < ncar) {  // smhip_carried_anchor {ref_strand, target, query, distance}
+            raw_nx[u] = *reinterpret_cast<const uint4 *>(a.carried + dc.car0 + i);
+            continue;
+          }
+          const uint32_t j = i - ncar;
+          uint32_t lo = k_hint[u], hi = nq;  // the query k with qoff[k] <= j < qoff[k + 1]
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (qoff[mid] <= j) lo = mid; else hi = mid;
+          }
+          k_hint[u] = lo;
+          const uint32_t qi = q0 + lo;
+          raw_nx[u] = load_hit(qi, slots_of(qi), j - qoff[lo]);
+          qpos_nx[u] = (lo + 1u) * a.step + dc.qso;  // position + query_start_offset
+        }
+      };
+      fetch(0);
+      for (uint32_t T = 0; T < n_tiles; ++T) {
+        Decoded dv[2];
+        bool live[2];
+        uint32_t pb[2] = {0, 0}, lpos[2] = {0, 0};
+        // count: position of the record among the tile's records of its part
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          live[u] = T * kTile + (uint32_t)u * kBigThreads + tid < n;
+          if (!live[u]) continue;
+          dv[u] = qpos_nx[u] == 0xFFFFFFFFu ? Decoded{raw_nx[u].x, raw_nx[u].y, raw_nx[u].z, __uint_as_float(raw_nx[u].w)}
+                                            : decode_hit(raw_nx[u], qpos_nx[u]);
+          pb[u] = part_of(dv[u]);
+          lpos[u] = atomicAdd(&tcount[pb[u]], 1u);
+        }
+        if (T + 1 < n_tiles) fetch(T + 1);  // (in flight while this tile is binned and copied out)
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the tile's part counts by one wave; the parts' running positions move on
+          uint32_t tot = 0;
+          for (uint32_t k = 0; k < scan_per; ++k) tot += tcount[scan_per * tid + k];
+          const uint32_t incl = (uint32_t)WaveScanAdd((int)tot);
+          uint32_t run = incl - tot;
+          for (uint32_t k = 0; k < scan_per; ++k) {
+            const uint32_t b = scan_per * tid + k;  // (< 64 scan_per <= kMaxParts + 63: the tables have that room)
+            const uint32_t h = tcount[b];
+            tstart[b] = run;
+            run += h;
+            const uint32_t g = pcount[b];
+            tgpos[b] = g;
+            pcount[b] = g + h;
+            tcount[b] = 0;
+          }
+        }
+        __syncthreads();
+        // place: the tile's records sorted by part in LDS, each with its destination in the part's slice
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (live[u]) {
+            const uint32_t b = pb[u];
+            const uint32_t pos = tgpos[b] + lpos[u];  // position inside the part = the key's index field
+            const uint32_t slot = tstart[b] + lpos[u];
+            if ((strad[b >> 5] >> (b & 31u)) & 1u) atomicAdd(&gcnt[min(dv[u].grp, kGroupsLds - 1u)], 1u);
+            const uint64_t key = (((uint64_t)dv[u].grp << (32 + ibits)) | ((uint64_t)dv[u].tpos << ibits)) | ((uint64_t)pos & idx_mask);
+            tile_rec[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), dv[u].qpos, __float_as_uint(dv[u].dist));
+            tile_dst[slot] = pos < kSlice ? b * kSlice + pos : 0xFFFFFFFFu;  // (a full slice: counted, not written)
+          }
+        const uint32_t tile_n = min(kTile, n - T * kTile);
+        __syncthreads();
+        // copy out: consecutive threads take consecutive records of the binned tile -- runs of one part, i.e.
+        // consecutive addresses
+        for (uint32_t sl = tid; sl < tile_n; sl += kBigThreads) {
+          const uint32_t d = tile_dst[sl];
+          if (d != 0xFFFFFFFFu) recs_out[d] = tile_rec[sl];
+        }
+      }
+      for (uint32_t k = tid; k < kMaxParts; k += kBigThreads)
+        if (pcount[k] > kSlice) s_overflow = 1u;
+      __syncthreads();
+      if (s_overflow) {  // (uniform) a part outgrew its slice (skewed targets): the chunk goes to the exact route's launch
+        if (tid == 0) w.redo[atomicAdd(&w.counters[3], 1u)] = c;
+        continue;
+      }
+    } else {
+      // ---- pass 1 of the exact route: part sizes
+      for_each_anchor([&](const Decoded &dv) { atomicAdd(&pcount[part_of(dv)], 1u); });
+      __syncthreads();
+    }
     PHASE_MARK(9);
     if (tid < 64) {  // exclusive scan of the part sizes by one wave
       constexpr uint32_t kPer = kMaxParts / 64;
@@ -444,7 +604,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
       for (uint32_t k = 0; k < kPer; ++k) {
         pstart[kPer * tid + k] = run;
         run += h[k];
-        pcount[kPer * tid + k] = 0;  // becomes the insertion cursor
+        pcount[kPer * tid + k] = 0;  // becomes the insertion cursor of the exact route
       }
       if (tid == 63) pstart[kMaxParts] = run;  // == n
     }
@@ -455,7 +615,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
     uint32_t *tab = w.part_tab + (size_t)c * kPartTab;
     for (uint32_t k = tid; k <= P; k += kBigThreads) tab[k] = pstart[k];
     const bool narrow = ((1ull << rbits) / P) + 2ull <= (1ull << 23);
-    constexpr uint32_t kPartsPerThread = kMaxParts / kBigThreads;
+    constexpr bool slices = kLines;  // the records lie in the parts' fixed slices (else at the exact offsets)
     uint32_t my_cls[kPartsPerThread], my_pos[kPartsPerThread], my_m[kPartsPerThread];
 #pragma unroll
     for (uint32_t j = 0; j < kPartsPerThread; ++j) {
@@ -481,43 +641,41 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
     for (uint32_t j = 0; j < kPartsPerThread; ++j) {
       const uint32_t pi = tid + j * kBigThreads;
       if (my_cls[j] == 2) {
-        w.items[cls_base[2] + my_pos[j]] = (c << kPartBits) | pi;
+        w.items[cls_base[2] + my_pos[j]] = (c << kPartBits) | pi;  // (only ever on the exact route: m > 1024 > kSlice)
       } else if (my_cls[j] < 2) {
         const uint64_t A = base + pstart[pi];
         const uint64_t dlo = (((uint64_t)pi << rbits) + P - 1) / P;  // part_of(.) == pi  <=>  dlo <= dense < the next dlo
-        (my_cls[j] ? w.recs[1] : w.recs[0])[cls_base[my_cls[j]] + my_pos[j]] =
+        const uint32_t at = cls_base[my_cls[j]] + my_pos[j];
+        (my_cls[j] ? w.recs[1] : w.recs[0])[at] =
             make_uint4((uint32_t)A, (uint32_t)(A >> 32) | (my_m[j] << 16), (uint32_t)dlo, (uint32_t)(dlo >> 32));
+        (my_cls[j] ? w.rin[1] : w.rin[0])[at] = rec0 + (slices ? (uint64_t)pi * kSlice : (uint64_t)pstart[pi]);
       }
     }
-    if (fold_groups) {
-      __syncthreads();  // tab / records have read pstart: its top bit now marks the parts that straddle a group boundary
+    if (fold_groups) {  // whole parts inside one group: their sizes
 #pragma unroll
       for (uint32_t j = 0; j < kPartsPerThread; ++j) {
         const uint32_t pi = tid + j * kBigThreads;
-        if (pi < P && my_m[j]) {
-          const uint64_t lo = (((uint64_t)pi << rbits) + P - 1) / P;  // dense keys of the part: [lo, hi)
-          const uint64_t hi = min<uint64_t>(((((uint64_t)pi + 1) << rbits) + P - 1) / P, range);
-          const uint32_t g_lo = (uint32_t)(lo / span), g_hi = (uint32_t)((hi - 1) / span);
-          if (g_lo == g_hi) atomicAdd(&gcnt[min(g_lo, kGroupsLds - 1u)], my_m[j]);
-          else pstart[pi] |= 0x80000000u;
+        if (pi < P && my_m[j] && !((strad[pi >> 5] >> (pi & 31u)) & 1u)) {
+          const uint64_t lo = (((uint64_t)pi << rbits) + P - 1) / P;
+          atomicAdd(&gcnt[min((uint32_t)(lo / span), kGroupsLds - 1u)], my_m[j]);
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
     PHASE_MARK(10);
-    // ---- pass 2: decode again, into the parts' slices of the chunk's records {key, query position, distance}
-    // (16 bytes, ONE scattered store per anchor: three separate columns cost 4.0 ms instead of 3.0 at 32 Mb -
-    // the pass is bound by write requests, not bytes).  The records take the room of the chunk's 2n keys.
-    uint4 *recs_out = reinterpret_cast<uint4 *>(a.keys) + base;
-    for_each_anchor([&](const Decoded &dv) {
-      const uint32_t b = part_of(dv);
-      const uint32_t pos = atomicAdd(&pcount[b], 1u);
-      const uint32_t ps = pstart[b];
-      const uint32_t dst = (ps & 0x7FFFFFFFu) + pos;
-      if (ps >> 31) atomicAdd(&gcnt[min(dv.grp, kGroupsLds - 1u)], 1u);  // (a part with a group boundary inside)
-      const uint64_t key = (((uint64_t)dv.grp << (32 + ibits)) | ((uint64_t)dv.tpos << ibits)) | ((uint64_t)pos & idx_mask);
-      recs_out[dst] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), dv.qpos, __float_as_uint(dv.dist));
-    });
+    if constexpr (!kLines) {
+      // ---- pass 2 of the exact route: decode again, into the parts' exact slices of the chunk's records (16 bytes,
+      // ONE scattered store per anchor: three separate columns cost 4.0 ms instead of 3.0 at 32 Mb - the pass is
+      // bound by write requests, not bytes)
+      for_each_anchor([&](const Decoded &dv) {
+        const uint32_t b = part_of(dv);
+        const uint32_t pos = atomicAdd(&pcount[b], 1u);
+        const uint32_t dst = pstart[b] + pos;
+        if ((strad[b >> 5] >> (b & 31u)) & 1u) atomicAdd(&gcnt[min(dv.grp, kGroupsLds - 1u)], 1u);
+        const uint64_t key = (((uint64_t)dv.grp << (32 + ibits)) | ((uint64_t)dv.tpos << ibits)) | ((uint64_t)pos & idx_mask);
+        recs_out[dst] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), dv.qpos, __float_as_uint(dv.dist));
+      });
+    }
     if (fold_groups) {  // group boundaries of the sorted chunk: exclusive prefix sums of the non-empty groups' sizes
       __syncthreads();
       if (tid < 64) {
@@ -599,7 +757,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void SortPartKernel(SortArgs a, ui
     if (m == 0) continue;  // (uniform)
     const uint64_t base = a.anchor_off[c];
     const uint64_t span = (uint64_t)tab[kMaxParts + 2] + 1ull;
-    uint4 *recs = reinterpret_cast<uint4 *>(a.keys) + base + b0;  // the part's records {key, qpos, dist} (SortPartitionKernel)
+    uint4 *recs = reinterpret_cast<uint4 *>(a.keys) + RecOff(base, c) + b0;  // the part's records {key, qpos, dist} (SortPartitionKernel, exact route)
     const uint32_t *u_qpos = reinterpret_cast<const uint32_t *>(recs) + 2;
     const float *u_dist = reinterpret_cast<const float *>(recs) + 3;
     uint32_t *s_tpos = a.s_tpos + base + b0, *s_qpos = a.s_qpos + base + b0, *s_grp = a.s_grp + base + b0;
@@ -839,6 +997,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
   const uint32_t lane = threadIdx.x;
   const uint32_t n_items = w.counters[cls];
   const uint4 *recs = cls ? w.recs[1] : w.recs[0];
+  const uint64_t *rin = cls ? w.rin[1] : w.rin[0];  // where each part's records lie (SortPartitionKernel)
   const uint64_t idx_mask = (1ull << ibits) - 1ull;
   uint32_t it = blockIdx.x;
   if (it >= n_items) return;
@@ -851,8 +1010,8 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
   constexpr bool PREFETCH = KPL == 8;
   const uint4 *rec_base = reinterpret_cast<const uint4 *>(a.keys);
   const uint64_t span = (uint64_t)*a.span_bound + 1ull;
-  auto prefetch = [&](const uint4 &rc, u32x4 (&dst)[8]) {
-    const uint4 *src0 = rec_base + ((uint64_t)rc.x | ((uint64_t)(rc.y & 0xFFFFu) << 32));
+  auto prefetch = [&](const uint4 &rc, uint64_t a_in, u32x4 (&dst)[8]) {
+    const uint4 *src0 = rec_base + a_in;
     const uint32_t m = rc.y >> 16;
     // (as inline assembly, or the compiler sinks the loads below the network to save registers; the matching
     // wait is WaitRecs)
@@ -869,8 +1028,9 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
   asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
   uint4 rec = recs[it + opaque0];
   uint4 rec_next = recs[min(it + gridDim.x, last) + opaque0];
+  uint64_t ain = rin[it + opaque0], ain_next = rin[min(it + gridDim.x, last) + opaque0];
   u32x4 kn[8];
-  if (PREFETCH) prefetch(rec, kn);
+  if (PREFETCH) prefetch(rec, ain, kn);
   for (;;) {
     const uint64_t A = (uint64_t)rec.x | ((uint64_t)(rec.y & 0xFFFFu) << 32);
     const uint32_t m = rec.y >> 16;  // 0 < m <= CAP
@@ -885,7 +1045,7 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
       const uint32_t i = lane + 64u * t;
       uint4 rv;
       if (PREFETCH) rv = make_uint4(kn[t & 7].x, kn[t & 7].y, kn[t & 7].z, kn[t & 7].w);
-      else rv = rec_base[A + min(i, m - 1u)];
+      else rv = rec_base[ain + min(i, m - 1u)];
       key_stage[i + i / KPL] = i < m ? ((uint64_t)rv.x | ((uint64_t)rv.y << 32)) : ~0ull;
       col_q[Pad(i)] = rv.z;  // (slots beyond the part get the clamped copies: never read)
       col_d[Pad(i)] = rv.w;
@@ -908,8 +1068,9 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
     PHASE_MARK(5);
     const uint32_t it_next = it + gridDim.x;
     const bool more = it_next < n_items;
-    if (PREFETCH) prefetch(rec_next, kn);  // (past the end: the last part again, unused)
+    if (PREFETCH) prefetch(rec_next, ain_next, kn);  // (past the end: the last part again, unused)
     const uint4 rec_next2 = recs[min(it_next + gridDim.x, last) + opaque0];
+    const uint64_t ain_next2 = rin[min(it_next + gridDim.x, last) + opaque0];
     __builtin_amdgcn_sched_barrier(0);  // all of the above is ISSUED before the network starts
     PHASE_MARK(0);
     if constexpr (NARROW) BitonicWave32(k32, lane);
@@ -987,6 +1148,8 @@ __global__ __launch_bounds__(64) void SortPartWaveKernel(SortArgs a, uint32_t ib
     it = it_next;
     rec = rec_next;
     rec_next = rec_next2;
+    ain = ain_next;
+    ain_next = ain_next2;
   }
   PHASE_FLUSH();
 }
@@ -1111,10 +1274,16 @@ hipError_t LaunchCarriedMaxTarget(smhip_ctx *ctx, const smhip_carried_anchor *ca
   return hipGetLastError();
 }
 
-hipError_t InitSortAttributes() {  // per device (smhip_init): the workgroup part sort keeps up to 8192 keys in LDS
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)((size_t)kPartLdsKeys * sizeof(uint64_t)));
+hipError_t InitSortAttributes() {  // per device (smhip_init): the workgroup part sort keeps up to 8192 keys in LDS,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((size_t)kPartLdsKeys * sizeof(uint64_t)));
+  if (e != hipSuccess) return e;  // ... the partition kernel's whole-line route a tile of 2048 records beside its tables
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartitionKernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kTileLdsBytes);
 }
+
+// 16-byte records the sort needs in a.keys for n_anchors_total anchors in n_chunks chunks (RecOff)
+uint64_t SortRecordRoom(uint64_t n_anchors_total, uint32_t n_chunks) { return RecOff(n_anchors_total, n_chunks) + 4; }
 
 hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint64_t n_anchors_total) {
   uint32_t gbits = 1;
@@ -1126,7 +1295,7 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   // more than the anchors allow), three counters
   const uint64_t max_items = std::min<uint64_t>((uint64_t)n_chunks * kMaxParts,
                                                 2 * (n_anchors_total / kPartTarget) + 3ull * n_chunks + 4);
-  const size_t words = (size_t)n_chunks * kPartTab + 9 * max_items + 8;
+  const size_t words = (size_t)n_chunks * (kPartTab + 1) + 13 * max_items + 16;
   hipError_t e = ctx->sort_tmp.Reserve(words * sizeof(uint32_t));
   if (e != hipSuccess) return e;
   BigSortWork w;
@@ -1134,10 +1303,22 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   w.part_tab = w.counters + 4;
   w.recs[0] = reinterpret_cast<uint4 *>(w.part_tab + (((size_t)n_chunks * kPartTab + 3) & ~(size_t)3));  // (16-byte aligned:
   w.recs[1] = w.recs[0] + max_items;                                                                       // counters is)
-  w.items = reinterpret_cast<uint32_t *>(w.recs[1] + max_items);
+  w.rin[0] = reinterpret_cast<uint64_t *>(w.recs[1] + max_items);
+  w.rin[1] = w.rin[0] + max_items;
+  w.items = reinterpret_cast<uint32_t *>(w.rin[1] + max_items);
+  w.redo = w.items + max_items;
   if ((e = hipMemsetAsync(w.counters, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(SortPartitionKernel, dim3(std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads))), dim3(kBigThreads),
-                     0, ctx->stream, a, n_chunks, gbits, ibits, w);
+  const uint32_t part_blocks = std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads));
+  if (ctx->knobs.sort_lines != 0) {  // (knob sort_lines = 0: the exact two-pass route for every chunk, A/B)
+    hipLaunchKernelGGL(SortPartitionKernel<true>, dim3(part_blocks), dim3(kBigThreads), kTileLdsBytes, ctx->stream, a, n_chunks,
+                       gbits, ibits, w, (const uint32_t *)nullptr);
+    // the chunks it listed (none, as a rule: the launch then ends at once)
+    hipLaunchKernelGGL(SortPartitionKernel<false>, dim3(std::min<uint32_t>(part_blocks, 256)), dim3(kBigThreads), 0, ctx->stream, a,
+                       n_chunks, gbits, ibits, w, (const uint32_t *)w.redo);
+  } else {
+    hipLaunchKernelGGL(SortPartitionKernel<false>, dim3(part_blocks), dim3(kBigThreads), 0, ctx->stream, a, n_chunks, gbits,
+                       ibits, w, (const uint32_t *)nullptr);
+  }
   // one wave per part (persistent: the grid fills the chip, every wave takes parts in turn); the parts beyond
   // a wave's registers - rare - go to the workgroup version
   const uint32_t wave_grid = (uint32_t)std::min<uint64_t>(max_items, 256 * 18);
