@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--contig-len", type=int, default=750000)
     ap.add_argument("--walk-blocks", type=int, default=0, help="tree-walker workgroups per CU (0 = default)")
     ap.add_argument("--fast-cap", type=int, default=0, help="fast hit slots per query (0 = default)")
+    ap.add_argument("--search-mode", default="auto", choices=["auto", "exact", "set"],
+                    help="smhip_params.search_mode (auto: decided from the index census)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU-baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive timed region")
@@ -160,6 +162,7 @@ def main():
             dv.params.walk_blocks_per_cu = args.walk_blocks
         if args.fast_cap:
             dv.params.hits_per_query_fast = args.fast_cap
+        dv.params.search_mode = {"auto": 0, "exact": 1, "set": 2}[args.search_mode]
     ix = None
     t_build = 0.0
     if rank == 0:
@@ -374,7 +377,9 @@ def main():
                     break
             except Exception:
                 traffic = None
-        basis = traffic if traffic else own_bytes
+        # without a counter profile of this code and workload: the SURVEY 8(d) weights on the walker's own visits
+        # (what a perfect layout would have to move) -- the honest algorithmic fraction, never above the peak
+        basis = traffic if traffic else useful_bytes
         achieved = basis / (seed_ms * 1e-3) / 1e9 if seed_ms > 0 else 0.0
         # (128-byte READ requests of the profile: the random-line ceiling is a read ceiling)
         lines_per_s = (read_lines or traffic / 128.0) / (seed_ms * 1e-3) if traffic and seed_ms > 0 else None
@@ -448,7 +453,9 @@ def main():
                           "TCC_EA0_RDREQ + WRITE_SIZE per launch (profiles/r3_calibration.json); they INCLUDE Infinity-Cache "
                           "hits, so frac is an upper bound on HBM utilisation -- divided by THIS run's launch duration "
                           "(the profile's own: profile_launch_ms)" if traffic else
-                          "the walker's own algorithmic bytes (no counter profile of this workload shape under profiles/)"),
+                          "SURVEY 8(d) algorithmic bytes on the walker's own visits (16 B per tree level of a record read, 28 B per "
+                          "point tested, 24 B per anchor, samples in, result out) -- no counter profile of this code and workload "
+                          "shape under profiles/"),
                 "profile_launch_ms": round(prof_ms, 4) if prof_ms else None,
                 # 128-byte lines per second against the 52 G random lines / s tools/micro/random_lines.hip measures beyond L2
                 "frac_of_random_line_ceiling": round(lines_per_s / RANDOM_LINES_PER_S, 4) if lines_per_s else None,

@@ -75,19 +75,23 @@ typedef struct {
                                      (the census behind bench.py's algorithmic bytes) */
   uint32_t search_mode;           /* how smhip_map_run and smhip_seed_lookup walk the tree (same hits, same anchors,
                                      same PAF in every mode; speed only):
-                                       SMHIP_SEARCH_AUTO  the order-free set walk over quad records, its queries
-                                                          beyond num_nearest_points hits searched a second time in the
-                                                          reference's order -- unless the index (smhip_index_upload's
-                                                          census of its own points) or the batches seen so far say that
-                                                          more than set_walk_max_over_cap of the queries would be:
-                                                          then everything in the reference's order at once;
+                                       SMHIP_SEARCH_AUTO  the order-free set walk over quad records; of a query with
+                                                          more than num_nearest_points hits the first num_nearest_points
+                                                          IN THE REFERENCE'S TRAVERSAL ORDER are kept
+                                                          (spatial_index.cc:371-372) by ranking the hits found
+                                                          (root-to-leaf path strings; seed_lookup.hip).  Where the
+                                                          ranking does not apply (num_nearest_points > 8192) such
+                                                          queries are searched a second time in the reference's order,
+                                                          and an index or a context with more than
+                                                          set_walk_max_over_cap of them searches everything in that
+                                                          order at once;
                                        SMHIP_SEARCH_EXACT always the reference's traversal order (binary records);
-                                       SMHIP_SEARCH_SET   always the set walk (+ the second search).
+                                       SMHIP_SEARCH_SET   always the set walk.
                                      smhip_seed_lookup: AUTO = EXACT (hits reported in nanoflann's order); SET reports
                                      every query's hits in the set walk's own order (the same SET of hits).
                                      An index without quad records (no inner node) is always walked in EXACT mode. */
-  float set_walk_max_over_cap;    /* AUTO: share of queries beyond the hit cap above which the set walk is not used
-                                     (0.0005) */
+  float set_walk_max_over_cap;    /* AUTO without the ranking: share of queries beyond the hit cap above which the
+                                     set walk is not used (0.0005) */
 } smhip_params;
 #define SMHIP_SEARCH_AUTO 0u
 #define SMHIP_SEARCH_EXACT 1u
@@ -165,7 +169,7 @@ int smhip_resolved_params(smhip_ctx *ctx, smhip_params *out);
  * from the environment ONCE, in smhip_init, and only when SMHIP_DEV=1 is set there as well; this call sets a knob of
  * a live context and is refused (SMHIP_ESTATE) for a context created without SMHIP_DEV=1.  Names (lower case):
  * lane_blocks_per_cu, xcd_ranges, scan_threshold, classes, bucket_bits, handout, sdtw_ring, sync_run, pool_min,
- * spec_tight, float_gap, sort_lines. */
+ * spec_tight, float_gap, sort_lines, second_search. */
 int smhip_dev_knob(smhip_ctx *ctx, const char *name, long long value);
 /* GPUs visible to this process (0 when there is none / no HIP runtime). */
 int smhip_device_count(void);
@@ -358,6 +362,10 @@ int smhip_refine_path_download(smhip_ctx *ctx, float *dist, int64_t *end_pos, in
  * smhip_map_run searched: 0 in the reference's traversal order (binary records), 1 the reference's own node set
  * (reference_walk), 2 order-free over quad records (nodes_visited then counts 128-byte quad records). */
 int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
+/* The anchor sort of the last smhip_map_run: parts sorted by one wave with 32-bit keys [0], by one wave with 64-bit keys
+ * [1], by a workgroup [2]; chunks that left the whole-line partition route for the exact one because a part outgrew
+ * its slice [3] (sort.hip). */
+int smhip_debug_sort_stats(smhip_ctx *ctx, uint32_t out[4]);
 int smhip_timing_enable(smhip_ctx *ctx, int on);
 int smhip_timing_reset(smhip_ctx *ctx);
 int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64_t *launches);

@@ -27,7 +27,7 @@ const KnobName kKnobNames[] = {{"lane_blocks_per_cu", &DevKnobs::lane_blocks_per
                                {"bucket_bits", &DevKnobs::bucket_bits}, {"handout", &DevKnobs::handout},
                                {"sdtw_ring", &DevKnobs::sdtw_ring}, {"sync_run", &DevKnobs::sync_run},
                                {"spec_tight", &DevKnobs::spec_tight}, {"float_gap", &DevKnobs::float_gap},
-                               {"sort_lines", &DevKnobs::sort_lines}};
+                               {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search}};
 // the environment's knobs, honoured only behind SMHIP_DEV=1 (read once per context, in smhip_init)
 DevKnobs ReadDevKnobs() {
   DevKnobs k;
@@ -61,6 +61,7 @@ void ForgetIndexHistory(smhip_ctx *ctx) {
   ctx->pool_hint = 0;
   ctx->census_valid = false;
   ctx->census_hits.clear();
+  ctx->slot_leaf_valid = false;
 }
 int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
   return Fail(ctx, e == hipErrorOutOfMemory ? SMHIP_ENOMEM : SMHIP_EHIP,
@@ -274,7 +275,7 @@ void smhip_destroy(smhip_ctx *ctx) {
                     &ctx->dl_off, &ctx->dl_compact, &ctx->sort_tmp, &ctx->rp_rows, &ctx->rp_cap, &ctx->rp_toff, &ctx->rp_poff, &ctx->rp_tgt,
                     &ctx->rp_qoff, &ctx->rp_qlen, &ctx->rp_lo, &ctx->rp_hi, &ctx->rp_width, &ctx->rp_celloff, &ctx->rp_codes,
                     &ctx->rp_dist, &ctx->rp_end, &ctx->rp_path, &ctx->rp_plen, &ctx->rp_start,
-                    &ctx->scan_tmp, &ctx->ix_quads, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
+                    &ctx->scan_tmp, &ctx->ix_slot_leaf, &ctx->ix_quads, &ctx->ix_nodes, &ctx->ix_tab, &ctx->ix_pts, &ctx->qrec, &ctx->walk_stack, &ctx->ev_scratch, &ctx->ref_sig, &ctx->ref_off, &ctx->refine_dist, &ctx->refine_end, &ctx->q_keys, &ctx->q_order, &ctx->q_hist, &ctx->q_nodes, &ctx->q_points, &ctx->ix_vind, &ctx->ix_bbox, &ctx->samples,
                     &ctx->qstart, &ctx->carried, &ctx->carried_off, &ctx->feat, &ctx->stdv,
                     &ctx->results, &ctx->nq, &ctx->q_off, &ctx->chunk_anchor_cnt, &ctx->anchor_off,
                     &ctx->n_groups, &ctx->q_count, &ctx->q_ovf_off, &ctx->region_tab, &ctx->ovf_list,
@@ -1066,7 +1067,7 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
                   &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};
   for (DevBuf *b : b4) HIPCHK(b->Reserve(na * 4));
-  HIPCHK(ctx->keys.Reserve(std::max<uint64_t>(SortRecordRoom(na, R), na) * 2 * sizeof(uint64_t)));  // the sort's records (4/3 per anchor)
+  HIPCHK(ctx->keys.Reserve(std::max<uint64_t>(SortRecordRoom(na, R), na) * 2 * sizeof(uint64_t)));  // the sort's records (5/3 per anchor)
   HIPCHK(ctx->used.Reserve(na));
   HIPCHK(ctx->out_anchors.Reserve(na * sizeof(smhip_carried_anchor)));
   SortArgs sa;
@@ -1161,7 +1162,7 @@ uint64_t SpecCapAnchors(const smhip_ctx *ctx, uint32_t R) {
 // unsorted and sorted columns, score, predecessor, group starts, sort records, flags, chain anchors.
 bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap, uint64_t na_cap) {
   const uint64_t per_query = (uint64_t)p->hits_per_query_fast * sizeof(Hit) + kOvfLevels * 4 + 32 * 2 + 4 * 6 + 64 * sizeof(Hit);
-  const uint64_t per_anchor = 11 * 4 + 2 * sizeof(uint64_t) * 4 / 3 + 6 + 1 + sizeof(smhip_carried_anchor);
+  const uint64_t per_anchor = 11 * 4 + 2 * sizeof(uint64_t) * 5 / 3 + 6 + 1 + sizeof(smhip_carried_anchor);
   uint64_t have_q = ctx->q_count.cap / 4, have_a = ctx->score.cap / 4;  // what these buffers hold already
   const uint64_t grow = (nq_cap > have_q ? (nq_cap - have_q) * per_query : 0) + (na_cap > have_a ? (na_cap - have_a) * per_anchor : 0);
   if (grow == 0) return true;
@@ -1179,6 +1180,7 @@ bool CapacitiesAffordable(smhip_ctx *ctx, const smhip_params *p, uint64_t nq_cap
 // batch decides nothing -- beyond set_walk_max_over_cap: every query in the reference's order from the next batch on.
 void LearnOverCap(smhip_ctx *ctx, const smhip_params *p, uint64_t NQ, uint32_t over_cap) {
   if (ctx->last_walk_mode != 2) return;
+  if ((uint32_t)p->num_nearest_points <= 8192u && !ctx->knobs.second_search) return;  // (ranked, not searched twice)
   ctx->seen_queries += NQ;
   ctx->seen_over_cap += over_cap;
   if (ctx->seen_queries >= 20000 && (double)ctx->seen_over_cap > (double)p->set_walk_max_over_cap * (double)ctx->seen_queries)
@@ -1294,12 +1296,19 @@ double CensusShareAbove(const smhip_ctx *ctx, uint32_t cap) {
 // What the caller left automatic, decided from a census of the resident index (IndexCensus: the hit counts of 4096
 // of its own points used as queries -- reads are noisy copies of such windows).
 //  * hits_per_query_fast == 0: the power of two that holds three quarters of the sample's queries entirely, within
-//    [512, 2048] (hits beyond the fast slots go to the shared overflow pool: correct at any size, slower);
-//  * search_mode AUTO: the set walk, unless more than set_walk_max_over_cap of the sample lies beyond
-//    num_nearest_points hits (such queries are searched twice) or the batches so far said so (LearnOverCap).
+//    [512, 2048] and a sixth of the device (hits beyond the fast slots go to the shared overflow pool: correct at
+//    any size, slower);
+//  * search_mode AUTO: the set walk whenever the index has quad records.  Its queries beyond num_nearest_points hits
+//    are settled by ranking the hits it found (seed_lookup.hip OverCapSelectKernel), which costs little however
+//    many there are.  Only where that is not available (num_nearest_points > 8192, or the second_search knob) such
+//    queries are searched a second time in the reference's order, one lane each: then an index whose census puts
+//    more than set_walk_max_over_cap of the sample beyond the cap, or a context that has met as many in its
+//    batches (LearnOverCap), searches everything in the reference's order at once.
 int ResolveParams(smhip_ctx *ctx, smhip_params *rp) {
   const bool want_fast = rp->hits_per_query_fast == 0;
-  const bool want_mode = rp->search_mode == SMHIP_SEARCH_AUTO && ctx->index.quads && !ctx->walk_exact_only && !rp->reference_walk;
+  const bool ranked = (uint32_t)rp->num_nearest_points <= 8192u && !ctx->knobs.second_search;  // (kSelMaxKeep)
+  const bool want_mode = rp->search_mode == SMHIP_SEARCH_AUTO && ctx->index.quads && !ranked && !ctx->walk_exact_only &&
+                         !rp->reference_walk;
   if ((want_fast || want_mode) && (!ctx->census_valid || ctx->census_radius != rp->search_radius)) {
     HIPCHK(IndexCensus(ctx, *rp, 4096));
     ctx->census_valid = true;
@@ -1320,7 +1329,7 @@ int ResolveParams(smhip_ctx *ctx, smhip_params *rp) {
     rp->hits_per_query_fast = fast;
   }
   if (rp->search_mode == SMHIP_SEARCH_AUTO) {
-    const bool exact = !ctx->index.quads || ctx->walk_exact_only ||
+    const bool exact = !ctx->index.quads || (!ranked && ctx->walk_exact_only) ||
                        (want_mode && CensusShareAbove(ctx, (uint32_t)rp->num_nearest_points) > (double)rp->set_walk_max_over_cap);
     rp->search_mode = exact ? SMHIP_SEARCH_EXACT : SMHIP_SEARCH_SET;
   }
@@ -1723,6 +1732,20 @@ int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]) {
   out[4] = ctx->spec_reruns;
   out[5] = ctx->spec_runs;
   out[6] = (uint32_t)ctx->last_walk_mode;
+  return SMHIP_OK;
+}
+
+int smhip_debug_sort_stats(smhip_ctx *ctx, uint32_t out[4]) {
+  if (!ctx || !out) return SMHIP_EINVAL;
+  memset(out, 0, 4 * sizeof(uint32_t));
+  if (!ctx->sort_tmp.p || !ctx->run_done) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
+  HIPCHK(hipMemcpyAsync(out, ctx->sort_tmp.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));  // (LaunchSort: the counters lead the scratch)
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return SMHIP_OK;
 }
 

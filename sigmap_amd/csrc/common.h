@@ -131,6 +131,8 @@ struct DevKnobs {
   int spec_tight = 0;          // SMHIP_SPEC_TIGHT: 1 halves the query capacity of a speculative batch, 2 the anchor capacity
   int float_gap = 0;           // SMHIP_FLOAT_GAP=1: division form of the chaining gap tests
   int sort_lines = -1;         // SMHIP_SORT_LINES: 0 = scattered-record partition only, 1 = LDS-binned whole-line partition
+  int second_search = 0;       // SMHIP_SECOND_SEARCH=1: queries beyond the hit cap are searched again in the reference's
+                               // order (round 3) instead of ranking the set walk's hits
 };
 
 // -DSMHIP_PHASE_PROF (tools/phase_prof.sh, never in the shipped library): thread 0 of every workgroup adds
@@ -213,6 +215,8 @@ struct smhip_ctx {
   int dim = 0;
   smhip::IndexView index{};
   smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, ix_quads, scan_tmp;
+  smhip::DevBuf ix_slot_leaf;     // block of eight point slots -> leaf ordinal (seed_lookup.hip OverCapSelectKernel), derived
+  bool slot_leaf_valid = false;   // lazily from leaf_tab by the context itself, whichever way the index arrived
   int last_walk_mode = 0;         // search mode of the last smhip_map_run: 0 exact order, 1 census, 2 order-free (quad records)
   uint64_t leaf_pts_bytes = 0, leaf_vind_bytes = 0;
   smhip::DevBuf max_tpos;       // [0] largest target position of the resident index, [1] ... and of the batch's carried anchors

@@ -97,6 +97,9 @@ struct Sink {
   uint64_t pool_cap;
   uint32_t stop_at_cap;  // second search of the queries beyond the cap: a query ends with its nnp-th hit, its totals
                          // (hits, nodes, points) stay those of the first search
+  uint32_t store_all;    // set walk whose over-cap queries are RANKED afterwards (OverCapSelectKernel): every hit is
+                         // stored, also beyond the nnp-th in this walk's own order -- which of them the reference
+                         // keeps is decided from the whole set
 };
 
 // nanoflann.hpp:1006-1023 computeInitialDistances (low test, then high test, per dimension)
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         h.position = (uint64_t)sv.z | ((uint64_t)sv.w << 32);
         h.dist = res;
         h.slot = mine.x + t;
-        const bool emit = hit && ord < sink.nnp;
+        const bool emit = hit && (ord < sink.nnp || sink.store_all);
         if (emit && ord < sink.fast_cap) {
           // (a GLOBAL store: through the generic pointer read back from LDS it was a flat store, which the LDS
           // accesses after it have to wait for)
@@ -1167,6 +1170,222 @@ __global__ void OverCapCollectKernel(const QueryRec *__restrict__ qrec, const ui
   }
 }
 
+// ---- Queries beyond the hit cap without a second search.  The set walk has every hit of such a query (H >
+// num_nearest_points of them, in the query's slots and overflow segments); the reference keeps the FIRST
+// num_nearest_points in its traversal order (spatial_index.cc:371-372).  That order is a depth-first walk that takes
+// the child on the query's side of the split first (nanoflann.hpp:1384-1399: diff1 + diff2 < 0 -> child1) and scans a
+// leaf's points in index order, so a hit's place in it is decided by the root-to-leaf path of its leaf: the string
+// of "the far child was taken" bits, most significant first -- paths of different leaves part at some node, where
+// the near one comes first -- and, inside a leaf, by the point's slot.  So: (A) every hit gets its leaf's path
+// string as a 64-bit key, left aligned (a descent by leaf ordinal: the first child's subtree of an inner record
+// holds second-child-index - own-index leaves), written over the hit's position word; (B) a radix select finds
+// the key of the num_nearest_points-th hit; (C) the hits at or below it that lie beyond the first
+// num_nearest_points records change places with the records they displace (the kept hits' ORDER does not matter: the
+// anchors are sorted afterwards); (D) the kept records get their positions back from the point blocks.  One
+// workgroup per query, everything in place.  A tree deeper than 64 levels does not fit the key: such a query is
+// handed on to the search in the reference's order (list2), as before.
+constexpr uint32_t kSelThreads = 256;
+constexpr uint32_t kSelMaxKeep = 8192;  // room for the displaced records' indices; a larger num_nearest_points: the second search
+
+__global__ void SlotLeafKernel(const uint32_t *__restrict__ leaf_tab, uint64_t n_leaves, uint32_t *__restrict__ slot_leaf) {
+  for (uint64_t l = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; l < n_leaves; l += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t w = leaf_tab[l], n = w >> 27;
+    const uint64_t b0 = w & 0x07FFFFFFu;  // first block of eight 32-byte slots
+    for (uint32_t b = 0; b < (n + 7u) / 8u; ++b) slot_leaf[b0 + b] = (uint32_t)l;
+  }
+}
+
+__device__ __forceinline__ Hit *HitAt(const Sink &sink, uint32_t qi, uint32_t i) {
+  if (i < sink.fast_cap) return sink.region.At(qi, i);
+  const uint32_t k = i - sink.fast_cap;
+  const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
+  const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
+  return sink.pool + (size_t)sink.ovf_tab[(size_t)qi * kOvfLevels + level] + (k - first);
+}
+
+// the path string of leaf `leaf` for query q (see above); false: deeper than 64 levels
+__device__ __forceinline__ bool PathKey(const IndexView &ix, const QueryRec &r, uint32_t leaf, uint64_t &key, uint32_t &depth_out) {
+  uint32_t node = ix.root_ref, lo = 0, depth = 0;
+  uint64_t k = 0;
+  while (!(node & kLeafTag)) {
+    if (depth == 64u) return false;
+    const uint4 rec = ix.inner[(size_t)node * 4];
+    const uint32_t feat = (rec.z >> 28) & 7u;
+    const float val = feat == 0 ? r.q[0] : feat == 1 ? r.q[1] : feat == 2 ? r.q[2] : feat == 3 ? r.q[3] : feat == 4 ? r.q[4] : r.q[5];
+    const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
+    const bool near_first = (diff1 + diff2) < 0;  // nanoflann.hpp:1384
+    const uint32_t ref1 = rec.z & (kLeafTag | kIdxMask), ref2 = rec.w & (kLeafTag | kIdxMask);
+    const uint32_t n1 = (ref2 & kLeafTag) ? (ref2 & kIdxMask) - lo : ref2 - node;  // leaves below the first child
+    const bool go_first = leaf < lo + n1;
+    k = (k << 1) | (go_first != near_first ? 1ull : 0ull);
+    node = go_first ? ref1 : ref2;
+    if (!go_first) lo += n1;
+    ++depth;
+  }
+  key = depth ? k << (64u - depth) : 0ull;
+  depth_out = depth;
+  return true;
+}
+
+__global__ __launch_bounds__(kSelThreads) void OverCapSelectKernel(IndexView ix, const uint32_t *__restrict__ slot_leaf,
+                                                                   const QueryRec *__restrict__ list,
+                                                                   const uint32_t *__restrict__ n_list, Sink sink,
+                                                                   QueryRec *__restrict__ list2, uint32_t *__restrict__ n_list2) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint16_t posB[kSelMaxKeep];  // (indices below num_nearest_points <= 8192)
+  __shared__ uint32_t eq_slot[32];
+  __shared__ uint32_t s_bin, s_rem, s_neq, s_depth, s_wave[2][kSelThreads / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t total = *n_list;
+  const uint4 *pts4 = reinterpret_cast<const uint4 *>(ix.leaf_pts);
+  auto position_of = [&](uint32_t slot) {
+    const uint4 v = pts4[2 * (size_t)slot + 1];  // {v4, v5, position lo, position hi}
+    return (uint64_t)v.z | ((uint64_t)v.w << 32);
+  };
+  for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+    const QueryRec r = list[it];
+    const uint32_t qi = r.k, H = sink.q_count[qi], keep = sink.nnp;
+    __syncthreads();  // the previous query is done with the shared arrays
+    if (tid == 0) s_depth = 0;
+    // a hit the pool had no room for (the batch is flagged and searched again with a larger pool): nothing to do here
+    bool missing = false;
+    if (H > sink.fast_cap && tid < (uint32_t)kOvfLevels) {
+      const uint32_t last_level = 31u - (uint32_t)__clz((int)((H - 1u - sink.fast_cap) / sink.fast_cap + 1));
+      missing = last_level >= (uint32_t)kOvfLevels ||
+                (tid <= last_level && sink.ovf_tab[(size_t)qi * kOvfLevels + tid] == 0xFFFFFFFFu);
+    }
+    if (__syncthreads_or(missing ? 1 : 0)) continue;
+    // ---- A: the keys.  A thread takes a contiguous run of the hits: consecutive hits mostly share their leaf (a
+    // leaf's hits are emitted together), and with it the key
+    const uint32_t run = (H + kSelThreads - 1u) / kSelThreads;
+    const uint32_t i0 = min(H, tid * run), i1 = min(H, i0 + run);
+    bool bad = false;
+    {
+      uint32_t last_leaf = 0xFFFFFFFFu, max_depth = 0;
+      uint64_t last_key = 0;
+      for (uint32_t i = i0; i < i1; ++i) {
+        Hit *hp = HitAt(sink, qi, i);
+        const uint32_t leaf = slot_leaf[hp->slot >> 3];
+        if (leaf != last_leaf) {
+          uint32_t depth = 0;
+          if (!PathKey(ix, r, leaf, last_key, depth)) bad = true;
+          max_depth = max(max_depth, depth);
+          last_leaf = leaf;
+        }
+        hp->position = last_key;
+      }
+      if (max_depth) atomicMax(&s_depth, max_depth);
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {  // a path beyond 64 levels: the positions back, the query to the ordered search
+      for (uint32_t i = i0; i < i1; ++i) {
+        Hit *hp = HitAt(sink, qi, i);
+        hp->position = position_of(hp->slot);
+      }
+      if (tid == 0) list2[atomicAdd(n_list2, 1u)] = r;
+      continue;
+    }
+    // ---- B: the key of the keep-th hit in key order (ties: the hits of one leaf), eight bits per pass
+    // (no key has a bit below its path's length: with paths of at most s_depth levels the passes beyond
+    // ceil(s_depth / 8) would all pick digit 0)
+    uint64_t prefix = 0;
+    uint32_t remaining = keep;
+    const int n_pass = (int)max((s_depth + 7u) / 8u, 1u);
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const int shift = 56 - 8 * pass;
+      hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < H; i += 4 * kSelThreads) {  // (four loads in flight)
+        uint64_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = HitAt(sink, qi, min(i + (uint32_t)u * kSelThreads, H - 1u))->position;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + (uint32_t)u * kSelThreads < H && (pass == 0 || (key[u] >> (shift + 8)) == prefix))
+            atomicAdd(&hist[(uint32_t)(key[u] >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        uint32_t c[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c[k] = hist[4 * tid + k];
+          tot += c[k];
+        }
+        uint32_t before = (uint32_t)WaveScanAdd((int)tot) - tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (before < remaining && before + c[k] >= remaining) {  // exactly one bin: the matching keys number >= remaining
+            s_bin = 4 * tid + k;
+            s_rem = remaining - before;
+          }
+          before += c[k];
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | s_bin;
+      remaining = s_rem;
+      __syncthreads();
+    }
+    const uint64_t kstar = prefix << (8 * (8 - n_pass));  // `remaining` of the hits with this key -- one leaf's -- are kept: the lowest slots
+    if (tid == 0) s_neq = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < H; i += kSelThreads) {
+      const Hit *hp = HitAt(sink, qi, i);
+      if (hp->position == kstar) {
+        const uint32_t e = atomicAdd(&s_neq, 1u);
+        if (e < 32u) eq_slot[e] = hp->slot;
+      }
+    }
+    __syncthreads();
+    const uint32_t n_eq = min(s_neq, 32u);  // (a leaf holds at most 21 points)
+    auto selected = [&](uint64_t key, uint32_t slot) {
+      if (key != kstar) return key < kstar;
+      uint32_t below = 0;
+      for (uint32_t e = 0; e < n_eq; ++e) below += eq_slot[e] < slot ? 1u : 0u;
+      return below < remaining;
+    };
+    // ---- C: kept hits beyond the first `keep` records take the places of the dropped ones among them (both in
+    // index order; the dropped ones all come first: their indices are collected before any kept one needs them)
+    uint32_t n_b = 0, n_a = 0;
+    for (uint32_t base = 0; base < H; base += kSelThreads) {
+      const uint32_t i = base + tid;
+      const bool live = i < H;
+      uint4 rec = make_uint4(0, 0, 0, 0);
+      if (live) rec = *reinterpret_cast<const uint4 *>(HitAt(sink, qi, i));
+      const bool sel = live && selected((uint64_t)rec.x | ((uint64_t)rec.y << 32), rec.w);
+      const bool is_b = live && i < keep && !sel, is_a = live && i >= keep && sel;
+      const uint64_t mb = __ballot(is_b), ma = __ballot(is_a);
+      if (lane == 0) {
+        s_wave[0][wave] = (uint32_t)__popcll(mb);
+        s_wave[1][wave] = (uint32_t)__popcll(ma);
+      }
+      __syncthreads();
+      uint32_t off_b = n_b, off_a = n_a, tot_b = 0, tot_a = 0;
+#pragma unroll
+      for (uint32_t w2 = 0; w2 < kSelThreads / 64; ++w2) {
+        if (w2 < wave) {
+          off_b += s_wave[0][w2];
+          off_a += s_wave[1][w2];
+        }
+        tot_b += s_wave[0][w2];
+        tot_a += s_wave[1][w2];
+      }
+      const uint64_t below = (1ull << lane) - 1ull;
+      if (is_b) posB[off_b + (uint32_t)__popcll(mb & below)] = (uint16_t)i;
+      __syncthreads();
+      if (is_a) *reinterpret_cast<uint4 *>(HitAt(sink, qi, posB[off_a + (uint32_t)__popcll(ma & below)])) = rec;
+      n_b += tot_b;
+      n_a += tot_a;
+      __syncthreads();
+    }
+    // ---- D: the kept records' positions back (the word held the key)
+    for (uint32_t i = tid; i < keep; i += kSelThreads) {
+      Hit *hp = HitAt(sink, qi, i);
+      hp->position = position_of(hp->slot);
+    }
+  }
+}
+
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const QueryRec *qrec, const uint32_t *n_queries_dev,
                       uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride,
                       uint32_t blocks_override = 0) {
@@ -1328,7 +1547,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
                             uint32_t *q_nodes, uint32_t *q_points, uint32_t *counters, Hit *pool,
                             uint32_t *ovf_tab, uint64_t pool_cap) {
   Sink sink{region, p.hits_per_query_fast, (uint32_t)p.num_nearest_points, q_count, q_nodes, q_points,
-            nullptr, counters, pool, ovf_tab, pool_cap, 0u};
+            nullptr, counters, pool, ovf_tab, pool_cap, 0u, 0u};
   const QueryRec *qr = reinterpret_cast<const QueryRec *>(qrec);
   const uint32_t *order = nullptr, *range_end = nullptr;
   uint32_t range_stride = 0;
@@ -1352,8 +1571,11 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
     return LaunchWalk(ctx, p, kWalkExact, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                       range_stride);
   ctx->last_walk_mode = kWalkSet;
+  const bool ranked = (uint32_t)p.num_nearest_points <= kSelMaxKeep && !ctx->knobs.second_search;
+  sink.store_all = ranked ? 1u : 0u;
   e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
                  range_stride);
+  sink.store_all = 0u;
   if (e != hipSuccess) return e;
   // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal
   // order (spatial_index.cc:371-372), so they are searched again in that order; their slots, overflow segments
@@ -1362,11 +1584,31 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   // device: counters[7]; the range cursors [16..23] start again.
   QueryRec *list = reinterpret_cast<QueryRec *>(const_cast<uint32_t *>(order));
   if ((e = hipMemsetAsync(counters + 16, 0, 8 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(counters + 7, 0, sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(counters + 6, 0, 2 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(OverCapCollectKernel, dim3(1024), dim3(256), 0, ctx->stream, qr, q_off + n_chunks, q_count,
                      (uint32_t)p.num_nearest_points, list, counters + 7);
+  const uint32_t *second_n = counters + 7;
+  if (ranked) {
+    // ... or, rather: the set walk's hits are RANKED in the reference's order and the first num_nearest_points kept
+    // (OverCapSelectKernel); only the queries of a tree too deep for the ranking's keys (counters[6] of them, list2)
+    // are searched again
+    if (!ctx->slot_leaf_valid) {  // block of eight point slots -> leaf, once per resident index
+      const uint64_t blocks = (ctx->leaf_pts_bytes / 32 + 7) / 8 + 8;
+      if ((e = ctx->ix_slot_leaf.Reserve(blocks * sizeof(uint32_t))) != hipSuccess) return e;
+      hipLaunchKernelGGL(SlotLeafKernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->index.leaf_tab, ctx->index.n_leaves,
+                         ctx->ix_slot_leaf.as<uint32_t>());
+      ctx->slot_leaf_valid = true;
+    }
+    if ((e = ctx->ovf_list.Reserve(n_queries_max * sizeof(QueryRec))) != hipSuccess) return e;
+    QueryRec *list2 = ctx->ovf_list.as<QueryRec>();
+    hipLaunchKernelGGL(OverCapSelectKernel, dim3(2048), dim3(kSelThreads), 0, ctx->stream, ctx->index,
+                       ctx->ix_slot_leaf.as<uint32_t>(), list, counters + 7, sink, list2, counters + 6);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    list = list2;
+    second_n = counters + 6;
+  }
   sink.stop_at_cap = 1u;
-  return LaunchWalk(ctx, p, kWalkExact, list, counters + 7, 0, sink, nullptr, 0);
+  return LaunchWalk(ctx, p, kWalkExact, list, second_n, 0, sink, nullptr, 0);
 }
 
 // Census of the index: `samples` of its own points (the first point of evenly spaced leaves) as queries, hit counts
@@ -1413,7 +1655,7 @@ hipError_t IndexCensus(smhip_ctx *ctx, const smhip_params &p, uint32_t samples) 
   uint32_t range_stride = 0;
   if ((e = BuildQueryOrder(ctx, qr, nullptr, samples, samples, &order, &range_end, &range_stride)) != hipSuccess) return done(e);
   Sink sink{HitSlots{d_tab.as<Hit *>(), 31u, 1u}, 1u, 1u, d_cnt.as<uint32_t>(), nullptr, nullptr, nullptr,
-            ctx->counters.as<uint32_t>(), nullptr, nullptr, 0, 0u};
+            ctx->counters.as<uint32_t>(), nullptr, nullptr, 0, 0u, 0u};
   const int saved_mode = ctx->last_walk_mode;
   e = LaunchWalk(ctx, p, ctx->index.quads ? kWalkSet : kWalkExact, reinterpret_cast<const QueryRec *>(order), nullptr, samples,
                  sink, range_end, range_stride);
@@ -1438,7 +1680,7 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   uint32_t range_stride = 0;
   if ((e = BuildQueryOrder(ctx, qr, nullptr, n, n, &order, &range_end, &range_stride)) != hipSuccess) return e;
   // the test entry point reports the first `cap` hits of every query (no pool, no 5000 cut)
-  Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0, 0u};
+  Sink sink{region, cap, cap, q_count, q_nodes, q_points, nullptr, counters, nullptr, nullptr, 0, 0u, 0u};
   ScopedTimer t(ctx, T_SEED);
   // the per-stage entry point reports hits in the reference's traversal order, or -- SMHIP_SEARCH_SET -- as the
   // mapping path's order-free walk over quad records finds them (same set; an index without quads: exact walk)

@@ -286,12 +286,15 @@ struct BigSortWork {   // global scratch of the large-chunk path (LaunchSort)
 };
 
 // The record scratch (a.keys as 16-byte records) of chunk c starts at RecOff(anchor_off[c], c).  The whole-line
-// route gives every part a fixed slice of kSlice records (parts aim at kPartTarget = 3/4 of it), so a chunk of n
-// anchors may need (n / kPartTarget + 3) * kSlice = 4 n / 3 + 1536 records: consecutive chunks' regions differ by
-// at least 4 (n / 3 - 2 / 3) + 4 + 2048.  (LaunchSort sizes a.keys for RecOff(total anchors, n_chunks).)
-constexpr uint32_t kSlice = 512;
+// route gives every part a fixed slice of kSlice records.  Parts aim at kPartTarget = 384 anchors and a read's true
+// locus adds a hundred or two to ONE part of its chunk: with slices of 512 every seventh chunk of a 250 Mb reference
+// outgrew one and took the exact route; 640 leaves that to skewed target distributions (a part of 513 .. 640 keys is
+// sorted by the wave kernel's 64-bit network: one per chunk).  A chunk of n anchors may need
+// (n / kPartTarget + 3) * kSlice = 5 n / 3 + 1920 records: consecutive chunks' regions differ by at least
+// 5 (n / 3 - 2 / 3) + 5 + 2048.  (LaunchSort sizes a.keys for RecOff(total anchors, n_chunks).)
+constexpr uint32_t kSlice = 640;
 __host__ __device__ __forceinline__ uint64_t RecOff(uint64_t anchor_off, uint64_t c) {
-  return 4ull * (anchor_off / 3ull + c) + 2048ull * c;
+  return 5ull * (anchor_off / 3ull + c) + 2048ull * c;
 }
 
 // ---- decode: anchor i of a chunk = carried anchor i, or hit (i - ncar - qoff[k]) of the chunk's query k

@@ -363,6 +363,12 @@ class DeviceMapper:
                     "smhip_index_census")
         return out[:n.value]
 
+    def sort_stats(self):
+        """[parts by 32-bit wave sort, by 64-bit wave sort, by workgroup sort, chunks on the exact partition route]."""
+        out = np.zeros(4, dtype=np.uint32)
+        self._check(self.L.smhip_debug_sort_stats(self._h, ptr(out)), "smhip_debug_sort_stats")
+        return out
+
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint32)
         self._check(self.L.smhip_debug_counters(self._h, ptr(out)), "smhip_debug_counters")

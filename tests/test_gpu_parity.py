@@ -325,6 +325,17 @@ def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, bloc
     finally:
         device.params.walk_blocks_per_cu = 0
         device.params.reference_walk = 0
+    if blocks == 0 and strict == 0:
+        # the sort's whole-line partition route took every chunk (no part outgrew its slice); the exact two-pass
+        # route (knob sort_lines = 0) gives the same records
+        st_sort = device.sort_stats()
+        assert st_sort[3] == 0 and st_sort[0] + st_sort[1] > len(pa), st_sort
+        device.set_knob("sort_lines", 0)
+        try:
+            assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes()
+            assert device.sort_stats()[3] == 0
+        finally:
+            device.set_knob("sort_lines", -1)
     names = ["contig0", "contig1", "contig2"]
     lines = _paf_lines(res, pa, names, ref_lens)
     mapped = 0
@@ -573,21 +584,29 @@ def test_pipeline_hit_cap_truncation_matches_oracle(small_world):
     tree = po.OracleTree(ix.values.copy())
     for cap in (5, 5000):
         for fast in (3, 128):   # truncation inside the fast slots and inside the overflow pass
-            # SET: the order-free walk, then the queries beyond the cap -- here, with cap 5, all of them -- searched a
-            # second time in the reference's order; AUTO: the census of the index sees that every query is beyond the
-            # cap and searches everything in the reference's order at once.  Same records.
+            # The order-free set walk, then the queries beyond the cap -- here, with cap 5, all of them -- settled (a)
+            # by ranking the hits found in the reference's traversal order and keeping the first `cap` (the rule), (b)
+            # by a second search in the reference's order (knob second_search: round 3's route; AUTO then lets the
+            # census of the index pick the reference's order for everything), (c) EXACT from the start.  Same records.
             dev = pipeline.DeviceMapper(0)
             dev.upload_index(ix)
             dev.params.num_nearest_points = cap
             dev.params.hits_per_query_fast = fast
+            res = dev.map_chunks(samples, offsets, n_refs=1)          # AUTO: set walk + ranking
+            c = dev.debug_counters()
+            assert c[6] == 2 and (c[7] > 100) == (cap == 5)
+            same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
+            dev.set_knob("second_search", 1)
             dev.params.search_mode = _abi.SEARCH_SET
-            res = dev.map_chunks(samples, offsets, n_refs=1)
-            assert dev.debug_counters()[6] == 2
+            again = dev.map_chunks(samples, offsets, n_refs=1)
+            assert dev.debug_counters()[6] == 2 and all(np.array_equal(res[k], again[k]) for k in same)
             dev.params.search_mode = _abi.SEARCH_AUTO
             again = dev.map_chunks(samples, offsets, n_refs=1)
-            assert dev.debug_counters()[6] == (0 if cap == 5 else 2)
-            same = [k for k in res.dtype.names if k not in ("nodes_visited", "points_tested")]
-            assert all(np.array_equal(res[k], again[k]) for k in same)
+            assert dev.debug_counters()[6] == (0 if cap == 5 else 2) and all(np.array_equal(res[k], again[k]) for k in same)
+            dev.set_knob("second_search", 0)
+            dev.params.search_mode = _abi.SEARCH_EXACT
+            again = dev.map_chunks(samples, offsets, n_refs=1)
+            assert dev.debug_counters()[6] == 0 and all(np.array_equal(res[k], again[k]) for k in same)
             dev.close()
             assert (res["hits_total"] > res["n_queries"] * 4).sum() >= 2   # repeats: seeds with 12 hits each
             for i, x in enumerate(pa):
@@ -606,9 +625,10 @@ def test_repeat_injected_cloud_second_search_at_the_default_cap(small_world):
     """A repeat-injected reference: one 600-base unit copied 5600 times at offsets of 1e-6, so that every seed
     of a read of the unit has 5600 hits -- beyond the DEFAULT cap of 5000 (spatial_index.cc:371-372), with the fast
     slots at 512: the set walk writes four levels of overflow segments per query, OverCapCollectKernel lists every
-    hitting query, and the second search (reference order, stop_at_cap) allocates and writes them again.  A fresh
-    context per route: SET (set walk + second search), EXACT, and AUTO (the index census sees the repeats and picks
-    the reference's order without paying the double search).  Chains against the oracle's so_generate_chains."""
+    hitting query, and either the hits are ranked in the reference's traversal order and the first 5000 kept
+    (OverCapSelectKernel: records moved between slots and overflow segments), or -- knob second_search, round 3's
+    route -- a second search in the reference's order (stop_at_cap) allocates and writes the segments again.  A
+    fresh context per route, incl. AUTO and EXACT.  Chains against the oracle's so_generate_chains."""
     lm = small_world["lm"]
     rng = np.random.default_rng(8)
     unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)])
@@ -631,7 +651,8 @@ def test_repeat_injected_cloud_second_search_at_the_default_cap(small_world):
     tree.close()
     assert sum(1 for _, st in want if st.hits >= 100 * copies) >= 3     # reads of the + strand: ~100 seeds x 5600 hits
     same = None
-    for mode, fast, walked in ((_abi.SEARCH_SET, 512, 2), (_abi.SEARCH_SET, 0, 2), (_abi.SEARCH_EXACT, 512, 0), (_abi.SEARCH_AUTO, 0, 0)):
+    for mode, fast, second, walked in ((_abi.SEARCH_AUTO, 512, 0, 2), (_abi.SEARCH_AUTO, 0, 0, 2), (_abi.SEARCH_SET, 512, 1, 2),
+                                       (_abi.SEARCH_SET, 0, 1, 2), (_abi.SEARCH_EXACT, 512, 0, 0), (_abi.SEARCH_AUTO, 0, 1, 0)):
         dev = pipeline.DeviceMapper(0)       # fresh: nothing learnt from earlier batches
         dev.upload_index(ix)
         if mode == _abi.SEARCH_AUTO:
@@ -639,11 +660,12 @@ def test_repeat_injected_cloud_second_search_at_the_default_cap(small_world):
             assert len(census) == 4096 and census[len(census) // 100] >= copies   # (nearly) every sampled point: 5600+ hits
         dev.params.search_mode = mode
         dev.params.hits_per_query_fast = fast
+        dev.set_knob("second_search", second)
         res = dev.map_chunks(samples, offsets, n_refs=1)
         c = dev.debug_counters()
         assert c[6] == walked and (res["status"] == 0).all(), (mode, c[:8])
-        if mode == _abi.SEARCH_SET:
-            assert c[7] >= 300                    # queries the set walk handed to the second search
+        if walked == 2:
+            assert c[7] >= 300                    # queries beyond the cap: ranked, or handed to the second search
         for i, (chains, st) in enumerate(want):
             assert res[i]["n_anchors"] == st.anchors and res[i]["hits_total"] == st.hits and res[i]["n_chains"] == len(chains)
             for k, ch in enumerate(chains[:4]):
@@ -682,6 +704,14 @@ def test_pipeline_heavy_ties_large_chunks(small_world):
     samples, offsets = _batch(pa)
     res = dev.map_chunks(samples, offsets, n_refs=1)
     assert (res["status"] == 0).all() and res["n_anchors"].min() > 16384
+    # a hundred equal targets in a row outgrow the fixed slices of the whole-line partition route: every chunk
+    # takes the exact route, and parts go to the workgroup sorter
+    st_sort = dev.sort_stats()
+    assert st_sort[3] == len(pa) and st_sort[2] > 0, st_sort
+    dev.set_knob("sort_lines", 0)           # the exact route for every chunk from the start: the same records
+    res0 = dev.map_chunks(samples, offsets, n_refs=1)
+    dev.set_knob("sort_lines", -1)
+    assert res0.tobytes() == res.tobytes()
     tree = po.OracleTree(ix.values.copy())
     for i, x in enumerate(pa):
         f, _ = po.generate_events(x)
