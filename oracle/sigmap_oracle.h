@@ -9,11 +9,12 @@
  * reference's coordinates depend on FMA contraction, so the pin is "no contraction").
  *
  * Parity pin status (see oracle/README.md for the full statement):
- *   - so_detect_events (A2-A6), so_kdtree_build / so_radius_search (A10, N1, T9) and
- *     so_level_means (pore_model.cc) are pinned against the REAL reference code,
+ *   - so_detect_events (A2-A6), so_kdtree_build / so_radius_search (A10, N1, T9),
+ *     so_level_means (pore_model.cc), so_format_paf (A18: the PAF row text, output_tools.h) and
+ *     so_reverse_complement (sequence_batch.h) are pinned against the REAL reference code,
  *     compiled from /root/reference/src by oracle/Makefile into oracle/_ref/.
  *   - so_add_signal (A1), so_zscore / so_generate_events tail (A7-A8), so_generate_chains (A9, A11-A16),
- *     so_map_read (A17-A18) and so_sdtw (D4) restate translation units
+ *     so_map_read (A17: the decisions and the fields of the row) and so_sdtw (D4) restate translation units
  *     (signal_batch.cc, sigmap.cc, spatial_index.cc, fast_dtw.cc) that cannot be compiled in this image
  *     without a stand-in for <slow5/slow5.h>: PARITY UNPINNED for those functions.
  *

@@ -7,14 +7,15 @@
 #   full  = all counter passes + the default bench run (the bench default shape);
 #   short = the traffic and LDS passes only (the other BASELINE shapes).
 set -u
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r3_yeast}; MODE=${2:-full}; shift; shift
+TAG=${1:-r4_yeast}; MODE=${2:-full}; shift; shift
 SHAPE="$*"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 echo "$SHAPE" > $OUT/shape.txt
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcie $SHAPE"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pcie --no-same-reads $SHAPE"
 if [ "$MODE" = full ]; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt_bench.json 2> $OUT/kt_err.log
 fi
@@ -30,7 +31,7 @@ i=0
 run_pass() {
   i=$((i+1))
   echo "$1" > $OUT/pmc_$i.counters
-  timeout 1500 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1 $SHAPE > /dev/null 2> $OUT/pmc_${i}_err.log
+  timeout 1500 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --no-same-reads --depth 1 $SHAPE > /dev/null 2> $OUT/pmc_${i}_err.log
 }
 for c in "${PASSES_SHORT[@]}"; do run_pass "$c"; done
 if [ "$MODE" = full ]; then

@@ -53,7 +53,7 @@ def traffic_json(tag, red, per, shape_txt):
     if os.path.exists(ks):
         for r in csv.DictReader(open(ks)):
             if r["kernel"] == seed:
-                avg_ns = float(r["avg_ns"])
+                avg_ns = float(r.get("avg_ns_main") or r["avg_ns"])  # (the launches of the batch's size)
     import hashlib
     h = hashlib.sha256()
     for f in ("sigmap_amd/csrc/seed_lookup.hip", "sigmap_amd/csrc/common.h"):
@@ -81,7 +81,7 @@ def traffic_json(tag, red, per, shape_txt):
                 "these requests, so this is an UPPER bound on HBM traffic",
         "source": f"profiles/{tag}_pmc_per_launch.csv: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) "
                   f"-- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --depth 1 {shape_txt}; mean per launch of "
-                  f"{seed}; calibration profiles/r3_calibration.json",
+                  f"{seed} (launches of the batch's size: the small census launch is left out); calibration profiles/r3_calibration.json",
     }
     json.dump(out, open(os.path.join(red, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     return out
@@ -96,11 +96,26 @@ def reduce(tag):
         if not ks:
             continue
         rows = list(csv.DictReader(open(ks[-1])))  # newest run
+        # avg_ns_main: the mean over the launches of the batch's size only -- a kernel is also launched on small
+        # inputs (the census of the index: 4096 queries through the walker), which rocprof's own average includes;
+        # launches shorter than a quarter of the kernel's median are left out (from the kernel trace, when it is there)
+        main = {}
+        kt = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_trace.csv")), key=os.path.getmtime)
+        if kt:
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(kt[-1])):
+                dur[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            for k, v in dur.items():
+                med = sorted(v)[len(v) // 2]
+                kept = [x for x in v if x >= 0.25 * med]
+                main[k] = (sum(kept) / len(kept), len(kept))
         with open(os.path.join(red, f"{tag}_kernel_stats{suffix}.csv"), "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns", "avg_ns_main", "calls_main"])
             for r in rows:
-                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                m = main.get(short(r["Name"]), (float(r["AverageNs"]), int(r["Calls"])))
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"],
+                            "%.1f" % m[0], m[1]])
     per = collections.defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
@@ -108,15 +123,19 @@ def reduce(tag):
         cc = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
         if not cc:
             continue
-        agg = collections.defaultdict(lambda: collections.defaultdict(float))
-        disp = collections.defaultdict(set)
+        # per dispatch, then the mean over the dispatches of the batch's size: those whose first counter reaches a
+        # quarter of the kernel's median (the census of the index sends 4096 queries through the walker: not a step)
+        by_disp = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
         for r in csv.DictReader(open(cc[-1])):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            disp[k].add(r["Dispatch_Id"])
-        for k, v in agg.items():
-            for c, val in v.items():
-                per[k][c] = val / max(1, len(disp[k]))
+            by_disp[short(r["Kernel_Name"])][r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, disp in by_disp.items():
+            names = sorted({c for v in disp.values() for c in v})
+            lead = names[0]
+            vals = sorted(v.get(lead, 0.0) for v in disp.values())
+            med = vals[len(vals) // 2]
+            kept = [v for v in disp.values() if v.get(lead, 0.0) >= 0.25 * med] or list(disp.values())
+            for c in names:
+                per[k][c] = sum(v.get(c, 0.0) for v in kept) / len(kept)
     counters = sorted({c for v in per.values() for c in v})
     with open(os.path.join(red, f"{tag}_pmc_per_launch.csv"), "w", newline="") as f:
         w = csv.writer(f)
