@@ -427,8 +427,9 @@ def main():
                 "chunks_with_capacity_flags": status_bad,
                 "overflow_queries": int(dev.debug_counters()[1]),
                 "fast_hit_slots_per_query": int(dev.resolved_params().hits_per_query_fast),
-                "search_mode": {1: "reference order (binary records)", 2: "set walk (quad records) + second search of "
-                                "over-cap queries"}.get(int(dev.resolved_params().search_mode), "?"),
+                "search_mode": {1: "reference order (binary records)", 2: "set walk (quad records); queries beyond the hit "
+                                "cap: the first num_nearest_points hits in the reference's order picked by ranking"}.get(
+                                    int(dev.resolved_params().search_mode), "?"),
                 "index_census_hits": (lambda h: {"q50": int(h[len(h) // 2]), "q75": int(h[len(h) * 3 // 4]),
                                                  "q90": int(h[len(h) * 9 // 10]), "max": int(h[-1]), "mean": round(float(h.mean()), 1),
                                                  "share_over_5000": round(float((h > 5000).mean()), 5)})(dev.index_census()),

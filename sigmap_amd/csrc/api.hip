@@ -46,7 +46,7 @@ DevKnobs ReadDevKnobs() {
 
 namespace {
 int FinishRun(smhip_ctx *ctx);  // (defined with smhip_map_run: settles a speculative batch)
-int ResolveParams(smhip_ctx *ctx, smhip_params *rp);
+int ResolveParams(smhip_ctx *ctx, smhip_params *rp, uint32_t n_chunks);
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
   return code;
@@ -927,7 +927,7 @@ int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_
   smhip_params p;
   smhip_default_params(&p);
   if (ctx->have_index) {  // (the automatic number of fast slots comes from the census of the index)
-    int rc = ResolveParams(ctx, &p);
+    int rc = ResolveParams(ctx, &p, n_chunks);
     if (rc) return rc;
   } else {
     p.hits_per_query_fast = 512;
@@ -1304,7 +1304,7 @@ double CensusShareAbove(const smhip_ctx *ctx, uint32_t cap) {
 //    queries are searched a second time in the reference's order, one lane each: then an index whose census puts
 //    more than set_walk_max_over_cap of the sample beyond the cap, or a context that has met as many in its
 //    batches (LearnOverCap), searches everything in the reference's order at once.
-int ResolveParams(smhip_ctx *ctx, smhip_params *rp) {
+int ResolveParams(smhip_ctx *ctx, smhip_params *rp, uint32_t n_chunks) {
   const bool want_fast = rp->hits_per_query_fast == 0;
   const bool ranked = (uint32_t)rp->num_nearest_points <= 8192u && !ctx->knobs.second_search;  // (kSelMaxKeep)
   const bool want_mode = rp->search_mode == SMHIP_SEARCH_AUTO && ctx->index.quads && !ranked && !ctx->walk_exact_only &&
@@ -1323,7 +1323,7 @@ int ResolveParams(smhip_ctx *ctx, smhip_params *rp) {
     // have been seen)
     size_t free_b = 0, total_b = 0;
     if (fast > 512 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const uint64_t nq_est = (uint64_t)std::max(ctx->n_chunks, 1u) * (ctx->hint_q_per_chunk ? ctx->hint_q_per_chunk * 5 / 4 : 288);
+      const uint64_t nq_est = (uint64_t)std::max(n_chunks, 1u) * (ctx->hint_q_per_chunk ? ctx->hint_q_per_chunk * 5 / 4 : 288);
       while (fast > 512 && nq_est * fast * sizeof(Hit) > total_b / 6) fast >>= 1;
     }
     rp->hits_per_query_fast = fast;
@@ -1402,7 +1402,7 @@ int smhip_map_run(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   // The index census (first batch after the index arrived) resolves what the caller left automatic.
   smhip_params rp = *p;
   {
-    const int rc0 = ResolveParams(ctx, &rp);
+    const int rc0 = ResolveParams(ctx, &rp, R);
     if (rc0) return rc0;
   }
   p = &rp;

@@ -361,10 +361,11 @@ __device__ __forceinline__ void ScanQueryOffsets(const SortArgs &a, uint32_t q0,
 //    exact slice, one scattered store per anchor.
 constexpr uint32_t kBigThreads = 1024;  // (256 / 512: 4.2 / 4.4 ms against 3.6 ms at 32 Mb)
 constexpr uint32_t kGroupsLds = 1024;  // (reference, strand) groups counted in LDS by the partition kernel; more: GroupStartKernel
-constexpr uint32_t kTile = 2 * kBigThreads;  // records per tile of the whole-line route
-constexpr size_t kTileLdsBytes = (size_t)kTile * (sizeof(uint4) + sizeof(uint32_t));  // the tile's records + destinations
-template <bool kLines>
-__global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a, uint32_t n_chunks, uint32_t gbits,
+// records per tile of the whole-line route = RPT per thread: 2 (2048: two workgroups per CU), or -- large chunks, whose
+// hundreds of parts get only a few records each per tile -- 4 (4096: runs twice as long, one workgroup per CU)
+constexpr size_t TileLdsBytes(int rpt) { return (size_t)rpt * kBigThreads * (sizeof(uint4) + sizeof(uint32_t)); }  // records + destinations
+template <bool kLines, int RPT>
+__global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKernel(SortArgs a, uint32_t n_chunks, uint32_t gbits,
                                                                        uint32_t ibits, BigSortWork w,
                                                                        const uint32_t *__restrict__ redo_list) {
   __shared__ uint32_t qoff[kMaxQueriesPerChunk + 2];
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
   // whole-line route: per-tile counts / starts / running positions of the parts, the query hand-out, the verdict
   __shared__ uint32_t tcount[kLines ? kMaxParts + 64 : 1], tstart[kLines ? kMaxParts + 64 : 1], tgpos[kLines ? kMaxParts + 64 : 1];
   __shared__ uint32_t s_overflow;
+  constexpr uint32_t kTile = (uint32_t)RPT * kBigThreads;
   extern __shared__ __align__(16) unsigned char tile_mem[];  // kLines: uint4 tile_rec[kTile], uint32_t tile_dst[kTile]
   uint4 *tile_rec = reinterpret_cast<uint4 *>(tile_mem);
   uint32_t *tile_dst = reinterpret_cast<uint32_t *>(tile_mem + (size_t)kTile * sizeof(uint4));
@@ -495,12 +497,12 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
       // answer bounds the search from below).  A tile's records are fetched while the tile before it is binned.
       const uint32_t n_tiles = (n + kTile - 1u) / kTile;
       const uint32_t scan_per = (P + 63u) / 64u;  // parts per lane of the tile scan (one wave)
-      uint32_t k_hint[2] = {0u, 0u};
-      uint4 raw_nx[2];
-      uint32_t qpos_nx[2];  // query position of a hit; ~0: a carried anchor (the record holds its own)
+      uint32_t k_hint[RPT] = {};
+      uint4 raw_nx[RPT];
+      uint32_t qpos_nx[RPT];  // query position of a hit; ~0: a carried anchor (the record holds its own)
       auto fetch = [&](uint32_t T) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RPT; ++u) {
           const uint32_t i = T * kTile + (uint32_t)u * kBigThreads + tid;
           raw_nx[u] = make_uint4(0, 0, 0, 0);
           qpos_nx[u] = 0xFFFFFFFFu;
@@ -523,12 +525,12 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
       };
       fetch(0);
       for (uint32_t T = 0; T < n_tiles; ++T) {
-        Decoded dv[2];
-        bool live[2];
-        uint32_t pb[2] = {0, 0}, lpos[2] = {0, 0};
+        Decoded dv[RPT];
+        bool live[RPT];
+        uint32_t pb[RPT] = {}, lpos[RPT] = {};
         // count: position of the record among the tile's records of its part
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RPT; ++u) {
           live[u] = T * kTile + (uint32_t)u * kBigThreads + tid < n;
           if (!live[u]) continue;
           dv[u] = qpos_nx[u] == 0xFFFFFFFFu ? Decoded{raw_nx[u].x, raw_nx[u].y, raw_nx[u].z, __uint_as_float(raw_nx[u].w)}
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(kBigThreads, 8) void SortPartitionKernel(SortArgs a
         __syncthreads();
         // place: the tile's records sorted by part in LDS, each with its destination in the part's slice
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < RPT; ++u)
           if (live[u]) {
             const uint32_t b = pb[u];
             const uint32_t pos = tgpos[b] + lpos[u];  // position inside the part = the key's index field
@@ -1281,8 +1283,11 @@ hipError_t InitSortAttributes() {  // per device (smhip_init): the workgroup par
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)kPartLdsKeys * sizeof(uint64_t)));
   if (e != hipSuccess) return e;  // ... the partition kernel's whole-line route a tile of 2048 records beside its tables
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartitionKernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)kTileLdsBytes);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartitionKernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)TileLdsBytes(2));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(SortPartitionKernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)TileLdsBytes(4));
 }
 
 // 16-byte records the sort needs in a.keys for n_anchors_total anchors in n_chunks chunks (RecOff)
@@ -1313,13 +1318,20 @@ hipError_t LaunchSort(smhip_ctx *ctx, const SortArgs &a, uint32_t n_chunks, uint
   if ((e = hipMemsetAsync(w.counters, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess) return e;
   const uint32_t part_blocks = std::min<uint32_t>(n_chunks, 256 * (2048 / kBigThreads));
   if (ctx->knobs.sort_lines != 0) {  // (knob sort_lines = 0: the exact two-pass route for every chunk, A/B)
-    hipLaunchKernelGGL(SortPartitionKernel<true>, dim3(part_blocks), dim3(kBigThreads), kTileLdsBytes, ctx->stream, a, n_chunks,
-                       gbits, ibits, w, (const uint32_t *)nullptr);
+    // tiles of 4096 for batches of large chunks (beyond ~100 parts a tile of 2048 gives a part fewer than 20 records);
+    // knob sort_lines = 2 / 4: that tile size whatever the batch
+    const bool big_tiles = ctx->knobs.sort_lines == 4 || (ctx->knobs.sort_lines != 2 && n_anchors_total / n_chunks > 40000);
+    if (big_tiles)
+      hipLaunchKernelGGL((SortPartitionKernel<true, 4>), dim3(std::min<uint32_t>(n_chunks, 256)), dim3(kBigThreads), TileLdsBytes(4),
+                         ctx->stream, a, n_chunks, gbits, ibits, w, (const uint32_t *)nullptr);
+    else
+      hipLaunchKernelGGL((SortPartitionKernel<true, 2>), dim3(part_blocks), dim3(kBigThreads), TileLdsBytes(2), ctx->stream, a,
+                         n_chunks, gbits, ibits, w, (const uint32_t *)nullptr);
     // the chunks it listed (none, as a rule: the launch then ends at once)
-    hipLaunchKernelGGL(SortPartitionKernel<false>, dim3(std::min<uint32_t>(part_blocks, 256)), dim3(kBigThreads), 0, ctx->stream, a,
-                       n_chunks, gbits, ibits, w, (const uint32_t *)w.redo);
+    hipLaunchKernelGGL((SortPartitionKernel<false, 2>), dim3(std::min<uint32_t>(part_blocks, 256)), dim3(kBigThreads), 0, ctx->stream,
+                       a, n_chunks, gbits, ibits, w, (const uint32_t *)w.redo);
   } else {
-    hipLaunchKernelGGL(SortPartitionKernel<false>, dim3(part_blocks), dim3(kBigThreads), 0, ctx->stream, a, n_chunks, gbits,
+    hipLaunchKernelGGL((SortPartitionKernel<false, 2>), dim3(part_blocks), dim3(kBigThreads), 0, ctx->stream, a, n_chunks, gbits,
                        ibits, w, (const uint32_t *)nullptr);
   }
   // one wave per part (persistent: the grid fills the chip, every wave takes parts in turn); the parts beyond

@@ -861,6 +861,61 @@ def test_speculative_batches_equal_the_reading_route(small_world, oracle_tree):
     dev.close()
 
 
+def test_repeated_speculative_batch_does_not_read_refilled_slots(small_world, oracle_tree):
+    """A speculative batch that outgrows a capacity is mapped again when its results are collected.  By then the
+    caller may have refilled the batch's read slots with the NEXT batch's reads (smhip_reads_upload_raw queues its
+    conversion behind the batch's kernels: bench.py's PCIe-inclusive region does exactly that): the repeat starts from
+    the feature signals of the first pass, so the records are those of the reads the batch was selected from --
+    compared with the oracle's -- and the next batch then maps the new reads."""
+    genome, lm, ix, ref_lens = small_world["genome"], small_world["lm"], small_world["ix"], small_world["ref_lens"]
+    raw_a = small_world["raw"][:24]
+    raw_b, _ = synth.simulate_reads(genome, lm, 24, 505)
+    dev = pipeline.DeviceMapper(0)
+    dev.upload_index(ix)
+    dev.configure_reads(24, 4000)
+
+    def upload(raw):
+        flat = np.ascontiguousarray(np.concatenate(raw), dtype=np.int16)
+        off = np.concatenate([[0], np.cumsum([len(r) for r in raw])]).astype(np.uint64)
+        dev.upload_raw(flat, off, synth.DIGITISATION, synth.RANGE, synth.OFFSET, want_len=False)
+        return flat   # (kept alive by the caller until the next sync)
+
+    def expect(raw):
+        out = []
+        for r in raw:
+            x = po.add_signal(r, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+            out.append(po.map_read(oracle_tree, ix.positions, x, 3, ref_lens))
+        return out
+
+    slots, chunk0 = np.arange(24, dtype=np.uint32), np.zeros(24, np.uint32)
+    keep = upload(raw_a)
+    dev.select(slots, chunk0, 4000); dev.run(3); dev.sync()
+    base_a = dev.download()                                   # reading route: learns the totals
+    for tight in (1, 2, 0):                                    # query guard, anchor guard, no guard
+        keep = upload(raw_a)
+        dev.sync()
+        dev.set_knob("spec_tight", tight)
+        dev.select(slots, chunk0, 4000)
+        dev.run(3)                                            # speculative: everything enqueued, nothing waited for
+        keep2 = upload(raw_b)                                 # the next batch's reads into the SAME slots, right away
+        dev.sync()                                            # finds the guard's flag and maps the batch again
+        res = dev.download()
+        dev.set_knob("spec_tight", 0)
+        assert res.tobytes() == base_a.tobytes(), tight
+        dev.select(slots, chunk0, 4000); dev.run(3); dev.sync()
+        res_b = dev.download()
+        for i, m in enumerate(expect(raw_b)[:8]):
+            assert res_b[i]["n_chains"] == m.n_chains and res_b[i]["n_anchors"] == m.stats.anchors, (tight, i)
+            if m.n_chains:
+                assert res_b[i]["chains"][0]["score"] == np.float32(m.s1)
+    c = dev.debug_counters()
+    assert c[4] >= 2 and c[5] >= 3, c[:8]                     # two repeats, at least three speculative runs
+    for i, m in enumerate(expect(raw_a)[:8]):
+        assert base_a[i]["n_chains"] == m.n_chains and base_a[i]["n_anchors"] == m.stats.anchors
+    del keep, keep2
+    dev.close()
+
+
 def test_contexts_of_a_gpu_share_one_reference_signal(device, small_world):
     """smhip_reference_share: a second context refines against the reference signal the first one uploaded
     (one copy per GPU, like the index) and gets the same distances; smhip_mem_info reports the device's memory."""
