@@ -27,7 +27,8 @@ const KnobName kKnobNames[] = {{"lane_blocks_per_cu", &DevKnobs::lane_blocks_per
                                {"bucket_bits", &DevKnobs::bucket_bits}, {"handout", &DevKnobs::handout},
                                {"sdtw_ring", &DevKnobs::sdtw_ring}, {"sync_run", &DevKnobs::sync_run},
                                {"spec_tight", &DevKnobs::spec_tight}, {"float_gap", &DevKnobs::float_gap},
-                               {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search}};
+                               {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search},
+                               {"classify_dense", &DevKnobs::classify_dense}};
 // the environment's knobs, honoured only behind SMHIP_DEV=1 (read once per context, in smhip_init)
 DevKnobs ReadDevKnobs() {
   DevKnobs k;

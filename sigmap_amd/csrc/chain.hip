@@ -50,6 +50,7 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 
 constexpr uint32_t kTile = 64;    // anchors per tile of the classify kernel: one per lane
 constexpr uint32_t kRing = 128;   // its LDS ring per wave: the tile and the 64 anchors before it
+constexpr uint32_t kDensePairs = 512;  // (anchor, predecessor) pairs of a tile the dense route takes; more: lockstep scans
 constexpr int kPf = 4;            // predecessors fetched ahead of the sequential scan: one 16-byte load per column
 static_assert(kPf == 4, "the lane DP fetches a block of predecessors as one uint4");
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
@@ -110,14 +111,40 @@ __device__ __forceinline__ bool GapTestsPass(int32_t td, int32_t qd, int max_gap
   return gap_length < max_gap_length && gap_scale < 5.0f && gap_scale > 0.75f;
 }
 
+// (float)(1 - 0.2 * (double)dist / (double)radius), spatial_index.cc:437-438 -- the start score's factor, wanted for 94 %
+// of the anchors.  A double division costs ~30 instruction slots; x * RN(1 / R) is within 3 units of 2^-53 of x / R,
+// so with |q| <= 4 |y| the difference 1 - q is within 34 ulp of the reference's y -- and the float result can only
+// differ when y lies that close to the midpoint of two floats (the low 29 mantissa bits of the double = 0x10000000):
+// those (2.4e-7 of the values), and everything outside the range where the bound holds, take the division.
+__device__ __forceinline__ float StartCoef(float dist, double radius, double inv_radius) {
+  const double x = 0.2 * (double)dist;
+  const double q = x * inv_radius, y = 1.0 - q;
+  const uint32_t low = (uint32_t)__double_as_longlong(y) & 0x1FFFFFFFu;
+  const uint32_t off = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
+  const double ay = fabs(y);
+  const bool safe = fabs(q) <= 4.0 * ay && off > 64u && ay >= 0x1p-100 && ay <= 0x1p100;
+  if (safe) return (float)y;
+  return (float)(1 - x / radius);
+}
+
+__device__ __forceinline__ uint32_t WaveScanMaxU32(uint32_t v) {  // inclusive, like common.h's scans
+#define SM_STEP(CTRL, ROWS) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false))
+  SM_STEP(0x111, 0xF); SM_STEP(0x112, 0xF); SM_STEP(0x114, 0xF); SM_STEP(0x118, 0xF); SM_STEP(0x142, 0xA); SM_STEP(0x143, 0xC);
+#undef SM_STEP
+  return v;
+}
+
 template <bool kIntGap>
 __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t n_chunks,
                                                            const uint32_t *__restrict__ tile_off, float radius, int dim,
                                                            int max_gap_length, int max_target_gap_length,
-                                                           int chaining_band_length, int max_num_skips) {
+                                                           int chaining_band_length, int max_num_skips,
+                                                           uint32_t dense_k) {
   // Every WAVE works on its own: no workgroup barrier anywhere (the 256-anchor tiles of the first version spent a
   // fifth of their time waiting at the barrier behind the wave with the longest backward scan).
   __shared__ uint32_t s_gmax_all[4][kTile + 2];  // maxima of the buckets the tile touches, relative to its first bucket
+  __shared__ uint32_t s_head_all[4][kDensePairs];  // pair e -> the anchor whose window it belongs to (dense route); 0 between tiles
+  __shared__ uint32_t s_found_all[4][kTile];       // ... and whether one of an anchor's pairs passed; 0 between tiles
   // The ring as three 4-byte COLUMNS (target, query, bucket): a scan step reads target and query only -- whether a
   // predecessor lies in another bucket is an index comparison with the start of the anchor's own bucket -- i.e. two
   // ds_read_b32 whose lanes hit 64 different banks while they run in step, where the packed {target, query, bucket, -}
@@ -125,7 +152,10 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.53).
   __shared__ uint32_t s_ring_t_all[4][kRing], s_ring_q_all[4][kRing], s_ring_g_all[4][kRing];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t *s_gmax = s_gmax_all[wave];
+  const double inv_radius = 1.0 / (double)radius;
+  uint32_t *s_gmax = s_gmax_all[wave], *s_head = s_head_all[wave], *s_found = s_found_all[wave];
+  for (uint32_t e = lane; e < kDensePairs; e += 64) s_head[e] = 0;
+  s_found[lane] = 0;
   uint32_t *s_ring_t = s_ring_t_all[wave], *s_ring_q = s_ring_q_all[wave], *s_ring_g = s_ring_g_all[wave];
   // Every wave takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1, ...): one
   // search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p in slot p & 127)
@@ -228,70 +258,128 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       if (m) bstart_carry = t0 + (63u - (uint32_t)__clzll((long long)m));  // the bucket of the tile's last anchor
     }
     PHASE_MARK(1);
-    // ---- the backward scans of the tile's 64 anchors, in lockstep and WITHOUT BRANCHES while the predecessors
-    // are in the ring: a step is one 16-byte LDS read and ~25 predicated VALU operations for all lanes (the
-    // per-lane branches of the sequential form cost three times that per step).  `found`: a predecessor passed
-    // the gap tests (the anchor is not isolated); `active` ends at a bucket start, beyond the target gap, after
-    // max_num_skips + 1 failed candidates, with `found`, or when the band is used up.
     const int32_t ct = (int32_t)my_t, cq = (int32_t)my_q;
     bool found = false;
-    bool active = ai < n && ai > 0;
-    uint32_t pj = ai;  // the next predecessor is pj - 1
-    int32_t skips = 0;
-    uint32_t steps = 0;
-    // (two predecessors per round: both ring reads are issued before either is looked at -- the second one's address
-    // does not depend on the first one's outcome, only whether it counts does -- so the ballot, the branch and the
-    // LDS round trip are paid once per pair)
-    auto step1 = [&](uint32_t r_t, uint32_t r_q) {
-      const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
-      const int32_t pt = (int32_t)r_t, pq = (int32_t)r_q;
-      const bool other_bucket = pj - 1u < bstart;  // (go: pj > w0 >= 0)
-      const bool same_pos = pq == cq || pt == ct;                     // `continue`: not evaluated, no skip counted
-      const bool far = pt + max_target_gap_length < ct;               // `break`
-      const int32_t td = ct - pt, qd = cq - pq;
-      const bool evaluated = !other_bucket && !same_pos && !far && qd >= 0;
-      const bool pass = evaluated && GapTestsPass<kIntGap>(td, qd, max_gap_length);
-      const bool fail = evaluated && !pass;
-      if (go) {
-        found = pass;
-        skips += fail ? 1 : 0;
-        // (a far predecessor ends the scan also when it shares the query position: every older predecessor of
-        // the bucket is farther still, so the reference's loop `continue`s or `break`s its way out of the bucket
-        // without evaluating anything)
-        active = !(other_bucket || far || pass || skips > max_num_skips);
-        --pj;
-        ++steps;
+    // ---- WINDOWS.  The predecessors an anchor's scan can evaluate are the anchors of its bucket before it that are
+    // not beyond the target gap: a contiguous window [lo, ai) (targets ascend inside a bucket).  While a window holds
+    // no more than max_num_skips + 1 (and chaining_band_length) anchors the scan cannot end early except by finding a
+    // predecessor that passes: `found` is then the OR over the window, in any order -- so the pairs (anchor,
+    // predecessor) of the tile are laid out densely over the lanes (1.8 per anchor at the default parameters, where
+    // the lockstep scans run as long as the longest of 64 windows: 13 predecessors for 3 useful ones per lane).
+    uint32_t k = 0;
+    if (dense_k) {
+      // k = how many of ai - 1, ai - 2, ... are near: bisection on the count (five ring reads; 31 = "31 or more")
+      const uint32_t dmax = (ai < n && ai > 0) ? min(ai - max(bstart, w0), 31u) : 0u;
+#pragma unroll
+      for (uint32_t step = 16; step >= 1; step >>= 1) {
+        const uint32_t cand = k + step;
+        const bool near = (int32_t)s_ring_t[(ai - cand) & (kRing - 1)] + max_target_gap_length >= ct;
+        if (cand <= dmax && near) k = cand;
       }
-    };
-    for (;;) {
-      const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
-      if (!__ballot(go)) break;
-      const uint32_t t1 = s_ring_t[(pj - 1u) & (kRing - 1)], q1 = s_ring_q[(pj - 1u) & (kRing - 1)];
-      const uint32_t t2 = s_ring_t[(pj - 2u) & (kRing - 1)], q2 = s_ring_q[(pj - 2u) & (kRing - 1)];  // (counts only if the
-      step1(t1, q1);                                                                                 // first one leaves the
-      step1(t2, q2);                                                                                 // lane active)
     }
-    // lanes whose scan leaves the ring (64+ predecessors back: dense true-locus regions): the sequential form,
-    // predecessors from memory
-    if (active && pj > 0 && pj <= w0 && steps < (uint32_t)chaining_band_length) {
-      for (; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
-        if (pj < bstart) break;  // bucket start
-        const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
-        if (pq == cq || pt == ct) continue;
-        if (pt + max_target_gap_length < ct) break;
+    PHASE_MARK(6);
+    const uint32_t s_incl = (uint32_t)WaveScanAdd((int)k);
+    const uint32_t n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)s_incl, 63);
+    if (dense_k && !__ballot(k > dense_k) && n_pairs <= kDensePairs) {
+      const uint32_t s_mine = s_incl - k;  // my pairs are [s_mine, s_mine + k): predecessors ai - 1, ai - 2, ...
+#ifdef SMHIP_PHASE_PROF
+      if (threadIdx.x == 0) {
+        atomicAdd(&g_phase_prof[20], 1ull);
+        atomicAdd(&g_phase_prof[22], (unsigned long long)((n_pairs + 63) / 64));
+        atomicAdd(&g_phase_prof[23], (unsigned long long)n_pairs);
+      }
+#endif
+      if (k) s_head[s_mine] = ((lane + 1u) << 16) | s_mine;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      uint32_t carry = 0;
+      for (uint32_t e0 = 0; e0 < n_pairs; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint32_t h = s_head[e];
+        s_head[e] = 0;
+        h = max(WaveScanMaxU32(h), carry);  // the last head at or before e
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
+        const uint32_t il = (h >> 16) - 1u, ia = t0 + il, pj = ia - 1u - (e - (h & 0xFFFFu));
+        const int32_t it_ = (int32_t)s_ring_t[ia & (kRing - 1)], iq = (int32_t)s_ring_q[ia & (kRing - 1)];
+        const int32_t pt = (int32_t)s_ring_t[pj & (kRing - 1)], pq = (int32_t)s_ring_q[pj & (kRing - 1)];
+        const int32_t td = it_ - pt, qd = iq - pq;
+        const bool pass = e < n_pairs && pq != iq && pt != it_ && qd >= 0 && GapTestsPass<kIntGap>(td, qd, max_gap_length);
+        if (pass) s_found[il & 63u] = 1u;  // (few do)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      found = s_found[lane] != 0;
+      s_found[lane] = 0;
+      PHASE_MARK(7);
+    } else {
+#ifdef SMHIP_PHASE_PROF
+      if (threadIdx.x == 0) atomicAdd(&g_phase_prof[21], 1ull);
+#endif
+      // ---- the backward scans of the tile's 64 anchors, in lockstep and WITHOUT BRANCHES while the predecessors
+      // are in the ring: a step is one 16-byte LDS read and ~25 predicated VALU operations for all lanes (the
+      // per-lane branches of the sequential form cost three times that per step).  `found`: a predecessor passed
+      // the gap tests (the anchor is not isolated); `active` ends at a bucket start, beyond the target gap, after
+      // max_num_skips + 1 failed candidates, with `found`, or when the band is used up.
+      bool active = ai < n && ai > 0;
+      uint32_t pj = ai;  // the next predecessor is pj - 1
+      int32_t skips = 0;
+      uint32_t steps = 0;
+      // (two predecessors per round: both ring reads are issued before either is looked at -- the second one's address
+      // does not depend on the first one's outcome, only whether it counts does -- so the ballot, the branch and the
+      // LDS round trip are paid once per pair)
+      auto step1 = [&](uint32_t r_t, uint32_t r_q) {
+        const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
+        const int32_t pt = (int32_t)r_t, pq = (int32_t)r_q;
+        const bool other_bucket = pj - 1u < bstart;  // (go: pj > w0 >= 0)
+        const bool same_pos = pq == cq || pt == ct;                     // `continue`: not evaluated, no skip counted
+        const bool far = pt + max_target_gap_length < ct;               // `break`
         const int32_t td = ct - pt, qd = cq - pq;
-        if (qd < 0) continue;
-        if (GapTestsPass<kIntGap>(td, qd, max_gap_length)) {
-          found = true;
-          break;
+        const bool evaluated = !other_bucket && !same_pos && !far && qd >= 0;
+        const bool pass = evaluated && GapTestsPass<kIntGap>(td, qd, max_gap_length);
+        const bool fail = evaluated && !pass;
+        if (go) {
+          found = pass;
+          skips += fail ? 1 : 0;
+          // (a far predecessor ends the scan also when it shares the query position: every older predecessor of
+          // the bucket is farther still, so the reference's loop `continue`s or `break`s its way out of the bucket
+          // without evaluating anything)
+          active = !(other_bucket || far || pass || skips > max_num_skips);
+          --pj;
+          ++steps;
         }
-        if (++skips > max_num_skips) break;
+      };
+      for (;;) {
+        const bool go = active && pj > w0 && steps < (uint32_t)chaining_band_length;
+        if (!__ballot(go)) break;
+        const uint32_t t1 = s_ring_t[(pj - 1u) & (kRing - 1)], q1 = s_ring_q[(pj - 1u) & (kRing - 1)];
+        const uint32_t t2 = s_ring_t[(pj - 2u) & (kRing - 1)], q2 = s_ring_q[(pj - 2u) & (kRing - 1)];  // (counts only if the
+        step1(t1, q1);                                                                                 // first one leaves the
+        step1(t2, q2);                                                                                 // lane active)
+      }
+      // lanes whose scan leaves the ring (64+ predecessors back: dense true-locus regions): the sequential form,
+      // predecessors from memory
+      if (active && pj > 0 && pj <= w0 && steps < (uint32_t)chaining_band_length) {
+        for (; pj-- > 0 && steps < (uint32_t)chaining_band_length; ++steps) {
+          if (pj < bstart) break;  // bucket start
+          const int32_t pt = (int32_t)tpos[pj], pq = (int32_t)qpos[pj];
+          if (pq == cq || pt == ct) continue;
+          if (pt + max_target_gap_length < ct) break;
+          const int32_t td = ct - pt, qd = cq - pq;
+          if (qd < 0) continue;
+          if (GapTestsPass<kIntGap>(td, qd, max_gap_length)) {
+            found = true;
+            break;
+          }
+          if (++skips > max_num_skips) break;
+        }
       }
     }
     PHASE_MARK(2);
     if (ai < n) {
       if (!found) {
-        const float coef = (float)(1 - 0.2 * (double)my_dist / (double)radius);
+        const float coef = StartCoef(my_dist, (double)radius, inv_radius);
         const float sc = coef * (float)dim;
         score[ai] = sc;
         pred[ai] = ai;
@@ -1421,14 +1509,18 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   // (integer form of the gap-scale tests: exact for target gaps below 2^21, see GapTestsPass)
   // (SMHIP_FLOAT_GAP: test knob, read per call -- the float form also where the integer one is valid)
   const bool int_gap = p.max_target_gap_length >= 0 && p.max_target_gap_length < (1 << 21) && !ctx->knobs.float_gap;
+  // windows of up to dense_k predecessors are evaluated as dense pairs (the scan cannot end early inside them);
+  // knob classify_dense = 0: lockstep scans for every tile
+  const uint32_t dense_k = ctx->knobs.classify_dense == 0 ? 0u
+      : (uint32_t)std::max(0, std::min(std::min(p.max_num_skips + 1, p.chaining_band_length), 32));
   if (int_gap)
     hipLaunchKernelGGL(ChainClassifyKernel<true>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
-                       p.max_num_skips);
+                       p.max_num_skips, dense_k);
   else
     hipLaunchKernelGGL(ChainClassifyKernel<false>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
-                       p.max_num_skips);
+                       p.max_num_skips, dense_k);
   hipLaunchKernelGGL(ChainPendingKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.max_target_gap_length, n_pending,
                      n_items);
   if ((e = LaunchScanU32(ctx, n_items, n_chunks, ioff)) != hipSuccess) return e;

@@ -45,6 +45,16 @@ def _run_and_compare(dev, chunks, n_refs, shuffle_seed=0):
     res, anchors, aoff = dev.chain_anchors(np.concatenate(flat) if flat else np.zeros(0, _abi.CARRIED_DTYPE), offs, n_refs,
                                            with_anchors=True)
     allc, coff = dev.download_chains()      # every primary chain, not only the record's first four
+    # the classifier's other route (lockstep predecessor scans for every tile instead of dense pairs): the same bytes
+    dev.set_knob("classify_dense", 0)
+    try:
+        res0, anchors0, aoff0 = dev.chain_anchors(np.concatenate(flat) if flat else np.zeros(0, _abi.CARRIED_DTYPE), offs,
+                                                  n_refs, with_anchors=True)
+        allc0, coff0 = dev.download_chains()
+    finally:
+        dev.set_knob("classify_dense", -1)
+    assert res0.tobytes() == res.tobytes() and anchors0.tobytes() == anchors.tobytes() and np.array_equal(aoff0, aoff)
+    assert allc0.tobytes() == allc.tobytes() and np.array_equal(coff0, coff)
     out = []
     for i, c in enumerate(chunks):
         want = po.chain_anchors(c[0], c[1], c[2], c[3], n_refs)

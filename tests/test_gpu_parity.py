@@ -330,12 +330,19 @@ def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, bloc
         # route (knob sort_lines = 0) gives the same records
         st_sort = device.sort_stats()
         assert st_sort[3] == 0 and st_sort[0] + st_sort[1] > len(pa), st_sort
-        device.set_knob("sort_lines", 0)
         try:
-            assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes()
-            assert device.sort_stats()[3] == 0
+            for lines in (0, 4):   # 4: the route's tiles of 4096 records (what batches of large chunks take)
+                device.set_knob("sort_lines", lines)
+                assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes()
+                assert device.sort_stats()[3] == 0
         finally:
             device.set_knob("sort_lines", -1)
+        # the chain classifier's lockstep predecessor scans for every tile (default: dense pairs where the windows allow)
+        device.set_knob("classify_dense", 0)
+        try:
+            assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes()
+        finally:
+            device.set_knob("classify_dense", -1)
     names = ["contig0", "contig1", "contig2"]
     lines = _paf_lines(res, pa, names, ref_lens)
     mapped = 0
@@ -708,10 +715,12 @@ def test_pipeline_heavy_ties_large_chunks(small_world):
     # takes the exact route, and parts go to the workgroup sorter
     st_sort = dev.sort_stats()
     assert st_sort[3] == len(pa) and st_sort[2] > 0, st_sort
-    dev.set_knob("sort_lines", 0)           # the exact route for every chunk from the start: the same records
-    res0 = dev.map_chunks(samples, offsets, n_refs=1)
+    for lines in (0, 4):                    # the exact route for every chunk from the start / tiles of 4096: the same records
+        dev.set_knob("sort_lines", lines)
+        res0 = dev.map_chunks(samples, offsets, n_refs=1)
+        assert res0.tobytes() == res.tobytes()
+        assert lines == 0 or dev.sort_stats()[3] == len(pa)
     dev.set_knob("sort_lines", -1)
-    assert res0.tobytes() == res.tobytes()
     tree = po.OracleTree(ix.values.copy())
     for i, x in enumerate(pa):
         f, _ = po.generate_events(x)
