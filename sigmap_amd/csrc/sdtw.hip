@@ -516,6 +516,7 @@ __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_
   uint32_t t = lane == 0 ? 64u : lane;
   float tv = 0.0f;
   int32_t lo = 1, hi = 0, gend = 0x7FFFFFFF;  // a row past T: never in the band, never left
+  uint32_t d_last = 0;                        // the diagonal on which this row reaches the last query column (none: 0)
   auto load_row = [&]() {
     if (t <= T) {
       const int32_t centre = cen[t];
@@ -523,10 +524,12 @@ __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_
       lo = max(centre - half32, 1);
       hi = min(centre + half32, Q32);
       gend = (int32_t)t + centre + half32;  // last diagonal with a cell of this row inside the band
+      d_last = t + Q;
     } else {
       lo = 1;
       hi = 0;
       gend = 0x7FFFFFFF;
+      d_last = 0;
     }
   };
   load_row();
@@ -539,16 +542,17 @@ __global__ __launch_bounds__(64) void SdtwChainSystolicKernel(const smhip_chunk_
     const float b_in =
         __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
     const int32_t q = (int32_t)d - (int32_t)t;
-    const float qv = qs[min(max(q - 1, 0), Q32 - 1)];
+    int32_t qi;  // q - 1 clamped to the query (any valid address outside the band): one v_med3_i32
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(qi) : "v"(q - 1), "v"(Q32 - 1));
+    const float qv = qs[qi];
     // boundary constants of sigmap.cc:1263-1271
     const float a = q == 1 ? 0.0f : (t == 1 ? FLT_MAX : a_prev);
     const float b = t == 1 ? FLT_MAX : b_in;
     const float cc = q == 1 ? 0.0f : v1;
-    float m = a;
-    if (b < m) m = b;
-    if (cc < m) m = cc;
+    // std::min({a, b, c}) of non-negative values without NaN: one v_min3_f32 (the compare / select chain was four)
+    const float m = __builtin_fminf(__builtin_fminf(a, b), cc);
     const float v = (q >= lo && q <= hi) ? fabsf(tv - qv) + m : FLT_MAX;
-    if (q == Q32 && t <= T) {
+    if (d == d_last) {  // q == Q in a row of the window
       if (v < best || (v == best && t < best_t)) {
         best = v;
         best_t = t;
