@@ -139,12 +139,18 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
                                                            const uint32_t *__restrict__ tile_off, float radius, int dim,
                                                            int max_gap_length, int max_target_gap_length,
                                                            int chaining_band_length, int max_num_skips,
-                                                           uint32_t dense_k) {
+                                                           uint32_t dense_k, uint32_t resolve) {
   // Every WAVE works on its own: no workgroup barrier anywhere (the 256-anchor tiles of the first version spent a
   // fifth of their time waiting at the barrier behind the wave with the longest backward scan).
   __shared__ uint32_t s_gmax_all[4][kTile + 2];  // maxima of the buckets the tile touches, relative to its first bucket
   __shared__ uint32_t s_head_all[4][kDensePairs];  // pair e -> the anchor whose window it belongs to (dense route); 0 between tiles
   __shared__ uint32_t s_found_all[4][kTile];       // ... and whether one of an anchor's pairs passed; 0 between tiles
+  // chaining inside the classifier (below): an anchor's best passing predecessor {score bits, ring position}, whether
+  // one of its passing predecessors is itself waiting for the DP; both 0 between tiles.  And the ring's fourth
+  // column: an anchor's start-score factor.
+  __shared__ unsigned long long s_best_all[4][kTile];
+  __shared__ uint32_t s_unres_all[4][kTile];
+  __shared__ float s_ring_c_all[4][kRing];
   // The ring as three 4-byte COLUMNS (target, query, bucket): a scan step reads target and query only -- whether a
   // predecessor lies in another bucket is an index comparison with the start of the anchor's own bucket -- i.e. two
   // ds_read_b32 whose lanes hit 64 different banks while they run in step, where the packed {target, query, bucket, -}
@@ -156,6 +162,14 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   uint32_t *s_gmax = s_gmax_all[wave], *s_head = s_head_all[wave], *s_found = s_found_all[wave];
   for (uint32_t e = lane; e < kDensePairs; e += 64) s_head[e] = 0;
   s_found[lane] = 0;
+  unsigned long long *s_best = s_best_all[wave];
+  uint32_t *s_unres = s_unres_all[wave];
+  float *s_ring_c = s_ring_c_all[wave];
+  s_best[lane] = 0ull;
+  s_unres[lane] = 0;
+  // which anchors of the PREVIOUS tile were left to the DP kernels (bit l: anchor t0 - 64 + l); all of them when the
+  // previous tile was another wave's
+  unsigned long long fmask_prev = 0ull;
   uint32_t *s_ring_t = s_ring_t_all[wave], *s_ring_q = s_ring_q_all[wave], *s_ring_g = s_ring_g_all[wave];
   // Every wave takes a contiguous range of the flat tile sequence (tiles of chunk 0, of chunk 1, ...): one
   // search for its first chunk, then tile after tile.  Inside a chunk the LDS ring (anchor p in slot p & 127)
@@ -209,6 +223,8 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       s_ring_g[ai & (kRing - 1)] = nx_g;
       my_dist = nx_d;
     }
+    const float my_coef = StartCoef(my_dist, (double)radius, inv_radius);
+    if (ai < n) s_ring_c[ai & (kRing - 1)] = my_coef;
     const uint32_t my_t = nx_t, my_q = nx_q, my_g = nx_g;
     have_nx = tile + 1 < tile_end && tile + 1 < tile_off[c + 1];
     if (have_nx) {
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       s_ring_q[p & (kRing - 1)] = qpos[p];
       s_ring_g[p & (kRing - 1)] = grp[p];
     }
+    if (!ring_valid) fmask_prev = t0 > 0 ? ~0ull : 0ull;  // (another wave's tile: nothing is known about its anchors)
     s_gmax[lane] = 0;
     if (lane < 2) s_gmax[kTile + lane] = 0;
     // bucket ordinal of the tile's first anchor: carried over from the previous tile, or one search
@@ -260,6 +277,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     PHASE_MARK(1);
     const int32_t ct = (int32_t)my_t, cq = (int32_t)my_q;
     bool found = false;
+    bool settled = false;  // found, and chained here
+    float settled_score = 0.0f;
+    uint32_t settled_pred = 0;
     // ---- WINDOWS.  The predecessors an anchor's scan can evaluate are the anchors of its bucket before it that are
     // not beyond the target gap: a contiguous window [lo, ai) (targets ascend inside a bucket).  While a window holds
     // no more than max_num_skips + 1 (and chaining_band_length) anchors the scan cannot end early except by finding a
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       uint32_t carry = 0;
+      uint32_t n_pass = 0;  // passing pairs so far (wave-uniform): listed in the part of the pair table already consumed
       for (uint32_t e0 = 0; e0 < n_pairs; e0 += 64) {
         const uint32_t e = e0 + lane;
         uint32_t h = s_head[e];
@@ -305,13 +326,64 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         const int32_t pt = (int32_t)s_ring_t[pj & (kRing - 1)], pq = (int32_t)s_ring_q[pj & (kRing - 1)];
         const int32_t td = it_ - pt, qd = iq - pq;
         const bool pass = e < n_pairs && pq != iq && pt != it_ && qd >= 0 && GapTestsPass<kIntGap>(td, qd, max_gap_length);
-        if (pass) s_found[il & 63u] = 1u;  // (few do)
+        const unsigned long long pm = __ballot(pass);
+        if (pass) {  // (few do)
+          s_found[il & 63u] = 1u;
+          // {anchor's lane, predecessor's position in [t0 - 64, t0 + 64)}: at most e0 + 64 pairs have been looked at,
+          // so the slot lies in the part of the table this loop has read and cleared
+          if (resolve) s_head[n_pass + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (il & 63u) | ((pj + 64u - t0) << 8);
+        }
+        n_pass += (uint32_t)__popcll(pm);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       found = s_found[lane] != 0;
       s_found[lane] = 0;
+      // ---- CHAINING HERE what does not need the DP kernels.  The DP of an anchor (spatial_index.cc:436-541) takes the
+      // best of its own start score and, over the predecessors that pass, their score + the matching term -- the
+      // first one met (the nearest) among equals, and only a strict improvement replaces the start score --; failing
+      // predecessors only count skips, and inside a window of <= max_num_skips + 1 the skip limit cannot end the
+      // scan.  So when every PASSING predecessor of an anchor is itself isolated (its score is its start score, known
+      // here), the anchor's score and predecessor are a maximum over its passing pairs: taken with one 64-bit LDS
+      // atomic per pair, {score bits | predecessor position} (scores are positive).  Two thirds of the anchors with a
+      // passing predecessor are settled this way; an anchor with a passing predecessor that waits for the DP (this
+      // tile's or the previous one's found mask; anything about another wave's tile counts as waiting) waits too.
+      const unsigned long long fcur = __ballot(found);
+      if (resolve && n_pass) {
+        for (uint32_t b = 0; b < n_pass; b += 64) {
+          const uint32_t idx = b + lane;
+          const uint32_t ent = s_head[idx];
+          s_head[idx] = 0;
+          const uint32_t il = ent & 63u, rel = ent >> 8;  // (lanes past the list read 0: harmless addresses)
+          const bool waits = rel < 64u ? ((fmask_prev >> rel) & 1ull) != 0 : ((fcur >> (rel & 63u)) & 1ull) != 0;
+          const uint32_t ia = t0 + il, pj = t0 + rel - 64u;
+          const int32_t it_ = (int32_t)s_ring_t[ia & (kRing - 1)], iq = (int32_t)s_ring_q[ia & (kRing - 1)];
+          const int32_t pt = (int32_t)s_ring_t[pj & (kRing - 1)], pq = (int32_t)s_ring_q[pj & (kRing - 1)];
+          const float ci = s_ring_c[ia & (kRing - 1)], cj = s_ring_c[pj & (kRing - 1)];
+          const int32_t m = min(min(it_ - pt, iq - pq), dim);
+          const float curv = cj * (float)dim + (float)m * ci;  // ps[kk] + matching
+          if (idx < n_pass) {
+            if (waits || !(curv > 0.0f)) s_unres[il] = 1u;
+            else atomicMax(&s_best[il], ((unsigned long long)__float_as_uint(curv) << 32) | rel);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        if (found && s_unres[lane] == 0) {
+          const unsigned long long bb = s_best[lane];
+          const float sc0 = my_coef * (float)dim;
+          if (sc0 > 0.0f) {  // (the maximum above compared score bits: positive scores only)
+            const float curv = __uint_as_float((uint32_t)(bb >> 32));
+            settled = true;
+            settled_score = curv > sc0 ? curv : sc0;
+            settled_pred = curv > sc0 ? t0 + ((uint32_t)bb & 0xFFu) - 64u : ai;
+          }
+        }
+        s_unres[lane] = 0;
+        s_best[lane] = 0ull;
+      }
       PHASE_MARK(7);
     } else {
 #ifdef SMHIP_PHASE_PROF
@@ -377,13 +449,15 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
       }
     }
     PHASE_MARK(2);
+    fmask_prev = __ballot(found);  // (for the next tile: an anchor settled here still counts -- its score is not its start score)
     if (ai < n) {
-      if (!found) {
-        const float coef = StartCoef(my_dist, (double)radius, inv_radius);
-        const float sc = coef * (float)dim;
+      if (!found || settled) {
+        const float sc = settled ? settled_score : my_coef * (float)dim;
         score[ai] = sc;
-        pred[ai] = ai;
-        used[ai] = 0;
+        pred[ai] = settled ? settled_pred : ai;
+        // (chained here: listed by ChainPendingKernel for the end search -- its score can reach min_chaining_score --
+        // but not for the DP; that kernel clears the flag)
+        used[ai] = settled ? 3 : 0;
         atomicMax(&s_gmax[ord - first_ord], __float_as_uint(sc));  // (a tile of 64 anchors touches <= 64 buckets)
       } else {
         used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
@@ -405,6 +479,12 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
   PHASE_FLUSH();
 }
 
+// The anchors that wait for the DP kernels, listed per chunk in index order: in the free half of the chunk's region of
+// the sort's key buffer (16 bytes per anchor: bucket maxima and their prefix maxima take the first 8).
+__device__ __forceinline__ uint32_t *DpList(const ChainArgs &a, uint64_t base, uint32_t n) {
+  return reinterpret_cast<uint32_t *>(a.scratch + 2 * base) + 2 * (size_t)n;
+}
+
 // ---- C0b: the anchors left for the sequential DP, listed per chunk in index order (one workgroup per
 // chunk: an ordered compaction of the flags), and cut into ITEMS: maximal runs of listed anchors of one
 // bucket in which consecutive ones lie within max_target_gap_length on the target.  The predecessor
@@ -415,16 +495,20 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
 __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_target_gap_length,
                                                           uint32_t *__restrict__ n_pending,
                                                           uint32_t *__restrict__ n_items) {
-  __shared__ uint32_t s_wave[4], s_wave8[8][4];
-  __shared__ uint32_t s_run;
+  __shared__ uint32_t s_wave[4], s_wave8[8][4], s_wave8d[8][4];
+  __shared__ uint32_t s_run, s_run_d;
   const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t base = a.anchor_off[c];
   const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
   const uint32_t *tpos = a.s_tpos + base, *grp = a.s_grp + base;
-  const uint8_t *used = a.used + base;
-  uint32_t *pending = a.pending + base;
+  uint8_t *used = a.used + base;
+  // TWO lists, both in index order: `scored` = every anchor with a passing predecessor (flags 2 and 3: what the end
+  // search has to look at -- an isolated anchor's score is below min_chaining_score), and `pending` = those of them
+  // that wait for the DP kernels (flag 2; 3 = chained by the classifier: the flag is cleared here)
+  uint32_t *scored = a.pending + base;
+  uint32_t *pending = DpList(a, base, n);
   uint32_t *items = a.lists + base;  // (ChainEndsKernel reuses this array for the chains' anchor lists afterwards)
-  if (tid == 0) s_run = 0;
+  if (tid == 0) s_run = s_run_d = 0;
   __syncthreads();
   // 8192 flags per round: a thread takes one aligned word (four consecutive anchors) of each of eight
   // 1024-flag rows; the eight loads are in flight together and the eight rows are scanned side by side, so a
@@ -434,50 +518,74 @@ __global__ __launch_bounds__(256) void ChainPendingKernel(ChainArgs a, int max_t
   const uint32_t *used_w = reinterpret_cast<const uint32_t *>(used - shift);
   const uint32_t n_words = (n + shift + 3u) / 4u;
   for (uint32_t w0 = 0; w0 < n_words; w0 += 8 * 256) {
-    uint32_t f[8], cnt[8], incl[8];
+    uint32_t f[8], fd[8], cnt[8], incl[8], cntd[8], incld[8];
+    bool any_d = false;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const uint32_t wi = w0 + (uint32_t)p * 256u + tid;
       const uint32_t w4 = wi < n_words ? used_w[wi] : 0u;
       const int64_t i0 = (int64_t)wi * 4 - (int64_t)shift;  // anchor of the word's first byte
-      uint32_t bits = ((w4 & 0xFFu) == 2u ? 1u : 0u) | (((w4 >> 8) & 0xFFu) == 2u ? 2u : 0u) |
-                      (((w4 >> 16) & 0xFFu) == 2u ? 4u : 0u) | ((w4 >> 24) == 2u ? 8u : 0u);
+      // (flags are 0, 2 or 3: bit 1 = listed, bit 0 = chained already)
+      uint32_t bits = ((w4 >> 1) & 1u) | ((w4 >> 8) & 2u) | ((w4 >> 15) & 4u) | ((w4 >> 22) & 8u);
+      const uint32_t done = (w4 & 1u) | ((w4 >> 7) & 2u) | ((w4 >> 14) & 4u) | ((w4 >> 21) & 8u);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (i0 + k < 0 || i0 + k >= (int64_t)n) bits &= ~(1u << k);  // bytes before the first / after the last anchor
       f[p] = bits;
+      fd[p] = bits & ~done;
       cnt[p] = (uint32_t)__popc(bits);
       incl[p] = cnt[p];
+      cntd[p] = (uint32_t)__popc(fd[p]);
+      incld[p] = cntd[p];
+      any_d = any_d || (bits & done) != 0;
     }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) incl[p] = (uint32_t)WaveScanAdd((int)incl[p]);
-    if (lane == 63) {
-#pragma unroll
-      for (int p = 0; p < 8; ++p) s_wave8[p][wave] = incl[p];
-    }
-    __syncthreads();
-    uint32_t row_base = s_run, total = 0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      uint32_t off = row_base + incl[p] - cnt[p];
-      for (uint32_t w2 = 0; w2 < wave; ++w2) off += s_wave8[p][w2];
-      const uint32_t row_total = s_wave8[p][0] + s_wave8[p][1] + s_wave8[p][2] + s_wave8[p][3];
-      const uint32_t i0 = (w0 + (uint32_t)p * 256u + tid) * 4u - shift;  // (only used where a flag is set: then in range)
+      incl[p] = (uint32_t)WaveScanAdd((int)incl[p]);
+      incld[p] = (uint32_t)WaveScanAdd((int)incld[p]);
+    }
+    if (lane == 63) {
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k)
-        if (f[p] & (1u << k)) pending[off++] = i0 + k;
-      row_base += row_total;
-      total += row_total;
+      for (int p = 0; p < 8; ++p) {
+        s_wave8[p][wave] = incl[p];
+        s_wave8d[p][wave] = incld[p];
+      }
     }
     __syncthreads();
-    if (tid == 0) s_run += total;
+    uint32_t row_base = s_run, total = 0, row_base_d = s_run_d, total_d = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      uint32_t off = row_base + incl[p] - cnt[p], offd = row_base_d + incld[p] - cntd[p];
+      for (uint32_t w2 = 0; w2 < wave; ++w2) {
+        off += s_wave8[p][w2];
+        offd += s_wave8d[p][w2];
+      }
+      const uint32_t row_total = s_wave8[p][0] + s_wave8[p][1] + s_wave8[p][2] + s_wave8[p][3];
+      const uint32_t row_total_d = s_wave8d[p][0] + s_wave8d[p][1] + s_wave8d[p][2] + s_wave8d[p][3];
+      const uint32_t i0 = (w0 + (uint32_t)p * 256u + tid) * 4u - shift;  // (only used where a flag is set: then in range)
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (f[p] & (1u << k)) scored[off++] = i0 + k;
+        if (fd[p] & (1u << k)) pending[offd++] = i0 + k;
+        else if (any_d && (f[p] & (1u << k))) used[i0 + k] = 0;  // chained by the classifier: an ordinary anchor from here on
+      }
+      row_base += row_total;
+      total += row_total;
+      row_base_d += row_total_d;
+      total_d += row_total_d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_run += total;
+      s_run_d += total_d;
+    }
     __syncthreads();
   }
-  const uint32_t npend = s_run;
+  const uint32_t npend = s_run_d;  // (of the DP list: what the items below are cut from)
   __threadfence_block();
   __syncthreads();
   if (tid == 0) {
-    n_pending[c] = npend;
+    n_pending[c] = s_run;  // (of the scored list: ChainEndsKernel's)
     s_run = 0;
   }
   __syncthreads();
@@ -555,7 +663,7 @@ __device__ __forceinline__ void DpSmallItems(const ChainArgs &a, const uint32_t 
   uint32_t *pred = a.pred + base;
   uint8_t *used = a.used + base;
   uint32_t *gmax = reinterpret_cast<uint32_t *>(a.scratch + 2 * base);
-  const uint32_t *pending = a.pending + base;
+  const uint32_t *pending = DpList(a, base, (uint32_t)(a.anchor_off[c + 1] - base));
   const uint32_t s = gstart[g];
   PHASE_MARK(8);
   // The anchors of the slice are chained in order (each may read the scores of the ones before),
@@ -850,7 +958,7 @@ __device__ __forceinline__ void DpBigItems(const ChainArgs &a, const uint32_t *_
     const uint32_t n = (uint32_t)(a.anchor_off[c + 1] - base);
     const uint32_t G = a.n_groups[c];
     const uint32_t *gstart = a.group_start + base;
-    const uint32_t *pending = a.pending + base;
+    const uint32_t *pending = DpList(a, base, n);
     const uint32_t s = gstart[g], e = g + 1 < G ? gstart[g + 1] : n;
     const uint32_t ng = e - s;
     const uint32_t *tpos = a.s_tpos + base + s, *qpos = a.s_qpos + base + s;
@@ -1513,14 +1621,16 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   // knob classify_dense = 0: lockstep scans for every tile
   const uint32_t dense_k = ctx->knobs.classify_dense == 0 ? 0u
       : (uint32_t)std::max(0, std::min(std::min(p.max_num_skips + 1, p.chaining_band_length), 32));
+  // ... and an anchor whose passing predecessors are all isolated is chained there (knob classify_resolve = 0: left to the DP)
+  const uint32_t resolve = ctx->knobs.classify_resolve == 0 ? 0u : 1u;
   if (int_gap)
     hipLaunchKernelGGL(ChainClassifyKernel<true>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
-                       p.max_num_skips, dense_k);
+                       p.max_num_skips, dense_k, resolve);
   else
     hipLaunchKernelGGL(ChainClassifyKernel<false>, dim3(tile_blocks), dim3(256), 0, ctx->stream, a, n_chunks, tile_off,
                        p.search_radius, kMaxDim, p.max_gap_length, p.max_target_gap_length, p.chaining_band_length,
-                       p.max_num_skips, dense_k);
+                       p.max_num_skips, dense_k, resolve);
   hipLaunchKernelGGL(ChainPendingKernel, dim3(n_chunks), dim3(256), 0, ctx->stream, a, p.max_target_gap_length, n_pending,
                      n_items);
   if ((e = LaunchScanU32(ctx, n_items, n_chunks, ioff)) != hipSuccess) return e;

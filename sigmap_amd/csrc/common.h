@@ -130,6 +130,7 @@ struct DevKnobs {
   long long pool_min = -1;     // SMHIP_POOL_MIN: initial overflow-pool size (>= 0: also forces the reading route)
   int spec_tight = 0;          // SMHIP_SPEC_TIGHT: 1 halves the query capacity of a speculative batch, 2 the anchor capacity
   int float_gap = 0;           // SMHIP_FLOAT_GAP=1: division form of the chaining gap tests
+  int classify_resolve = -1;   // SMHIP_CLASSIFY_RESOLVE=0: the classifier leaves every anchor with a passing predecessor to the DP kernels
   int classify_dense = -1;     // SMHIP_CLASSIFY_DENSE=0: lockstep predecessor scans for every tile of the chain classifier
   int sort_lines = -1;         // SMHIP_SORT_LINES: 0 = exact two-pass partition only; 2 / 4 = whole-line partition with tiles of 2048 / 4096 whatever the batch
   int second_search = 0;       // SMHIP_SECOND_SEARCH=1: queries beyond the hit cap are searched again in the reference's

@@ -45,16 +45,19 @@ def _run_and_compare(dev, chunks, n_refs, shuffle_seed=0):
     res, anchors, aoff = dev.chain_anchors(np.concatenate(flat) if flat else np.zeros(0, _abi.CARRIED_DTYPE), offs, n_refs,
                                            with_anchors=True)
     allc, coff = dev.download_chains()      # every primary chain, not only the record's first four
-    # the classifier's other route (lockstep predecessor scans for every tile instead of dense pairs): the same bytes
-    dev.set_knob("classify_dense", 0)
-    try:
-        res0, anchors0, aoff0 = dev.chain_anchors(np.concatenate(flat) if flat else np.zeros(0, _abi.CARRIED_DTYPE), offs,
-                                                  n_refs, with_anchors=True)
-        allc0, coff0 = dev.download_chains()
-    finally:
-        dev.set_knob("classify_dense", -1)
-    assert res0.tobytes() == res.tobytes() and anchors0.tobytes() == anchors.tobytes() and np.array_equal(aoff0, aoff)
-    assert allc0.tobytes() == allc.tobytes() and np.array_equal(coff0, coff)
+    # the classifier's other routes -- lockstep predecessor scans for every tile instead of dense pairs; every anchor
+    # with a passing predecessor left to the DP kernels instead of chained in the classifier where that is possible --:
+    # the same bytes
+    for knob in ("classify_dense", "classify_resolve"):
+        dev.set_knob(knob, 0)
+        try:
+            res0, anchors0, aoff0 = dev.chain_anchors(np.concatenate(flat) if flat else np.zeros(0, _abi.CARRIED_DTYPE), offs,
+                                                      n_refs, with_anchors=True)
+            allc0, coff0 = dev.download_chains()
+        finally:
+            dev.set_knob(knob, -1)
+        assert res0.tobytes() == res.tobytes() and anchors0.tobytes() == anchors.tobytes() and np.array_equal(aoff0, aoff), knob
+        assert allc0.tobytes() == allc.tobytes() and np.array_equal(coff0, coff), knob
     out = []
     for i, c in enumerate(chunks):
         want = po.chain_anchors(c[0], c[1], c[2], c[3], n_refs)

@@ -338,11 +338,12 @@ def test_pipeline_paf_identical_to_oracle(device, small_world, oracle_tree, bloc
         finally:
             device.set_knob("sort_lines", -1)
         # the chain classifier's lockstep predecessor scans for every tile (default: dense pairs where the windows allow)
-        device.set_knob("classify_dense", 0)
-        try:
-            assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes()
-        finally:
-            device.set_knob("classify_dense", -1)
+        for knob in ("classify_dense", "classify_resolve"):   # (... / nothing chained inside the classifier)
+            device.set_knob(knob, 0)
+            try:
+                assert device.map_chunks(samples, offsets, n_refs=3).tobytes() == res.tobytes(), knob
+            finally:
+                device.set_knob(knob, -1)
     names = ["contig0", "contig1", "contig2"]
     lines = _paf_lines(res, pa, names, ref_lens)
     mapped = 0

@@ -57,6 +57,7 @@ def main(rounds, first):
         dev.params.search_mode = int(rng.choice([_abi.SEARCH_AUTO, _abi.SEARCH_AUTO, _abi.SEARCH_EXACT, _abi.SEARCH_SET]))
         dev.set_knob("sort_lines", int(rng.choice([-1, -1, 0, 4])))   # the sort's whole-line partition route, or the exact one
         dev.set_knob("classify_dense", int(rng.choice([-1, -1, 0])))   # dense pairs or lockstep scans in the chain classifier
+        dev.set_knob("classify_resolve", int(rng.choice([-1, -1, 0])))  # ... chaining what it can itself, or nothing
         dev.set_knob("second_search", int(rng.choice([0, 0, 1])))  # over-cap queries: ranked, or searched a second time
         # the hit cap: lowered caps put (nearly) every query beyond it -- the set walk's second search in the
         # reference's order, or, once the context has seen such a batch, the exact walk for everything
