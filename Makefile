@@ -38,13 +38,13 @@ $(LIBDIR)/libsigmap_host.so: $(HOST_SRCS) $(wildcard $(HOST)/*.h) include/sigmap
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) $(HDF5_FLAGS) $(ZSTD_FLAGS) -shared -o $@ $(HOST_SRCS) -lz -ldl $(HDF5_LIBS) $(ZSTD_LIBS)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/sigmap_hip.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/knobs.h include/sigmap_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # sort.hip prefetches with inline-assembly loads the compiler does not track: the device assembly of the same
 # flags is checked for any use of a load's destination registers before the matching wait (tools/check_asm_prefetch.py)
-build/sort.asmcheck: $(CSRC)/sort.hip $(CSRC)/common.h include/sigmap_hip.h tools/check_asm_prefetch.py
+build/sort.asmcheck: $(CSRC)/sort.hip $(CSRC)/common.h $(CSRC)/knobs.h include/sigmap_hip.h tools/check_asm_prefetch.py
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S $(CSRC)/sort.hip -o build/sort.device.s
 	python3 tools/check_asm_prefetch.py build/sort.device.s
