@@ -22,7 +22,13 @@
 namespace smhip {
 namespace {
 constexpr int kRowStride = kMaxSamples + 4;  // floats per chunk row of the scratch arrays
-constexpr int kBlk = 8;                      // samples fetched ahead of the sequential chains
+#ifndef SMHIP_PREFIX_PRE
+#define SMHIP_PREFIX_PRE 16
+#endif
+#ifndef SMHIP_FEAT_BLK
+#define SMHIP_FEAT_BLK 8
+#endif
+constexpr int kBlk = SMHIP_FEAT_BLK;         // values fetched ahead of the sequential chains
 // ... of the peak picker: a lane walks its own segment of a t-statistic row, so its 4-byte reads pull a whole
 // 128-byte line each; 32 samples = the line is consumed while it is still in the L1 (8: 357 us and 6.5 x the rows'
 // bytes from the fabric per launch; 16: 310 us; 32: 297 us)
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(64) void PrefixKernel(const float *__restrict__ sam
   // blocks of kPre samples, the next block's loads in flight while the current one is added up
   // (the additions are a dependent chain; a lane's loads are 4-byte reads 16 KB apart from its
   // neighbours', so a block costs a full memory round trip)
-  constexpr int kPre = 16;
+  constexpr int kPre = SMHIP_PREFIX_PRE;
   float cur[kPre], nxt[kPre];
   if (kPre <= n) {
 #pragma unroll
@@ -392,15 +398,27 @@ __global__ __launch_bounds__(64) void FeatureKernel(uint32_t n_chunks, const uin
     SD /= (double)(uint64_t)(E - 1);
     SD = sqrt(SD);
     float last = 0.0f;
-    for (i = 0; i < E; ++i) {
-      const float z = (float)(((double)m[i] - mean) / SD);
-      if (i == 0 || (double)fabsf(z - last) > compress_delta) {
+    auto keep = [&](uint32_t at, float mv, float sv) {
+      const float z = (float)(((double)mv - mean) / SD);
+      if (at == 0 || (double)fabsf(z - last) > compress_delta) {
         fo[F] = z;
-        if (so) so[F] = sd[i];
+        if (so) so[F] = sv;
         last = z;
         ++F;
       }
+    };
+    // (blocks of values fetched together, like the two passes above: one memory round trip per block, not per event)
+    for (i = 0; i + kBlk <= E; i += kBlk) {
+      float v[kBlk], w[kBlk];
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) {
+        v[k] = m[i + k];
+        w[k] = so ? sd[i + k] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) keep(i + k, v[k], w[k]);
     }
+    for (; i < E; ++i) keep(i, m[i], so ? sd[i] : 0.0f);
   }
   uint32_t Q = 0;
   // sigmap.cc:660 (> 50 features) and spatial_index.cc:326-356,403-408: seeds at
