@@ -35,8 +35,19 @@ constexpr int kBlk = SMHIP_FEAT_BLK;         // values fetched ahead of the sequ
 // bytes from the fabric per launch; 16: 310 us; 32: 297 us)
 constexpr int kPeakBlk = 32;
 
+// x / w for a window length w: five of these per t-statistic were half of the kernel's instructions (an IEEE f32
+// division is ten).  q = x * RN(1 / w), corrected once with the exact remainder (two FMAs), is the correctly rounded
+// quotient -- checked EXHAUSTIVELY for every w in 1 .. 64 and every float with 2^-100 <= |x| <= 2^100
+// (tools/micro/div_by_window_check.c: the remainder must not underflow, hence the range); anything else divides.
+constexpr uint32_t kFastDivMaxW = 64;
+__device__ __forceinline__ float DivW(float x, float wf, float rw) {
+  const float q = x * rw;
+  return __fmaf_rn(__fmaf_rn(-q, wf, x), rw, q);
+}
+__device__ __forceinline__ bool DivWRange(float lo_abs, float hi_abs) { return lo_abs >= 0x1p-100f && hi_abs <= 0x1p100f; }
+
 // event.h:89-110 for one i in [w, n-w]
-__device__ __forceinline__ float TStatAt(const float *ps, const float *pss, uint32_t i, uint32_t w) {
+__device__ __forceinline__ float TStatAt(const float *ps, const float *pss, uint32_t i, uint32_t w, float rw, bool fast_w) {
   const float wf = (float)w;
   float sum1 = ps[i];
   float sumsq1 = pss[i];
@@ -46,12 +57,21 @@ __device__ __forceinline__ float TStatAt(const float *ps, const float *pss, uint
   }
   const float sum2 = ps[i + w] - ps[i];
   const float sumsq2 = pss[i + w] - pss[i];
-  const float mean1 = sum1 / wf;
-  const float mean2 = sum2 / wf;
-  float combined_var = sumsq1 / wf - mean1 * mean1 + sumsq2 / wf - mean2 * mean2;
+  const float a1 = fabsf(sum1), a2 = fabsf(sum2), a3 = fabsf(sumsq1), a4 = fabsf(sumsq2);
+  float combined_var, delta_mean;
+  if (fast_w && DivWRange(fminf(fminf(a1, a2), fminf(a3, a4)), fmaxf(fmaxf(a1, a2), fmaxf(a3, a4)))) {
+    const float mean1 = DivW(sum1, wf, rw), mean2 = DivW(sum2, wf, rw);
+    combined_var = DivW(sumsq1, wf, rw) - mean1 * mean1 + DivW(sumsq2, wf, rw) - mean2 * mean2;
+    delta_mean = mean2 - mean1;
+  } else {
+    const float mean1 = sum1 / wf;
+    const float mean2 = sum2 / wf;
+    combined_var = sumsq1 / wf - mean1 * mean1 + sumsq2 / wf - mean2 * mean2;
+    delta_mean = mean2 - mean1;
+  }
   combined_var = fmaxf(combined_var, FLT_MIN);
-  const float delta_mean = mean2 - mean1;
-  return (float)(fabs((double)delta_mean) / sqrt((double)(combined_var / wf)));
+  const float cvw = (fast_w && DivWRange(combined_var, combined_var)) ? DivW(combined_var, wf, rw) : combined_var / wf;
+  return (float)(fabs((double)delta_mean) / sqrt((double)cvw));
 }
 
 struct Detector {  // event.h:45-56
@@ -140,10 +160,12 @@ __global__ __launch_bounds__(256) void TStatKernel(const uint32_t *__restrict__ 
   }
   __syncthreads();
   float *t1 = t1_all + (size_t)c * kRowStride, *t2 = t2_all + (size_t)c * kRowStride;
+  const bool fast1 = w1 >= 1 && w1 <= kFastDivMaxW, fast2 = w2 >= 1 && w2 <= kFastDivMaxW;
+  const float rw1 = 1.0f / (float)(w1 ? w1 : 1u), rw2 = 1.0f / (float)(w2 ? w2 : 1u);
   for (uint32_t i = tid; i <= n; i += 256) {
     float a = 0.0f, b = 0.0f;
-    if (!(n < 2 * w1 || w1 < 2) && i >= w1 && i <= n - w1) a = TStatAt(ps, pss, i, w1);
-    if (!(n < 2 * w2 || w2 < 2) && i >= w2 && i <= n - w2) b = TStatAt(ps, pss, i, w2);
+    if (!(n < 2 * w1 || w1 < 2) && i >= w1 && i <= n - w1) a = TStatAt(ps, pss, i, w1, rw1, fast1);
+    if (!(n < 2 * w2 || w2 < 2) && i >= w2 && i <= n - w2) b = TStatAt(ps, pss, i, w2, rw2, fast2);
     t1[i] = a;
     t2[i] = b;
   }
