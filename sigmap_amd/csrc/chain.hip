@@ -1620,7 +1620,7 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   // windows of up to dense_k predecessors are evaluated as dense pairs (the scan cannot end early inside them);
   // knob classify_dense = 0: lockstep scans for every tile
   const uint32_t dense_k = ctx->knobs.classify_dense == 0 ? 0u
-      : (uint32_t)std::max(0, std::min(std::min(p.max_num_skips + 1, p.chaining_band_length), 32));
+      : (uint32_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>((int64_t)p.max_num_skips + 1, p.chaining_band_length), 32));
   // ... and an anchor whose passing predecessors are all isolated is chained there (knob classify_resolve = 0: left to the DP)
   const uint32_t resolve = ctx->knobs.classify_resolve == 0 ? 0u : 1u;
   if (int_gap)
