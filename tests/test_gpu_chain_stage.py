@@ -263,6 +263,57 @@ def test_tangled_random_anchor_sets(cdev):
     assert sum(1 for w in want if len(w) >= 2) > 50 and sum(1 for w in want if len(w) == 0) >= 1
 
 
+def test_routes_agree_under_other_skip_band_and_gap_limits(cdev):
+    """The oracle has the reference's constants (25 skips, band 5000, target gap 5000).  With other limits the
+    classifier's window rule changes (dense pairs and its own chaining only inside windows of min(skips + 1, band)
+    predecessors), so its three routes -- dense pairs + chaining, dense pairs only, lockstep scans -- and the DP kernels
+    behind them must still produce the same bytes."""
+    rng = np.random.default_rng(23)
+    chunks = []
+    for c in range(60):
+        parts = []
+        for _ in range(int(rng.integers(1, 6))):
+            rs = int(rng.integers(0, 4))
+            n = int(rng.integers(2, 150))
+            t0, q0 = int(rng.integers(0, 30000)), int(rng.integers(0, 1500))
+            step = int(rng.integers(1, 12))
+            k = np.arange(n)
+            t = t0 + step * k + rng.integers(-2, 3, size=n)
+            q = q0 + step * k + rng.integers(-2, 3, size=n)
+            d = rng.uniform(0, 0.0799, size=n).astype(np.float32)
+            parts.append([np.full(n, rs, np.uint32), np.clip(t, 0, None).astype(np.uint32), np.clip(q, 0, None).astype(np.uint32), d])
+        m = int(rng.integers(0, 400))
+        parts.append([rng.integers(0, 4, size=m).astype(np.uint32), rng.integers(0, 32000, size=m).astype(np.uint32),
+                      rng.integers(0, 1700, size=m).astype(np.uint32), rng.uniform(0, 0.0799, size=m).astype(np.float32)])
+        chunks.append(_cat(*parts))
+    flat, offs = [], [0]
+    for c in chunks:
+        a = np.zeros(len(c[0]), dtype=_abi.CARRIED_DTYPE)
+        a["ref_strand"], a["target_position"], a["query_position"], a["distance"] = c
+        flat.append(a)
+        offs.append(offs[-1] + len(a))
+    flat = np.concatenate(flat)
+    saved = (cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length)
+    try:
+        for skips, band, gap in ((3, 5000, 5000), (0, 5000, 5000), (25, 4, 5000), (40, 5000, 300), (7, 9, 60)):
+            cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length = skips, band, gap
+            got = []
+            for knobs in ({}, {"classify_resolve": 0}, {"classify_dense": 0}):
+                for k, v in knobs.items():
+                    cdev.set_knob(k, v)
+                try:
+                    res, anchors, aoff = cdev.chain_anchors(flat, offs, 2, with_anchors=True)
+                    allc, coff = cdev.download_chains()
+                finally:
+                    for k in knobs:
+                        cdev.set_knob(k, -1)
+                got.append((res.tobytes(), anchors.tobytes(), aoff.tobytes(), allc.tobytes(), coff.tobytes()))
+            assert got[0] == got[1] == got[2], (skips, band, gap)
+            assert (res["status"] == 0).all() and res["n_chains"].sum() > 20, (skips, band, gap)
+    finally:
+        cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length = saved
+
+
 def test_generate_chains_from_features_equals_the_sample_route(cdev, small_world, oracle_tree):
     """smhip_generate_chains (features in: SpatialIndex::GenerateChains' own inputs) gives the records the whole path
     gives from the samples of the same chunks, and the oracle's so_generate_chains -- also with a query start offset
