@@ -169,7 +169,7 @@ int smhip_resolved_params(smhip_ctx *ctx, smhip_params *out);
  * from the environment ONCE, in smhip_init, and only when SMHIP_DEV=1 is set there as well; this call sets a knob of
  * a live context and is refused (SMHIP_ESTATE) for a context created without SMHIP_DEV=1.  Names (lower case):
  * lane_blocks_per_cu, xcd_ranges, scan_threshold, classes, bucket_bits, handout, sdtw_ring, sync_run, pool_min,
- * spec_tight, float_gap, sort_lines, second_search. */
+ * spec_tight, float_gap, sort_lines, second_search, classify_dense, classify_resolve. */
 int smhip_dev_knob(smhip_ctx *ctx, const char *name, long long value);
 /* GPUs visible to this process (0 when there is none / no HIP runtime). */
 int smhip_device_count(void);
