@@ -1,6 +1,8 @@
 // chain.hip -- chaining DP, traceback, primary-chain selection and MAPQ.  Kernels: C0 classify (a wave per
-// 64-anchor tile: which anchors are settled without the sequential DP), C0b pending (a workgroup per chunk:
-// the unsettled anchors listed and cut into independent items, one descriptor each), C1 lane DP (a lane per
+// 64-anchor tile: which anchors have no predecessor that passes the gap tests -- their predecessor windows laid
+// out as dense (anchor, predecessor) pairs --, and the chaining of those whose passing predecessors are all of
+// that kind), C0b pending (a workgroup per chunk: the anchors with a passing predecessor listed for the end
+// search, those still unsettled listed and cut into independent items, one descriptor each), C1 lane DP (a lane per
 // short item) beside C1b wave DP (a wave per long item, on the context's auxiliary stream), C2 ends (a wave
 // per chunk: chain ends, traceback), C3 finalize (a wave per chunk: primary chains, MAPQ, statistics).
 //
