@@ -1084,14 +1084,20 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
     auto consider = [&](uint32_t ai, float sc) {
       if (sc > run_max) run_max = sc;
       if (sc >= min_chaining_score && sc > run_max / 2) {  // spatial_index.cc:545-549
-        Cand cnd{sc, ai - s};
-        uint32_t pos = ntop;  // keep the best three in sorted order (num_best_chains <= 3)
-        while (pos > 0 && CandBefore(cnd, top[pos - 1])) --pos;
-        if (pos < 3) {
-          for (uint32_t kk = (ntop < 3 ? ntop : 2); kk > pos; --kk) top[kk] = top[kk - 1];
-          top[pos] = cnd;
-          if (ntop < 3) ++ntop;
+        // keep the best three in sorted order (num_best_chains <= 3).  Constant indices only: with a position
+        // computed at run time the three candidates lived in scratch memory, a round trip per comparison
+        const Cand cnd{sc, ai - s};
+        if (ntop < 1 || CandBefore(cnd, top[0])) {
+          top[2] = top[1];
+          top[1] = top[0];
+          top[0] = cnd;
+        } else if (ntop < 2 || CandBefore(cnd, top[1])) {
+          top[2] = top[1];
+          top[1] = cnd;
+        } else if (ntop < 3 || CandBefore(cnd, top[2])) {
+          top[2] = cnd;
         }
+        if (ntop < 3) ++ntop;
       }
     };
     if (pending_only) {
@@ -1204,7 +1210,7 @@ __global__ __launch_bounds__(64) void ChainEndsKernel(ChainArgs a, int min_num_a
       const uint32_t direction = (grp_id & 1) == 0 ? 1u : 0u;  // strand 0 = Positive
       uint32_t cursor = s;  // chain anchor lists are packed into this bucket's own slice of `lists`
       for (uint32_t k = 0; k < lim; ++k) {
-        const uint32_t end_abs = s + top[k].idx;
+        const uint32_t end_abs = s + (k == 0 ? top[0].idx : (k == 1 ? top[1].idx : top[2].idx));
         if (!used[end_abs]) {
           // (the reference's loop, with pred[p] fetched beside used[p]: one memory round trip per
           // chain anchor instead of two dependent ones)
