@@ -171,39 +171,42 @@ __global__ __launch_bounds__(256) void TStatKernel(const uint32_t *__restrict__ 
   }
 }
 
-// One step of one detector, event.h:128-180.
-__device__ __forceinline__ void DetectorStep(Detector *d, int k, float cur, uint32_t i, float peak_height,
-                                             uint16_t *peaks, uint32_t &np) {
+// One step of one detector, event.h:128-180, WITHOUT BRANCHES: every condition of the state machine is evaluated and
+// the new state is a select -- a wave runs 64 of these machines in step, and as nested branches every step cost it a
+// dozen jumps around a few instructions each (the picker ran at a third of its instruction rate).  Returns whether
+// the step emits a peak, and its position in `pos_out`.
+__device__ __forceinline__ bool DetectorStep(Detector *d, int k, float cur, uint32_t i, float peak_height, uint32_t &pos_out) {
   Detector &det = d[k];
-  if (det.masked_to >= i) return;
-  if (det.peak_pos == -1) {
-    if (cur < det.peak_value) {
-      det.peak_value = cur;
-    } else if (cur - det.peak_value > peak_height) {
-      det.peak_value = cur;
-      det.peak_pos = (int)i;
-    }
-  } else {
-    if (cur > det.peak_value) {
-      det.peak_value = cur;
-      det.peak_pos = (int)i;
-    }
-    if (k == 0) {
-      if (det.peak_value > det.threshold) {
-        d[1].masked_to = (uint64_t)det.peak_pos + det.window_length;
-        d[1].peak_pos = -1;
-        d[1].peak_value = FLT_MAX;
-        d[1].valid_peak = false;
-      }
-    }
-    if (det.peak_value - cur > peak_height && det.peak_value > det.threshold) det.valid_peak = true;
-    if (det.valid_peak && ((uint64_t)i - (uint64_t)det.peak_pos) > det.window_length / 2) {
-      peaks[np++] = (uint16_t)det.peak_pos;
-      det.peak_pos = -1;
-      det.peak_value = cur;
-      det.valid_peak = false;
-    }
+  const bool active = !(det.masked_to >= (uint64_t)i);
+  const bool none = det.peak_pos == -1;
+  // no peak candidate yet: follow the signal down; a rise of more than peak_height makes one
+  const bool lower = cur < det.peak_value;
+  const bool rise = !lower && cur - det.peak_value > peak_height;
+  const float a_value = (lower || rise) ? cur : det.peak_value;
+  const int a_pos = rise ? (int)i : -1;
+  // a candidate: follow the signal up
+  const bool higher = cur > det.peak_value;
+  const float b_value = higher ? cur : det.peak_value;
+  const int b_pos = higher ? (int)i : det.peak_pos;
+  const bool over = b_value > det.threshold;
+  if (k == 0) {  // a short-window peak above its threshold masks the long-window detector
+    const bool m = active && !none && over;
+    d[1].masked_to = m ? (uint64_t)(int64_t)b_pos + det.window_length : d[1].masked_to;
+    d[1].peak_pos = m ? -1 : d[1].peak_pos;
+    d[1].peak_value = m ? FLT_MAX : d[1].peak_value;
+    d[1].valid_peak = m ? false : d[1].valid_peak;
   }
+  const bool valid = det.valid_peak || (b_value - cur > peak_height && over);
+  const bool emit_b = valid && ((uint64_t)i - (uint64_t)(int64_t)b_pos) > (uint64_t)(det.window_length / 2);
+  const bool emit = active && !none && emit_b;
+  pos_out = (uint32_t)b_pos;
+  const float n_value = none ? a_value : (emit_b ? cur : b_value);
+  const int n_pos = none ? a_pos : (emit_b ? -1 : b_pos);
+  const bool n_valid = none ? det.valid_peak : (emit_b ? false : valid);
+  det.peak_value = active ? n_value : det.peak_value;
+  det.peak_pos = active ? n_pos : det.peak_pos;
+  det.valid_peak = active ? n_valid : det.valid_peak;
+  return emit;
 }
 
 // E3 -- event.h:117-182: sequential in i, short detector first.  A lane per chunk would leave the
@@ -248,10 +251,27 @@ __device__ __forceinline__ PeakState ShflUpState(const PeakState &s, int delta) 
   return r;
 }
 
-// steps [ib, ie) of both detectors; peaks go to out[np++] when out != nullptr
+// steps [ib, ie) of both detectors; kEmit: peaks go to the lane's list -- its first kPeakLds - 1 entries are a column
+// in LDS (entry k at out[k * 64]; written at EVERY step, with the position of whichever candidate there is, and kept
+// only when np moves on; the last LDS entry takes the writes of a longer list), later ones to far[k] in memory (rare:
+// a segment of 250 steps averages 30 peaks)
+constexpr uint32_t kPeakLds = 64;
+template <bool kEmit>
 __device__ __forceinline__ void RunSteps(Detector *d, const float *__restrict__ t1, const float *__restrict__ t2,
-                                         uint32_t ib, uint32_t ie, float peak_height, uint16_t *out, uint32_t &np) {
-  uint16_t sink[1];
+                                         uint32_t ib, uint32_t ie, float peak_height, uint16_t *out, uint16_t *far,
+                                         uint32_t &np) {
+  auto push = [&](bool e, uint32_t pos) {
+    out[min(np, kPeakLds - 1u) * 64u] = (uint16_t)pos;
+    if (e && np >= kPeakLds - 1u) far[np] = (uint16_t)pos;
+    np += e ? 1u : 0u;
+  };
+  auto both = [&](float a, float b, uint32_t i) {
+    uint32_t pos;
+    const bool e0 = DetectorStep(d, 0, a, i, peak_height, pos);
+    if (kEmit) push(e0, pos);
+    const bool e1 = DetectorStep(d, 1, b, i, peak_height, pos);
+    if (kEmit) push(e1, pos);
+  };
   uint32_t i = ib;
   for (; i + kPeakBlk <= ie; i += kPeakBlk) {
     float a[kPeakBlk], b[kPeakBlk];
@@ -262,29 +282,9 @@ __device__ __forceinline__ void RunSteps(Detector *d, const float *__restrict__ 
       b[k] = vb.x; b[k + 1] = vb.y; b[k + 2] = vb.z; b[k + 3] = vb.w;
     }
 #pragma unroll
-    for (int k = 0; k < kPeakBlk; ++k) {
-      if (out) {
-        DetectorStep(d, 0, a[k], i + k, peak_height, out, np);
-        DetectorStep(d, 1, b[k], i + k, peak_height, out, np);
-      } else {
-        uint32_t z = 0;
-        DetectorStep(d, 0, a[k], i + k, peak_height, sink, z);
-        z = 0;
-        DetectorStep(d, 1, b[k], i + k, peak_height, sink, z);
-      }
-    }
+    for (int k = 0; k < kPeakBlk; ++k) both(a[k], b[k], i + k);
   }
-  for (; i < ie; ++i) {
-    if (out) {
-      DetectorStep(d, 0, t1[i], i, peak_height, out, np);
-      DetectorStep(d, 1, t2[i], i, peak_height, out, np);
-    } else {
-      uint32_t z = 0;
-      DetectorStep(d, 0, t1[i], i, peak_height, sink, z);
-      z = 0;
-      DetectorStep(d, 1, t2[i], i, peak_height, sink, z);
-    }
-  }
+  for (; i < ie; ++i) both(t1[i], t2[i], i);
 }
 
 __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ clen, uint32_t n_chunks,
@@ -305,13 +305,15 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ cl
   const float *t1 = t1_all + row, *t2 = t2_all + row;
   const uint32_t S = (n + kPeakSegs - 1) / kPeakSegs;
   const uint32_t beg = min(n, seg * S), end = min(n, beg + S);
-  uint16_t *mine = seg_peaks_all + row + beg;  // a segment of S steps emits at most S peaks
+  __shared__ uint16_t s_pk[kPeakLds * 64];  // the lanes' peak lists: entry k of lane l at [k * 64 + l]
+  uint16_t *mine = s_pk + lane;
+  uint16_t *far = seg_peaks_all + row + beg;  // ... beyond kPeakLds - 1 entries (a segment of S steps emits at most S peaks)
   Detector d[2] = {{thr1, w1, 0, -1, FLT_MAX, false}, {thr2, w2, 0, -1, FLT_MAX, false}};
   uint32_t np = 0;
   // speculative run: warm-up from the initial state, then the segment
-  RunSteps(d, t1, t2, beg > kPeakWarm ? beg - kPeakWarm : 0u, beg, peak_height, nullptr, np);
+  RunSteps<false>(d, t1, t2, beg > kPeakWarm ? beg - kPeakWarm : 0u, beg, peak_height, nullptr, nullptr, np);
   PeakState start = SaveState(d);
-  RunSteps(d, t1, t2, beg, end, peak_height, mine, np);
+  RunSteps<true>(d, t1, t2, beg, end, peak_height, mine, far, np);
   PeakState fin = SaveState(d);
   // check against the predecessor segment's end state; re-run what started from a wrong state
   for (int round = 0; round < kPeakSegs; ++round) {
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ cl
       start = prev;
       LoadState(d, prev);
       np = 0;
-      RunSteps(d, t1, t2, beg, end, peak_height, mine, np);
+      RunSteps<true>(d, t1, t2, beg, end, peak_height, mine, far, np);
       fin = SaveState(d);
     }
   }
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64) void PeakKernel(const uint32_t *__restrict__ cl
   }
   if (live) {
     uint16_t *peaks = peaks_all + row;
-    for (uint32_t k = 0; k < np; ++k) peaks[before + k] = mine[k];
+    for (uint32_t k = 0; k < np; ++k) peaks[before + k] = k < kPeakLds - 1u ? mine[k * 64u] : far[k];
     if (seg == kPeakSegs - 1) n_peaks[c] = before + np;
   }
 }

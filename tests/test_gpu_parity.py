@@ -58,6 +58,33 @@ def test_events_kernel_matches_reference_golden(device):
         assert np.array_equal(bits(feat[r, :nf[r]]), bits(f))
 
 
+def test_events_dense_peaks_beyond_the_lds_peak_lists(device):
+    """Square waves of period 6 and 8 samples give a peak every three or four samples: 84 / 63 events in a segment of
+    250 samples -- more than the 63 entries of a lane's peak list in LDS (the rest goes to the list in memory),
+    resp. exactly as many.  Every stage against the oracle (its event detection is pinned to the real event.h)."""
+    rng = np.random.default_rng(5)
+    k = np.arange(4000)
+    pa = []
+    for period, amp in ((6, 10.0), (8, 30.0), (6, 30.0)):
+        pa.append((90 + amp * (((k // (period // 2)) % 2) * 2 - 1) + 0.5 * rng.standard_normal(4000)).astype(np.float32))
+    mixed = pa[0].copy()
+    mixed[2000:] = (90 + 12 * rng.standard_normal(2000)).astype(np.float32)   # dense first half, ordinary second half
+    pa.append(mixed)
+    samples, offsets = _batch(pa)
+    feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    raw = device.events_raw(len(pa))
+    dense = 0
+    for i, x in enumerate(pa):
+        f, s = po.generate_events(x)
+        ev, _ = po.detect_events(x)
+        assert st[i] == 0 and ne[i] == len(ev) and nf[i] == len(f), i
+        assert np.array_equal(bits(feat[i, :nf[i]]), bits(f)) and np.array_equal(bits(stdv[i, :nf[i]]), bits(s)), i
+        starts = np.array([e[0] for e in ev]) if not hasattr(ev, "dtype") else ev["start"]
+        assert np.array_equal(raw["start"][i, :len(ev)], np.asarray(starts, dtype=np.uint32)), i
+        dense = max(dense, int(np.histogram(starts, bins=np.arange(0, 4001, 250))[0].max()))
+    assert dense > 70
+
+
 def test_events_edge_cases(device):
     flat = np.full(4000, 90.0, np.float32)                       # no peaks at all
     short = np.linspace(60, 120, 10).astype(np.float32)         # shorter than two windows
