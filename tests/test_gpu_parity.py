@@ -85,6 +85,23 @@ def test_events_dense_peaks_beyond_the_lds_peak_lists(device):
     assert dense > 70
 
 
+def test_events_of_scaled_signals_across_the_fast_division_range(device):
+    """The t-statistics divide by the window length with a reciprocal form inside 2^-100 <= |x| <= 2^100 and with the
+    IEEE division outside (events.hip, DivW).  Signals scaled so that the window sums / sums of squares lie inside the
+    range, straddle its lower end (scale 1e-17: sums of squares around 2^-100 = 7.9e-31) and fall below it: features bit
+    for bit against the oracle in every case (the thresholds on the t-statistic do not see the scale)."""
+    rng = np.random.default_rng(3)
+    base = (90 + 12 * rng.standard_normal(4000)).astype(np.float32)
+    pa = [(base * np.float32(sc)).astype(np.float32) for sc in (1.0, 1e-14, 1e-17, 1e-19, 1e9)]
+    samples, offsets = _batch(pa)
+    feat, stdv, nf, ne, st = device.events(samples, offsets, feat_stride=2736)
+    for i, x in enumerate(pa):
+        f, s = po.generate_events(x)
+        ev, _ = po.detect_events(x)
+        assert st[i] == 0 and ne[i] == len(ev) and nf[i] == len(f) and nf[i] > 100, i
+        assert np.array_equal(bits(feat[i, :nf[i]]), bits(f)) and np.array_equal(bits(stdv[i, :nf[i]]), bits(s)), i
+
+
 def test_events_edge_cases(device):
     flat = np.full(4000, 90.0, np.float32)                       # no peaks at all
     short = np.linspace(60, 120, 10).astype(np.float32)         # shorter than two windows
