@@ -366,6 +366,14 @@ int smhip_debug_counters(smhip_ctx *ctx, uint32_t out[16]);
  * [1], by a workgroup [2]; chunks that left the whole-line partition route for the exact one because a part outgrew
  * its slice [3] (sort.hip). */
 int smhip_debug_sort_stats(smhip_ctx *ctx, uint32_t out[4]);
+/* Device-side sweeps of the two division-free forms of this build against the expressions they replace, over every
+ * float whose bit pattern lies in [lo_bits, hi_bits): the chain classifier's start-score factor
+ * (float)(1 - 0.2 * (double)dist / (double)radius) (spatial_index.cc:437-438; chain.hip StartCoef) and the
+ * t-statistics' x / (float)w (event.h:95-108; events.hip DivW, w = a window length).  *mismatches = values whose
+ * results differ in any bit (tests/test_gpu_parity.py sweeps all non-negative distances below 8 radii and every
+ * float of either sign; tools/micro/ holds the same sweeps for the host). */
+int smhip_debug_start_coef_sweep(smhip_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, float radius, uint64_t *mismatches);
+int smhip_debug_div_window_sweep(smhip_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint32_t w, uint64_t *mismatches);
 int smhip_timing_enable(smhip_ctx *ctx, int on);
 int smhip_timing_reset(smhip_ctx *ctx);
 int smhip_timing_get(smhip_ctx *ctx, const char *kernel, double *mean_ms, uint64_t *launches);

@@ -25,6 +25,7 @@ HIP_SYMBOLS = [
     "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
     "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params", "smhip_features_upload", "smhip_generate_chains",
     "smhip_chain_anchors", "smhip_map_download_chains", "smhip_debug_sort_stats",
+    "smhip_debug_start_coef_sweep", "smhip_debug_div_window_sweep",
 ]
 HOST_SYMBOLS = [
     "smhost_index_build", "smhost_index_from_points", "smhost_index_load", "smhost_index_save",
@@ -252,6 +253,8 @@ def hip_lib():
         L.smhip_chain_anchors.argtypes = [vp, C.POINTER(Params), u32, vp, vp, u32, vp]
         L.smhip_map_download_chains.argtypes = [vp, vp, u64, vp]
         L.smhip_debug_sort_stats.argtypes = [vp, vp]
+        L.smhip_debug_start_coef_sweep.argtypes = [vp, u32, u32, C.c_float, vp]
+        L.smhip_debug_div_window_sweep.argtypes = [vp, u32, u32, u32, vp]
         L.smhip_refine_path_run.argtypes = [vp, u32, u32]
         L.smhip_refine_path_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64]
         L.smhip_dtw_path.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]

@@ -1707,6 +1707,42 @@ hipError_t LaunchChainGather(smhip_ctx *ctx, const smhip_chunk_result *results, 
 }
 }  // namespace smhip
 
+// ---- smhip_debug_start_coef_sweep: the classifier's start-score factor (StartCoef: reciprocal multiply + guard band)
+// against the reference's expression, on the device, for every float whose bit pattern lies in [lo_bits, hi_bits)
+namespace smhip {
+namespace {
+__global__ void StartCoefSweepKernel(uint32_t lo_bits, uint64_t count, float radius, unsigned long long *mismatches) {
+  const double inv_radius = 1.0 / (double)radius;
+  unsigned long long bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float d = __uint_as_float(lo_bits + (uint32_t)i);
+    const float fast = StartCoef(d, (double)radius, inv_radius);
+    const float want = (float)(1 - 0.2 * (double)d / (double)radius);  // spatial_index.cc:437-438
+    bad += __float_as_uint(fast) != __float_as_uint(want) ? 1ull : 0ull;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+}  // namespace smhip
+extern "C" int smhip_debug_start_coef_sweep(smhip_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, float radius,
+                                            uint64_t *mismatches) {
+  if (!ctx || !mismatches || hi_bits < lo_bits) return SMHIP_EINVAL;
+  unsigned long long *dev = nullptr;
+  if (hipMalloc(&dev, sizeof *dev) != hipSuccess) return SMHIP_ENOMEM;
+  int rc = SMHIP_OK;
+  if (hipMemsetAsync(dev, 0, sizeof *dev, ctx->stream) != hipSuccess) rc = SMHIP_EHIP;
+  if (rc == SMHIP_OK && hi_bits > lo_bits)
+    hipLaunchKernelGGL(smhip::StartCoefSweepKernel, dim3(4096), dim3(256), 0, ctx->stream, lo_bits,
+                       (uint64_t)hi_bits - lo_bits, radius, dev);
+  unsigned long long host = 0;
+  if (rc == SMHIP_OK && (hipMemcpyAsync(&host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = SMHIP_EHIP;
+  (void)hipFree(dev);
+  *mismatches = host;
+  return rc;
+}
+
 #ifdef SMHIP_PHASE_PROF
 extern "C" int smhip_debug_chain_prof(unsigned long long *out32, int reset) {
   if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(smhip::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess)

@@ -685,3 +685,42 @@ hipError_t LaunchScanU32ToU64(smhip_ctx *ctx, const uint32_t *in, uint32_t n, ui
   return hipGetLastError();
 }
 }  // namespace smhip
+
+// ---- smhip_debug_div_window_sweep: the t-statistics' x / w (DivW inside its range, the IEEE division outside: exactly
+// what TStatAt does) against x / w, on the device, for every float whose bit pattern lies in [lo_bits, hi_bits)
+namespace smhip {
+namespace {
+__global__ void DivWindowSweepKernel(uint32_t lo_bits, uint64_t count, uint32_t w, unsigned long long *mismatches) {
+  const float wf = (float)w, rw = 1.0f / wf;
+  const bool fast_w = w >= 1 && w <= kFastDivMaxW;
+  unsigned long long bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float(lo_bits + (uint32_t)i);
+    const float ax = fabsf(x);
+    const float got = (fast_w && DivWRange(ax, ax)) ? DivW(x, wf, rw) : x / wf;
+    const float want = x / wf;
+    const bool same = __float_as_uint(got) == __float_as_uint(want) || (got != got && want != want);
+    bad += same ? 0ull : 1ull;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+}  // namespace smhip
+extern "C" int smhip_debug_div_window_sweep(smhip_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint32_t w,
+                                            uint64_t *mismatches) {
+  if (!ctx || !mismatches || hi_bits < lo_bits || w == 0) return SMHIP_EINVAL;
+  unsigned long long *dev = nullptr;
+  if (hipMalloc(&dev, sizeof *dev) != hipSuccess) return SMHIP_ENOMEM;
+  int rc = SMHIP_OK;
+  if (hipMemsetAsync(dev, 0, sizeof *dev, ctx->stream) != hipSuccess) rc = SMHIP_EHIP;
+  if (rc == SMHIP_OK && hi_bits > lo_bits)
+    hipLaunchKernelGGL(smhip::DivWindowSweepKernel, dim3(4096), dim3(256), 0, ctx->stream, lo_bits,
+                       (uint64_t)hi_bits - lo_bits, w, dev);
+  unsigned long long host = 0;
+  if (rc == SMHIP_OK && (hipMemcpyAsync(&host, dev, sizeof host, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = SMHIP_EHIP;
+  (void)hipFree(dev);
+  *mismatches = host;
+  return rc;
+}

@@ -363,6 +363,22 @@ class DeviceMapper:
                     "smhip_index_census")
         return out[:n.value]
 
+    def start_coef_sweep(self, lo_bits, hi_bits, radius):
+        """Mismatches of the classifier's start-score factor against the reference's expression over the floats with
+        bit patterns in [lo_bits, hi_bits) (smhip_debug_start_coef_sweep)."""
+        out = C.c_uint64(0)
+        self._check(self.L.smhip_debug_start_coef_sweep(self._h, lo_bits, hi_bits, C.c_float(radius), C.byref(out)),
+                    "smhip_debug_start_coef_sweep")
+        return out.value
+
+    def div_window_sweep(self, lo_bits, hi_bits, w):
+        """Mismatches of the t-statistics' x / w against the IEEE division over the floats with bit patterns in
+        [lo_bits, hi_bits) (smhip_debug_div_window_sweep)."""
+        out = C.c_uint64(0)
+        self._check(self.L.smhip_debug_div_window_sweep(self._h, lo_bits, hi_bits, w, C.byref(out)),
+                    "smhip_debug_div_window_sweep")
+        return out.value
+
     def sort_stats(self):
         """[parts by 32-bit wave sort, by 64-bit wave sort, by workgroup sort, chunks on the exact partition route]."""
         out = np.zeros(4, dtype=np.uint32)

@@ -102,6 +102,19 @@ def test_events_of_scaled_signals_across_the_fast_division_range(device):
         assert np.array_equal(bits(feat[i, :nf[i]]), bits(f)) and np.array_equal(bits(stdv[i, :nf[i]]), bits(s)), i
 
 
+def test_division_free_forms_on_the_device_over_every_float(device):
+    """The two arithmetic shortcuts of the device code, swept ON THE DEVICE against the expressions they replace:
+    the classifier's start-score factor for every non-negative distance below 8 radii (four radii), and the
+    t-statistics' x / w for EVERY float bit pattern (both signs, denormals, infinities, NaNs) and several window lengths
+    incl. the defaults and one beyond the fast form's range.  No value may differ in any bit."""
+    for radius in (0.08, 0.15, 0.05, 1.0):
+        hi = int(np.float32(8.0 * radius).view(np.uint32))
+        assert device.start_coef_sweep(0, hi, radius) == 0, radius
+    for w in (3, 6, 2, 5, 7, 64, 65, 1000):
+        assert device.div_window_sweep(0, 0x80000000, w) == 0, w            # +0 .. +NaN
+        assert device.div_window_sweep(0x80000000, 0xFFFFFFFF, w) == 0, w   # -0 .. -NaN
+
+
 def test_events_edge_cases(device):
     flat = np.full(4000, 90.0, np.float32)                       # no peaks at all
     short = np.linspace(60, 120, 10).astype(np.float32)         # shorter than two windows
