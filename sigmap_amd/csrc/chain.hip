@@ -1628,7 +1628,8 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   // windows of up to dense_k predecessors are evaluated as dense pairs (the scan cannot end early inside them);
   // knob classify_dense = 0: lockstep scans for every tile
   const uint32_t dense_k = ctx->knobs.classify_dense == 0 ? 0u
-      : (uint32_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>((int64_t)p.max_num_skips + 1, p.chaining_band_length), 32));
+      : (uint32_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>((int64_t)p.max_num_skips + 1, p.chaining_band_length), 30));
+  // (30, not 31: the kernel's window count saturates at 31 = "31 or more", which must always be beyond dense_k)
   // ... and an anchor whose passing predecessors are all isolated is chained there (knob classify_resolve = 0: left to the DP)
   const uint32_t resolve = ctx->knobs.classify_resolve == 0 ? 0u : 1u;
   if (int_gap)

@@ -286,6 +286,19 @@ def test_routes_agree_under_other_skip_band_and_gap_limits(cdev):
         parts.append([rng.integers(0, 4, size=m).astype(np.uint32), rng.integers(0, 32000, size=m).astype(np.uint32),
                       rng.integers(0, 1700, size=m).astype(np.uint32), rng.uniform(0, 0.0799, size=m).astype(np.float32)])
         chunks.append(_cat(*parts))
+    # ... and an anchor that chains to the trunk only past k failing predecessors, k around the 31 at which the
+    # classifier's window count saturates (with a skip limit of 40 every one of these chains goes through)
+    # (the anchor is made the FIRST of a 64-anchor tile -- isolated fillers in an earlier bucket -- so that its tile holds
+    # few pairs and takes the dense route: a tile with all those predecessors in it exceeds the route's pair budget)
+    for k in (29, 30, 31, 32, 35):
+        fill = 64 - 11 - k
+        fillers = [np.zeros(fill, np.uint32), (7000 * np.arange(fill)).astype(np.uint32), np.full(fill, 5, np.uint32),
+                   np.full(fill, D0, np.float32)]
+        trunk = _diag(9890, 9890, 11, rs=1)
+        bad = [np.ones(k, np.uint32), np.full(k, 9995, np.uint32), (10000 - 3000 - np.arange(k)).astype(np.uint32),
+               np.full(k, D0, np.float32)]
+        chunks.append(_cat(fillers, trunk, bad, _one(1, 10000, 10000)))
+    n_long = 5
     flat, offs = [], [0]
     for c in chunks:
         a = np.zeros(len(c[0]), dtype=_abi.CARRIED_DTYPE)
@@ -295,7 +308,9 @@ def test_routes_agree_under_other_skip_band_and_gap_limits(cdev):
     flat = np.concatenate(flat)
     saved = (cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length)
     try:
-        for skips, band, gap in ((3, 5000, 5000), (0, 5000, 5000), (25, 4, 5000), (40, 5000, 300), (7, 9, 60)):
+        # ((40, 5000, 5000): windows of 31 and more predecessors with a skip limit above the dense route's 30)
+        for skips, band, gap in ((3, 5000, 5000), (0, 5000, 5000), (25, 4, 5000), (40, 5000, 300), (7, 9, 60), (40, 5000, 5000),
+                                 (31, 5000, 5000), (29, 5000, 5000)):
             cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length = skips, band, gap
             got = []
             for knobs in ({}, {"classify_resolve": 0}, {"classify_dense": 0}):
@@ -310,6 +325,8 @@ def test_routes_agree_under_other_skip_band_and_gap_limits(cdev):
                 got.append((res.tobytes(), anchors.tobytes(), aoff.tobytes(), allc.tobytes(), coff.tobytes()))
             assert got[0] == got[1] == got[2], (skips, band, gap)
             assert (res["status"] == 0).all() and res["n_chains"].sum() > 20, (skips, band, gap)
+            if (skips, band, gap) == (40, 5000, 5000):   # (12 anchors: the trunk's 11 + the anchor behind the failing ones)
+                assert [int(r["chains"][0]["n_anchors"]) for r in res[-n_long:]] == [12] * n_long
     finally:
         cdev.params.max_num_skips, cdev.params.chaining_band_length, cdev.params.max_target_gap_length = saved
 
