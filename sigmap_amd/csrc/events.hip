@@ -9,12 +9,13 @@
 // the z-score sums are sequential f64 (sigmap.cc:1135-1146) and the compression carries the
 // last kept value; the t-statistic mixes f32 with f64 fabs/sqrt/div (event.h:109).
 //
-// Mapping: the order-dependent stages run ONE LANE PER CHUNK (64 chunks per wavefront, loads
-// issued kBlk samples ahead of the dependent chain), the order-free stages (t-statistics,
+// Mapping: the order-dependent stages run ONE LANE PER CHUNK (64 chunks per wavefront; blocks of
+// values fetched ahead of the dependent chain, four per load instruction) -- the peak picker one
+// lane per SEGMENT of a chunk, speculatively, then checked --, the order-free stages (t-statistics,
 // event means) run one thread per element.  Five small kernels over HBM-resident scratch rows:
 //   E1 PrefixKernel (lane/chunk) -> E2 TStatKernel (thread/sample, LDS-staged prefix sums)
-//   -> E3 PeakKernel (lane/chunk) -> E4 EventMeanKernel (thread/event) -> E5 FeatureKernel
-//   (lane/chunk).
+//   -> E3 PeakKernel (lane/segment, a branch-free state machine) -> E4 EventMeanKernel
+//   (thread/event) -> E5 FeatureKernel (lane/chunk).
 #include <float.h>
 
 
