@@ -141,6 +141,28 @@ def main(rounds, first):
                 print("   REFINE MISMATCH read %d (%s): band %d pad %d gpu (%r, %d) oracle (%r, %d)" % (
                     i, kind[i], band, pad, dist[i], end[i], d, t0 + e if e >= 0 else -1))
         mism += rmis
+        # other chaining limits than the reference's constants (no oracle for those): the chain classifier's routes --
+        # dense pairs with its own chaining, dense pairs only, lockstep scans -- and the DP kernels behind them must agree
+        saved = (dev.params.max_num_skips, dev.params.chaining_band_length, dev.params.max_target_gap_length, dev.params.max_gap_length)
+        dev.params.max_num_skips = int(rng.choice([0, 2, 7, 25, 31, 40]))
+        dev.params.chaining_band_length = int(rng.choice([3, 20, 5000]))
+        dev.params.max_target_gap_length = int(rng.choice([200, 1000, 5000, 20000]))
+        dev.params.max_gap_length = int(rng.choice([50, 2000]))
+        got = []
+        for knobs in ({"classify_dense": -1, "classify_resolve": -1}, {"classify_resolve": 0}, {"classify_dense": 0}):
+            for k, v in knobs.items():
+                dev.set_knob(k, v)
+            try:
+                r2 = dev.map_chunks(samples, offsets, n_refs=n_contigs)
+            finally:
+                dev.set_knob("classify_dense", -1)
+                dev.set_knob("classify_resolve", -1)
+            got.append(tuple(r2[k].tobytes() for k in same))
+        if not (got[0] == got[1] == got[2]):
+            mism += 1
+            print("   CLASSIFIER ROUTES DISAGREE (skips %d band %d target gap %d gap %d)" % (
+                dev.params.max_num_skips, dev.params.chaining_band_length, dev.params.max_target_gap_length, dev.params.max_gap_length))
+        dev.params.max_num_skips, dev.params.chaining_band_length, dev.params.max_target_gap_length, dev.params.max_gap_length = saved
         print("seed %d: %d contigs %s, %d reads, params (G=%d strict=%d fast=%d cap=%d r=%.2f search=%d walked=%d): %d mismatches, %d mapped"
               % (seed, n_contigs, lens, n_reads, dev.params.walk_blocks_per_cu, dev.params.reference_walk,
                  dev.params.hits_per_query_fast, nnp, radius, dev.params.search_mode, int(dev.debug_counters()[6]), mism,
