@@ -7,6 +7,7 @@
 #include <math.h>
 int main(int argc, char **argv) {
   int w0 = argc > 1 ? atoi(argv[1]) : 2, w1 = argc > 2 ? atoi(argv[2]) : 16;
+  unsigned long long total_bad = 0;
   for (int w = w0; w <= w1; ++w) {
     const float wf = (float)w, rw = 1.0f / wf;
     uint64_t bad = 0;
@@ -27,6 +28,7 @@ int main(int argc, char **argv) {
     }
     printf("w %d: mismatches %llu\n", w, (unsigned long long)bad);
     fflush(stdout);
+    total_bad += bad;
   }
-  return 0;
+  return total_bad ? 1 : 0;
 }
