@@ -9,9 +9,12 @@ are replicated by one RCCL broadcast each, every rank maps its own 10 000-chunk 
 no data-path collective), and the reported value is (chunks of all ranks) / (max over ranks of the
 timed region).
 
-Two timed regions of EXACTLY K steps each, both fenced by barrier + synchronize:
+Timed regions of EXACTLY K steps each, every one fenced by barrier + synchronize on both sides, the time = max
+over ranks; each kind is timed --repeats times (after one discarded round, the kinds taking turns) and reported
+as the MEDIAN region with min / max / all beside it:
   value          : inputs resident in HBM when the region starts (the reads were converted from their
                    ADC counts into the contexts' slots beforehand) -- the contract's definition;
+  same_reads     : the same, one read set for every step (comparison only);
   pcie_inclusive : every step first copies its reads' int16 ADC counts from pinned host memory
                    (DMA on a copy stream) and converts them on the device ("reads
                    resident in host RAM").
@@ -67,6 +70,9 @@ def parse():
                     help="with one rank: run the index replication collectives anyway (one-rank process group over "
                          "--backend, six dist.broadcast calls) and map the contexts beyond the first from the broadcast "
                          "copy -- exercises the N > 1 transport on a one-GPU box")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="every timed region (EXACTLY --steps steps, fenced) is timed this many times after one discarded "
+                         "region; value / ms_per_step are the MEDIAN region, min / max / all are printed beside it")
     ap.add_argument("--depth", type=int, default=4,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
@@ -284,51 +290,80 @@ def main():
     serial = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "kernels": kernel_times([dev])}
     pool.for_each(lambda dv: dv.timing_reset())
 
-    # ---- timed region 1 (value): EXACTLY K steps, inputs resident in HBM, each on the context that is
-    # free next; the contexts start a fraction of a step apart (inside the timed region), so that their
-    # tree walks alternate from the first step on
+    # ---- timed regions.  Three kinds, every one EXACTLY K steps between two fences (barrier + synchronize on both sides),
+    # the time taken as the max over ranks:
+    #   resident (`value`)  : inputs resident in HBM, step i maps read set i mod n_sets;
+    #   same_reads          : the same with ONE read set for every step and context (what rounds 1-3 timed);
+    #   pcie_inclusive      : every step first copies its reads' ADC counts from pinned host memory and converts them.
+    # All three assign steps to contexts the same way (static: context k runs steps k, k + depth, ...; contexts start a
+    # fraction of a step apart, inside the region).  The kinds take turns -- resident, same, pcie, resident, ... -- one
+    # discarded round first, then `--repeats` rounds; a kind's figure is the MEDIAN of its regions, with min / max / all.
     stagger = (serial["ms_per_step"] * 1e-3 / len(pool.devs)) if len(pool.devs) > 1 else 0.0
-    fence()
-    t0 = time.perf_counter()
-    results = pool.run_steps(args.steps, step, stagger_s=stagger)
-    fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    res, refined = results[-1]
-    contexts_agree = all(r.tobytes() == expected[i % n_sets][0].tobytes() for i, (r, _) in enumerate(results))
-    kern = kernel_times(pool.devs)  # (with batches in flight: brackets include queueing behind the other stream)
+    K = args.steps
 
-    # the same K steps with ONE read set mapped by every step on every context (what this file timed in rounds 1-3):
-    # reported once next to `value`, which it would overstate if walking the same leaves a quarter step apart helped
-    same_reads = None
-    if n_sets > 1 and not args.no_same_reads:
-        fence()
-        t0 = time.perf_counter()
-        pool.run_steps(args.steps, lambda dv, i: step(dv, i, fixed_set=0), stagger_s=stagger)
-        fence()
-        dt_same = max_over_ranks(time.perf_counter() - t0)
-        same_reads = {"value": round(R * world * args.steps / dt_same, 1), "ms_per_step": round(dt_same / args.steps * 1e3, 3),
-                      "vs_value": round(dt / dt_same, 4)}
-
-    # ---- timed region 2 (pcie_inclusive): the same K steps, each starting with the DMA of its reads'
-    # ADC counts from pinned host memory and their conversion on the device
-    pcie = None
-    if not args.no_pcie:
+    def region(kind):
+        if kind == "pcie":
+            # (a step's reads are copied exactly once: by the step itself, or by the context's previous step while
+            # that one's kernels ran; the last step of a context prefetches nothing)
+            fn = lambda dv, i: step(dv, i, with_upload=True, prefetch_next=i + n_ctx < K)   # noqa: E731
+        elif kind == "same":
+            fn = lambda dv, i: step(dv, i, fixed_set=0)   # noqa: E731
+        else:
+            fn = step
         pool.for_each(lambda dv: dv.timing_reset())
         fence()
         t0 = time.perf_counter()
-        # (a step's reads are copied exactly once: by the step itself, or by the context's previous step while
-        # that one's kernels ran; the last step of a context prefetches nothing)
-        results2 = pool.run_steps(args.steps, lambda dv, i: step(dv, i, with_upload=True,
-                                                                 prefetch_next=i + n_ctx < args.steps),
-                                  stagger_s=stagger, static=True)
+        results = pool.run_steps(K, fn, stagger_s=stagger, static=True)
         fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
         prefetched.clear()
-        dt2 = max_over_ranks(time.perf_counter() - t0)
-        same2 = all(r.tobytes() == expected[i % n_sets][0].tobytes() for i, (r, _) in enumerate(results2))
-        pcie = {"value": round(R * world * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                "h2d_bytes_per_step": int(R * CHUNK * 2), "results_identical": bool(same2),
-                "convert_kernel_ms": kernel_times(pool.devs)["convert"]["mean_ms"],
-                "vs_resident": round(dt / dt2, 4),
+        if kind == "same":
+            ok = all(r.tobytes() == expected[0][0].tobytes() for r, _ in results)
+        else:
+            ok = all(r.tobytes() == expected[i % n_sets][0].tobytes() for i, (r, _) in enumerate(results))
+        return dt, results, ok, kernel_times(pool.devs)
+
+    kinds = ["resident"]
+    if n_sets > 1 and not args.no_same_reads:
+        kinds.append("same")
+    if not args.no_pcie:
+        kinds.append("pcie")
+    times = {k: [] for k in kinds}
+    agree = {k: True for k in kinds}
+    last = {}
+    for rep in range(max(1, args.repeats) + 1):
+        for kind in kinds:
+            dt_r, results_r, ok, kern_r = region(kind)
+            agree[kind] = agree[kind] and ok
+            if rep == 0:
+                continue                      # the discarded round
+            times[kind].append(dt_r)
+            last[kind] = (results_r, kern_r)
+
+    def spread(kind):
+        ts = sorted(times[kind])
+        med = float(np.median(ts))
+        return med, {"repeats": len(ts), "median_ms_per_step": round(med / K * 1e3, 3),
+                     "min_ms_per_step": round(ts[0] / K * 1e3, 3), "max_ms_per_step": round(ts[-1] / K * 1e3, 3),
+                     "all_ms_per_step": [round(t / K * 1e3, 3) for t in times[kind]],   # in the order they were timed
+                     "value_at_min": round(R * world * K / ts[0], 1), "value_at_max": round(R * world * K / ts[-1], 1)}
+
+    dt, value_spread = spread("resident")
+    res, refined = last["resident"][0][-1]
+    contexts_agree = agree["resident"]
+    kern = last["resident"][1]  # (with batches in flight: brackets include queueing behind the other streams)
+    same_reads = None
+    if "same" in kinds:
+        dt_same, sp = spread("same")
+        same_reads = {"value": round(R * world * K / dt_same, 1), "ms_per_step": round(dt_same / K * 1e3, 3),
+                      "vs_value": round(dt / dt_same, 4), "results_identical": bool(agree["same"]), "spread": sp}
+    pcie = None
+    if "pcie" in kinds:
+        dt2, sp = spread("pcie")
+        pcie = {"value": round(R * world * K / dt2, 1), "ms_per_step": round(dt2 / K * 1e3, 3),
+                "h2d_bytes_per_step": int(R * CHUNK * 2), "results_identical": bool(agree["pcie"]),
+                "convert_kernel_ms": last["pcie"][1]["convert"]["mean_ms"],
+                "vs_resident": round(dt / dt2, 4), "spread": sp,
                 "what": "every step's reads are copied as int16 ADC counts from pinned host memory (hipMemcpyAsync on a "
                         "copy stream) and converted on the device before mapping; a context starts the copy of its "
                         "next step's reads (another read set, other slots) while the current step's kernels run"}
@@ -392,6 +427,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "timing": dict(value_spread, what=f"value / ms_per_step = the MEDIAN of {len(times['resident'])} timed regions of exactly "
+                           f"{args.steps} steps each (one discarded region first; the regions of the kinds resident / same_reads / "
+                           "pcie_inclusive take turns; same static step-to-context assignment in all three)"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -463,6 +501,11 @@ def main():
                 # SURVEY 8(d) weights on the walker's own node visits and point tests: what a perfect layout would move
                 "useful_bytes_per_launch": useful_bytes,
                 "useful_bytes_frac": round(useful_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seed_ms > 0 else None,
+                # the WHOLE STEP against the roofline (north_star's ">= 40 % of HBM roofline"): the same useful bytes -- SURVEY
+                # 8(d)'s weights on the walker's own visits, samples in, anchors written and read, result out: every stage's
+                # algorithmic bytes, per GPU -- over ms_per_step of the timed region instead of the walker's launch
+                "step_useful_frac": round(useful_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                "step_useful_gbs": round(useful_bytes / (dt / args.steps) / 1e9, 1),
                 "frac_of_measured_streaming_ceiling": round(achieved / HBM_STREAM_GBS, 4),
                 "launch_ms": round(seed_ms, 4),
                 "measured": "HIP events on the context stream around the SeedWalkKernel launch, serial pass of this run "

@@ -283,6 +283,10 @@ int smhip_reads_download_pa(smhip_ctx *ctx, uint32_t slot, float *pa, uint32_t c
  * few GB take 40 ms per GB on this platform -- tools/micro/malloc_cost.hip -- which a caller that times
  * its mapping phase wants outside that span, like the index load). */
 int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_chunk);
+/* The same with the parameters the caller will map with (NULL: the defaults): the fast hit slots per query are
+ * resolved for THEIR search radius and hit cap -- from the same census of the index smhip_map_run resolves them
+ * from, so the first batch finds its buffers at their final sizes and the census is taken once. */
+int smhip_batch_reserve_for(smhip_ctx *ctx, const smhip_params *params, uint32_t n_chunks, uint32_t queries_per_chunk);
 /* Pinned (page-locked) host memory for the raw reads: DMA at link rate, truly asynchronous copies. */
 int smhip_host_alloc(void **out, size_t bytes);
 void smhip_host_free(void *p);

@@ -550,6 +550,12 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
   smhip_index_dev d;
   int rc = smhip_index_export(ctx, &d);
   if (rc) return rc;
+  // the call walks over the peers' devices: whatever the exit, the caller's current device is what it was
+  struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } guard;
   const uint64_t bytes[6] = {d.nodes_bytes, d.leaf_tab_bytes, d.leaf_pts_bytes, d.leaf_vind_bytes, d.bbox_bytes, d.quads_bytes};
   void *root_ptr[6] = {d.nodes, d.leaf_tab, d.leaf_pts, d.leaf_vind, d.bbox, d.quads};
   // peers: their own buffers for the six walker arrays
@@ -567,17 +573,24 @@ int smhip_index_bcast(smhip_ctx *const *ctxs, int n_gpus, int root) {
   std::vector<int> devs((size_t)n_gpus);
   for (int i = 0; i < n_gpus; ++i) devs[i] = ctxs[i]->device;
   int nr = nc.CommInitAll(comms.data(), n_gpus, devs.data());
-  if (nr != 0) return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(nr));
-  // ONE broadcast per array, all ranks of this process inside one group call
+  if (nr != 0) {
+    for (auto c : comms)
+      if (c) (void)nc.CommDestroy(c);
+    return Fail(ctx, SMHIP_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(nr));
+  }
+  // ONE broadcast per array, all ranks of this process inside one group call.  Every rank names ITS OWN
+  // buffer as both send and receive buffer (in place): the root's is the source, a peer's send buffer is ignored by the
+  // collective's semantics -- but RCCL compares the two pointers (the in-place test) and registers what it is given, so
+  // a peer never hands it a pointer into another GPU's memory
   for (int a = 0; a < 6 && nr == 0; ++a) {
     if (bytes[a] == 0) continue;  // (an index without quad records)
     nr = nc.GroupStart();
     for (int i = 0; i < n_gpus && nr == 0; ++i) {
       smhip_ctx *p = ctxs[i];
       DevBuf *b[6] = {&p->ix_nodes, &p->ix_tab, &p->ix_pts, &p->ix_vind, &p->ix_bbox, &p->ix_quads};
-      void *recv = i == root ? root_ptr[a] : b[a]->p;
+      void *own = i == root ? root_ptr[a] : b[a]->p;
       if (hipSetDevice(p->device) != hipSuccess) nr = 1;
-      if (nr == 0) nr = nc.Broadcast(root_ptr[a], recv, bytes[a], /*ncclUint8*/ 1, root, comms[i], p->stream);
+      if (nr == 0) nr = nc.Broadcast(own, own, bytes[a], /*ncclUint8*/ 1, root, comms[i], p->stream);
     }
     const int ge = nc.GroupEnd();
     if (nr == 0) nr = ge;
@@ -922,11 +935,16 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
 }
 
 int smhip_batch_reserve(smhip_ctx *ctx, uint32_t n_chunks, uint32_t queries_per_chunk) {
+  return smhip_batch_reserve_for(ctx, nullptr, n_chunks, queries_per_chunk);
+}
+
+int smhip_batch_reserve_for(smhip_ctx *ctx, const smhip_params *params, uint32_t n_chunks, uint32_t queries_per_chunk) {
   if (!ctx) return SMHIP_EINVAL;
   if (n_chunks == 0 || queries_per_chunk == 0) return Fail(ctx, SMHIP_EINVAL, "counts must be positive");
   HIPCHK(hipSetDevice(ctx->device));
   smhip_params p;
-  smhip_default_params(&p);
+  if (params) p = *params;
+  else smhip_default_params(&p);
   if (ctx->have_index) {  // (the automatic number of fast slots comes from the census of the index)
     int rc = ResolveParams(ctx, &p, n_chunks);
     if (rc) return rc;

@@ -53,6 +53,19 @@ __device__ __forceinline__ bool ChainGreater(const ChainTmp &a, const ChainTmp &
 constexpr uint32_t kTile = 64;    // anchors per tile of the classify kernel: one per lane
 constexpr uint32_t kRing = 128;   // its LDS ring per wave: the tile and the 64 anchors before it
 constexpr uint32_t kDensePairs = 512;  // (anchor, predecessor) pairs of a tile the dense route takes; more: lockstep scans
+// The classifier's window count is a bisection with steps kWindowStep0, kWindowStep0 / 2, .., 1: it saturates at
+// kWindowSat = "that many or more".  The dense route is only valid for windows it has counted EXACTLY, so the largest
+// window it may take (kDenseKMax, the cap of dense_k in LaunchChain) lies strictly below the saturation value; a pair's
+// table entry packs {lane + 1 : 16 bits | first pair : 16 bits} and a passing pair's {lane : 8 | ring position : 8+}.
+constexpr uint32_t kWindowStep0 = 16;
+constexpr uint32_t kWindowSat = 2 * kWindowStep0 - 1;  // 31
+constexpr uint32_t kDenseKMax = 30;
+static_assert((kWindowStep0 & (kWindowStep0 - 1)) == 0, "the bisection halves its step down to 1");
+static_assert(kDenseKMax < kWindowSat, "a saturated window count must never pass for a dense window");
+static_assert(kWindowSat < kTile, "a window must fit the 64 anchors the ring holds before the tile");
+static_assert(kDensePairs <= 0xFFFFu, "first-pair field of a pair-table entry is 16 bits");
+static_assert(kDensePairs >= kTile, "the passing-pair list is written into the consumed part of the pair table");
+static_assert(kRing == 2 * kTile && kRing <= 256, "ring positions relative to t0 - 64 fit the entry's 8-bit field");
 constexpr int kPf = 4;            // predecessors fetched ahead of the sequential scan: one 16-byte load per column
 static_assert(kPf == 4, "the lane DP fetches a block of predecessors as one uint4");
 constexpr int kBigPendingMin = 24; // buckets with more unsettled anchors than this are chained by a whole wave ...
@@ -291,9 +304,9 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     uint32_t k = 0;
     if (dense_k) {
       // k = how many of ai - 1, ai - 2, ... are near: bisection on the count (five ring reads; 31 = "31 or more")
-      const uint32_t dmax = (ai < n && ai > 0) ? min(ai - max(bstart, w0), 31u) : 0u;
+      const uint32_t dmax = (ai < n && ai > 0) ? min(ai - max(bstart, w0), kWindowSat) : 0u;
 #pragma unroll
-      for (uint32_t step = 16; step >= 1; step >>= 1) {
+      for (uint32_t step = kWindowStep0; step >= 1; step >>= 1) {
         const uint32_t cand = k + step;
         const bool near = (int32_t)s_ring_t[(ai - cand) & (kRing - 1)] + max_target_gap_length >= ct;
         if (cand <= dmax && near) k = cand;
@@ -1628,7 +1641,7 @@ hipError_t LaunchChain(smhip_ctx *ctx, const smhip_params &p, const ChainArgs &a
   // windows of up to dense_k predecessors are evaluated as dense pairs (the scan cannot end early inside them);
   // knob classify_dense = 0: lockstep scans for every tile
   const uint32_t dense_k = ctx->knobs.classify_dense == 0 ? 0u
-      : (uint32_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>((int64_t)p.max_num_skips + 1, p.chaining_band_length), 30));
+      : (uint32_t)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>((int64_t)p.max_num_skips + 1, p.chaining_band_length), kDenseKMax));
   // (30, not 31: the kernel's window count saturates at 31 = "31 or more", which must always be beyond dense_k)
   // ... and an anchor whose passing predecessors are all isolated is chained there (knob classify_resolve = 0: left to the DP)
   const uint32_t resolve = ctx->knobs.classify_resolve == 0 ? 0u : 1u;

@@ -536,6 +536,11 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
           dv[u] = qpos_nx[u] == 0xFFFFFFFFu ? Decoded{raw_nx[u].x, raw_nx[u].y, raw_nx[u].z, __uint_as_float(raw_nx[u].w)}
                                             : decode_hit(raw_nx[u], qpos_nx[u]);
           pb[u] = part_of(dv[u]);
+          if (dv[u].grp >> gbits) {  // a (reference, strand) group the batch's n_refs does not have: an invalid carried
+            live[u] = false;         // anchor (or an index that does not match n_refs).  Never placed: its part may lie
+            s_overflow = 2u;         // beyond the chunk's slices; the chunk is flagged below
+            continue;
+          }
           lpos[u] = atomicAdd(&tcount[pb[u]], 1u);
         }
         if (T + 1 < n_tiles) fetch(T + 1);  // (in flight while this tile is binned and copied out)
@@ -579,16 +584,26 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
         }
       }
       for (uint32_t k = tid; k < kMaxParts; k += kBigThreads)
-        if (pcount[k] > kSlice) s_overflow = 1u;
+        if (pcount[k] > kSlice) atomicOr(&s_overflow, 1u);
       __syncthreads();
-      if (s_overflow) {  // (uniform) a part outgrew its slice (skewed targets): the chunk goes to the exact route's launch
+      if (s_overflow == 1u) {  // (uniform) a part outgrew its slice (skewed targets): the chunk goes to the exact route's launch
         if (tid == 0) w.redo[atomicAdd(&w.counters[3], 1u)] = c;
         continue;
       }
     } else {
       // ---- pass 1 of the exact route: part sizes
-      for_each_anchor([&](const Decoded &dv) { atomicAdd(&pcount[part_of(dv)], 1u); });
+      for_each_anchor([&](const Decoded &dv) {
+        if (dv.grp >> gbits) s_overflow = 2u;
+        atomicAdd(&pcount[part_of(dv)], 1u);
+      });
       __syncthreads();
+    }
+    if (s_overflow & 2u) {  // (uniform) an anchor outside the batch's (reference, strand) groups: flagged, no anchors
+      if (tid == 0) {
+        a.results[c].n_anchors = 0u;
+        a.results[c].status |= SMHIP_ST_SORT_CAP;
+      }
+      continue;
     }
     PHASE_MARK(9);
     if (tid < 64) {  // exclusive scan of the part sizes by one wave

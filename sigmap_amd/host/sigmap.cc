@@ -211,7 +211,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   for (auto &gpu : ctxs)
     for (smhip_ctx *c : gpu)
       if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
-          smhip_batch_reserve(c, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
+          smhip_batch_reserve_for(c, &dp, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
         ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
                         " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
   phase("Reserved read slots and batch buffers");

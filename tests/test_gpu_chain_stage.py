@@ -429,3 +429,37 @@ def test_class_methods_forward_to_the_device(small_world, oracle_tree):
         assert na2.value == sum(int(c["n_anchors"]) for c in allc)
         dev.close()
     ix.close()
+
+
+@pytest.mark.parametrize("sort_lines", [-1, 0])
+def test_anchor_outside_the_batchs_groups_flags_its_chunk_only(cdev, sort_lines):
+    """A caller-supplied anchor whose ref_strand names a (reference, strand) group the batch does not have
+    (>= 2^ceil(log2(2 n_refs))) has no place in the sort's partition: on the whole-line route its part would lie
+    beyond the chunk's slices of the record scratch.  The chunk is flagged SMHIP_ST_SORT_CAP and yields no anchors
+    and no chains; its neighbours -- before and after it in the record scratch -- are mapped as if it were not
+    there.  Both partition routes."""
+    n_refs = 3          # groups 0..5, group field of 3 bits: 8 .. are invalid
+    good = _cat(_diag(1000, 10, 40), _diag(90000, 5, 30, rs=3))
+    bad = _cat(_diag(5000, 10, 700), _one(9, 7000, 50), _one(0xFFFFFFFF, 1, 2), _diag(400000, 20, 600, rs=5))
+    chunks = [good, bad, _cat(_diag(300, 7, 25, rs=2)), good]
+    flat, offs = [], [0]
+    for c in chunks:
+        a = np.zeros(len(c[0]), dtype=_abi.CARRIED_DTYPE)
+        a["ref_strand"], a["target_position"], a["query_position"], a["distance"] = c
+        flat.append(a)
+        offs.append(offs[-1] + len(a))
+    cdev.set_knob("sort_lines", sort_lines)
+    try:
+        res, anchors, aoff = cdev.chain_anchors(np.concatenate(flat), offs, n_refs, with_anchors=True)
+    finally:
+        cdev.set_knob("sort_lines", -1)
+    assert res[1]["status"] & 16 and res[1]["n_anchors"] == 0 and res[1]["n_chains"] == 0
+    assert int(aoff[2] - aoff[1]) == 0
+    for i in (0, 2, 3):
+        c = chunks[i]
+        want = po.chain_anchors(c[0], c[1], c[2], c[3], n_refs)
+        assert res[i]["status"] == 0 and res[i]["n_anchors"] == len(c[0]) and res[i]["n_chains"] == len(want) > 0
+        for k, ch in enumerate(want[:4]):
+            g = res[i]["chains"][k]
+            assert bits(np.float32(g["score"])) == bits(np.float32(ch["score"])) and g["n_anchors"] == ch["n_anchors"]
+    assert res[0]["chains"].tobytes() == res[3]["chains"].tobytes()
