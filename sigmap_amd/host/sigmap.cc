@@ -207,6 +207,13 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       }
     }
   }
+  // ... and no more than a context's share of its GPU's block of reads: reads are admitted in input order by whichever
+  // context has free slots, and a context with room for the whole block would take all of it and leave the GPU's other
+  // contexts -- whose kernels fill the gaps between its chunk rounds -- without work
+  {
+    const size_t block_reads = (num_reads + (size_t)num_gpus - 1) / (size_t)num_gpus;
+    lane_budget = std::max<size_t>(1, std::min(lane_budget, (block_reads + (size_t)num_streams - 1) / (size_t)num_streams));
+  }
   // read slots of every context: set-up like the index, before the mapping span
   for (auto &gpu : ctxs)
     for (smhip_ctx *c : gpu)
@@ -223,7 +230,24 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   block[num_gpus] = num_reads;
   for (int g = 0; g < num_gpus; ++g) cursor[g] = block[g];
   std::vector<std::mutex> cursor_mutex((size_t)num_gpus);
+  // Where a lane's wall time goes, chunk round by chunk round (SIGMAP_STREAM_STATS=1: one `STREAM_STATS {json}` line on
+  // stderr after the mapping span; tools/stream_bench.py).  "device" = from the first call that enqueues a round's work
+  // to the return of smhip_map_sync -- the host thread only waits there; everything else is host time between rounds.
+  struct LaneStats {
+    double admit = 0, build = 0, device = 0, download = 0, anchors = 0, decide = 0;
+    uint64_t rounds = 0, chunks = 0, carried_up = 0, anchors_down = 0, continued = 0, max_batch = 0;
+  };
+  const bool want_stats = getenv("SIGMAP_STREAM_STATS") != nullptr;
+  LaneStats total_stats;
+  std::mutex stats_mutex;
   auto lane = [&](int g, smhip_ctx *ctx) {
+    LaneStats ls;
+    double t_mark = GetRealTime();
+    auto lap = [&](double &acc) {
+      const double now = GetRealTime();
+      acc += now - t_mark;
+      t_mark = now;
+    };
     std::vector<uint32_t> free_slots(lane_budget);
     for (size_t k = 0; k < lane_budget; ++k) free_slots[k] = (uint32_t)(lane_budget - 1 - k);
     std::vector<size_t> batch, in_flight;
@@ -285,6 +309,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         }
         r0 = r1;
       }
+      lap(ls.admit);
       if (in_flight.empty()) {
         if (a == b) break;  // nothing in flight, nothing left to admit
         continue;
@@ -301,6 +326,11 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       }
       results.resize(batch.size());
       out_off.resize(batch.size() + 1);
+      ls.rounds += 1;
+      ls.chunks += batch.size();
+      ls.carried_up += carried.size();
+      ls.max_batch = std::max<uint64_t>(ls.max_batch, batch.size());
+      lap(ls.build);
       int rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)batch.size(), qstart.data(),
                                   carried.empty() ? nullptr : carried.data(),
                                   carried.empty() ? nullptr : carried_off.data());
@@ -308,6 +338,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
       if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
       if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+      lap(ls.device);
       dts.resize(batch.size());
       dte.resize(batch.size());
       if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
@@ -325,6 +356,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       // spatial_index.cc:303-322) only when some read of the batch goes on to another chunk
       if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
       if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+      lap(ls.download);
       bool any_continues = false;
       for (size_t bi = 0; bi < batch.size() && !any_continues; ++bi) {
         const size_t r = batch[bi];
@@ -342,7 +374,9 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
           rc = SMHIP_OK;
         }
         if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
+        ls.anchors_down += out_off[batch.size()];
       }
+      lap(ls.anchors);
       in_flight.clear();
       for (size_t bi = 0; bi < batch.size(); ++bi) {
         const size_t r = batch[bi];
@@ -374,7 +408,15 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         }
         finish(r);
       }
+      ls.continued += in_flight.size();
+      lap(ls.decide);
     }
+    std::lock_guard<std::mutex> lock(stats_mutex);
+    total_stats.admit += ls.admit; total_stats.build += ls.build; total_stats.device += ls.device;
+    total_stats.download += ls.download; total_stats.anchors += ls.anchors; total_stats.decide += ls.decide;
+    total_stats.rounds += ls.rounds; total_stats.chunks += ls.chunks; total_stats.carried_up += ls.carried_up;
+    total_stats.anchors_down += ls.anchors_down; total_stats.continued += ls.continued;
+    total_stats.max_batch = std::max(total_stats.max_batch, ls.max_batch);
   };
   {
     std::vector<std::thread> workers;
@@ -384,7 +426,22 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     lane(0, ctxs[0][0]);
     for (auto &w : workers) w.join();
   }
-  std::cerr << "Finished mapping in " << GetRealTime() - t_map << ", # reads: " << num_reads << "\n";
+  const double map_span = GetRealTime() - t_map;
+  std::cerr << "Finished mapping in " << map_span << ", # reads: " << num_reads << "\n";
+  if (want_stats) {
+    const LaneStats &t = total_stats;
+    const double lanes = (double)num_gpus * num_streams;
+    char buf[1024];
+    snprintf(buf, sizeof buf,
+             "STREAM_STATS {\"reads\": %zu, \"span_s\": %.6f, \"lanes\": %d, \"chunks_in_flight_per_lane\": %zu, \"rounds\": %llu, "
+             "\"chunks\": %llu, \"max_batch\": %llu, \"carried_anchors_uploaded\": %llu, \"anchors_downloaded\": %llu, "
+             "\"lane_seconds\": {\"admit_upload\": %.6f, \"build_batch\": %.6f, \"device\": %.6f, \"download_results\": %.6f, "
+             "\"download_anchors\": %.6f, \"decide\": %.6f}}",
+             num_reads, map_span, (int)lanes, lane_budget, (unsigned long long)t.rounds, (unsigned long long)t.chunks,
+             (unsigned long long)t.max_batch, (unsigned long long)t.carried_up, (unsigned long long)t.anchors_down, t.admit, t.build,
+             t.device, t.download, t.anchors, t.decide);
+    std::cerr << buf << "\n";
+  }
 
   // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
   // (whichever GPU and context mapped a read)
