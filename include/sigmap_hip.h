@@ -269,6 +269,18 @@ int smhip_reads_configure(smhip_ctx *ctx, uint32_t n_slots, uint32_t keep_sample
 int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *raw_offsets,
                            const float *digitisation, const float *range, const float *offset,
                            const uint32_t *slots, uint32_t n_reads, uint32_t *pa_len);
+/* PIECES of reads -- e.g. the one chunk of each read a streaming round maps (sigmap.cc:647-652) -- that live in PINNED
+ * host memory (smhip_host_alloc), pulled over PCIe by a kernel of the context's stream: one launch for any number of
+ * scattered pieces, no staging copy on the host, and only the samples that are mapped ever cross the link.  Piece r =
+ * pieces[r][0 .. piece_len[r]) is converted and filtered like a read of smhip_reads_upload_raw and REPLACES the content
+ * of slot slots[r] (slots == NULL: slot r).  expect_len (optional): the filtered length of every piece as the caller
+ * counted it (SignalBatch's load phase: pa = ((float)raw + offset) * (range / digitisation), 30 < pa < 200, the same
+ * f32 operations); a piece of which the device keeps another number of samples makes the next call that collects
+ * results fail with SMHIP_ECAP -- a chunk cut by the host's count would not be the reference's chunk.  Asynchronous:
+ * the arrays passed are free on return, the pieces must stay untouched until the batch that maps them is collected. */
+int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, const uint32_t *piece_len,
+                              const float *digitisation, const float *range, const float *offset,
+                              const uint32_t *slots, const uint32_t *expect_len, uint32_t n_pieces);
 /* The next batch: chunk c = filtered samples [chunk_index[c] * chunk_size, + chunk_size) of slot
  * slots[c], clipped to the slot's length (sigmap.cc:647-652).  Other arguments as smhip_batch_upload. */
 int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t chunk_size,

@@ -59,6 +59,21 @@ uint64_t smhost_level_means(const float *level_means, int kmer_size, const char 
 uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation, float range,
                           float offset, float *out);
 
+/* `sigmap -m` sizes its chunk rounds with this before the first batch (--batch-chunks is a request, the loaded index
+ * and the device's free memory decide): chunks one of `contexts` device contexts may have in flight, from the fast hit
+ * slots and the mean hits per query of the index census (smhip_index_census).  host/mapping_logic.h. */
+uint64_t smhost_chunk_budget(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
+                             uint32_t contexts);
+
+/* Raw mode of the same function (the CLI's load phase): the read stays as ADC counts; what the reference's AddSignal
+ * yields as signal_values.size() -- the FILTERED length (sigmap.cc:643: num_chunks = length / chunk_size) -- is counted,
+ * and bounds[c] = the raw position at which the filtered array has c * chunk_size samples, c = 0 .. min(length /
+ * chunk_size, max_chunks): chunk c of the filtered array (sigmap.cc:647-652) = the survivors of raw[bounds[c] ..
+ * bounds[c + 1]).  Returns the number of bounds written (<= cap). */
+uint32_t smhost_chunk_bounds(const int16_t *raw, uint32_t n_raw, float digitisation, float range, float offset,
+                             uint32_t chunk_size, uint32_t max_chunks, uint32_t *bounds, uint32_t cap,
+                             uint64_t *filtered_length);
+
 /* SignalBatch::LoadAllReadSignals, signal_batch.cc:24-67: every FAST5 file (single- or multi-read,
  * signal_batch.cc:69-151), every BLOW5 file (signal_batch.cc:153-210; the binary SLOW5 layout parsed
  * directly -- record compression none / zlib / zstd, no signal compression) and every .sgr file under

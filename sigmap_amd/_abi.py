@@ -22,7 +22,7 @@ HIP_SYMBOLS = [
     "smhip_reference_upload", "smhip_reference_share", "smhip_mem_info", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
-    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_batch_reserve_for", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
+    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_batch_reserve_for", "smhip_reads_upload_pieces", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
     "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params", "smhip_features_upload", "smhip_generate_chains",
     "smhip_chain_anchors", "smhip_map_download_chains", "smhip_debug_sort_stats",
     "smhip_debug_start_coef_sweep", "smhip_debug_div_window_sweep",
@@ -35,7 +35,7 @@ HOST_SYMBOLS = [
     "smhost_signals_get", "smhost_write_fast5", "smhost_write_blow5", "smhost_have_zstd", "smhost_shard_range", "smhost_print_alignment",
     "smhost_format_paf_record", "smhost_sequences_load", "smhost_sequences_free", "smhost_sequences_count",
     "smhost_sequences_num_bases", "smhost_sequences_get", "smhost_index_bind_device", "smhost_generate_chains",
-    "smhost_generate_events",
+    "smhost_generate_events", "smhost_chunk_bounds", "smhost_chunk_budget",
 ]
 
 
@@ -148,6 +148,11 @@ def host_lib():
         L.smhost_level_means.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, C.c_void_p]
         L.smhost_raw_to_pa.restype = C.c_uint32
         L.smhost_raw_to_pa.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.smhost_chunk_budget.restype = C.c_uint64
+        L.smhost_chunk_budget.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32]
+        L.smhost_chunk_bounds.restype = C.c_uint32
+        L.smhost_chunk_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint32, C.c_void_p]
         L.smhost_signals_load.restype = C.c_void_p
         L.smhost_signals_load.argtypes = [C.c_char_p]
         L.smhost_signals_free.argtypes = [C.c_void_p]
@@ -239,6 +244,7 @@ def hip_lib():
         L.smhip_reads_download_pa.argtypes = [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]
         L.smhip_batch_reserve.argtypes = [vp, u32, u32]
         L.smhip_batch_reserve_for.argtypes = [vp, vp, u32, u32]
+        L.smhip_reads_upload_pieces.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32]
         L.smhip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
         L.smhip_host_free.argtypes = [vp]
         L.smhip_host_free.restype = None

@@ -12,6 +12,8 @@
 
 #include <mutex>
 
+#include <chrono>
+
 #include "common.h"
 
 using namespace smhip;
@@ -48,6 +50,7 @@ DevKnobs ReadDevKnobs() {
 namespace {
 int FinishRun(smhip_ctx *ctx);  // (defined with smhip_map_run: settles a speculative batch)
 int ResolveParams(smhip_ctx *ctx, smhip_params *rp, uint32_t n_chunks);
+int ReserveAnchorBuffers(smhip_ctx *ctx, uint64_t na_cap, uint32_t R);
 int Fail(smhip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->last_error = msg;
   return code;
@@ -155,8 +158,23 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
     memcpy(st + n_chunks, carried_offsets, ((size_t)n_chunks + 1) * sizeof(uint32_t));
     HIPCHK(hipMemcpyAsync(ctx->carried_off.p, st + n_chunks, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
                           hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->carried.p, carried, n_carried * sizeof(smhip_carried_anchor), hipMemcpyHostToDevice,
-                          ctx->stream));
+    // the anchors through pinned memory of the context: one DMA, and the caller's array is free on return without
+    // anybody waiting for the stream.  (The staging is reused by the next batch's call: by then this batch has been
+    // collected -- every route to its results synchronises the stream.)
+    const size_t bytes = (size_t)n_carried * sizeof(smhip_carried_anchor);
+    if (bytes > ctx->h_carried_cap) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));  // (nothing may still be reading the old staging)
+      if (ctx->h_carried) (void)hipHostFree(ctx->h_carried);
+      ctx->h_carried = nullptr;
+      ctx->h_carried_cap = 0;
+      const size_t want = bytes + bytes / 2 + 4096;
+      HIPCHK(hipHostMalloc(&ctx->h_carried, want, hipHostMallocDefault));
+      ctx->h_carried_cap = want;
+    }
+    if (bytes) {
+      memcpy(ctx->h_carried, carried, bytes);
+      HIPCHK(hipMemcpyAsync(ctx->carried.p, ctx->h_carried, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
   } else {
     HIPCHK(hipMemsetAsync(ctx->carried_off.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
   }
@@ -245,6 +263,16 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
     smhip_destroy(ctx);
     return SMHIP_EHIP;
   }
+  {  // smhip_reads_upload_pieces: the event behind its staging copies, the mismatch word the device writes
+    void *flag = nullptr;
+    if (hipEventCreateWithFlags(&ctx->pieces_staged, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(&flag, 64, hipHostMallocDefault) != hipSuccess) {
+      smhip_destroy(ctx);
+      return SMHIP_EHIP;
+    }
+    ctx->h_piece_flag = static_cast<uint32_t *>(flag);
+    *ctx->h_piece_flag = 0;
+  }
   ctx->timers.resize(T_COUNT);
   for (int i = 0; i < T_COUNT; ++i) ctx->timers[i].name = kTimerNames[i];
   *out = ctx;
@@ -268,6 +296,12 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
   if (ctx->convert_done) (void)hipEventDestroy(ctx->convert_done);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+  if (ctx->h_pieces) (void)hipHostFree(ctx->h_pieces);
+  if (ctx->h_piece_flag) (void)hipHostFree(ctx->h_piece_flag);
+  if (ctx->h_carried) (void)hipHostFree(ctx->h_carried);
+  if (ctx->pieces_staged) (void)hipEventDestroy(ctx->pieces_staged);
+  ctx->pieces_src.Free();
+  ctx->pieces_expect.Free();
   if (ctx->h_run_info) (void)hipHostFree(ctx->h_run_info);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (DevBuf &b : ctx->pa_segs) b.Free();
@@ -882,6 +916,81 @@ int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *r
   return SMHIP_OK;
 }
 
+int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, const uint32_t *piece_len,
+                              const float *digitisation, const float *range, const float *offset, const uint32_t *slots,
+                              const uint32_t *expect_len, uint32_t n_pieces) {
+  if (!ctx || !pieces || !piece_len || !digitisation || !range || !offset) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->n_slots == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_reads_upload_pieces before smhip_reads_configure");
+  if (n_pieces == 0) return SMHIP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->pieces_pending) {  // the previous call's staging has been read
+    HIPCHK(hipEventSynchronize(ctx->pieces_staged));
+    ctx->pieces_pending = false;
+  }
+  const size_t n = n_pieces;
+  const size_t meta_bytes = n * sizeof(RawReadMeta), seg_bytes = (n + 1) * sizeof(uint32_t), src_bytes = n * sizeof(PieceSrc),
+               exp_bytes = expect_len ? n * sizeof(uint32_t) : 0;
+  const size_t stage_bytes = meta_bytes + src_bytes + seg_bytes + exp_bytes + 64;
+  if (stage_bytes > ctx->h_pieces_cap) {
+    if (ctx->h_pieces) (void)hipHostFree(ctx->h_pieces);
+    ctx->h_pieces = nullptr;
+    ctx->h_pieces_cap = 0;
+    HIPCHK(hipHostMalloc(&ctx->h_pieces, stage_bytes * 2, hipHostMallocDefault));
+    ctx->h_pieces_cap = stage_bytes * 2;
+  }
+  char *hp = static_cast<char *>(ctx->h_pieces);
+  RawReadMeta *meta = reinterpret_cast<RawReadMeta *>(hp);
+  PieceSrc *src = reinterpret_cast<PieceSrc *>(hp + meta_bytes);
+  uint32_t *seg_start = reinterpret_cast<uint32_t *>(hp + meta_bytes + src_bytes);
+  uint32_t *expect = reinterpret_cast<uint32_t *>(hp + meta_bytes + src_bytes + seg_bytes);
+  uint64_t n_segs = 0, units = 0;
+  for (uint32_t r = 0; r < n_pieces; ++r) {
+    const uint64_t addr = (uint64_t)(uintptr_t)pieces[r];
+    if ((addr & 1ull) || (!pieces[r] && piece_len[r])) return Fail(ctx, SMHIP_EINVAL, "a piece is not an int16 array");
+    const uint32_t slot = slots ? slots[r] : r;
+    if (slot >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
+    if (!(digitisation[r] != 0.0f)) return Fail(ctx, SMHIP_EINVAL, "digitisation must be non-zero");
+    const uint32_t phase = (uint32_t)(addr & 15ull) >> 1;  // the piece keeps its place inside a 16-byte unit
+    if (units > 0xFFFFFFF0ull) return Fail(ctx, SMHIP_EINVAL, "too many samples in one upload");
+    src[r] = PieceSrc{addr, (uint32_t)units, piece_len[r]};
+    meta[r] = RawReadMeta{units * 8 + phase, piece_len[r], slot, digitisation[r], range[r], offset[r], 0u};
+    units += ((uint64_t)phase + piece_len[r] + 7) / 8;
+    seg_start[r] = (uint32_t)n_segs;
+    n_segs += RawSegments(piece_len[r]);
+    if (n_segs > 0x7FFFFFFFull) return Fail(ctx, SMHIP_EINVAL, "too many samples in one upload");
+  }
+  seg_start[n_pieces] = (uint32_t)n_segs;
+  if (expect_len) memcpy(expect, expect_len, exp_bytes);
+  // (the staged samples are also what smhip_reads_upload_raw copies into: its DMA waits for convert_done, recorded below)
+  HIPCHK(ctx->reads_raw.Reserve(std::max<uint64_t>(units, 1) * 16));
+  HIPCHK(ctx->reads_meta.Reserve(meta_bytes));
+  HIPCHK(ctx->reads_segstart.Reserve(seg_bytes));
+  HIPCHK(ctx->reads_seg.Reserve(n_segs * 2 * sizeof(uint32_t)));
+  HIPCHK(ctx->reads_len.Reserve(n * sizeof(uint32_t)));
+  HIPCHK(ctx->pieces_src.Reserve(src_bytes));
+  HIPCHK(ctx->pieces_expect.Reserve(std::max<size_t>(exp_bytes, 4)));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->convert_done, 0));  // (ordered anyway on this stream; cheap)
+  HIPCHK(hipMemcpyAsync(ctx->reads_meta.p, meta, meta_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->pieces_src.p, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->reads_segstart.p, seg_start, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (expect_len) HIPCHK(hipMemcpyAsync(ctx->pieces_expect.p, expect, exp_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->pieces_staged, ctx->stream));
+  ctx->pieces_pending = true;
+  {
+    ScopedTimer t(ctx, T_CONVERT);
+    HIPCHK(LaunchGatherPieces(ctx, ctx->pieces_src.as<PieceSrc>(), n_pieces, ctx->reads_raw.p));
+    HIPCHK(LaunchRawConvert(ctx, ctx->reads_raw.as<int16_t>(), ctx->reads_meta.as<RawReadMeta>(),
+                            ctx->reads_segstart.as<uint32_t>(), n_pieces, (uint32_t)n_segs, ctx->reads_seg.as<uint32_t>(),
+                            ctx->reads_seg.as<uint32_t>() + n_segs,
+                            SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
+                            ctx->slot_len.as<uint32_t>(), ctx->reads_len.as<uint32_t>()));
+    if (expect_len)
+      HIPCHK(LaunchCheckPieceLen(ctx, ctx->reads_len.as<uint32_t>(), ctx->pieces_expect.as<uint32_t>(), n_pieces, ctx->h_piece_flag));
+  }
+  HIPCHK(hipEventRecord(ctx->convert_done, ctx->stream));
+  return SMHIP_OK;
+}
+
 int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t chunk_size,
                        uint32_t n_chunks, const uint32_t *query_start_offsets, const smhip_carried_anchor *carried,
                        const uint32_t *carried_offsets) {
@@ -922,7 +1031,8 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   ctx->chunk_src = nullptr;  // chunk_begin holds addresses (in floats)
   int rc = UploadBatchSideInputs(ctx, n_chunks, query_start_offsets, carried, carried_offsets);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned: safe to reuse on return
+  // (no wait: every caller-owned array went through pinned staging of the context, so it is free on return; the
+  // staging itself is next written by the following batch's calls, after this batch has been collected)
   ctx->batch_is_features = false;
   ctx->n_chunks = n_chunks;
   ctx->n_samples = (uint64_t)n_chunks * chunk_size;
@@ -968,6 +1078,19 @@ int smhip_batch_reserve_for(smhip_ctx *ctx, const smhip_params *params, uint32_t
   }
   HIPCHK(ctx->qrec.Reserve(nq * 32));
   HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * sizeof(Hit)));
+  // ... and the anchor-sized ones at the index's own estimate: the census' mean of min(hits, num_nearest_points) per
+  // query, a quarter on top (what a speculative batch would ask for) -- within a sixth of the device; a batch that
+  // needs more grows them as before
+  if (ctx->have_index && !ctx->census_hits.empty()) {
+    double sum = 0;
+    for (uint32_t h : ctx->census_hits) sum += std::min<uint32_t>(h, (uint32_t)p.num_nearest_points);
+    const uint64_t na = (uint64_t)((double)nq * (sum / (double)ctx->census_hits.size()) * 1.25) + (1u << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && na * 110 < total_b / 6 && na * 110 * 2 < free_b) {
+      int rc = ReserveAnchorBuffers(ctx, na, n_chunks);
+      if (rc) return rc;
+    }
+  }
   return SMHIP_OK;
 }
 
@@ -1079,9 +1202,8 @@ int EnqueueSearch(smhip_ctx *ctx, const smhip_params *p, uint32_t R, uint64_t nq
   return SMHIP_OK;
 }
 
-// per-anchor buffers for up to na_cap anchors, sort, chaining
-int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t R, uint64_t na_cap, const HitSlots &hit_slots) {
-  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+// the buffers EnqueueBack sizes from the anchor count
+int ReserveAnchorBuffers(smhip_ctx *ctx, uint64_t na_cap, uint32_t R) {
   const uint64_t na = std::max<uint64_t>(na_cap, 1);
   DevBuf *b4[] = {&ctx->a_tpos, &ctx->a_qpos, &ctx->a_dist, &ctx->a_grp, &ctx->s_tpos, &ctx->s_qpos,
                   &ctx->s_dist, &ctx->s_grp, &ctx->score, &ctx->pred, &ctx->group_start};
@@ -1089,6 +1211,16 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   HIPCHK(ctx->keys.Reserve(std::max<uint64_t>(SortRecordRoom(na, R), na) * 2 * sizeof(uint64_t)));  // the sort's records (5/3 per anchor)
   HIPCHK(ctx->used.Reserve(na));
   HIPCHK(ctx->out_anchors.Reserve(na * sizeof(smhip_carried_anchor)));
+  return SMHIP_OK;
+}
+
+// per-anchor buffers for up to na_cap anchors, sort, chaining
+int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t R, uint64_t na_cap, const HitSlots &hit_slots) {
+  smhip_chunk_result *results = ctx->results.as<smhip_chunk_result>();
+  {
+    int rc = ReserveAnchorBuffers(ctx, na_cap, R);
+    if (rc) return rc;
+  }
   SortArgs sa;
   sa.q_off = ctx->q_off.as<uint32_t>();
   sa.q_count = ctx->q_count.as<uint32_t>();
@@ -1216,11 +1348,16 @@ void LearnTotals(smhip_ctx *ctx, uint32_t R, uint64_t NQ, uint64_t NA) {
 // the synchronous route: both totals are read back and the buffers sized exactly
 int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, bool reuse_features = false) {
   const uint32_t R = ctx->n_chunks;
+  const bool trace = TraceAlloc();  // SMHIP_TRACE_ALLOC=1: where the host waits on this route, on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   int rc = EnqueueFront(ctx, p, R, reuse_features);
   if (rc) return rc;
+  if (trace) fprintf(stderr, "[smhip] sync route, %u chunks: front enqueued %.2f ms\n", R, since());
   uint32_t NQ = 0;
   HIPCHK(hipMemcpyAsync(&NQ, ctx->q_off.as<uint32_t>() + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (trace) fprintf(stderr, "[smhip] sync route: front done %.2f ms (%u queries)\n", since(), NQ);
   // (buffers are reserved at the capacity a speculative batch of this size would ask for next, so that the
   // switch to that route does not reallocate -- a hipFree synchronises the whole device)
   ctx->hint_q_per_chunk = std::max<uint64_t>(ctx->hint_q_per_chunk, ((uint64_t)NQ + R - 1) / R);
@@ -1235,7 +1372,9 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, bool re
     uint32_t hc[26] = {0};
     HIPCHK(hipMemcpyAsync(&NA, ctx->anchor_off.as<uint64_t>() + R, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hc, ctx->counters.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+    if (trace) fprintf(stderr, "[smhip] sync route: search enqueued %.2f ms\n", since());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (trace) fprintf(stderr, "[smhip] sync route: search done %.2f ms\n", since());
     LearnOverCap(ctx, p, NQ, hc[7]);
     if (!hc[3] || attempt > 0) break;  // hc[3]: pool exhausted (kept as SMHIP_ST_HIT_POOL_FULL if it persists)
     const uint64_t demand = (((uint64_t)hc[25] << 32) | hc[24]) + (1u << 20);
@@ -1246,7 +1385,9 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, bool re
   LearnTotals(ctx, R, NQ, NA);
   uint64_t na_cap = NA;
   if (CapacitiesAffordable(ctx, p, 0, SpecCapAnchors(ctx, R))) na_cap = std::max(na_cap, SpecCapAnchors(ctx, R));
-  return EnqueueBack(ctx, p, n_refs, R, na_cap, hit_slots);
+  rc = EnqueueBack(ctx, p, n_refs, R, na_cap, hit_slots);
+  if (trace) fprintf(stderr, "[smhip] sync route: back enqueued %.2f ms (%llu anchors)\n", since(), (unsigned long long)NA);
+  return rc;
 }
 
 // the speculative route: nothing is read back; capacities from the totals of earlier batches
@@ -1286,6 +1427,12 @@ int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) 
 // refinement that was enqueued behind it.
 int FinishRun(smhip_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_piece_flag && *ctx->h_piece_flag) {
+    *ctx->h_piece_flag = 0;
+    ctx->spec_pending = false;
+    return Fail(ctx, SMHIP_ECAP, "smhip_reads_upload_pieces: the device's (30, 200) pA filter kept another number of samples of a piece "
+                                 "than expect_len says -- the chunk would not be the reference's chunk");
+  }
   if (!ctx->spec_pending) return SMHIP_OK;
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);

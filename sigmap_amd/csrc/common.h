@@ -41,6 +41,12 @@ struct RawReadMeta {  // one read of smhip_reads_upload_raw (32 B)
   uint32_t pad;
 };
 
+struct PieceSrc {  // one piece of smhip_reads_upload_pieces (16 B)
+  uint64_t src;  // address of its first ADC sample in pinned host memory
+  uint32_t dst;  // first 16-byte unit of the piece in the staging buffer
+  uint32_t n;    // samples
+};
+
 // Per-query hit slots (fast_cap hits of 16 B per query).  The whole array is 20-30 GB for a batch of
 // 16 384 chunks, and a device allocation beyond 4 GB costs tens of ms per GB on this platform
 // (tools/micro/malloc_chunks.hip: 8 x 3.9 GB in 1.4 ms, one 27 GB block in 3 s), so it is cut into
@@ -225,6 +231,18 @@ struct smhip_ctx {
   uint32_t n_slots = 0, reads_keep = 0;
   void *h_meta = nullptr;              // pinned host staging of the per-read records + segment starts
   size_t h_meta_cap = 0;
+  // smhip_reads_upload_pieces: its own pinned staging (records, segment starts, piece sources, expected lengths), the
+  // event behind the copies that read it, the device copies of the last two, and the mismatch flag (pinned, written
+  // by the device)
+  void *h_pieces = nullptr;
+  size_t h_pieces_cap = 0;
+  hipEvent_t pieces_staged = nullptr;
+  bool pieces_pending = false;
+  smhip::DevBuf pieces_src, pieces_expect;
+  uint32_t *h_piece_flag = nullptr;
+  // carried anchors of smhip_batch_select staged in pinned memory (the call then returns without waiting)
+  void *h_carried = nullptr;
+  size_t h_carried_cap = 0;
   std::vector<uint64_t> h_chunk_begin; // scratch of smhip_batch_upload
   std::vector<uint32_t> h_chunk_len;
   // per-chunk intermediates.  ev_rows: where the last LaunchEvents put its scratch rows inside
@@ -350,6 +368,8 @@ uint32_t RawSegments(uint32_t n_raw);
 hipError_t LaunchRawConvert(smhip_ctx *ctx, const int16_t *raw, const RawReadMeta *meta, const uint32_t *seg_start,
                             uint32_t n_reads, uint32_t n_segs, uint32_t *seg_count, uint32_t *seg_base, SlotView pa,
                             uint32_t *slot_len, uint32_t *read_len);
+hipError_t LaunchGatherPieces(smhip_ctx *ctx, const PieceSrc *src, uint32_t n, void *staged);
+hipError_t LaunchCheckPieceLen(smhip_ctx *ctx, const uint32_t *read_len, const uint32_t *expect, uint32_t n, uint32_t *host_flag);
 hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t n_chunks,
                               uint32_t chunk_size, SlotView pa, const uint32_t *slot_len, uint64_t *cbegin,
                               uint32_t *clen);

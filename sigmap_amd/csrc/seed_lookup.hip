@@ -1601,14 +1601,20 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
     }
     if ((e = ctx->ovf_list.Reserve(n_queries_max * sizeof(QueryRec))) != hipSuccess) return e;
     QueryRec *list2 = ctx->ovf_list.as<QueryRec>();
-    hipLaunchKernelGGL(OverCapSelectKernel, dim3(2048), dim3(kSelThreads), 0, ctx->stream, ctx->index,
+    // (how many workgroups: the queries beyond the cap are counted on the device, the grid is chosen here.  An index whose
+    // census holds no such query -- every 12 Mb-sized reference -- gets a token grid: these launches, empty then, and the
+    // one below otherwise wait for room behind the other contexts' kernels for nothing.  Speed only: each workgroup
+    // strides over whatever the list holds.)
+    const bool census_over_cap = ctx->census_hits.empty() || ctx->census_hits.back() > (uint32_t)p.num_nearest_points;
+    hipLaunchKernelGGL(OverCapSelectKernel, dim3(census_over_cap ? 2048 : 128), dim3(kSelThreads), 0, ctx->stream, ctx->index,
                        ctx->ix_slot_leaf.as<uint32_t>(), list, counters + 7, sink, list2, counters + 6);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     list = list2;
     second_n = counters + 6;
   }
   sink.stop_at_cap = 1u;
-  return LaunchWalk(ctx, p, kWalkExact, list, second_n, 0, sink, nullptr, 0);
+  // (ranked: only the queries of a tree too deep for the ranking's keys are left -- none on any index built so far)
+  return LaunchWalk(ctx, p, kWalkExact, list, second_n, 0, sink, nullptr, 0, ranked ? 64u : 0u);
 }
 
 // Census of the index: `samples` of its own points (the first point of evenly spaced leaves) as queries, hit counts

@@ -86,6 +86,36 @@ __global__ __launch_bounds__(64) void RawSegScanKernel(const RawReadMeta *__rest
   slot_len[meta[r].slot] = acc;
 }
 
+// ---- pieces of reads pulled over PCIe by the GPU itself (smhip_reads_upload_pieces).  The host keeps the reads'
+// ADC counts in PINNED memory, which the device can address: workgroup r copies the n samples of piece r into the
+// staging buffer, where the conversion kernels above find them.  A piece keeps its phase inside a 16-byte unit
+// (sample i of a piece whose first sample sits at byte a of its unit lands at sample 8 dst + a / 2 + i), so that
+// all of it but a few samples at either end moves as aligned 16-byte loads and stores, a kilobyte per wave and
+// instruction; nothing outside [src, src + 2 n) is read.  One launch for any number of scattered pieces, no staging
+// copy on the host.
+__global__ __launch_bounds__(256) void GatherPiecesKernel(const PieceSrc *__restrict__ src, int16_t *__restrict__ staged) {
+  const PieceSrc p = src[blockIdx.x];
+  const uint32_t a = (uint32_t)(p.src & 15ull) >> 1;                     // samples before the piece in its first unit
+  const int16_t *from = reinterpret_cast<const int16_t *>(p.src);
+  int16_t *to = staged + (size_t)p.dst * 8 + a;
+  const uint32_t head = min(p.n, (8u - a) & 7u);                         // samples up to the first unit boundary
+  const uint32_t units = (p.n - head) >> 3, tail0 = head + units * 8;
+  if (threadIdx.x < head) to[threadIdx.x] = from[threadIdx.x];
+  const uint4 *f4 = reinterpret_cast<const uint4 *>(from + head);
+  uint4 *t4 = reinterpret_cast<uint4 *>(to + head);
+  for (uint32_t u = threadIdx.x; u < units; u += 256) t4[u] = f4[u];
+  if (threadIdx.x < p.n - tail0) to[tail0 + threadIdx.x] = from[tail0 + threadIdx.x];
+}
+
+// filtered length of every piece against what the host counted (SignalBatch's load phase): a difference means the two
+// do not agree on the (30, 200) pA filter -- the chunk would not be the reference's chunk.  The flag is a word of
+// pinned host memory.
+__global__ void CheckPieceLenKernel(const uint32_t *__restrict__ read_len, const uint32_t *__restrict__ expect, uint32_t n,
+                                    uint32_t *__restrict__ host_flag) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && read_len[r] != expect[r]) atomicOr(host_flag, 1u);
+}
+
 // Batch descriptors from (slot, chunk index): chunk c = the slot's filtered samples
 // [chunk_index * chunk_size, + chunk_size) (sigmap.cc:647-652), clipped to what the slot holds.
 __global__ void SelectChunksKernel(const uint32_t *__restrict__ slots, const uint32_t *__restrict__ chunk_index,
@@ -115,6 +145,18 @@ hipError_t LaunchRawConvert(smhip_ctx *ctx, const int16_t *raw, const RawReadMet
                      seg_count, seg_base, slot_len, read_len);
   hipLaunchKernelGGL(RawConvertKernel<true>, dim3(n_segs), dim3(256), 0, ctx->stream, raw, meta, seg_start, n_reads,
                      seg_count, seg_base, pa);
+  return hipGetLastError();
+}
+
+hipError_t LaunchGatherPieces(smhip_ctx *ctx, const PieceSrc *src, uint32_t n, void *staged) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(GatherPiecesKernel, dim3(n), dim3(256), 0, ctx->stream, src, reinterpret_cast<int16_t *>(staged));
+  return hipGetLastError();
+}
+
+hipError_t LaunchCheckPieceLen(smhip_ctx *ctx, const uint32_t *read_len, const uint32_t *expect, uint32_t n, uint32_t *host_flag) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(CheckPieceLenKernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, read_len, expect, n, host_flag);
   return hipGetLastError();
 }
 

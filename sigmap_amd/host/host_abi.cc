@@ -201,6 +201,19 @@ uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation
   return (uint32_t)v.size();
 }
 
+uint32_t smhost_chunk_bounds(const int16_t *raw, uint32_t n_raw, float digitisation, float range, float offset,
+                             uint32_t chunk_size, uint32_t max_chunks, uint32_t *bounds, uint32_t cap,
+                             uint64_t *filtered_length) {
+  SignalBatch b;
+  b.KeepRaw([](size_t n) { return malloc(n); }, [](void *p) { free(p); }, (size_t)1 << 20, chunk_size, max_chunks);
+  b.AddSignal("", digitisation, range, offset, raw, n_raw);
+  const Signal &s = b.GetSignalAt(0);
+  if (filtered_length) *filtered_length = s.filtered_length;
+  const uint32_t n = (uint32_t)std::min<size_t>(s.chunk_bounds.size(), cap);
+  if (bounds) memcpy(bounds, s.chunk_bounds.data(), (size_t)n * sizeof(uint32_t));
+  return n;
+}
+
 void smhost_default_map_params(smhost_map_params *p) {
   const MappingParams d;
   p->search_radius = d.search_radius;
@@ -243,6 +256,11 @@ void smhost_shard_range(uint64_t n_items, int rank, int world, uint64_t *lo, uin
   sigmap::ShardRange((size_t)n_items, rank, world, &a, &b);
   if (lo) *lo = a;
   if (hi) *hi = b;
+}
+
+uint64_t smhost_chunk_budget(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
+                             uint32_t contexts) {
+  return (uint64_t)sigmap::ChunkBudgetForMemory(free_bytes, keep_samples, fast_slots, hits_per_query, contexts);
 }
 
 int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p) {

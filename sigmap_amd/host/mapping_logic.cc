@@ -1,6 +1,14 @@
 #include "mapping_logic.h"
 
 namespace sigmap {
+size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
+                            size_t contexts) {
+  const double per_chunk = (double)keep_samples * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
+                           288.0 * std::min(std::max(hits_per_query, 0.0), 5000.0) * 60.0 + 120000.0;
+  const double fit = (double)free_bytes * 0.5 / per_chunk / (double)std::max<size_t>(contexts, 1);
+  return fit < 1.0 ? 1 : (size_t)fit;
+}
+
 void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi) {
   if (world < 1) world = 1;
   // item i belongs to part floor(i * world / n): part r starts at ceil(r * n / world)

@@ -27,6 +27,15 @@ struct MappingParams {  // CLI defaults, sigmap.cc:1380-1419
 // [*lo, *hi).  Either pointer may be null.
 void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi);
 
+// Chunks one device context may have in flight so that `contexts` of them fit the GPU's free memory: per chunk a context
+// needs its slot of `keep_samples` floats, ~288 queries x (16 bytes x fast hit slots + ~1.4 KB of per-query records and
+// overflow pool) and ~60 bytes per anchor (288 x hits_per_query, capped at the reference's 5000 per query) + 120 KB of
+// per-chunk rows; half of the free memory is left to growth and to the other users of the device.  At least 1.
+// (12 Mb reference, 41 hits per query, 512 slots: 3.6 MB per chunk; 250 Mb, 850 hits, 1024 slots: 20 MB per chunk --
+// 8 000 chunks in flight are 160 GB.)
+size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
+                            size_t contexts);
+
 // Per-base CIGAR of a DTW path (print_alignment, fast_dtw.cc:160-209): codes 0 one-to-one, 1 one base
 // to several signals, 2 skip one signal, 3 skip one base; "(2M)(1M3I)(1D)...".  The format, including
 // that the run still open when the path ends is not written, is the reference's.

@@ -70,8 +70,14 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     std::cerr << what << " in " << now - t_phase << "s.\n";
     t_phase = now;
   };
+  const uint32_t chunk_size = 4000;
+  const uint32_t max_chunks = (uint32_t)std::max(0, params_.max_num_chunks);
   SignalBatch reads;
-  reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree);  // ADC counts stay 2 bytes/sample; the GPU converts
+  // ADC counts stay 2 bytes per sample in pinned memory; the GPU pulls, converts and filters the ONE chunk of every
+  // read a round maps (smhip_reads_upload_pieces).  What the reference's load phase computes per read -- the filtered
+  // length (PAF column 2, num_chunks) -- and where the chunks of the filtered array begin in the raw one are counted
+  // while loading (SignalBatch::AddSignal's arithmetic), so only samples that are mapped ever cross PCIe.
+  reads.KeepRaw(&Sigmap::PinnedAlloc, &Sigmap::PinnedFree, (size_t)256 << 20, chunk_size, max_chunks);
   reads.InitializeLoading(signal_directory_);
   const size_t num_reads = reads.LoadAllReadSignals();
   phase("Loaded read signals (first device use included)");
@@ -154,11 +160,9 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   dp.search_radius = params_.search_radius;
   dp.step_size = params_.read_seeding_step_size;
 
-  const uint32_t chunk_size = 4000;
   struct ReadState {
     uint32_t chunk_index = 0;  // next chunk to process
     uint32_t num_events = 0;
-    uint32_t slot = 0;         // resident slot on the read's context while it is in flight
     smhip_chunk_result last{};       // chains after the last GenerateChains call (zero = none yet)
     float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
     bool has_dt = false;
@@ -168,12 +172,13 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   };
   std::vector<ReadState> st(num_reads);
   std::vector<uint32_t> num_chunks(num_reads, 0);
-  for (size_t r = 0; r < num_reads; ++r) memset(&st[r].last, 0, sizeof(smhip_chunk_result));
-  const uint32_t max_chunks = (uint32_t)std::max(0, params_.max_num_chunks);
+  for (size_t r = 0; r < num_reads; ++r) {
+    memset(&st[r].last, 0, sizeof(smhip_chunk_result));
+    num_chunks[r] = (uint32_t)(reads.GetSignalLengthAt(r) / chunk_size);  // sigmap.cc:643
+  }
   // every context gets an equal share of the batch budget, so that `max_batch_chunks` bounds the
-  // chunks in flight on a GPU as it does with one context; a slot keeps the samples of the chunks
-  // a read may use (sigmap.cc:647: at most max_num_chunks), within 8 GiB of slots per context
-  const uint32_t keep = std::max<uint32_t>(1, std::min<uint32_t>(max_chunks, 1u << 16)) * chunk_size;
+  // chunks in flight on a GPU as it does with one context; a slot holds the one chunk of a read that a round maps
+  const uint32_t keep = chunk_size;
   size_t lane_budget = std::max<size_t>(1, max_batch_chunks / (size_t)num_streams);
   lane_budget = std::max<size_t>(1, std::min<size_t>(lane_budget, ((size_t)8 << 30) / ((size_t)keep * sizeof(float))));
   {
@@ -196,10 +201,10 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         const uint32_t q75 = census[((size_t)n_census * 3) / 4];
         while (fast_slots < 2048 && fast_slots < q75) fast_slots <<= 1;
       }
-      const double per_chunk = (double)keep * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
-                               288.0 * std::min(hits_per_query, 5000.0) * 60.0 + 120000.0;
       const size_t contexts_here = (size_t)num_streams * (share_device ? (size_t)num_gpus : 1u);
-      const size_t fit = (size_t)((double)free_b * 0.5 / per_chunk / (double)contexts_here);
+      // (development hook: SIGMAP_DEV_FREE_MB pretends the device has that much left -- the shrink path on a small index)
+      if (const char *fake = getenv("SIGMAP_DEV_FREE_MB")) free_b = std::min<uint64_t>(free_b, (uint64_t)atoll(fake) << 20);
+      const size_t fit = ChunkBudgetForMemory(free_b, keep, fast_slots, hits_per_query, contexts_here);
       if (fit < lane_budget) {
         std::cerr << "Chunks in flight per context limited to " << std::max<size_t>(fit, 1) << " of " << lane_budget
                   << " by the device's free memory (" << (free_b >> 20) << " MiB).\n";
@@ -222,6 +227,56 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
                         " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
   phase("Reserved read slots and batch buffers");
+  {
+    // Warm-up, part of the set-up like the index load: every context maps one round of first chunks -- as many as it
+    // will have in flight, taken from its GPU's first reads (again and again when those are fewer) -- and throws the
+    // results away.  What a context's FIRST batch otherwise pays inside the mapping span, measured at 40 ms of a 60 ms
+    // job of 10 000 reads (profiles/EXPERIMENTS.md, round 5): the scratch memory the runtime attaches to a hardware
+    // queue at the first kernel that needs it, buffers that grow (a hipFree waits for the whole device), the route with
+    // two host read-backs that sizes the later, speculative batches.  Results never depend on it.
+    std::vector<std::thread> warm;
+    std::vector<std::string> failed(ctxs.size() * (size_t)num_streams);
+    for (int g = 0; g < num_gpus; ++g)
+      for (size_t k = 0; k < ctxs[g].size(); ++k)
+        warm.emplace_back([&, g, k] {
+          smhip_ctx *ctx = ctxs[g][k];
+          size_t lo = 0, hi = 0;
+          ShardRange(num_reads, g, num_gpus, &lo, &hi);
+          std::vector<const int16_t *> pieces;
+          std::vector<uint32_t> plen, expect, slots, zeros;
+          std::vector<float> dig, rng, ofs;
+          for (size_t r = lo; r < hi && pieces.size() < lane_budget; ++r) {
+            const Signal &sig = reads.GetSignalAt(r);
+            if (sig.chunk_bounds.size() < 2) continue;  // (shorter than a chunk)
+            pieces.push_back(sig.raw);
+            plen.push_back(sig.chunk_bounds[1]);
+            dig.push_back(sig.digitisation); rng.push_back(sig.range); ofs.push_back(sig.offset);
+          }
+          if (pieces.empty() || max_chunks == 0) return;
+          const size_t have = pieces.size();
+          for (size_t i = have; i < lane_budget; ++i) {
+            pieces.push_back(pieces[i % have]); plen.push_back(plen[i % have]);
+            dig.push_back(dig[i % have]); rng.push_back(rng[i % have]); ofs.push_back(ofs[i % have]);
+          }
+          const uint32_t n = (uint32_t)pieces.size();
+          expect.assign(n, chunk_size); zeros.assign(n, 0u); slots.resize(n);
+          for (uint32_t i = 0; i < n; ++i) slots[i] = i;
+          std::vector<smhip_chunk_result> res(n);
+          int rc = smhip_reads_upload_pieces(ctx, pieces.data(), plen.data(), dig.data(), rng.data(), ofs.data(), nullptr,
+                                             expect.data(), n);
+          if (rc == SMHIP_OK) rc = smhip_batch_select(ctx, slots.data(), zeros.data(), chunk_size, n, zeros.data(), nullptr, nullptr);
+          if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
+          if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
+          if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
+          if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
+          if (rc == SMHIP_OK) rc = smhip_map_download(ctx, res.data(), nullptr, 0, nullptr);
+          if (rc != SMHIP_OK) failed[(size_t)g * (size_t)num_streams + k] = smhip_last_error(ctx);
+        });
+    for (auto &w : warm) w.join();
+    for (const auto &f : failed)
+      if (!f.empty()) ExitWithMessage("GPU warm-up batch failed: " + f);
+  }
+  phase("Warmed up the device contexts (one discarded round of first chunks each)");
   const double t_map = GetRealTime();
   // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
   // in order and stay with the context that admitted them (chain carry-over is per read)
@@ -238,76 +293,49 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     uint64_t rounds = 0, chunks = 0, carried_up = 0, anchors_down = 0, continued = 0, max_batch = 0;
   };
   const bool want_stats = getenv("SIGMAP_STREAM_STATS") != nullptr;
+  const bool want_rounds = want_stats && atoi(getenv("SIGMAP_STREAM_STATS")) >= 2;  // ... and one line per chunk round
+  std::vector<std::string> round_lines;
   LaneStats total_stats;
   std::mutex stats_mutex;
   auto lane = [&](int g, smhip_ctx *ctx) {
-    LaneStats ls;
+    LaneStats ls, prev;
     double t_mark = GetRealTime();
     auto lap = [&](double &acc) {
       const double now = GetRealTime();
       acc += now - t_mark;
       t_mark = now;
     };
-    std::vector<uint32_t> free_slots(lane_budget);
-    for (size_t k = 0; k < lane_budget; ++k) free_slots[k] = (uint32_t)(lane_budget - 1 - k);
     std::vector<size_t> batch, in_flight;
-    std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, up_slots, pa_len;
-    std::vector<uint64_t> raw_off;
+    std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, plen, expect;
+    std::vector<const int16_t *> pieces;
     std::vector<float> dig, rng, ofs;
     std::vector<smhip_carried_anchor> carried, out_anchors;
     std::vector<smhip_chunk_result> results;
     std::vector<uint64_t> out_off;
     std::vector<float> dts, pdist;
     std::vector<int64_t> dte, pend, pstart;
-    std::vector<uint32_t> plen;
+    std::vector<uint32_t> plen_path;
     std::vector<uint64_t> poff;
     std::vector<uint8_t> pcodes;
     auto finish = [&](size_t r) {
       ReadState &s = st[r];
-      free_slots.push_back(s.slot);
       s.anchors.clear();
       s.anchors.shrink_to_fit();
       s.start_time = (GetRealTime() - s.start_time) * 1000;
     };
     while (true) {
       size_t a = 0, b = 0;
-      {  // admit new reads up to the free slots of this context
+      {  // admit new reads up to the chunks this context may have in flight
         std::lock_guard<std::mutex> lock(cursor_mutex[g]);
         a = cursor[g];
-        b = std::min(block[g + 1], a + free_slots.size());
+        b = std::min(block[g + 1], a + (lane_budget - std::min(lane_budget, in_flight.size())));
         cursor[g] = b;
       }
-      // their ADC counts go to the device, one DMA per run of reads inside one arena block
-      for (size_t r0 = a; r0 < b;) {
-        size_t r1 = r0;
-        const uint32_t blk = reads.GetSignalAt(r0).raw_block;
-        const int16_t *base = reads.RawBlockBase(blk);
-        raw_off.clear(); dig.clear(); rng.clear(); ofs.clear(); up_slots.clear();
-        const double now = GetRealTime();
-        for (; r1 < b && reads.GetSignalAt(r1).raw_block == blk; ++r1) {
-          const Signal &sig = reads.GetSignalAt(r1);
-          raw_off.push_back((uint64_t)(sig.raw - base));
-          dig.push_back(sig.digitisation);
-          rng.push_back(sig.range);
-          ofs.push_back(sig.offset);
-          st[r1].slot = free_slots.back();
-          free_slots.pop_back();
-          up_slots.push_back(st[r1].slot);
-          st[r1].start_time = now;
-        }
-        const Signal &last = reads.GetSignalAt(r1 - 1);
-        raw_off.push_back((uint64_t)(last.raw - base) + last.n_raw);
-        pa_len.resize(r1 - r0);
-        if (smhip_reads_upload_raw(ctx, base, raw_off.data(), dig.data(), rng.data(), ofs.data(), up_slots.data(),
-                                   (uint32_t)(r1 - r0), pa_len.data()) != SMHIP_OK)
-          ExitWithMessage(std::string("Read upload failed: ") + smhip_last_error(ctx));
-        for (size_t r = r0; r < r1; ++r) {
-          reads.SetFilteredLengthAt(r, pa_len[r - r0]);            // Signal::signal_values.size() of the reference
-          num_chunks[r] = (uint32_t)(pa_len[r - r0] / chunk_size);  // sigmap.cc:643
-          if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
-          else in_flight.push_back(r);
-        }
-        r0 = r1;
+      const double now = GetRealTime();
+      for (size_t r = a; r < b; ++r) {
+        st[r].start_time = now;
+        if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
+        else in_flight.push_back(r);
       }
       lap(ls.admit);
       if (in_flight.empty()) {
@@ -315,25 +343,37 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         continue;
       }
       batch = in_flight;
-      slots.clear(); chunk_idx.clear(); qstart.clear(); carried.clear();
+      const size_t nb = batch.size();
+      pieces.resize(nb); plen.resize(nb); expect.assign(nb, chunk_size); dig.resize(nb); rng.resize(nb); ofs.resize(nb);
+      slots.resize(nb); chunk_idx.assign(nb, 0u); qstart.resize(nb);
+      carried.clear();
       carried_off.assign(1, 0);
-      for (size_t r : batch) {
-        slots.push_back(st[r].slot);
-        chunk_idx.push_back(st[r].chunk_index);
-        qstart.push_back(st[r].num_events);
+      for (size_t bi = 0; bi < nb; ++bi) {
+        const size_t r = batch[bi];
+        const Signal &sig = reads.GetSignalAt(r);
+        const uint32_t c = st[r].chunk_index;  // (< min(num_chunks, max_chunks): chunk_bounds has c + 2 entries)
+        pieces[bi] = sig.raw + sig.chunk_bounds[c];
+        plen[bi] = sig.chunk_bounds[c + 1] - sig.chunk_bounds[c];
+        dig[bi] = sig.digitisation; rng[bi] = sig.range; ofs[bi] = sig.offset;
+        slots[bi] = (uint32_t)bi;  // a slot lives for one round: chunk bi of the batch
+        qstart[bi] = st[r].num_events;
         carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
         carried_off.push_back((uint32_t)carried.size());
       }
-      results.resize(batch.size());
-      out_off.resize(batch.size() + 1);
+      results.resize(nb);
+      out_off.resize(nb + 1);
       ls.rounds += 1;
-      ls.chunks += batch.size();
+      ls.chunks += nb;
       ls.carried_up += carried.size();
-      ls.max_batch = std::max<uint64_t>(ls.max_batch, batch.size());
+      ls.max_batch = std::max<uint64_t>(ls.max_batch, nb);
       lap(ls.build);
-      int rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)batch.size(), qstart.data(),
-                                  carried.empty() ? nullptr : carried.data(),
-                                  carried.empty() ? nullptr : carried_off.data());
+      // the round's chunks: pulled from the pinned arena by the device, converted, filtered (exactly chunk_size survivors
+      // each, by the load phase's count), one slot per chunk
+      int rc = smhip_reads_upload_pieces(ctx, pieces.data(), plen.data(), dig.data(), rng.data(), ofs.data(), nullptr,
+                                         expect.data(), (uint32_t)nb);
+      if (rc == SMHIP_OK)
+        rc = smhip_batch_select(ctx, slots.data(), chunk_idx.data(), chunk_size, (uint32_t)nb, qstart.data(),
+                                carried.empty() ? nullptr : carried.data(), carried.empty() ? nullptr : carried_off.data());
       if (rc == SMHIP_OK) rc = smhip_map_run(ctx, &dp, num_refs);
       if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_run(ctx, (uint32_t)sdtw_band, 32);
       if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
@@ -344,11 +384,11 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       if (rc == SMHIP_OK && sdtw_band > 0) rc = smhip_refine_download(ctx, dts.data(), dte.data());
       if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) {
         pdist.resize(batch.size()); pend.resize(batch.size()); pstart.resize(batch.size());
-        plen.resize(batch.size()); poff.resize(batch.size() + 1);
-        rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(), nullptr, 0);
+        plen_path.resize(batch.size()); poff.resize(batch.size() + 1);
+        rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen_path.data(), poff.data(), nullptr, 0);
         if (rc == SMHIP_OK) {
           pcodes.resize(std::max<uint64_t>(poff[batch.size()], 1));
-          rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen.data(), poff.data(),
+          rc = smhip_refine_path_download(ctx, pdist.data(), pend.data(), pstart.data(), plen_path.data(), poff.data(),
                                           pcodes.data(), pcodes.size());
         }
       }
@@ -393,7 +433,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
           s.has_dt = sdtw_band > 0 && dte[bi] >= 0;
           s.dt = dts[bi];
           s.cigar.clear();
-          if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen[bi]);
+          if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen_path[bi]);
           s.num_events += res.n_features;
           stop = ShouldStopMapping(res, params_);
           if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
@@ -410,6 +450,16 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       }
       ls.continued += in_flight.size();
       lap(ls.decide);
+      if (want_rounds) {
+        char line[256];
+        snprintf(line, sizeof line, "STREAM_ROUND ctx %p t %.3f ms: %zu chunks (%zu carried anchors), ms: admit %.3f build %.3f device %.3f "
+                 "results %.3f anchors %.3f decide %.3f, %zu go on", (void *)ctx, (GetRealTime() - t_map) * 1e3, batch.size(), carried.size(),
+                 (ls.admit - prev.admit) * 1e3, (ls.build - prev.build) * 1e3, (ls.device - prev.device) * 1e3,
+                 (ls.download - prev.download) * 1e3, (ls.anchors - prev.anchors) * 1e3, (ls.decide - prev.decide) * 1e3, in_flight.size());
+        std::lock_guard<std::mutex> lock(stats_mutex);
+        round_lines.push_back(line);
+        prev = ls;
+      }
     }
     std::lock_guard<std::mutex> lock(stats_mutex);
     total_stats.admit += ls.admit; total_stats.build += ls.build; total_stats.device += ls.device;
@@ -441,6 +491,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
              (unsigned long long)t.max_batch, (unsigned long long)t.carried_up, (unsigned long long)t.anchors_down, t.admit, t.build,
              t.device, t.download, t.anchors, t.decide);
     std::cerr << buf << "\n";
+    for (const auto &l : round_lines) std::cerr << l << "\n";
   }
 
   // sigmap.cc:197-215: rows grouped by reference index, reads in input order inside a group
@@ -651,6 +702,10 @@ void ParseArgsAndRun(int argc, char *argv[]) {
 }  // namespace sigmap
 
 int main(int argc, char *argv[]) {
+  // The HIP runtime multiplexes a process's streams over 4 hardware queues unless told otherwise; the contexts of a
+  // GPU (--streams, three streams each) then wait for each other's kernels.  Read when the runtime initialises, i.e.
+  // at the first HIP call below; a value in the caller's environment wins.
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   sigmap::ParseArgsAndRun(argc, argv);
   return 0;
 }

@@ -10,11 +10,43 @@
 #include "utils.h"
 
 namespace sigmap {
-void SignalBatch::KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes) {
+void SignalBatch::KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes, uint32_t chunk_size, uint32_t max_chunks) {
   raw_mode_ = true;
   alloc_ = alloc;
   free_ = free_fn;
   block_bytes_ = block_bytes;
+  chunk_size_ = chunk_size;
+  max_chunks_ = max_chunks;
+}
+
+// Survivors of the (30, 200) pA filter among raw[0 .. n) -- signal_batch.cc:139-151's arithmetic: f32 add, f32 multiply,
+// two comparisons -- and the raw positions at which the filtered array reaches chunk_size, 2 chunk_size, ... samples.
+static size_t CountFiltered(const int16_t *raw, size_t n, float offset, float scale, uint32_t chunk_size, uint32_t max_chunks,
+                            std::vector<uint32_t> *bounds) {
+  size_t kept = 0, next = chunk_size;  // `next`: the filtered length at which the next chunk is complete
+  bounds->assign(1, 0u);
+  constexpr size_t kBlock = 512;
+  for (size_t i0 = 0; i0 < n; i0 += kBlock) {
+    const size_t m = std::min(kBlock, n - i0);
+    uint32_t cnt = 0;
+    for (size_t i = 0; i < m; ++i) {  // (vectorises: no dependence but the sum)
+      const float pa = ((float)raw[i0 + i] + offset) * scale;
+      cnt += (pa > 30 && pa < 200) ? 1u : 0u;
+    }
+    if (chunk_size && bounds->size() <= max_chunks && kept + cnt >= next) {  // a chunk ends inside this block
+      size_t k = kept;
+      for (size_t i = 0; i < m; ++i) {
+        const float pa = ((float)raw[i0 + i] + offset) * scale;
+        if (pa > 30 && pa < 200 && ++k == next) {
+          bounds->push_back((uint32_t)(i0 + i + 1));
+          next += chunk_size;
+          if (bounds->size() > max_chunks) break;
+        }
+      }
+    }
+    kept += cnt;
+  }
+  return kept;
 }
 
 SignalBatch::~SignalBatch() {
@@ -42,6 +74,8 @@ void SignalBatch::AddSignal(const std::string &id, float digitisation, float ran
     s.n_raw = n_raw;
     s.raw_block = (uint32_t)(blocks_.size() - 1);
     b.used += n_raw;
+    if (chunk_size_)
+      s.filtered_length = CountFiltered(s.raw, n_raw, offset, range / digitisation, chunk_size_, max_chunks_, &s.chunk_bounds);
     signals_.push_back(std::move(s));
     return;
   }

@@ -31,6 +31,11 @@ struct Signal {
   size_t n_raw = 0;
   uint32_t raw_block = 0;        // arena block holding the samples
   size_t filtered_length = 0;
+  // ... and, when the batch was told the chunk size (KeepRaw), where the chunks the mapper cuts out of the FILTERED
+  // array (sigmap.cc:637-652) begin in the RAW one: chunk c = the survivors of raw[chunk_bounds[c] .. chunk_bounds[c + 1]),
+  // exactly chunk_size of them; min(filtered_length / chunk_size, max_chunks) + 1 entries.  Counted at load time with
+  // AddSignal's own arithmetic, so the mapper can send the device one chunk's samples at a time.
+  std::vector<uint32_t> chunk_bounds;
   size_t GetSignalLength() const { return raw ? filtered_length : signal_values.size(); }
 };
 
@@ -70,7 +75,9 @@ class SignalBatch {
   // straddles two blocks.  Call before loading.
   typedef void *(*ArenaAlloc)(size_t bytes);
   typedef void (*ArenaFree)(void *p);
-  void KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes = (size_t)256 << 20);
+  // chunk_size > 0: every read also gets its filtered length and chunk_bounds (above) at load time.
+  void KeepRaw(ArenaAlloc alloc, ArenaFree free_fn, size_t block_bytes = (size_t)256 << 20, uint32_t chunk_size = 0,
+               uint32_t max_chunks = 0);
   bool raw_mode() const { return raw_mode_; }
   void SetFilteredLengthAt(size_t i, size_t n) { signals_[i].filtered_length = n; }
   // arena block b: base pointer (int16) and samples used
@@ -88,6 +95,7 @@ class SignalBatch {
   ArenaAlloc alloc_ = nullptr;
   ArenaFree free_ = nullptr;
   size_t block_bytes_ = 0;
+  uint32_t chunk_size_ = 0, max_chunks_ = 0;
   std::vector<Block> blocks_;
 };
 

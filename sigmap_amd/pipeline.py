@@ -244,6 +244,23 @@ class DeviceMapper:
         self._check(self.L.smhip_batch_select(self._h, ptr(sl), ptr(ci), chunk_size, self.n_chunks, ptr(qs), ptr(ca),
                                               ptr(co)), "smhip_batch_select")
 
+    def upload_pieces(self, pinned, begins, lens, digitisation, rng, offset, slots=None, expect=None):
+        """Pieces pinned[begins[r] : begins[r] + lens[r]] of a PinnedArray's int16 samples, pulled over PCIe by the
+        device, converted, filtered, piece r into slot slots[r] (smhip_reads_upload_pieces).  Asynchronous."""
+        arr = pinned.array
+        assert arr.dtype == np.int16 and arr.ndim == 1
+        n = len(begins)
+        base = arr.ctypes.data
+        ptrs = (C.c_void_p * max(n, 1))(*[base + 2 * int(b) for b in begins])
+        ln = np.ascontiguousarray(lens, dtype=np.uint32)
+        dg = np.ascontiguousarray(np.broadcast_to(np.float32(digitisation), (n,)), dtype=np.float32)
+        rg = np.ascontiguousarray(np.broadcast_to(np.float32(rng), (n,)), dtype=np.float32)
+        of = np.ascontiguousarray(np.broadcast_to(np.float32(offset), (n,)), dtype=np.float32)
+        sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.uint32)
+        ex = None if expect is None else np.ascontiguousarray(expect, dtype=np.uint32)
+        self._check(self.L.smhip_reads_upload_pieces(self._h, ptrs, ptr(ln), ptr(dg), ptr(rg), ptr(of), ptr(sl), ptr(ex), n),
+                    "smhip_reads_upload_pieces")
+
     def download_pa(self, slot, cap):
         pa = np.zeros(cap, np.float32)
         kept, total = C.c_uint32(), C.c_uint32()

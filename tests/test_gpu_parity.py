@@ -172,6 +172,45 @@ def test_raw_conversion_matches_oracle_addsignal(device):
     pin.close()
 
 
+def test_pieces_pulled_from_pinned_memory_match_addsignal(device):
+    """smhip_reads_upload_pieces: pieces at every 2-byte phase of a 16-byte unit, of every length around the
+    kernel's unit and segment boundaries (0, 1, 7, 8, 9, ... 4096 +- 1, 9000), with samples on both sides of the
+    (30, 200) pA cuts, end up in their slots exactly as the oracle's AddSignal leaves them (signal_batch.cc:139-151);
+    the samples around a piece never leak into it; and a wrong expect_len makes the next collecting call fail."""
+    rng = np.random.default_rng(31)
+    total = 400000
+    pin = pipeline.PinnedArray((total,), np.int16)
+    pin.array[:] = rng.integers(-400, 1600, size=total).astype(np.int16)
+    lens = [0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 256, 257, 4000, 4095, 4096, 4097, 8191, 8192, 9000]
+    begins, ln = [], []
+    at = 3
+    for k, n in enumerate(lens * 2):
+        at += int(rng.integers(0, 40))            # any phase
+        begins.append(at)
+        ln.append(n)
+        at += n
+    assert at < total
+    dg, rg, of = synth.DIGITISATION, synth.RANGE, synth.OFFSET
+    n = len(begins)
+    device.configure_reads(n + 3, 9000)
+    want = [po.add_signal(pin.array[b:b + l], dg, rg, of) for b, l in zip(begins, ln)]
+    slots = (np.arange(n, dtype=np.uint32)[::-1] + 2).copy()    # not the identity
+    device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=[len(w) for w in want])
+    for r in range(n):
+        got, kept, tot = device.download_pa(int(slots[r]), 9000)
+        assert kept == tot == len(want[r]), (r, ln[r], kept, len(want[r]))
+        assert np.array_equal(bits(got), bits(want[r])), (r, ln[r])
+    # the check against the host's count
+    bad = [len(w) for w in want]
+    bad[5] += 1
+    device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=bad)
+    with pytest.raises(RuntimeError):
+        device.sync()
+    device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=[len(w) for w in want])
+    device.sync()                                 # ... and the context goes on
+    pin.close()
+
+
 def test_resident_reads_give_the_same_records_as_uploaded_pa(device, small_world):
     """The two ways of feeding a batch -- pA chunks uploaded with the batch, or chunks cut on the device
     out of resident reads converted from raw ADC counts -- give identical result records, for one-chunk
@@ -1374,6 +1413,16 @@ def test_cli_index_and_streaming_map_match_oracle(tmp_path, small_world):
         if "--sdtw-band" in extra:
             dt = lambda l: [f for f in l.split("\t") if f.startswith("dt:f:")]
             assert [dt(l) for l in gots] == [dt(l) for l in got2]
+    # a chunk budget the device's memory cannot hold (the 250 Mb reference with the default --batch-chunks 32768: 20 MB
+    # per chunk, tests/test_host_index.py has the arithmetic): the CLI shrinks the rounds, says so, maps on -- here with
+    # the free memory it may count on faked down to 64 MiB, which leaves a context a handful of chunks per round
+    r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                        "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / "out_m.paf"),
+                        "--batch-chunks", "32768"], capture_output=True, text=True,
+                       env=dict(os.environ, SIGMAP_DEV_FREE_MB="64"))
+    assert r.returncode == 0, r.stderr
+    assert "Chunks in flight per context limited to" in r.stderr and "by the device's free memory (64 MiB)" in r.stderr
+    assert [strip(l) for l in open(tmp_path / "out_m.paf").read().splitlines()] == exp
     # more GPUs than the box has: a loud failure, no partial output
     n_gpu = _abi.hip_lib().smhip_device_count()
     r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),

@@ -174,6 +174,51 @@ def test_host_addsignal_matches_oracle_addsignal():
                 assert list(want[:3]) == [31.0, 199.0, 100.0]
 
 
+def test_chunk_bounds_cut_the_filtered_array_like_the_reference():
+    """The CLI's load phase (SignalBatch raw mode, smhost_chunk_bounds): the filtered length is the oracle's
+    AddSignal length, and chunk c of the FILTERED array (sigmap.cc:643-652) is exactly what AddSignal keeps of
+    raw[bounds[c] .. bounds[c + 1]) -- the piece the mapper sends to the device for that chunk.  Reads that lose
+    samples to both cuts (so that chunk boundaries move in the raw array), chunk sizes that do and do not divide the
+    block the counter works in, a max_chunks that ends the table early, reads shorter than a chunk."""
+    from oracle import pyoracle as po
+    L = _abi.host_lib()
+    rng = np.random.default_rng(23)
+    for case in range(60):
+        n = int(rng.integers(0, 70000)) if case % 5 else int(rng.choice([0, 1, 511, 512, 513, 3999, 4000, 4001]))
+        cs = int(rng.choice([4000, 512, 100, 1, 4096]))
+        max_chunks = int(rng.choice([0, 1, 3, 30, 1000]))
+        dg, rg, of = (8192.0, 1467.61, 10.0) if case % 3 else (2048.0, 748.58, 6.0)
+        raw = rng.integers(300, 1000, size=n).astype(np.int16)
+        if n:   # runs and single samples outside (30, 200) pA
+            for _ in range(int(rng.integers(0, 12))):
+                at = int(rng.integers(0, n))
+                raw[at:at + int(rng.integers(1, 700))] = 32767 if rng.random() < 0.5 else -3000
+        filt = po.add_signal(raw, dg, rg, of)
+        bounds = np.zeros(max_chunks + 2, np.uint32)
+        flen = C.c_uint64()
+        nb = L.smhost_chunk_bounds(_abi.ptr(raw), n, dg, rg, of, cs, max_chunks, _abi.ptr(bounds), len(bounds), C.byref(flen))
+        assert flen.value == len(filt), case
+        assert nb == min(len(filt) // cs, max_chunks) + 1 and bounds[0] == 0, (case, nb, len(filt), cs, max_chunks)
+        for c in range(nb - 1):
+            piece = po.add_signal(raw[bounds[c]:bounds[c + 1]], dg, rg, of)
+            assert len(piece) == cs and np.array_equal(bits(piece), bits(filt[c * cs:(c + 1) * cs])), (case, c)
+
+
+def test_chunk_budget_for_the_baseline_reference_sizes():
+    """What `sigmap -m` lets a context have in flight (host/mapping_logic.h ChunkBudgetForMemory): the default request
+    of 32768 chunks over two contexts stands on a 12 Mb reference and is cut to a few thousand on a 250 Mb one
+    (4.98e8 points: ~850 hits per query, 1024 fast slots: 20 MB per chunk) instead of failing in hipMalloc; never 0."""
+    L = _abi.host_lib()
+    free = 250 << 30
+    small = L.smhost_chunk_budget(free, 4000, 512, 41.0, 2)
+    big = L.smhost_chunk_budget(free, 4000, 1024, 850.0, 2)
+    assert small >= 16384                      # 32768 / 2 contexts fits
+    assert 2000 <= big <= 4000                 # (the 250 Mb shard test maps 8 000-chunk batches in ~170 GB with ONE context)
+    assert big * 2 * 20.5e6 < free * 0.55
+    assert L.smhost_chunk_budget(1 << 20, 4000, 2048, 5000.0, 8) == 1
+    assert L.smhost_chunk_budget(free, 4000, 1024, 1e9, 2) == L.smhost_chunk_budget(free, 4000, 1024, 5000.0, 2)
+
+
 def test_paf_logic_matches_oracle(small_world, oracle_tree):
     """smhost_format_paf on records assembled from the ORACLE's chains reproduces the oracle's
     own PAF text: pins the host-side decision/format code independently of the GPU."""

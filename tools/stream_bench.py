@@ -125,6 +125,10 @@ def main():
         j = json.loads(st[-1][len("STREAM_STATS "):])
         j["process_wall_s"] = round(wall, 3)
         runs.append(j)
+    if os.environ.get("STREAM_ROUNDS_OUT"):    # one more run that logs every chunk round of every lane
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, SIGMAP_STREAM_STATS="2"))
+        with open(os.environ["STREAM_ROUNDS_OUT"], "w") as fh:
+            fh.write("\n".join(l for l in r.stderr.splitlines() if l.startswith("STREAM_")) + "\n")
     if a.rocprof_dir:
         os.makedirs(a.rocprof_dir, exist_ok=True)
         subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", a.rocprof_dir, "--"] + cmd,
