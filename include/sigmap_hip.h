@@ -322,6 +322,12 @@ int smhip_map_sync(smhip_ctx *ctx);
 int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results,
                        smhip_carried_anchor *chain_anchors, uint64_t chain_anchor_cap,
                        uint64_t *chain_anchor_offsets /* n_chunks+1 */);
+/* The chain anchors of SOME chunks of the batch -- the reads a streaming round carries into its next chunk
+ * (spatial_index.cc:303-322), which the caller knows once it has applied the stop rules to the result records:
+ * chain_anchor_offsets[i] .. [i + 1] = the anchors of all primary chains of chunk chunks[i], as smhip_map_download
+ * hands them out for every chunk.  SMHIP_ECAP when chain_anchor_cap is too small (offsets are valid then). */
+int smhip_map_download_anchors_of(smhip_ctx *ctx, const uint32_t *chunks, uint32_t n_listed, smhip_carried_anchor *chain_anchors,
+                                  uint64_t chain_anchor_cap, uint64_t *chain_anchor_offsets);
 /* EVERY primary chain of every chunk (the std::vector<SignalAnchorChain> GenerateChains hands back,
  * spatial_index.cc:552-576; the result record only holds the first SMHIP_TOPK), in rank order: chunk c's at
  * chains[chain_offsets[c] .. chain_offsets[c + 1]); their anchors are smhip_map_download's chain_anchors, chain after

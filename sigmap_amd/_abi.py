@@ -22,7 +22,7 @@ HIP_SYMBOLS = [
     "smhip_reference_upload", "smhip_reference_share", "smhip_mem_info", "smhip_refine_run", "smhip_refine_download", "smhip_debug_counters", "smhip_timing_enable", "smhip_timing_reset", "smhip_timing_get", "smhip_events", "smhip_events_raw",
     "smhip_seed_lookup", "smhip_sdtw_banded", "smhip_cwt_features",
     "smhip_reads_configure", "smhip_reads_upload_raw", "smhip_batch_select", "smhip_reads_download_pa",
-    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_batch_reserve_for", "smhip_reads_upload_pieces", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
+    "smhip_host_alloc", "smhip_host_free", "smhip_batch_reserve", "smhip_batch_reserve_for", "smhip_reads_upload_pieces", "smhip_map_download_anchors_of", "smhip_index_export_copy", "smhip_index_bcast", "smhip_index_bcast_loopback", "smhip_device_count", "smhip_dtw_path", "smhip_refine_path_run", "smhip_refine_path_download",
     "smhip_index_census", "smhip_dev_knob", "smhip_resolved_params", "smhip_features_upload", "smhip_generate_chains",
     "smhip_chain_anchors", "smhip_map_download_chains", "smhip_debug_sort_stats",
     "smhip_debug_start_coef_sweep", "smhip_debug_div_window_sweep",
@@ -245,6 +245,7 @@ def hip_lib():
         L.smhip_batch_reserve.argtypes = [vp, u32, u32]
         L.smhip_batch_reserve_for.argtypes = [vp, vp, u32, u32]
         L.smhip_reads_upload_pieces.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32]
+        L.smhip_map_download_anchors_of.argtypes = [vp, vp, u32, vp, C.c_uint64, vp]
         L.smhip_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
         L.smhip_host_free.argtypes = [vp]
         L.smhip_host_free.restype = None

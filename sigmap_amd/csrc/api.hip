@@ -128,6 +128,21 @@ __global__ void CompactAnchorsKernel(const smhip_carried_anchor *__restrict__ sr
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[o + i] = src[b + i];
 }
 
+// the same for a LIST of chunks (smhip_map_download_anchors_of): counts of the listed chunks, then their anchors
+__global__ void ListedAnchorCountKernel(const uint32_t *__restrict__ list, uint32_t n, const uint32_t *__restrict__ cnt,
+                                        uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = cnt[list[i]];
+}
+__global__ void CompactListedAnchorsKernel(const smhip_carried_anchor *__restrict__ src, const uint64_t *__restrict__ anchor_off,
+                                           const uint32_t *__restrict__ list, const uint64_t *__restrict__ out_off,
+                                           smhip_carried_anchor *__restrict__ dst) {
+  const uint32_t i = blockIdx.x;
+  const uint64_t b = anchor_off[list[i]], o = out_off[i];
+  const uint32_t n = (uint32_t)(out_off[i + 1] - o);
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[o + k] = src[b + k];
+}
+
 __global__ void OrStatusKernel(smhip_chunk_result *results, uint32_t n, const uint32_t *counters) {
   uint32_t bits = 0;
   if (counters[0]) bits |= SMHIP_ST_STACK_FULL;
@@ -1078,6 +1093,9 @@ int smhip_batch_reserve_for(smhip_ctx *ctx, const smhip_params *params, uint32_t
   }
   HIPCHK(ctx->qrec.Reserve(nq * 32));
   HIPCHK(ctx->ovf_pool.Reserve((nq * 64 + (1u << 22)) * sizeof(Hit)));
+  if (ctx->res_fast != p.hits_per_query_fast) ctx->res_nq = 0;
+  ctx->res_fast = p.hits_per_query_fast;
+  ctx->res_nq = std::max(ctx->res_nq, nq);
   // ... and the anchor-sized ones at the index's own estimate: the census' mean of min(hits, num_nearest_points) per
   // query, a quarter on top (what a speculative batch would ask for) -- within a sixth of the device; a batch that
   // needs more grows them as before
@@ -1189,6 +1207,9 @@ int EnqueueSearch(smhip_ctx *ctx, const smhip_params *p, uint32_t R, uint64_t nq
   HIPCHK(ctx->qrec.Reserve(nq_cap * 32));
   HIPCHK(ctx->q_ovf_off.Reserve(nq_cap * kOvfLevels * sizeof(uint32_t)));
   HIPCHK(ctx->ovf_pool.Reserve(pool_cap * sizeof(Hit)));
+  if (ctx->res_fast != p->hits_per_query_fast) ctx->res_nq = 0;
+  ctx->res_fast = p->hits_per_query_fast;
+  ctx->res_nq = std::max(ctx->res_nq, nq_cap);
   HIPCHK(LaunchQueryExpand(ctx, *p, ctx->feat.as<float>(), kFeatStride, ctx->q_off.as<uint32_t>(), R, ctx->qrec.p));
   HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
   // (timers inside: "seed_order" = the visiting-order kernels, "seed_lookup" = the walker launch alone)
@@ -1211,6 +1232,7 @@ int ReserveAnchorBuffers(smhip_ctx *ctx, uint64_t na_cap, uint32_t R) {
   HIPCHK(ctx->keys.Reserve(std::max<uint64_t>(SortRecordRoom(na, R), na) * 2 * sizeof(uint64_t)));  // the sort's records (5/3 per anchor)
   HIPCHK(ctx->used.Reserve(na));
   HIPCHK(ctx->out_anchors.Reserve(na * sizeof(smhip_carried_anchor)));
+  ctx->res_na = std::max(ctx->res_na, na_cap);
   return SMHIP_OK;
 }
 
@@ -1394,6 +1416,10 @@ int RunBatchSync(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, bool re
 int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) {
   const uint32_t R = ctx->n_chunks;
   uint64_t nq_cap = SpecCapQueries(ctx, R), na_cap = SpecCapAnchors(ctx, R);
+  // ... or whatever the buffers already hold room for: a small batch after large ones (the tail of a streaming run, whose
+  // junk chunks have several times the queries per chunk of the chunks before them) then never outgrows a capacity
+  if (ctx->res_fast == p->hits_per_query_fast) nq_cap = std::max(nq_cap, std::min<uint64_t>(ctx->res_nq, 0xFFFFFFF0ull));
+  na_cap = std::max(na_cap, ctx->res_na);
   // (knob spec_tight: 1 halves the query capacity, 2 the anchor capacity, so that the guards fire and the batch is
   // repeated on the synchronous route)
   if (ctx->knobs.spec_tight == 1) nq_cap = std::max<uint64_t>((uint64_t)R * ctx->hint_q_per_chunk / 2, 1);
@@ -1633,6 +1659,51 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
   }
+  return SMHIP_OK;
+}
+
+int smhip_map_download_anchors_of(smhip_ctx *ctx, const uint32_t *chunks, uint32_t n_listed, smhip_carried_anchor *chain_anchors,
+                                  uint64_t chain_anchor_cap, uint64_t *chain_anchor_offsets) {
+  if (!ctx || !chain_anchor_offsets || (n_listed && (!chunks || !chain_anchors))) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download_anchors_of before smhip_map_run");
+  HIPCHK(hipSetDevice(ctx->device));
+  chain_anchor_offsets[0] = 0;
+  if (n_listed == 0 || ctx->n_chunks == 0) return SMHIP_OK;
+  for (uint32_t i = 0; i < n_listed; ++i)
+    if (chunks[i] >= ctx->n_chunks) return Fail(ctx, SMHIP_EINVAL, "listed chunk outside the batch");
+  {
+    int rc0 = FinishRun(ctx);
+    if (rc0) return rc0;
+  }
+  const uint64_t n = n_listed;
+  DevBuf &out_off = ctx->dl_off, &compact = ctx->dl_compact;
+  // [offsets: n + 1 x u64][list: n x u32][counts: n x u32]
+  HIPCHK(out_off.Reserve((n + 1) * sizeof(uint64_t) + 2 * n * sizeof(uint32_t)));
+  uint32_t *d_list = reinterpret_cast<uint32_t *>(out_off.as<uint64_t>() + n + 1), *d_cnt = d_list + n;
+  HIPCHK(StageReserve(ctx, (n + 1) * sizeof(uint64_t)));
+  memcpy(ctx->h_stage, chunks, n * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(d_list, ctx->h_stage, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(ListedAnchorCountKernel, dim3((n_listed + 255) / 256), dim3(256), 0, ctx->stream, d_list, n_listed,
+                     ctx->out_anchor_cnt.as<uint32_t>(), d_cnt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(LaunchScanU32ToU64(ctx, d_cnt, n_listed, out_off.as<uint64_t>()));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // (the list has left the staging)
+  HIPCHK(hipMemcpyAsync(ctx->h_stage, out_off.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(chain_anchor_offsets, ctx->h_stage, (n + 1) * sizeof(uint64_t));
+  const uint64_t total = chain_anchor_offsets[n];
+  if (total > chain_anchor_cap) return Fail(ctx, SMHIP_ECAP, "chain_anchor_cap too small");
+  if (total == 0) return SMHIP_OK;
+  HIPCHK(compact.Reserve(total * sizeof(smhip_carried_anchor)));
+  hipLaunchKernelGGL(CompactListedAnchorsKernel, dim3(n_listed), dim3(64), 0, ctx->stream,
+                     ctx->out_anchors.as<smhip_carried_anchor>(), ctx->anchor_off.as<uint64_t>(), d_list, out_off.as<uint64_t>(),
+                     compact.as<smhip_carried_anchor>());
+  HIPCHK(hipGetLastError());
+  // (through the pinned staging: one DMA instead of the pieces a copy into pageable memory is cut into)
+  HIPCHK(StageReserve(ctx, total * sizeof(smhip_carried_anchor)));
+  HIPCHK(hipMemcpyAsync(ctx->h_stage, compact.p, total * sizeof(smhip_carried_anchor), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  memcpy(chain_anchors, ctx->h_stage, total * sizeof(smhip_carried_anchor));
   return SMHIP_OK;
 }
 

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     }
     PHASE_MARK(2);
     fmask_prev = __ballot(found);  // (for the next tile: an anchor settled here still counts -- its score is not its start score)
+    uint32_t sc_bits = 0;  // score bits of an anchor finished here (positive floats order like their bits); 0: none
     if (ai < n) {
       if (!found || settled) {
         const float sc = settled ? settled_score : my_coef * (float)dim;
@@ -473,11 +474,20 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
         // (chained here: listed by ChainPendingKernel for the end search -- its score can reach min_chaining_score --
         // but not for the DP; that kernel clears the flag)
         used[ai] = settled ? 3 : 0;
-        atomicMax(&s_gmax[ord - first_ord], __float_as_uint(sc));  // (a tile of 64 anchors touches <= 64 buckets)
+        sc_bits = __float_as_uint(sc);
       } else {
         used[ai] = 2;  // listed for the sequential kernels by ChainPendingKernel
         pred[ai] = ord;  // (until the DP writes the predecessor: the anchor's bucket ordinal, which the DP needs)
       }
+    }
+    // bucket maxima of the tile.  Most tiles lie inside ONE bucket: 64 lanes raising the same LDS word were 64
+    // serialised passes of the atomic unit (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.39-0.40 for this kernel,
+    // profiles/r4_*_pmc_per_launch.csv); the maximum of the wave is six DPP steps.
+    if (ord_last == first_ord) {  // (wave-uniform)
+      const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane((int)WaveScanMaxU32(sc_bits), 63);
+      if (lane == 0) s_gmax[0] = mx;
+    } else if (sc_bits) {
+      atomicMax(&s_gmax[ord - first_ord], sc_bits);  // (a tile of 64 anchors touches <= 64 buckets)
     }
     PHASE_MARK(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");

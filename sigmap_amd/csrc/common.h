@@ -278,6 +278,11 @@ struct smhip_ctx {
   // speculative batches (api.hip RunBatchSpeculative): queries / non-carried anchors per chunk of the largest
   // batch so far, the pinned record the stream reports a batch's totals and flags in, what a repeat needs
   uint64_t hint_q_per_chunk = 0, hint_a_per_chunk = 0;
+  // the largest query / anchor capacities the grow-only buffers have been reserved for (res_fast: the fast hit slots per
+  // query the query-sized ones were laid out with): a later, smaller batch may use all of it -- a batch of the junk
+  // chunks of a streaming run has three times the queries per chunk its predecessors had
+  uint64_t res_nq = 0, res_na = 0;
+  uint32_t res_fast = 0;
   bool hint_valid = false, spec_pending = false;
   void *h_run_info = nullptr;
   void *h_stage = nullptr;   // pinned staging of small transfers to / from pageable caller memory (api.hip StageReserve)

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
-  const uint32_t hand_thr = max(scan_threshold >> 16, 1u);  // (the launch packs two thresholds into the argument)
+  uint32_t hand_thr = max(scan_threshold >> 16, 1u);  // (the launch packs two thresholds into the argument)
   scan_threshold &= 0xFFFFu;
   constexpr bool kSet = kMode == kWalkSet;
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
@@ -256,6 +256,21 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   // (a wave whose own range is exhausted takes from the other ranges), so that neither a lane nor
   // a wave nor an XCD idles while another still has a backlog.
   uint32_t pool_next = 0, pool_end = 0, victim = 0;
+  // ... 64 at a time when there is work for every lane of the launch; a SMALL batch (the tail rounds of a streaming
+  // run: a hundred chunks, 30 000 queries for 262 144 lanes) is spread thinly instead, 8 to 32 queries per wave: a
+  // wave lasts as long as its slowest query, and the slowest of 8 ends well before the slowest of 64 (2.1 -> ms of a
+  // 3 ms round: profiles/EXPERIMENTS.md, round 5).  Speed only.
+  uint32_t grab = 64u;
+  {
+    const uint32_t n_waves = gridDim.x * (uint32_t)(kThreads / 64);
+    const uint32_t per_wave = (total + n_waves - 1u) / n_waves;
+    if (per_wave <= 32u) grab = per_wave <= 8u ? 8u : per_wave <= 16u ? 16u : 32u;
+  }
+  if (lane >= grab) mode = M_IDLE;  // (the other lanes of such a wave never take a query)
+  if (grab < 64u) {                 // ... and the two thresholds, which count lanes, shrink with the lanes in use
+    scan_threshold = max(1u, scan_threshold * grab / 64u);
+    hand_thr = max(1u, hand_thr * grab / 64u);
+  }
   unsigned long long pt_scan = 0, pt_wait = 0, pt_fetchq = 0, pt_visit = 0, pt_scan_setup = 0, pt_scan_load = 0;
   const unsigned long long pt_begin = WALK_T();
   for (;;) {
@@ -523,13 +538,13 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         while (victim < n_ranges) {
           const uint32_t xx = (first_range + victim) % n_ranges;
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&cursors[xx], 64u);
+          if (lane == 0) base = atomicAdd(&cursors[xx], grab);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           const uint32_t rb = (range_end && xx) ? range_end[xx * range_stride - 1] : 0u;
           const uint32_t re = range_end ? range_end[(xx + 1) * range_stride - 1] : total;
           if (base < re - rb) {
             pool_next = rb + base;
-            pool_end = min(re, pool_next + 64u);
+            pool_end = min(re, pool_next + grab);
             got = true;
             break;
           }

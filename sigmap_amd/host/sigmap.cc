@@ -270,6 +270,15 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
           if (rc == SMHIP_OK && sdtw_band > 0 && sdtw_cigar) rc = smhip_refine_path_run(ctx, (uint32_t)sdtw_band, 32);
           if (rc == SMHIP_OK) rc = smhip_map_sync(ctx);
           if (rc == SMHIP_OK) rc = smhip_map_download(ctx, res.data(), nullptr, 0, nullptr);
+          if (rc == SMHIP_OK) {  // ... and the anchors of every chunk, as a later round may ask for them
+            std::vector<uint64_t> off(n + 1);
+            std::vector<smhip_carried_anchor> anch(1);
+            rc = smhip_map_download_anchors_of(ctx, slots.data(), n, anch.data(), 0, off.data());
+            if (rc == SMHIP_ECAP) {
+              anch.resize(off[n]);
+              rc = smhip_map_download_anchors_of(ctx, slots.data(), n, anch.data(), anch.size(), off.data());
+            }
+          }
           if (rc != SMHIP_OK) failed[(size_t)g * (size_t)num_streams + k] = smhip_last_error(ctx);
         });
     for (auto &w : warm) w.join();
@@ -290,7 +299,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   // to the return of smhip_map_sync -- the host thread only waits there; everything else is host time between rounds.
   struct LaneStats {
     double admit = 0, build = 0, device = 0, download = 0, anchors = 0, decide = 0;
-    uint64_t rounds = 0, chunks = 0, carried_up = 0, anchors_down = 0, continued = 0, max_batch = 0;
+    uint64_t rounds = 0, chunks = 0, carried_up = 0, anchors_down = 0, continued = 0, max_batch = 0, spec_runs = 0, spec_reruns = 0;
   };
   const bool want_stats = getenv("SIGMAP_STREAM_STATS") != nullptr;
   const bool want_rounds = want_stats && atoi(getenv("SIGMAP_STREAM_STATS")) >= 2;  // ... and one line per chunk round
@@ -306,7 +315,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       t_mark = now;
     };
     std::vector<size_t> batch, in_flight;
-    std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, plen, expect;
+    std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, plen, expect, want, want_at;
     std::vector<const int16_t *> pieces;
     std::vector<float> dig, rng, ofs;
     std::vector<smhip_carried_anchor> carried, out_anchors;
@@ -397,24 +406,32 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       if (rc == SMHIP_OK) rc = smhip_map_download(ctx, results.data(), nullptr, 0, nullptr);
       if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
       lap(ls.download);
-      bool any_continues = false;
-      for (size_t bi = 0; bi < batch.size() && !any_continues; ++bi) {
+      // the chains' anchors -- the next chunk's carry-over, spatial_index.cc:303-322 -- of the reads that go on to
+      // another chunk with NEW chains (a chunk with <= 50 features keeps the chains it came with, sigmap.cc:660), and of
+      // those only: two reads in three stop here
+      want.clear();
+      want_at.assign(batch.size(), 0xFFFFFFFFu);
+      for (size_t bi = 0; bi < batch.size(); ++bi) {
         const size_t r = batch[bi];
         const smhip_chunk_result &res = results[bi];
-        const bool stop = res.n_features > 50 && ShouldStopMapping(res, params_);
-        any_continues = !stop && st[r].chunk_index + 1 < num_chunks[r] && st[r].chunk_index + 1 < max_chunks;
+        if (res.n_features > 50 && !ShouldStopMapping(res, params_) && st[r].chunk_index + 1 < num_chunks[r] &&
+            st[r].chunk_index + 1 < max_chunks) {
+          want_at[bi] = (uint32_t)want.size();
+          want.push_back((uint32_t)bi);
+        }
       }
-      if (any_continues) {
+      if (!want.empty()) {
         uint64_t cap = std::max<uint64_t>(out_anchors.size(), 1 << 20);
+        out_off.resize(want.size() + 1);
         while (rc == SMHIP_OK) {
           out_anchors.resize(cap);
-          rc = smhip_map_download(ctx, results.data(), out_anchors.data(), cap, out_off.data());
+          rc = smhip_map_download_anchors_of(ctx, want.data(), (uint32_t)want.size(), out_anchors.data(), cap, out_off.data());
           if (rc != SMHIP_ECAP) break;
-          cap *= 4;
+          cap = std::max<uint64_t>(cap * 2, out_off[want.size()]);
           rc = SMHIP_OK;
         }
         if (rc != SMHIP_OK) ExitWithMessage(std::string("GPU mapping failed: ") + smhip_last_error(ctx));
-        ls.anchors_down += out_off[batch.size()];
+        ls.anchors_down += out_off[want.size()];
       }
       lap(ls.anchors);
       in_flight.clear();
@@ -436,8 +453,8 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
           if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen_path[bi]);
           s.num_events += res.n_features;
           stop = ShouldStopMapping(res, params_);
-          if (any_continues && !stop && s.chunk_index + 1 < num_chunks[r] && s.chunk_index + 1 < max_chunks)
-            s.anchors.assign(out_anchors.begin() + out_off[bi], out_anchors.begin() + out_off[bi + 1]);
+          if (want_at[bi] != 0xFFFFFFFFu)
+            s.anchors.assign(out_anchors.begin() + out_off[want_at[bi]], out_anchors.begin() + out_off[want_at[bi] + 1]);
         }
         if (!stop) {
           ++s.chunk_index;
@@ -461,7 +478,15 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         prev = ls;
       }
     }
+    {
+      uint32_t dc[16] = {0};  // [4] batches mapped a second time after a speculative run outgrew a buffer, [5] speculative runs
+      if (smhip_debug_counters(ctx, dc) == SMHIP_OK) {
+        ls.spec_reruns = dc[4];
+        ls.spec_runs = dc[5];
+      }
+    }
     std::lock_guard<std::mutex> lock(stats_mutex);
+    total_stats.spec_runs += ls.spec_runs; total_stats.spec_reruns += ls.spec_reruns;
     total_stats.admit += ls.admit; total_stats.build += ls.build; total_stats.device += ls.device;
     total_stats.download += ls.download; total_stats.anchors += ls.anchors; total_stats.decide += ls.decide;
     total_stats.rounds += ls.rounds; total_stats.chunks += ls.chunks; total_stats.carried_up += ls.carried_up;
@@ -485,10 +510,12 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     snprintf(buf, sizeof buf,
              "STREAM_STATS {\"reads\": %zu, \"span_s\": %.6f, \"lanes\": %d, \"chunks_in_flight_per_lane\": %zu, \"rounds\": %llu, "
              "\"chunks\": %llu, \"max_batch\": %llu, \"carried_anchors_uploaded\": %llu, \"anchors_downloaded\": %llu, "
+             "\"speculative_batches\": %llu, \"batches_mapped_twice\": %llu, "
              "\"lane_seconds\": {\"admit_upload\": %.6f, \"build_batch\": %.6f, \"device\": %.6f, \"download_results\": %.6f, "
              "\"download_anchors\": %.6f, \"decide\": %.6f}}",
              num_reads, map_span, (int)lanes, lane_budget, (unsigned long long)t.rounds, (unsigned long long)t.chunks,
-             (unsigned long long)t.max_batch, (unsigned long long)t.carried_up, (unsigned long long)t.anchors_down, t.admit, t.build,
+             (unsigned long long)t.max_batch, (unsigned long long)t.carried_up, (unsigned long long)t.anchors_down,
+             (unsigned long long)t.spec_runs, (unsigned long long)t.spec_reruns, t.admit, t.build,
              t.device, t.download, t.anchors, t.decide);
     std::cerr << buf << "\n";
     for (const auto &l : round_lines) std::cerr << l << "\n";

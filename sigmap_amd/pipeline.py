@@ -290,6 +290,18 @@ class DeviceMapper:
             self._check(rc, "smhip_map_download")
             return res, anchors[:int(offs[-1])], offs
 
+    def download_anchors_of(self, chunks):
+        """The chain anchors of the listed chunks of the batch (smhip_map_download_anchors_of): (anchors, offsets)."""
+        ch = np.ascontiguousarray(chunks, dtype=np.uint32)
+        offs = np.zeros(len(ch) + 1, dtype=np.uint64)
+        anchors = np.zeros(1, dtype=_abi.CARRIED_DTYPE)
+        rc = self.L.smhip_map_download_anchors_of(self._h, ptr(ch), len(ch), ptr(anchors), 0, ptr(offs))
+        if rc == -5:
+            anchors = np.zeros(int(offs[-1]), dtype=_abi.CARRIED_DTYPE)
+            rc = self.L.smhip_map_download_anchors_of(self._h, ptr(ch), len(ch), ptr(anchors), len(anchors), ptr(offs))
+        self._check(rc, "smhip_map_download_anchors_of")
+        return anchors[:int(offs[-1])], offs
+
     def download_chains(self):
         """Every primary chain of every chunk (smhip_map_download_chains): (records, offsets)."""
         offs = np.zeros(self.n_chunks + 1, dtype=np.uint64)

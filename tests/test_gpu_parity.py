@@ -1088,6 +1088,16 @@ def test_chain_anchor_carry_over_roundtrip(device, small_world, oracle_tree):
     device.upload_batch(samples, offsets)
     device.run(3); device.sync()
     r1, anchors, aoff = device.download(with_anchors=True)
+    # the anchors of SOME chunks (what a streaming round asks for: the reads that go on), any order, a chunk twice, none
+    for pick in ([7, 2, 2, 11, 0], list(range(12)), [5], []):
+        got, goff = device.download_anchors_of(pick)
+        assert len(goff) == len(pick) + 1 and goff[0] == 0
+        for k, c in enumerate(pick):
+            want = anchors[int(aoff[c]):int(aoff[c + 1])]
+            assert got[int(goff[k]):int(goff[k + 1])].tobytes() == want.tobytes(), (pick, k)
+    assert len(anchors) > 0
+    with pytest.raises(RuntimeError):
+        device.download_anchors_of([12])
     second = [x[4000:8000] for x in pa]
     samples2, offsets2 = _batch(second)
     qstart = np.array([r["n_features"] if r["n_features"] > 50 else 0 for r in r1], np.uint32)

@@ -155,6 +155,7 @@ def main():
         "rounds": j["rounds"], "lanes": j["lanes"], "mean_batch": round(j["chunks"] / max(j["rounds"], 1), 1), "max_batch": j["max_batch"],
         "chunks_in_flight_per_lane": j["chunks_in_flight_per_lane"],
         "carried_anchors_uploaded": j["carried_anchors_uploaded"], "anchors_downloaded": j["anchors_downloaded"],
+        "speculative_batches": j.get("speculative_batches"), "batches_mapped_twice": j.get("batches_mapped_twice"),
         "lane_seconds": ls,
         # a lane's wall time outside [first enqueue of a round, return of its sync]: stop rules, carry-over, admission
         "host_share_of_lane_time": round(host_between / max(lane_total, 1e-9), 4),
