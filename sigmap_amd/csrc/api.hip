@@ -976,6 +976,17 @@ int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, cons
   }
   seg_start[n_pieces] = (uint32_t)n_segs;
   if (expect_len) memcpy(expect, expect_len, exp_bytes);
+  // The device dereferences the pieces' addresses: memory it cannot reach would be a GPU fault, not an error code.  The
+  // first and the last piece are looked up (a lookup per piece would cost more than the upload); the contract -- every
+  // piece in memory from smhip_host_alloc -- is the caller's to keep for the rest.
+  for (uint32_t r : {0u, n_pieces - 1u}) {
+    if (piece_len[r] == 0) continue;
+    void *dev_view = nullptr;
+    if (hipHostGetDevicePointer(&dev_view, const_cast<int16_t *>(pieces[r]), 0) != hipSuccess || dev_view == nullptr) {
+      (void)hipGetLastError();
+      return Fail(ctx, SMHIP_EINVAL, "smhip_reads_upload_pieces: the pieces must lie in pinned host memory (smhip_host_alloc)");
+    }
+  }
   // (the staged samples are also what smhip_reads_upload_raw copies into: its DMA waits for convert_done, recorded below)
   HIPCHK(ctx->reads_raw.Reserve(std::max<uint64_t>(units, 1) * 16));
   HIPCHK(ctx->reads_meta.Reserve(meta_bytes));

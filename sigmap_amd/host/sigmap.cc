@@ -167,7 +167,6 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     float dt = 0;                    // sDTW distance of those chains' best (when --sdtw-band)
     bool has_dt = false;
     std::string cigar;               // per-base CIGAR of DTW()'s banded path (when --sdtw-cigar)
-    std::vector<smhip_carried_anchor> anchors;  // anchors of those chains
     double start_time = 0;
   };
   std::vector<ReadState> st(num_reads);
@@ -326,10 +325,13 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     std::vector<uint32_t> plen_path;
     std::vector<uint64_t> poff;
     std::vector<uint8_t> pcodes;
+    // the carry-over of the reads in flight (the anchors of their chains, spatial_index.cc:303-322), in in_flight order:
+    // next_off[i] .. next_off[i + 1] of next_carried belongs to in_flight[i].  Built while a round's results are looked
+    // at, handed to the next round as it is: an anchor is copied once on its way from one download to the next upload.
+    std::vector<smhip_carried_anchor> next_carried;
+    std::vector<uint32_t> next_off(1, 0u);
     auto finish = [&](size_t r) {
       ReadState &s = st[r];
-      s.anchors.clear();
-      s.anchors.shrink_to_fit();
       s.start_time = (GetRealTime() - s.start_time) * 1000;
     };
     while (true) {
@@ -343,8 +345,12 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       const double now = GetRealTime();
       for (size_t r = a; r < b; ++r) {
         st[r].start_time = now;
-        if (num_chunks[r] == 0 || max_chunks == 0) finish(r);
-        else in_flight.push_back(r);
+        if (num_chunks[r] == 0 || max_chunks == 0) {
+          finish(r);
+        } else {
+          in_flight.push_back(r);
+          next_off.push_back(next_off.back());  // (a new read carries nothing)
+        }
       }
       lap(ls.admit);
       if (in_flight.empty()) {
@@ -355,8 +361,10 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       const size_t nb = batch.size();
       pieces.resize(nb); plen.resize(nb); expect.assign(nb, chunk_size); dig.resize(nb); rng.resize(nb); ofs.resize(nb);
       slots.resize(nb); chunk_idx.assign(nb, 0u); qstart.resize(nb);
-      carried.clear();
-      carried_off.assign(1, 0);
+      carried.swap(next_carried);
+      carried_off.swap(next_off);  // (nb + 1 entries)
+      next_carried.clear();
+      next_off.assign(1, 0u);
       for (size_t bi = 0; bi < nb; ++bi) {
         const size_t r = batch[bi];
         const Signal &sig = reads.GetSignalAt(r);
@@ -366,8 +374,6 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         dig[bi] = sig.digitisation; rng[bi] = sig.range; ofs[bi] = sig.offset;
         slots[bi] = (uint32_t)bi;  // a slot lives for one round: chunk bi of the batch
         qstart[bi] = st[r].num_events;
-        carried.insert(carried.end(), st[r].anchors.begin(), st[r].anchors.end());
-        carried_off.push_back((uint32_t)carried.size());
       }
       results.resize(nb);
       out_off.resize(nb + 1);
@@ -453,13 +459,18 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
           if (sdtw_band > 0 && sdtw_cigar && pend[bi] >= 0) s.cigar = PrintAlignment(pcodes.data() + poff[bi], plen_path[bi]);
           s.num_events += res.n_features;
           stop = ShouldStopMapping(res, params_);
-          if (want_at[bi] != 0xFFFFFFFFu)
-            s.anchors.assign(out_anchors.begin() + out_off[want_at[bi]], out_anchors.begin() + out_off[want_at[bi] + 1]);
         }
         if (!stop) {
           ++s.chunk_index;
           if (s.chunk_index < num_chunks[r] && s.chunk_index < max_chunks) {
             in_flight.push_back(r);
+            // its carry-over: the new chains' anchors, or -- a chunk with <= 50 features -- the ones it came with
+            if (want_at[bi] != 0xFFFFFFFFu)
+              next_carried.insert(next_carried.end(), out_anchors.begin() + out_off[want_at[bi]],
+                                  out_anchors.begin() + out_off[want_at[bi] + 1]);
+            else
+              next_carried.insert(next_carried.end(), carried.begin() + carried_off[bi], carried.begin() + carried_off[bi + 1]);
+            next_off.push_back((uint32_t)next_carried.size());
             continue;
           }
         }

@@ -208,6 +208,11 @@ def test_pieces_pulled_from_pinned_memory_match_addsignal(device):
         device.sync()
     device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=[len(w) for w in want])
     device.sync()                                 # ... and the context goes on
+
+    class Pageable:                               # ordinary host memory: refused with an error code, not a GPU fault
+        array = np.zeros(20000, np.int16)
+    with pytest.raises(RuntimeError, match="pinned"):
+        device.upload_pieces(Pageable, [5, 9000], [4000, 4000], dg, rg, of)
     pin.close()
 
 
