@@ -59,6 +59,8 @@ def parse():
                     help="smhip_params.search_mode (auto: decided from the index census)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU-baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="skip the `streaming` block (tools/stream_bench.py: multi-chunk reads through `sigmap -m`, N = 1 only)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive timed region")
     ap.add_argument("--same-reads", action="store_true", help="one read set for every step and context (rounds 1-3)")
     ap.add_argument("--no-same-reads", action="store_true", help="skip the comparison region that maps one set every step")
@@ -532,6 +534,8 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(ix, raw[:4096], n_refs, ref_lens, args.cpu_seconds)
+        if world == 1 and not args.no_streaming and not args.no_cpu:
+            out["streaming"] = streaming_block(args)
         print(json.dumps(out), flush=True)
         phase_prof()
     if dist is not None:
@@ -539,6 +543,28 @@ def main():
         dist.destroy_process_group()
     del keepalive
     pinned.close()
+
+
+def streaming_block(args):
+    """The product's real mode beside the headline (never part of `value`): 10 000 reads of 8 chunks -- a
+    third junk-prefixed, 2 % junk throughout -- through the `sigmap -m` CLI in a child process (tools/stream_bench.py: its
+    own contexts, the reference's own "Finished mapping in" span, median of three runs, 32 sampled reads against the
+    oracle's streaming map).  A failure here never costs the bench line."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_bench.py"), "--reads", "10000", "--chunks-per-read", "8",
+                            "--contigs", str(args.contigs), "--contig-len", str(args.contig_len), "--check", "32"],
+                           capture_output=True, text=True, timeout=420, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or "no output")[-400:]}
+        j = json.loads(lines[-1])
+        keep = ("metric", "reads_per_s", "chunks_per_s", "span_s", "all_span_s", "reads", "chunks_per_read", "read_kinds",
+                "mean_chunks_used", "mapped_fraction", "rounds", "lanes", "mean_batch", "host_share_of_lane_time",
+                "host_ms_per_round", "device_ms_per_round", "lane_seconds", "batches_mapped_twice", "oracle_check", "cli")
+        return {k: j.get(k) for k in keep}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:400]}
 
 
 def walker_source_sha():

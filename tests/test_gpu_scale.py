@@ -309,3 +309,25 @@ def test_bench_one_rank_over_rccl_forced_broadcast():
     assert j["config"]["contexts_agree"] and j["config"]["census_results_identical"]
     assert j["config"]["chunks_with_capacity_flags"] == 0 and j["config"]["mapped_fraction"] > 0.95
     assert j["pcie_inclusive"]["results_identical"]
+
+
+def test_stream_bench_reads_that_use_every_chunk():
+    """tools/stream_bench.py end to end at a size a test can afford: 600 reads of 30 chunks through `sigmap -m` -- junk-
+    prefixed reads that map from a later chunk on with the junk's chains carried along, junk-only reads that use all
+    max_num_chunks = 30 chunks (sigmap.cc:647: the loop's own limit) --, one chunk per read and round pulled from pinned
+    memory by the device, 48 sampled reads of every kind against the oracle's streaming map (the script asserts 0
+    mismatches), the CLI's per-phase statistics present."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_bench.py"), "--reads", "600", "--chunks-per-read", "30",
+                        "--contigs", "4", "--contig-len", "300000", "--check", "48", "--runs", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["oracle_check"]["mismatches"] == 0 and j["oracle_check"]["reads"] >= 40
+    assert j["oracle_check"]["max_chunks_used"] >= 10 and j["read_kinds"]["junk_only"] >= 4
+    assert j["mean_chunks_used"] > 1.5 and j["rounds"] >= 30 and j["batches_mapped_twice"] == 0
+    assert set(j["lane_seconds"]) == {"admit_upload", "build_batch", "device", "download_results", "download_anchors", "decide"}
