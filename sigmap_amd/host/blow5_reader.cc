@@ -175,7 +175,8 @@ void SignalBatch::AddSignalsFromBLOW5(const std::string &path) {
     }
     uint64_t record_size = 0;
     memcpy(&record_size, sz, 8);
-    if (record_size == 0 || record_size > ((uint64_t)1 << 34)) ExitWithMessage("Corrupt BLOW5 record size in " + path);
+    if (record_size == 0 || record_size > ((uint64_t)1 << 34)) ExitWithMessage("Corrupt BLOW5 record size in " + path +
+                      " (this reader parses the binary SLOW5 layout itself and has never been checked against a slow5lib-written file: if slow5tools reads the file, report it)");
     packed.resize((size_t)record_size);
     if (fread(packed.data(), 1, packed.size(), f) != packed.size()) ExitWithMessage("Truncated BLOW5 record in " + path);
     const std::vector<unsigned char> *body = &packed;
@@ -217,7 +218,9 @@ void SignalBatch::AddSignalsFromBLOW5(const std::string &path) {
         if (len_raw) memcpy(raw.data(), body->data() + pos, (size_t)len_raw * sizeof(int16_t));
       }
     }
-    if (!ok) ExitWithMessage("Corrupt BLOW5 record in " + path);
+    if (!ok)
+      ExitWithMessage("Corrupt BLOW5 record in " + path +
+                      " (this reader parses the binary SLOW5 layout itself and has never been checked against a slow5lib-written file: if slow5tools reads the file, report it)");
     // signal_batch.cc:186-189: float digitisation = rec->digitisation (double -> float), likewise range, offset
     AddSignal(id, (float)digitisation, (float)range, (float)offset, raw.data(), raw.size());
   }
