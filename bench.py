@@ -75,8 +75,6 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="every timed region (EXACTLY --steps steps, fenced) is timed this many times after one discarded "
                          "region; value / ms_per_step are the MEDIAN region, min / max / all are printed beside it")
-    ap.add_argument("--packs", type=int, default=-1,
-                    help="development A/B (needs SMHIP_DEV=1): 1 = the set walk over pack records (seed_lookup.hip BuildPacks), 0 = quads")
     ap.add_argument("--depth", type=int, default=4,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
@@ -172,8 +170,6 @@ def main():
     pool = pipeline.MapperPool(local_rank, max(1, args.depth))
     dev = pool.first
     for dv in pool.devs:
-        if args.packs >= 0:
-            dv.set_knob("packs", args.packs)      # (before the index arrives: pack records are built at upload)
         if args.walk_blocks:
             dv.params.walk_blocks_per_cu = args.walk_blocks
         if args.fast_cap:

@@ -138,12 +138,6 @@ typedef struct {
                                                   boxes and references of a node's four grandchildren, derived from
                                                   `nodes` at upload); null / 0 for an index without them */
   uint64_t n_quads;
-  void *packs;      uint64_t packs_bytes;      /* 128 B per PACK record (round 5, an experiment behind the development knob
-                                                  `packs`: up to six frontier slots of a tree fragment per line, 8-bit
-                                                  boxes in the record's own frame; seed_lookup.hip BuildPacks); null / 0
-                                                  otherwise.  Shared by export / attach on one GPU; replicas made by a
-                                                  broadcast walk their quad records */
-  uint64_t n_packs;
 } smhip_index_dev;
 int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out);
 /* Borrow externally owned device arrays (e.g. torch tensors filled by broadcast). */

@@ -103,8 +103,7 @@ class IndexDev(C.Structure):
                 ("leaf_pts", C.c_void_p), ("leaf_pts_bytes", C.c_uint64),
                 ("leaf_vind", C.c_void_p), ("leaf_vind_bytes", C.c_uint64),
                 ("bbox", C.c_void_p), ("bbox_bytes", C.c_uint64),
-                ("quads", C.c_void_p), ("quads_bytes", C.c_uint64), ("n_quads", C.c_uint64),
-                ("packs", C.c_void_p), ("packs_bytes", C.c_uint64), ("n_packs", C.c_uint64)]
+                ("quads", C.c_void_p), ("quads_bytes", C.c_uint64), ("n_quads", C.c_uint64)]
 
 
 class IndexView(C.Structure):

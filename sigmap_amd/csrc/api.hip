@@ -29,7 +29,7 @@ const KnobName kKnobNames[] = {{"lane_blocks_per_cu", &DevKnobs::lane_blocks_per
                                {"bucket_bits", &DevKnobs::bucket_bits}, {"handout", &DevKnobs::handout},
                                {"sdtw_ring", &DevKnobs::sdtw_ring}, {"sync_run", &DevKnobs::sync_run},
                                {"spec_tight", &DevKnobs::spec_tight}, {"float_gap", &DevKnobs::float_gap},
-                               {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search}, {"packs", &DevKnobs::packs},
+                               {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search},
                                {"classify_dense", &DevKnobs::classify_dense}, {"classify_resolve", &DevKnobs::classify_resolve}};
 // the environment's knobs, honoured only behind SMHIP_DEV=1 (read once per context, in smhip_init)
 DevKnobs ReadDevKnobs() {
@@ -483,13 +483,6 @@ int smhip_index_upload(smhip_ctx *ctx, int dim, const float *values, const uint6
       ctx->have_index = false;
       return HipFail(ctx, qe, "quad records");
     }
-    if (ctx->knobs.packs > 0 && ctx->index.quads) {  // (experiment: pack records beside them)
-      const hipError_t pe = BuildPacks(ctx, 0.08f);
-      if (pe != hipSuccess) {
-        ctx->have_index = false;
-        return HipFail(ctx, pe, "pack records");
-      }
-    }
   }
   return SMHIP_OK;
 }
@@ -516,9 +509,6 @@ int smhip_index_export(smhip_ctx *ctx, smhip_index_dev *out) {
   out->quads = (void *)ctx->index.quads;
   out->quads_bytes = ctx->index.n_quads * 128;
   out->n_quads = ctx->index.n_quads;
-  out->packs = (void *)ctx->index.packs;
-  out->packs_bytes = ctx->index.n_packs * 128;
-  out->n_packs = ctx->index.n_packs;
   return SMHIP_OK;
 }
 
@@ -729,10 +719,6 @@ int smhip_index_attach(smhip_ctx *ctx, const smhip_index_dev *in) {
   ctx->index = IndexView{(const uint4 *)in->nodes, (const uint32_t *)in->leaf_tab, (const float *)in->leaf_pts,
                          (const uint32_t *)in->leaf_vind, (const float *)in->bbox, in->n_nodes, in->n_leaves,
                          in->m_size, in->root_ref, (const uint4 *)in->quads, in->n_quads};
-  if (in->packs && in->n_packs && in->packs_bytes >= in->n_packs * 128) {
-    ctx->index.packs = (const uint4 *)in->packs;
-    ctx->index.n_packs = in->n_packs;
-  }
   ctx->leaf_pts_bytes = in->leaf_pts_bytes;
   ctx->leaf_vind_bytes = in->leaf_vind_bytes;
   ctx->have_index = true;

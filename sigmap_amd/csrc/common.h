@@ -111,8 +111,6 @@ struct IndexView {
   uint32_t root_ref;          // 0 (inner record 0), or kLeafTag for a tree that is a single leaf
   const uint4 *quads;         // 8 x uint4 per quad record (seed_lookup.hip: BuildQuads), null: none (no inner node,
   uint64_t n_quads;           // or an index too large for them); the root's quad is number 0
-  const uint4 *packs;         // 8 x uint4 per PACK record (seed_lookup.hip: BuildPacks): a fragment of the tree with up to
-  uint64_t n_packs;           // six frontier slots, 8-bit boxes in the record's own frame; null: none
 };
 
 inline bool TraceAlloc() {
@@ -203,7 +201,7 @@ struct smhip_ctx {
   bool have_index = false, index_owned = false;
   int dim = 0;
   smhip::IndexView index{};
-  smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, ix_quads, ix_packs, scan_tmp;
+  smhip::DevBuf ix_nodes, ix_tab, ix_pts, ix_vind, ix_bbox, ix_quads, scan_tmp;
   smhip::DevBuf ix_slot_leaf;     // block of eight point slots -> leaf ordinal (seed_lookup.hip OverCapSelectKernel), derived
   bool slot_leaf_valid = false;   // lazily from leaf_tab by the context itself, whichever way the index arrived
   int last_walk_mode = 0;         // search mode of the last smhip_map_run: 0 exact order, 1 census, 2 order-free (quad records)
@@ -382,7 +380,6 @@ hipError_t LaunchSelectChunks(smhip_ctx *ctx, const uint32_t *slots, const uint3
                               uint32_t *clen);
 hipError_t LaunchScanU32(smhip_ctx *ctx, const uint32_t *in, uint32_t n, uint32_t *out_excl /*n+1*/);
 hipError_t BuildQuads(smhip_ctx *ctx);  // seed_lookup.hip: ctx->index.quads from ctx->index.inner
-hipError_t BuildPacks(smhip_ctx *ctx, float radius);  // seed_lookup.hip: ctx->index.packs (host DP over the downloaded inner records)
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,
                              const uint32_t *q_off, uint32_t n_chunks, void *qrec);
 hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *qrec, const uint32_t *q_off,

@@ -65,10 +65,6 @@
 // order never shows in the output.
 #include <stdlib.h>
 
-#include <algorithm>
-#include <cmath>
-#include <vector>
-
 #include "common.h"
 
 namespace smhip {
@@ -170,9 +166,7 @@ __device__ unsigned long long g_walk_prof[8];
 //                       one 128-byte record -- one whole fabric request -- holds the boxes of a node's four
 //                       GRANDCHILDREN, so a visit is four box tests and descends two levels of the tree for the one
 //                       line a binary record costs per level (the launch is bound by the rate of line requests).
-//        kWalkPack   -- the set walk over PACK records (BuildPacks: up to six frontier slots per line, 8-bit boxes in
-//                       the record's own frame) instead of quad records; the same hit sets (experiment, knob `packs`).
-enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2, kWalkPack = 3 };
+enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2 };
 constexpr int kSetThreads = 128;  // workgroup of the set walk: 10 KB of LDS per wave, eight workgroups per CU
 constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area; 6: +7 %, 4: +14 %)
 
@@ -186,8 +180,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   constexpr bool kStrict = kMode == kWalkCensus;
   uint32_t hand_thr = max(scan_threshold >> 16, 1u);  // (the launch packs two thresholds into the argument)
   scan_threshold &= 0xFFFFu;
-  constexpr bool kPack = kMode == kWalkPack;
-  constexpr bool kSet = kMode == kWalkSet || kPack;
+  constexpr bool kSet = kMode == kWalkSet;
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
   const uint32_t gl = blockIdx.x * kThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
@@ -611,7 +604,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         if (nsrc[r] != 0xFFFFFFFFu) {
-          const uint4 *g = (kPack ? ix.packs : ix.quads) + (size_t)nsrc[r] * 8 + part;
+          const uint4 *g = ix.quads + (size_t)nsrc[r] * 8 + part;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                            (__attribute__((address_space(3))) void *)(stage_w + r * 63), 16, 0, 0);
         }
@@ -648,78 +641,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         // ---- set walk: test both children's boxes; the first that passes is visited next, a second one is left on
         // the stack; leaves go to the FIFO at once.  A reference on the stack has passed its box test.
         uint32_t cur = 0xFFFFFFFFu;  // the node to go on with (none: pop)
-        if (kPack && !(node & kLeafTag)) {
-          // a pack record: the frame {lo01, lo23, lo45, sh}, then six slots {ref, lo8[0..3], lo8[4..5] | hi8[0..1] << 16,
-          // hi8[2..5]}.  The query goes into the frame's units once -- a = floor((ql - lo) >> sh), b = ceil((qh - lo) >>
-          // sh), saturating --, a slot's gap per dimension is max(a - hi8, lo8 - b, 0) in those units, and the slot is
-          // entered iff the sum of their squares is <= box_limit >> 2 sh: per dimension 2^sh times that gap is at most
-          // the gap to the slot's 8-bit box, which contains the 16-bit box the quad walk tests -- so every slot the
-          // quad walk's rule enters is entered here (the argument at BuildPacks); more never hurts.
-          const uint4 *mine = stage_w + lane * 7;
-          const uint4 fr = mine[0];
-          ++nn;  // (this mode's nodes_visited: the pack records read)
-          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-          const us2 k3 = {3, 3};
-          const uint32_t shv = fr.w & 15u;
-          const us2 sh2 = {(unsigned short)shv, (unsigned short)shv};
-          const unsigned short rnd = (unsigned short)((1u << shv) - 1u);
-          const us2 rnd2 = {rnd, rnd};
-#define SM_FRAME_A(qcw, low) \
-  ((us2)(__builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(__builtin_bit_cast(us2, qcw), k3), __builtin_bit_cast(us2, low)) >> sh2))
-#define SM_FRAME_B(qcw, low)                                                                                                     \
-  ((us2)(__builtin_elementwise_add_sat(                                                                                          \
-             __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(__builtin_bit_cast(us2, qcw), k3), __builtin_bit_cast(us2, low)), \
-             rnd2) >>                                                                                                            \
-         sh2))
-          const us2 a01 = SM_FRAME_A(qc01, fr.x), a23 = SM_FRAME_A(qc23, fr.y), a45 = SM_FRAME_A(qc45, fr.z);
-          const us2 b01 = SM_FRAME_B(qc01, fr.x), b23 = SM_FRAME_B(qc23, fr.y), b45 = SM_FRAME_B(qc45, fr.z);
-          // a query BELOW the frame in a dimension (qh < lo: b has saturated at 0) is that far from every slot on top of
-          // the slot's own offset: e = floor((lo - qh) >> sh), added to the low-side gap.  (Above the frame nothing is
-          // lost: a is not clamped to the frame's 255 units.)  Without it the gaps measure from the frame's edge and
-          // the walk enters five times the leaves.
-#define SM_FRAME_E(qcw, low) \
-  ((us2)(__builtin_elementwise_sub_sat(__builtin_bit_cast(us2, low), __builtin_elementwise_add_sat(__builtin_bit_cast(us2, qcw), k3)) >> sh2))
-          const us2 e01 = SM_FRAME_E(qc01, fr.x), e23 = SM_FRAME_E(qc23, fr.y), e45 = SM_FRAME_E(qc45, fr.z);
-#undef SM_FRAME_E
-#undef SM_FRAME_A
-#undef SM_FRAME_B
-          const uint32_t limit8 = box_limit >> (2u * shv);
-          // bytes 0, 1 (2, 3) of a word as a pair of 16-bit values
-#define SM_B01(w) __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, (w), 0x0c010c00u))
-#define SM_B23(w) __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, (w), 0x0c030c02u))
-#define SM_PGAP(av, hv, lv, bv, ev) \
-  __builtin_elementwise_max(__builtin_elementwise_sub_sat(av, hv), __builtin_elementwise_add_sat(__builtin_elementwise_sub_sat(lv, bv), ev))
-          auto take = [&](const uint4 &sl) {
-            const us2 g01 = SM_PGAP(a01, SM_B23(sl.z), SM_B01(sl.y), b01, e01);
-            const us2 g23 = SM_PGAP(a23, SM_B01(sl.w), SM_B23(sl.y), b23, e23);
-            const us2 g45 = SM_PGAP(a45, SM_B23(sl.w), SM_B01(sl.z), b45, e45);
-            const uint32_t sum = SM_BOXSUM(g01, g23, g45);
-            const uint32_t ref = sl.x;
-            if (sum > limit8 || ref == 0xFFFFFFFFu) return;
-            if ((ref & kLeafTag) && fifo_cnt < (uint32_t)kFifo) {
-              fifo[fifo_cnt++][threadIdx.x] = ref & kIdxMask;
-            } else if (!(ref & kLeafTag) && cur == 0xFFFFFFFFu) {
-              cur = ref;
-            } else if (sp < (uint32_t)kSetStack) {
-              lstk[sp][threadIdx.x] = ref;
-              ++sp;
-            } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
-              stk32[sp - (uint32_t)kSetStack] = ref;
-              ++sp;
-            } else {
-              atomicOr(&sink.counters[0], 1u);
-            }
-          };
-          take(mine[1]);
-          take(mine[2]);
-          take(mine[3]);
-          take(mine[4]);
-          take(mine[5]);
-          take(mine[6]);
-#undef SM_B01
-#undef SM_B23
-#undef SM_PGAP
-        } else if (!(node & kLeafTag)) {
+        if (!(node & kLeafTag)) {
           // a quad record: {ref[4]} then four boxes of six words {lo01, lo23, lo45, hi01, hi23, hi45}; an unused
           // slot has a box (lo 65535, hi 0 in every dimension) whose sum saturates for any query
           const uint4 *mine = stage_w + lane * 7;
@@ -1489,9 +1411,7 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
   // (the set walk's workgroups are half the size: the same knob counts them in pairs)
   const uint32_t set_blocks_per_cu = 2u * (uint32_t)blocks_per_cu;
-  // (knob packs: the set walk reads pack records where the index has them -- every caller's kWalkSet alike)
-  if (mode == kWalkSet && ctx->knobs.packs > 0 && ctx->index.packs) mode = kWalkPack;
-  if ((mode == kWalkSet || mode == kWalkPack) && env_thr <= 0) thr = kSetScanThreshold;
+  if (mode == kWalkSet && env_thr <= 0) thr = kSetScanThreshold;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
   {
@@ -1510,7 +1430,6 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
                      range_stride, (uint32_t)thr)
   if (mode == kWalkCensus) SM_WALK(kWalkCensus, kSeedThreads, blocks);
   else if (mode == kWalkSet) SM_WALK(kWalkSet, kSetThreads, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
-  else if (mode == kWalkPack) SM_WALK(kWalkPack, kSetThreads, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
   else SM_WALK(kWalkExact, kSeedThreads, blocks);
 #undef SM_WALK
   return hipGetLastError();
@@ -1596,225 +1515,6 @@ hipError_t BuildQuads(smhip_ctx *ctx) {
   ix.quads = ctx->ix_quads.as<uint4>();
   ix.n_quads = n_quads;
   return done(hipSuccess);
-}
-
-// ---- PACK records (round 5, an experiment behind the knob `packs`): the set walk's node array with up to SIX frontier
-// slots per 128-byte line instead of the quad record's four.  A record holds a FRAGMENT of the tree -- its head and
-// any inner descendants it swallows -- and lists the fragment's frontier: inner nodes that head records of their own,
-// or leaves.  Which nodes head a record and what shape each fragment takes is free (the walker tests the slots' own
-// tight boxes, whatever lies between them and the head): a bottom-up knapsack DP over the tree picks heads and shapes
-// that minimise the expected number of records a query fetches, with the node's box grown by the search radius as
-// the weight of fetching its record (tools/micro/blocking_sim.cc: 93.6 records per query instead of the quads'
-// 126.9 on the 12 Mb index, 111 instead of 158 on the 250 Mb one).
-//   layout (the same seven 16-byte parts of a 128-byte line the quad walk fetches):
-//     part 0      : frame {lo01, lo23, lo45 (u16 pairs on the index's box grid), sh}
-//     parts 1 .. 6: slot  {ref, lo8[0..3], lo8[4..5] | hi8[0..1] << 16, hi8[2..5]}
-//   a slot's box in grid units = frame.lo + (lo8 << sh) .. frame.lo + (hi8 << sh), rounded OUTWARDS (lo8 floor, hi8
-//   ceil), sh = the smallest shift that brings the fragment's widest extent below 256: an 8-bit box contains the 16-bit
-//   one, so the walker enters a superset of the boxes the quad walk enters -- never fewer hits, and the hits themselves
-//   are decided by the exact distance in the leaves.  ref = pack number, kLeafTag | leaf ordinal, or 0xFFFFFFFF (unused).
-// Built on the HOST from the downloaded binary records (the DP is a sequential pass in reverse pre-order: children have
-// higher indices than their parents), uploaded like the quads.
-namespace {
-constexpr int kPackSlots = 6;
-struct PackBox {
-  uint16_t lo[6], hi[6];
-};
-inline void ChildBoxHost(const uint32_t *rec /* 16 words of an inner record */, int which, PackBox *b) {
-  const uint32_t *w = rec + 4 + 6 * which;  // {lo01, lo23, lo45, hi01, hi23, hi45}
-  for (int d = 0; d < 6; d += 2) {
-    b->lo[d] = (uint16_t)(w[d / 2] & 0xFFFFu);
-    b->lo[d + 1] = (uint16_t)(w[d / 2] >> 16);
-    b->hi[d] = (uint16_t)(w[3 + d / 2] & 0xFFFFu);
-    b->hi[d + 1] = (uint16_t)(w[3 + d / 2] >> 16);
-  }
-}
-}  // namespace
-
-hipError_t BuildPacks(smhip_ctx *ctx, float radius) {
-  IndexView &ix = ctx->index;
-  ix.packs = nullptr;
-  ix.n_packs = 0;
-  const uint64_t n = ix.n_inner;
-  if (n == 0 || n > (64ull << 20)) return hipSuccess;
-  std::vector<uint32_t> rec((size_t)n * 16);
-  hipError_t e = hipMemcpyAsync(rec.data(), ix.inner, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream);
-  if (e != hipSuccess) return e;
-  float grid[8] = {0};
-  if ((e = hipMemcpyAsync(grid, ix.bbox + 12, 7 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
-  const double step = grid[6] > 0 ? (double)grid[6] : 1.0;
-  const double grow = 2.0 * std::sqrt((double)radius) / step;  // the radius on both sides, in grid steps
-  auto child = [&](uint64_t x, int i) { return rec[x * 16 + 2 + i] & (kLeafTag | kIdxMask); };
-  // every inner node's own box (held by its parent's record; the root's: the union of its children's)
-  std::vector<PackBox> box((size_t)n);
-  for (uint64_t x = 0; x < n; ++x)
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t c = child(x, i);
-      if (!(c & kLeafTag)) ChildBoxHost(&rec[x * 16], i, &box[c]);
-    }
-  {
-    PackBox a, b;
-    ChildBoxHost(&rec[0], 0, &a);
-    ChildBoxHost(&rec[0], 1, &b);
-    for (int d = 0; d < 6; ++d) {
-      box[0].lo[d] = std::min(a.lo[d], b.lo[d]);
-      box[0].hi[d] = std::max(a.hi[d], b.hi[d]);
-    }
-  }
-  // g[x][k]: expected fetches below x when x lies inside a fragment and may use up to k slots; g[x][1] = x heads a record
-  constexpr int K = kPackSlots;
-  std::vector<float> g((size_t)n * (K + 1), 0.0f);
-  std::vector<uint8_t> split((size_t)n * (K + 1), 0);
-  const float zeros[K + 1] = {0};
-  for (uint64_t x = n; x-- > 0;) {
-    double w = 1.0;
-    for (int d = 0; d < 6; ++d) w *= (double)(box[x].hi[d] - box[x].lo[d]) + grow;
-    const uint32_t c1 = child(x, 0), c2 = child(x, 1);
-    const float *gl = (c1 & kLeafTag) ? zeros : &g[(size_t)c1 * (K + 1)];
-    const float *gr = (c2 & kLeafTag) ? zeros : &g[(size_t)c2 * (K + 1)];
-    float *gx = &g[(size_t)x * (K + 1)];
-    uint8_t *sx = &split[(size_t)x * (K + 1)];
-    double best = 1e300;
-    int bk = 1;
-    for (int k1 = 1; k1 < K; ++k1) {
-      const double c = (double)gl[k1] + (double)gr[K - k1];
-      if (c < best) {
-        best = c;
-        bk = k1;
-      }
-    }
-    sx[0] = (uint8_t)bk;  // the split a HEAD gives its two children
-    // (weights scaled so that floats hold the sums: the root's own weight is the largest single term)
-    gx[1] = (float)(w * 1e-18 + best);
-    for (int k = 2; k <= K; ++k) {
-      double b = gx[1];
-      uint8_t s = 0;  // 0: x itself is a slot (heads a record); else the slots handed to the first child
-      for (int k1 = 1; k1 < k; ++k1) {
-        const double c = (double)gl[k1] + (double)gr[k - k1];
-        if (c < b) {
-          b = c;
-          s = (uint8_t)k1;
-        }
-      }
-      gx[k] = (float)b;
-      sx[k] = s;
-    }
-  }
-  // heads, top-down (parents before children in pre-order), numbered in pre-order
-  std::vector<uint8_t> head((size_t)n, 0);
-  head[0] = 1;
-  struct Item {
-    uint32_t node;
-    int k;
-  };
-  std::vector<Item> st;
-  std::vector<uint32_t> slots_of;  // per head: up to K frontier refs (inner index or kLeafTag | ordinal), 0xFFFFFFFF unused
-  std::vector<uint32_t> head_at((size_t)n, 0xFFFFFFFFu);
-  uint64_t n_heads = 0;
-  for (uint64_t x = 0; x < n; ++x) {
-    if (!head[x]) continue;
-    head_at[x] = (uint32_t)n_heads++;
-    uint32_t fr[K];
-    int nf = 0;
-    st.clear();
-    const int k1 = split[(size_t)x * (K + 1)];
-    st.push_back(Item{child(x, 1), K - k1});
-    st.push_back(Item{child(x, 0), k1});
-    while (!st.empty()) {
-      const Item it = st.back();
-      st.pop_back();
-      if (it.node & kLeafTag) {
-        fr[nf++] = it.node;
-        continue;
-      }
-      const uint8_t s = it.k >= 2 ? split[(size_t)it.node * (K + 1) + it.k] : 0;
-      if (s == 0) {
-        head[it.node] = 1;
-        fr[nf++] = it.node;
-        continue;
-      }
-      st.push_back(Item{child(it.node, 1), it.k - (int)s});
-      st.push_back(Item{child(it.node, 0), (int)s});
-    }
-    for (int i = 0; i < K; ++i) slots_of.push_back(i < nf ? fr[i] : 0xFFFFFFFFu);
-  }
-  // parents of the frontier nodes hold their boxes: a second pass that knows, for every node, which record and child
-  // slot describes it
-  std::vector<uint32_t> parent_rec((size_t)n, 0);  // inner node -> (parent index << 1) | which child
-  std::vector<uint32_t> leaf_parent(ix.n_leaves, 0);
-  for (uint64_t x = 0; x < n; ++x)
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t c = child(x, i);
-      if (c & kLeafTag) leaf_parent[c & kIdxMask] = (uint32_t)((x << 1) | (uint32_t)i);
-      else parent_rec[c] = (uint32_t)((x << 1) | (uint32_t)i);
-    }
-  std::vector<uint32_t> out((size_t)n_heads * 32, 0);
-  uint64_t h = 0;
-  for (uint64_t x = 0; x < n; ++x) {
-    if (!head[x]) continue;
-    const uint32_t *fr = &slots_of[h * K];
-    PackBox sb[K];
-    uint16_t flo[6], fhi[6];
-    for (int d = 0; d < 6; ++d) {
-      flo[d] = 0xFFFF;
-      fhi[d] = 0;
-    }
-    int nf = 0;
-    for (; nf < K && fr[nf] != 0xFFFFFFFFu; ++nf) {
-      const uint32_t pr = (fr[nf] & kLeafTag) ? leaf_parent[fr[nf] & kIdxMask] : parent_rec[fr[nf]];
-      ChildBoxHost(&rec[(size_t)(pr >> 1) * 16], (int)(pr & 1u), &sb[nf]);
-      for (int d = 0; d < 6; ++d) {
-        flo[d] = std::min(flo[d], sb[nf].lo[d]);
-        fhi[d] = std::max(fhi[d], sb[nf].hi[d]);
-      }
-    }
-    uint32_t sh = 0;
-    for (int d = 0; d < 6; ++d)
-      while ((((uint32_t)(fhi[d] - flo[d]) + (1u << sh) - 1u) >> sh) > 255u) ++sh;
-    uint32_t *o = &out[h * 32];
-    o[0] = (uint32_t)flo[0] | ((uint32_t)flo[1] << 16);
-    o[1] = (uint32_t)flo[2] | ((uint32_t)flo[3] << 16);
-    o[2] = (uint32_t)flo[4] | ((uint32_t)flo[5] << 16);
-    o[3] = sh;
-    for (int i = 0; i < K; ++i) {
-      uint32_t *sl = o + 4 + 4 * i;
-      if (i >= nf) {  // unused: no reference, a box nothing is close to (lo 255, hi 0)
-        sl[0] = 0xFFFFFFFFu;
-        sl[1] = 0xFFFFFFFFu;
-        sl[2] = 0x0000FFFFu;
-        sl[3] = 0u;
-        continue;
-      }
-      uint8_t l8[6], h8[6];
-      for (int d = 0; d < 6; ++d) {
-        l8[d] = (uint8_t)(((uint32_t)(sb[i].lo[d] - flo[d])) >> sh);
-        h8[d] = (uint8_t)((((uint32_t)(sb[i].hi[d] - flo[d])) + (1u << sh) - 1u) >> sh);
-      }
-      sl[0] = (fr[i] & kLeafTag) ? fr[i] : head_at[fr[i]];
-      sl[1] = (uint32_t)l8[0] | ((uint32_t)l8[1] << 8) | ((uint32_t)l8[2] << 16) | ((uint32_t)l8[3] << 24);
-      sl[2] = (uint32_t)l8[4] | ((uint32_t)l8[5] << 8) | ((uint32_t)h8[0] << 16) | ((uint32_t)h8[1] << 24);
-      sl[3] = (uint32_t)h8[2] | ((uint32_t)h8[3] << 8) | ((uint32_t)h8[4] << 16) | ((uint32_t)h8[5] << 24);
-    }
-    ++h;
-  }
-  // (a frontier head's pack number is only known once it has been numbered: heads are numbered in pre-order and a
-  // frontier node comes after its record's head, so head_at of a LATER head is still unset in the loop above --
-  // patched here)
-  h = 0;
-  for (uint64_t x = 0; x < n; ++x) {
-    if (!head[x]) continue;
-    const uint32_t *fr = &slots_of[h * K];
-    for (int i = 0; i < K && fr[i] != 0xFFFFFFFFu; ++i)
-      if (!(fr[i] & kLeafTag)) out[h * 32 + 4 + 4 * i] = head_at[fr[i]];
-    ++h;
-  }
-  if ((e = ctx->ix_packs.Reserve((size_t)n_heads * 128)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(ctx->ix_packs.p, out.data(), (size_t)n_heads * 128, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
-  ix.packs = ctx->ix_packs.as<uint4>();
-  ix.n_packs = n_heads;
-  return hipSuccess;
 }
 
 hipError_t LaunchQueryExpand(smhip_ctx *ctx, const smhip_params &p, const float *feat, uint32_t feat_stride,

@@ -343,11 +343,8 @@ def _hit_sets_equal(idx, dist, n, ref_idx, ref_dist):
     return a == b
 
 
-@pytest.mark.parametrize("packs", [0, 1])
-def test_set_walk_matches_reference_golden(packs):
-    """(packs = 1: the same walk over PACK records -- up to six frontier slots per line, 8-bit boxes in the record's own
-    frame, seed_lookup.hip BuildPacks -- instead of quad records.)
-    The PRODUCTION search of the mapping path -- the order-free set walk over quad records (integer box sums on the
+def test_set_walk_matches_reference_golden():
+    """The PRODUCTION search of the mapping path -- the order-free set walk over quad records (integer box sums on the
     one-step grid, four-slot visits, 4-byte stack with spill) -- through the per-stage entry point
     (search_mode = SMHIP_SEARCH_SET): per query the same count and the same SET of (point id, distance bits) as the
     REAL nanoflann (tests/golden/kdtree.npz, nanoflann.hpp:1278-1410), queries outside the root box and exact data
@@ -355,7 +352,6 @@ def test_set_walk_matches_reference_golden(packs):
     g = np.load(os.path.join(GOLDEN, "kdtree.npz"))
     ix = pipeline.HostIndex.from_points(g["positions"], g["values"], threads=2)
     dev = pipeline.DeviceMapper(0)
-    dev.set_knob("packs", packs)     # (read when the index arrives: the records are built at upload)
     dev.upload_index(ix)
     dev.params.search_mode = _abi.SEARCH_SET
     off = g["hit_off"]
@@ -378,9 +374,8 @@ def test_set_walk_matches_reference_golden(packs):
     dev.close()
 
 
-@pytest.mark.parametrize("packs", [0, 1])
 @pytest.mark.parametrize("npts,max_leaf", [(6, 20), (21, 20), (26, 21), (45, 20), (300, 20), (2000, 21), (5000, 3)])
-def test_set_walk_small_trees_and_full_leaves(npts, max_leaf, packs):
+def test_set_walk_small_trees_and_full_leaves(npts, max_leaf):
     """Set walk on degenerate shapes: a tree that is one leaf (no quad records: the entry point falls back to the
     reference's order and says so), a root with two leaves (a quad with two used slots), 21-point leaves, deep narrow
     trees (max_leaf 3): the hit sets of the pinned oracle search, every query of the cloud plus far-away ones."""
@@ -388,7 +383,6 @@ def test_set_walk_small_trees_and_full_leaves(npts, max_leaf, packs):
     vals = rng.normal(size=npts).astype(np.float32)
     ix = pipeline.HostIndex.from_points(np.arange(npts, dtype=np.uint64) << 1, vals, max_leaf=max_leaf, threads=1)
     dev = pipeline.DeviceMapper(0)
-    dev.set_knob("packs", packs)
     dev.upload_index(ix)
     tree = po.OracleTree(ix.values.copy(), leaf_max=max_leaf)
     qs = [vals[i:i + 6] + rng.normal(scale=0.05, size=6).astype(np.float32) for i in range(0, max(1, npts - 5), max(1, npts // 400))]
