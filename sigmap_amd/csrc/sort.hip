@@ -543,8 +543,10 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
           }
           lpos[u] = atomicAdd(&tcount[pb[u]], 1u);
         }
+        PHASE_MARK(12);  // decode + count (waits for the tile's loads)
         if (T + 1 < n_tiles) fetch(T + 1);  // (in flight while this tile is binned and copied out)
         __syncthreads();
+        PHASE_MARK(13);  // query search + issue of the next tile's loads + barrier
         if (tid < 64) {  // exclusive scan of the tile's part counts by one wave; the parts' running positions move on
           uint32_t tot = 0;
           for (uint32_t k = 0; k < scan_per; ++k) tot += tcount[scan_per * tid + k];
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
           }
         }
         __syncthreads();
+        PHASE_MARK(14);  // scan of the tile's part counts (one wave) + barrier
         // place: the tile's records sorted by part in LDS, each with its destination in the part's slice
 #pragma unroll
         for (int u = 0; u < RPT; ++u)
@@ -578,10 +581,12 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
         __syncthreads();
         // copy out: consecutive threads take consecutive records of the binned tile -- runs of one part, i.e.
         // consecutive addresses
+        PHASE_MARK(15);  // placement in LDS + barrier
         for (uint32_t sl = tid; sl < tile_n; sl += kBigThreads) {
           const uint32_t d = tile_dst[sl];
           if (d != 0xFFFFFFFFu) recs_out[d] = tile_rec[sl];
         }
+        PHASE_MARK(7);  // copy out
       }
       for (uint32_t k = tid; k < kMaxParts; k += kBigThreads)
         if (pcount[k] > kSlice) atomicOr(&s_overflow, 1u);
