@@ -28,3 +28,37 @@ def test_reciprocal_division_by_the_default_windows_matches(tmp_path):
         r = subprocess.run([exe, w, w], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "mismatches 0" in r.stdout
+
+
+def test_blocking_sim_reproduces_the_quad_walks_record_count(tmp_path):
+    """tools/micro/blocking_sim.cc (how many tree records a set-walk query fetches under other record packings: the
+    experiment behind the round-5 decision on oct / pack records) builds and runs on a small real tree: the set walk's entry
+    rule on the nanoflann-identical tree of 20 000 points, heads at even depth = what BuildQuads marks; a packing with
+    more slots per record never fetches more records than one with fewer (the DP's optimum is monotone in K)."""
+    import re
+    import numpy as np
+    from sigmap_amd import pipeline
+    rng = np.random.default_rng(3)
+    vals = rng.normal(size=20005).astype(np.float32)
+    ix = pipeline.HostIndex.from_points(np.arange(len(vals), dtype=np.uint64) << 1, vals, threads=1)
+    nodes = np.ascontiguousarray(ix.nodes)
+    with open(tmp_path / "nodes.bin", "wb") as f:
+        f.write(np.int32(len(nodes)).tobytes()); f.write(nodes.tobytes())
+    for name, arr, dt in (("values", ix.values, np.float32), ("vind", ix.vind, np.uint32)):
+        a = np.ascontiguousarray(arr, dtype=dt)
+        with open(tmp_path / (name + ".bin"), "wb") as f:
+            f.write(np.int64(len(a)).tobytes()); f.write(a.tobytes())
+    qs = np.array([vals[i:i + 6] + rng.normal(scale=0.05, size=6).astype(np.float32) for i in range(0, 20000, 10)], np.float32)
+    with open(tmp_path / "queries.bin", "wb") as f:
+        f.write(np.int64(len(qs)).tobytes()); f.write(qs.tobytes())
+    exe = str(tmp_path / "blocking_sim")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "micro", "blocking_sim.cc"), "-o", exe], check=True)
+    r = subprocess.run([exe, str(tmp_path / "nodes.bin"), str(tmp_path / "values.bin"), str(tmp_path / "vind.bin"),
+                        str(tmp_path / "queries.bin"), "0.08"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rec = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^(.*?)\s+records/query\s+([0-9.]+)", r.stdout, re.M)}
+    assert rec["even depth (current quads)"] > 1.0
+    for w in ("geo", "emp"):
+        ks = [rec["dp-%s K=%d" % (w, k)] for k in (4, 6, 7, 8)]
+        assert ks == sorted(ks, reverse=True), ks
+    assert rec["dp-geo K=8"] < rec["even depth (current quads)"]
