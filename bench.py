@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="every timed region (EXACTLY --steps steps, fenced) is timed this many times after one discarded "
                          "region; value / ms_per_step are the MEDIAN region, min / max / all are printed beside it")
+    ap.add_argument("--stagger", type=float, default=1.0,
+                    help="the contexts of a region start this fraction of (serial step / depth) apart (0: all at once)")
     ap.add_argument("--depth", type=int, default=4,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
@@ -304,7 +306,7 @@ def main():
     # All three assign steps to contexts the same way (static: context k runs steps k, k + depth, ...; contexts start a
     # fraction of a step apart, inside the region).  The kinds take turns -- resident, same, pcie, resident, ... -- one
     # discarded round first, then `--repeats` rounds; a kind's figure is the MEDIAN of its regions, with min / max / all.
-    stagger = (serial["ms_per_step"] * 1e-3 / len(pool.devs)) if len(pool.devs) > 1 else 0.0
+    stagger = (args.stagger * serial["ms_per_step"] * 1e-3 / len(pool.devs)) if len(pool.devs) > 1 else 0.0
     K = args.steps
 
     def region(kind):
