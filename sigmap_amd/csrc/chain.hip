@@ -305,10 +305,18 @@ __global__ __launch_bounds__(256) void ChainClassifyKernel(ChainArgs a, uint32_t
     if (dense_k) {
       // k = how many of ai - 1, ai - 2, ... are near: bisection on the count (five ring reads; 31 = "31 or more")
       const uint32_t dmax = (ai < n && ai > 0) ? min(ai - max(bstart, w0), kWindowSat) : 0u;
+      // (round 5) ... and not beyond the target gap at which a predecessor can still PASS: the gap-scale test wants
+      // 4 qd > 3 td, and qd = cq - pq <= cq (query positions are unsigned), so a predecessor with td >= 4 cq / 3 fails
+      // whatever its query position.  Predecessors beyond that only ever count skips, after every one that could pass
+      // has been looked at (the scan goes from the nearest outwards), so `found` -- and the chaining pass below, which
+      // needs every PASSING predecessor -- are the same over this shorter window, which is the one that has to fit
+      // dense_k.  A read's first chunk has query positions below ~450: the window shrinks from 5 000 to <= 600 targets
+      // and the pairs of a noise tile from ~118 to ~15.  (Integer gap tests only: the float form keeps the full window.)
+      const int32_t reach = kIntGap ? min(max_target_gap_length, (int32_t)min((uint32_t)cq, 0x1FFFFFFFu) / 3 * 4 + 4) : max_target_gap_length;
 #pragma unroll
       for (uint32_t step = kWindowStep0; step >= 1; step >>= 1) {
         const uint32_t cand = k + step;
-        const bool near = (int32_t)s_ring_t[(ai - cand) & (kRing - 1)] + max_target_gap_length >= ct;
+        const bool near = (int32_t)s_ring_t[(ai - cand) & (kRing - 1)] + reach >= ct;
         if (cand <= dmax && near) k = cand;
       }
     }
