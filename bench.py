@@ -587,8 +587,12 @@ def phase_prof():
     from sigmap_amd import _abi
     fw = getattr(_abi.hip_lib(), "smhip_debug_walk_prof", None)
     if fw is not None:
-        wb = (ctypes.c_ulonglong * 8)()
+        wb = (ctypes.c_ulonglong * 16)()
         if fw(wb, 1) == 0 and wb[0]:
+            print("walk_prof maxima over the waves (shader-clock ticks; iterations): all %d (mean %.0f)  scan %d  hand-out %d  "
+                  "fetch wait %d  walk iterations %d  scan iterations %d;  first start to last end %.1f us (wall clock)" %
+                  (wb[8], wb[0] / max(wb[5], 1), wb[9], wb[10], wb[11], wb[12], wb[13], (wb[15] - wb[14]) / 100.0),
+                  file=sys.stderr, flush=True)
             names = ["all", "scan phase", "query hand-out", "node fetch wait", "visit logic", None, "scan set-up",
                      "scan point-load wait"]
             print("walk_prof (shader-clock ticks summed over %d waves): " % wb[5] +

@@ -21,6 +21,9 @@ struct DevKnobs {
   int classify_resolve = -1;   // SMHIP_CLASSIFY_RESOLVE=0: the classifier leaves every anchor with a passing predecessor to the DP kernels
   int classify_dense = -1;     // SMHIP_CLASSIFY_DENSE=0: lockstep predecessor scans for every tile of the chain classifier
   int sort_lines = -1;         // SMHIP_SORT_LINES: 0 = exact two-pass partition only; 2 / 4 = whole-line partition with tiles of 2048 / 4096 whatever the batch
+  int walk_share = -1;         // SMHIP_WALK_SHARE: 0 = never share a query's walk between the lanes of a wave, 1 = always (default: batches up to 4 096 chunks)
+  int walk_grab = 0;           // SMHIP_WALK_GRAB: shared walks, queries a wave takes at a time ...
+  int walk_grab_upto = 0;      // SMHIP_WALK_GRAB_UPTO: ... in launches of up to this many queries per wave
   int second_search = 0;       // SMHIP_SECOND_SEARCH=1: queries beyond the hit cap are searched again in the reference's
                                // order (round 3) instead of ranking the set walk's hits
 };

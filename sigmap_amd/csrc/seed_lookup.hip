@@ -116,7 +116,7 @@ struct Sink {
     }                                                         \
   }
 
-enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3 };
+enum : uint32_t { M_FETCH = 0, M_NODE = 1, M_DRAIN = 2, M_IDLE = 3, M_WAIT = 4, M_HDONE = 5 };  // (the last two: shared walks)
 
 // Sum over the six dimensions of (gap in grid steps)^2, three packed pairs, saturating at 2^32 - 1
 // (v_dot2_u32_u16 ... clamp): compared with radius / step^2 as an integer, no conversion to float.
@@ -145,7 +145,7 @@ __device__ __forceinline__ uint32_t AllocOverflowSegment(const Sink &sink, uint3
 }
 
 #ifdef SMHIP_PHASE_PROF  // tools/phase_prof.sh: shader-clock ticks per wave in the phases of the walker
-__device__ unsigned long long g_walk_prof[8];
+__device__ unsigned long long g_walk_prof[16];  // [8..13]: maxima over the waves; [14] / [15]: first start / last end (wall clock)
 #define WALK_T() clock64()
 #else
 #define WALK_T() 0ull
@@ -170,7 +170,16 @@ enum : int { kWalkExact = 0, kWalkCensus = 1, kWalkSet = 2 };
 constexpr int kSetThreads = 128;  // workgroup of the set walk: 10 KB of LDS per wave, eight workgroups per CU
 constexpr int kSetStack = 8;  // pending visits per lane kept in LDS by the set walk (deeper: the lane's spill area; 6: +7 %, 4: +14 %)
 
-template <int kMode, int kThreads>
+//
+// kShare (set walk of a SMALL batch only -- the rounds of a streaming run): lanes without a query of their own take
+// over pending subtrees of the other lanes of their wave.  With a query or fewer per lane a launch lasts as long as the
+// walk of its heaviest query, record after record on one lane (a thousand dependent fetches in a dense region while most
+// lanes of the chip are through); the set walk is order-free, so any pending reference of a query can be walked by any
+// lane as long as the query's hits are numbered in one place: the lane that was handed the query stays its MASTER (its
+// row of the scan phase's tables holds the coordinates, the hit count, the slot address and the overflow segment; the
+// helpers' scan entries name it as their owner), waits for its helpers when its own part is done (M_WAIT) and then
+// writes the query's totals.  Speed only: the same hit set, stored once each.
+template <int kMode, int kThreads, bool kShare = false>
 __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                                                const uint32_t *__restrict__ n_queries_dev,
                                                                uint32_t n_queries_host, Sink sink, float radius,
@@ -178,9 +187,13 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
                                                                const uint32_t *__restrict__ range_end,
                                                                uint32_t range_stride, uint32_t scan_threshold) {
   constexpr bool kStrict = kMode == kWalkCensus;
-  uint32_t hand_thr = max(scan_threshold >> 16, 1u);  // (the launch packs two thresholds into the argument)
-  scan_threshold &= 0xFFFFu;
+  // (the launch packs its thresholds into one argument: scan | thin hand-out of shared walks << 8 | hand-out << 16 |
+  // queries per wave / 8 up to which that thin hand-out applies << 24)
+  uint32_t hand_thr = max((scan_threshold >> 16) & 0xFFu, 1u);
+  const uint32_t share_grab = (scan_threshold >> 8) & 0xFFu, share_upto = (scan_threshold >> 24) * 8u;
+  scan_threshold &= 0xFFu;
   constexpr bool kSet = kMode == kWalkSet;
+  static_assert(!kShare || kSet, "only the order-free walk can be shared between lanes");
   if (n_queries_dev && *n_queries_dev == 0) return;  // (the second search of a batch without a query beyond the cap)
   const uint32_t gl = blockIdx.x * kThreads + threadIdx.x;
   float4 *stk = stack_mem + (size_t)gl * (kStackDepth * 2);
@@ -256,27 +269,108 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   // (a wave whose own range is exhausted takes from the other ranges), so that neither a lane nor
   // a wave nor an XCD idles while another still has a backlog.
   uint32_t pool_next = 0, pool_end = 0, victim = 0;
+
   // ... 64 at a time when there is work for every lane of the launch; a SMALL batch (the tail rounds of a streaming
   // run: a hundred chunks, 30 000 queries for 262 144 lanes) is spread thinly instead, 8 to 32 queries per wave: a
   // wave lasts as long as its slowest query, and the slowest of 8 ends well before the slowest of 64 (2.1 -> ms of a
   // 3 ms round: profiles/EXPERIMENTS.md, round 5).  Speed only.
   uint32_t grab = 64u;
+  uint32_t mlane = lane, hcnt = 0;  // kShare: the lane that holds this lane's query; helpers at work on this lane's query
   {
     const uint32_t n_waves = gridDim.x * (uint32_t)(kThreads / 64);
     const uint32_t per_wave = (total + n_waves - 1u) / n_waves;
     if (per_wave <= 32u) grab = per_wave <= 8u ? 8u : per_wave <= 16u ? 16u : 32u;
+    // (shared walks: the lanes without a query help the others, so fewer queries per wave at a time spread the heavy
+    // ones -- the head of the visiting order -- over more waves)
+    // (measured, ms per launch at 64 / 300 / 1 200 / 2 000 chunks: 4 at a time 0.51 / 0.88 / 1.90 / 2.79, 8: 0.64 / 0.82 / 1.62 /
+    // 2.37, 16: 0.66 / 0.82 / 1.45 / 2.06, 32: 0.67 / 1.22 / 1.41 / 1.81, as unshared: 0.64 / 1.24 / 1.90 / 2.16)
+    if (kShare) {
+      const uint32_t half = per_wave / 2u;
+      grab = half >= 64u ? 64u : half >= 32u ? 32u : half >= 16u ? 16u : half >= 8u ? 8u : 4u;
+      if (share_grab && per_wave <= share_upto) grab = share_grab;
+    }
   }
   if (lane >= grab) mode = M_IDLE;  // (the other lanes of such a wave never take a query)
   if (grab < 64u) {                 // ... and the two thresholds, which count lanes, shrink with the lanes in use
-    scan_threshold = max(1u, scan_threshold * grab / 64u);
+    if (!kShare) scan_threshold = max(1u, scan_threshold * grab / 64u);  // (shared: the helpers fill the wave)
     hand_thr = max(1u, hand_thr * grab / 64u);
   }
   unsigned long long pt_scan = 0, pt_wait = 0, pt_fetchq = 0, pt_visit = 0, pt_scan_setup = 0, pt_scan_load = 0;
   const unsigned long long pt_begin = WALK_T();
+#ifdef SMHIP_PHASE_PROF
+  const unsigned long long pt_wall_begin = wall_clock64();
+#endif
   for (;;) {
     const unsigned long long pt0 = WALK_T();
+    if (kShare) {
+      // helpers that are through report to their query's lane: its count of helpers, the statistics of their part
+      for (uint64_t fin = __ballot(mode == M_HDONE); fin; fin &= fin - 1ull) {
+        const int t = __builtin_ctzll(fin);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mlane, t);
+        const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)nn, t), tp = (uint32_t)__builtin_amdgcn_readlane((int)np, t);
+        if (lane == m) {
+          --hcnt;
+          nn += tn;
+          np += tp;
+        }
+      }
+      if (mode == M_HDONE) {
+        mode = M_IDLE;
+        mlane = lane;
+      }
+      if (mode == M_WAIT && hcnt == 0) {  // the last helper of this lane's query is through: the query is complete
+        sink.q_count[qi] = hits;
+        if (sink.q_nodes) sink.q_nodes[qi] = nn;
+        if (sink.q_points) sink.q_points[qi] = np;
+        mode = M_FETCH;
+      }
+      // Lanes with nothing to do (no query left anywhere, or never given one: a thin hand-out) take the OLDEST pending
+      // reference -- the largest subtree -- of a lane that has one, the k-th idle lane from the k-th such lane; the
+      // reference, the query's lane and its grid coordinates (all a walk needs: the float coordinates are only read
+      // in the scan phase, from the master's row) travel through the wave's staging area, which is free between two
+      // iterations.
+      const uint64_t idle_m = __ballot(mode == M_IDLE);
+      const uint64_t rich_m = idle_m ? __ballot(mode == M_NODE && sp >= 1u && sp <= (uint32_t)kSetStack) : 0ull;
+      if (rich_m) {
+        const uint64_t lt = (1ull << lane) - 1ull;
+        const uint32_t n_pairs = min((uint32_t)__popcll(idle_m), (uint32_t)__popcll(rich_m));
+        const uint32_t ri = (uint32_t)__popcll(idle_m & lt), rr = (uint32_t)__popcll(rich_m & lt);
+        const bool gives = ((rich_m >> lane) & 1ull) && rr < n_pairs, takes = ((idle_m >> lane) & 1ull) && ri < n_pairs;
+        if (gives) {
+          const uint32_t ref = lstk[0][threadIdx.x];
+#pragma unroll
+          for (int i = 0; i + 1 < kSetStack; ++i)
+            if ((uint32_t)i + 1u < sp) lstk[i][threadIdx.x] = lstk[i + 1][threadIdx.x];
+          --sp;
+          stage_w[2u * rr] = make_uint4(ref, mlane, qc01, qc23);
+          stage_w[2u * rr + 1u] = make_uint4(qc45, 0u, 0u, 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        if (takes) {
+          const uint4 ra = stage_w[2u * ri], rb = stage_w[2u * ri + 1u];
+          node = ra.x;
+          mlane = ra.y;
+          qc01 = ra.z;
+          qc23 = ra.w;
+          qc45 = rb.x;
+          sp = 0;
+          nn = 0;
+          np = 0;
+          mode = M_NODE;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        for (uint64_t tk = __ballot(takes); tk; tk &= tk - 1ull) {
+          const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mlane, __builtin_ctzll(tk));
+          if (lane == m) ++hcnt;
+        }
+      }
+    }
     const bool blocked = fifo_cnt == (uint32_t)kFifo || mode == M_DRAIN;
-    const bool active = !blocked && mode != M_IDLE;
+    const bool active = !blocked && mode != M_IDLE && (!kShare || mode != M_WAIT);
     const uint64_t act = __ballot(active);
     const uint64_t pend = __ballot(fifo_cnt > 0);
     if (act == 0 && pend == 0) break;
@@ -315,7 +409,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           if ((uint32_t)e < c) {
             const uint32_t nleaf = tab[e] >> 27;
             // {first 16-byte slot of the leaf's block, owner lane | points << 8 | flat position << 13}
-            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 3, lane | (nleaf << 8) | (run << 13));
+            ents[my_first + e] = make_uint2((tab[e] & 0x07FFFFFFu) << 3, (kShare ? mlane : lane) | (nleaf << 8) | (run << 13));
             run += nleaf;
             if (!kStrict) np += nleaf;  // (strict: counted when the leaf was visited)
           }
@@ -325,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       // registers through it)
       own_a[lane] = make_float4(q0, q1, q2, q3);
       own_b[lane] = make_uint4(__float_as_uint(q4), __float_as_uint(q5), qi, hits);
-      if (c > 0) {
+      if (c > 0 || kShare) {  // (shared walks: a master's row is read by its helpers' entries too)
         ovf_w[lane] = ovf_base;
         if (kSet) sbase_w[lane] = my_slots;
       }
@@ -411,13 +505,26 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         const uint64_t rb = __ballot(pt && (lane == 0 || owner != prev_owner));  // first lanes of the runs
         const uint64_t lowmask = (2ull << lane) - 1ull, below = (1ull << lane) - 1ull;
         const uint32_t run_first = 63u - (uint32_t)__clzll((long long)((rb & lowmask) | 1ull));
-        const uint32_t in_run_below = (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
+        // (shared walks: the entries of a query come from several lanes' FIFOs, so its points may form SEVERAL runs of a
+        // window; som = all lanes of the window with a point of this lane's query, one ballot per distinct query)
+        uint64_t som = 0;
+        if (kShare) {
+          for (uint64_t todo = rb; todo;) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)owner, __builtin_ctzll(todo));
+            const uint64_t m = __ballot(pt && owner == o);
+            if (pt && owner == o) som = m;
+            todo &= ~m;
+          }
+        }
+        const uint32_t in_run_below =
+            kShare ? (uint32_t)__popcll(hb & som & below) : (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
         const uint32_t ord = hbase + in_run_below;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();  // every lane has read its owner's count
         // the last lane of a run adds the run's hits to the owner's count
         const uint64_t next_is_first_or_idle = (rb | ~pb) >> 1;  // bit L: lane L + 1 starts a run or has no point
-        if (pt && (lane == 63u || ((next_is_first_or_idle >> lane) & 1ull) != 0)) {
+        if (kShare ? (pt && lane == 63u - (uint32_t)__clzll((long long)som))
+                   : (pt && (lane == 63u || ((next_is_first_or_idle >> lane) & 1ull) != 0))) {
           const uint32_t cnt = in_run_below + (hit ? 1u : 0u);
           if (cnt) *(reinterpret_cast<uint32_t *>(&own_b[owner]) + hits_word) = hbase + cnt;
         }
@@ -505,9 +612,13 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         q4 = __uint_as_float(rb.x); q5 = __uint_as_float(rb.y);
         hits = rb.w;
       }
-      if (c > 0) ovf_base = ovf_w[lane];
+      if (c > 0 || kShare) ovf_base = ovf_w[lane];
       fifo_cnt = 0;
-      if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
+      if (kShare && mode == M_DRAIN && mlane != lane) {
+        mode = M_HDONE;  // a helper's part of a query is through
+      } else if (kShare && mode == M_DRAIN && hcnt > 0) {
+        mode = M_WAIT;  // the query's own lane is through, helpers are not
+      } else if (mode == M_DRAIN) {  // query complete (plain stores; per-chunk sums: AnchorCountKernel)
         if (!sink.stop_at_cap) {
           sink.q_count[qi] = hits;
           if (sink.q_nodes) sink.q_nodes[qi] = nn;
@@ -537,11 +648,11 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         bool got = false;
         while (victim < n_ranges) {
           const uint32_t xx = (first_range + victim) % n_ranges;
+          const uint32_t rb = (range_end && xx) ? range_end[xx * range_stride - 1] : 0u;
+          const uint32_t re = range_end ? range_end[(xx + 1) * range_stride - 1] : total;
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(&cursors[xx], grab);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          const uint32_t rb = (range_end && xx) ? range_end[xx * range_stride - 1] : 0u;
-          const uint32_t re = range_end ? range_end[(xx + 1) * range_stride - 1] : total;
           if (base < re - rb) {
             pool_next = rb + base;
             pool_end = min(re, pool_next + grab);
@@ -706,6 +817,10 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         if (cur == 0xFFFFFFFFu) {  // stack empty: traversal of this query complete
           if (fifo_cnt > 0) {
             mode = M_DRAIN;  // its pending leaves are scanned first
+          } else if (kShare && mlane != lane) {
+            mode = M_HDONE;
+          } else if (kShare && hcnt > 0) {
+            mode = M_WAIT;
           } else {
             sink.q_count[qi] = hits;
             if (sink.q_nodes) sink.q_nodes[qi] = nn;
@@ -862,6 +977,14 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     atomicAdd(&g_walk_prof[5], 1ull);
     atomicAdd(&g_walk_prof[6], pt_scan_setup);
     atomicAdd(&g_walk_prof[7], pt_scan_load);
+    atomicMax(&g_walk_prof[8], pt_all);
+    atomicMax(&g_walk_prof[9], pt_scan);
+    atomicMax(&g_walk_prof[10], pt_fetchq);
+    atomicMax(&g_walk_prof[11], pt_wait);
+    atomicMax(&g_walk_prof[12], (unsigned long long)st_walk);
+    atomicMax(&g_walk_prof[13], (unsigned long long)st_scan);
+    atomicMin(&g_walk_prof[14], pt_wall_begin);
+    atomicMax(&g_walk_prof[15], (unsigned long long)wall_clock64());
   }
 #endif
   (void)pt_visit;
@@ -1168,6 +1291,8 @@ __global__ void QueryScatterKernel(const uint32_t *__restrict__ n_queries_dev, u
 constexpr int kLaneBlocksPerCU = 4;  // 40 KB of LDS per 256-thread workgroup
 constexpr int kScanThreshold = 4;    // blocked lanes of a wave that trigger a scan phase
 constexpr int kHandoutLanes = 4;     // idle lanes of a wave that trigger a hand-out of queries (1 / 2 / 4 / 8 / 16: 5.68 / 5.61 / 5.57 / 5.57 / 5.59 ms)
+constexpr uint32_t kShareMaxChunks = 4096;  // batches up to this many chunks (~ four queries per lane of the launch) share walks
+constexpr int kShareGrab = 0, kShareGrabUpto = 0;  // thin hand-out of shared walks: lanes per wave, up to this many queries per wave (0: as unshared)
 constexpr int kSetScanThreshold = 8;  // ... of the set walk (2 / 4 / 8 / 16: 6.52 / 6.44 / 6.35 / 6.44 ms)
 
 // The queries the set walk found more than num_nearest_points hits for are listed for a second search in the
@@ -1401,9 +1526,11 @@ __global__ __launch_bounds__(kSelThreads) void OverCapSelectKernel(IndexView ix,
   }
 }
 
+// small_batch: the host's knowledge that the launch has about a query per lane or fewer (the set walk then shares the
+// walk of a query between the lanes of a wave: SeedWalkKernel, kShare)
 hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const QueryRec *qrec, const uint32_t *n_queries_dev,
                       uint32_t n_queries_host, const Sink &sink, const uint32_t *range_end, uint32_t range_stride,
-                      uint32_t blocks_override = 0) {
+                      uint32_t blocks_override = 0, bool small_batch = false) {
   const int env_blocks = ctx->knobs.lane_blocks_per_cu, xcd_ranges = ctx->knobs.xcd_ranges,
             env_thr = ctx->knobs.scan_threshold;
   int blocks_per_cu = p.walk_blocks_per_cu ? (int)p.walk_blocks_per_cu : (env_blocks ? env_blocks : kLaneBlocksPerCU);
@@ -1417,20 +1544,28 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   {
     int hand = ctx->knobs.handout > 0 ? ctx->knobs.handout : kHandoutLanes;  // (experiment knob)
     if (hand < 1 || hand > 64) hand = kHandoutLanes;
-    thr |= hand << 16;  // (both thresholds travel in one kernel argument)
+    thr |= hand << 16;  // (the thresholds travel in one kernel argument)
+    const int sg = ctx->knobs.walk_grab > 0 ? ctx->knobs.walk_grab : kShareGrab;
+    const int su = ctx->knobs.walk_grab_upto > 0 ? ctx->knobs.walk_grab_upto : kShareGrabUpto;
+    thr |= (std::min(sg, 64) << 8) | (int)((uint32_t)std::min(su / 8, 255) << 24);
   }
+  // (walk_share: -1 = small batches share, 1 = every set walk, 0 = none: the A/B reference.  Alone on the GPU sharing
+  // wins at every size -- 51 % of the launch at 300 chunks, 16 % at 3 000, 5 % at 5 000, 1 % at 10 000 --, with four
+  // batches of 10 000 in flight it loses 2 %: 9.94 against 9.74 ms per step)
+  const bool share = mode == kWalkSet && ctx->knobs.walk_share != 0 && (small_batch || ctx->knobs.walk_share == 1);
   const uint32_t blocks = blocks_override ? blocks_override : 256 * blocks_per_cu;
   const size_t stack_bytes = (size_t)256 * 8 * kSeedThreads * kStackDepth * 2 * sizeof(float4);  // (any grid up to 8 per CU)
   hipError_t e = ctx->walk_stack.Reserve(stack_bytes);
   if (e != hipSuccess) return e;
   const uint32_t *re = xcd_ranges ? range_end : nullptr;
-#define SM_WALK(MODE, THREADS, BLOCKS)                                                                              \
-  hipLaunchKernelGGL((SeedWalkKernel<MODE, THREADS>), dim3(BLOCKS), dim3(THREADS), 0, ctx->stream, ctx->index, qrec, \
-                     n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re,         \
+#define SM_WALK(MODE, THREADS, SHARE, BLOCKS)                                                                          \
+  hipLaunchKernelGGL((SeedWalkKernel<MODE, THREADS, SHARE>), dim3(BLOCKS), dim3(THREADS), 0, ctx->stream, ctx->index,  \
+                     qrec, n_queries_dev, n_queries_host, sink, p.search_radius, ctx->walk_stack.as<float4>(), re,     \
                      range_stride, (uint32_t)thr)
-  if (mode == kWalkCensus) SM_WALK(kWalkCensus, kSeedThreads, blocks);
-  else if (mode == kWalkSet) SM_WALK(kWalkSet, kSetThreads, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
-  else SM_WALK(kWalkExact, kSeedThreads, blocks);
+  if (mode == kWalkCensus) SM_WALK(kWalkCensus, kSeedThreads, false, blocks);
+  else if (mode == kWalkSet && share) SM_WALK(kWalkSet, kSetThreads, true, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
+  else if (mode == kWalkSet) SM_WALK(kWalkSet, kSetThreads, false, blocks_override ? blocks_override : 256 * set_blocks_per_cu);
+  else SM_WALK(kWalkExact, kSeedThreads, false, blocks);
 #undef SM_WALK
   return hipGetLastError();
 }
@@ -1589,7 +1724,7 @@ hipError_t LaunchSeedLookup(smhip_ctx *ctx, const smhip_params &p, const void *q
   const bool ranked = (uint32_t)p.num_nearest_points <= kSelMaxKeep && !ctx->knobs.second_search;
   sink.store_all = ranked ? 1u : 0u;
   e = LaunchWalk(ctx, p, kWalkSet, reinterpret_cast<const QueryRec *>(order), q_off + n_chunks, 0, sink, range_end,
-                 range_stride);
+                 range_stride, 0, n_chunks <= kShareMaxChunks);
   sink.store_all = 0u;
   if (e != hipSuccess) return e;
   // Queries with more hits than num_nearest_points: which 5000 become anchors depends on the reference's traversal
@@ -1707,15 +1842,17 @@ hipError_t LaunchSeedLookupRaw(smhip_ctx *ctx, const smhip_params &p, const floa
   // mapping path's order-free walk over quad records finds them (same set; an index without quads: exact walk)
   const int mode = p.reference_walk ? kWalkCensus : (p.search_mode == SMHIP_SEARCH_SET && ctx->index.quads ? kWalkSet : kWalkExact);
   ctx->last_walk_mode = mode;
-  return LaunchWalk(ctx, p, mode, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride);
+  return LaunchWalk(ctx, p, mode, reinterpret_cast<const QueryRec *>(order), nullptr, n, sink, range_end, range_stride, 0,
+                    n <= kShareMaxChunks * 256u);
 }
 }  // namespace smhip
 
 #ifdef SMHIP_PHASE_PROF
-extern "C" int smhip_debug_walk_prof(unsigned long long *out8, int reset) {
-  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(smhip::g_walk_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int smhip_debug_walk_prof(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(smhip::g_walk_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[8] = {};
+    unsigned long long z[16] = {};
+    z[14] = ~0ull;
     if (hipMemcpyToSymbol(HIP_SYMBOL(smhip::g_walk_prof), z, sizeof z) != hipSuccess) return -1;
   }
   return 0;

@@ -355,14 +355,22 @@ def test_set_walk_matches_reference_golden():
     dev.upload_index(ix)
     dev.params.search_mode = _abi.SEARCH_SET
     off = g["hit_off"]
-    for blocks in (0, 1, 8):
+    # ... and with the walk of a query shared between the lanes of its wave (the default), not shared (knob walk_share
+    # 0: round 4's walk), and shared with two queries per wave at a time (62 lanes of every wave only ever help)
+    for blocks, share, grab in ((0, -1, 0), (1, -1, 0), (8, -1, 0), (0, 0, 0), (0, 1, 2), (1, 1, 64)):
         dev.params.walk_blocks_per_cu = blocks
+        dev.set_knob("walk_share", share)
+        dev.set_knob("walk_grab", grab)
+        dev.set_knob("walk_grab_upto", 2040 if grab else 0)
         counts, idx, dist, _, _ = dev.seed_lookup(g["queries"], cap=256)
         assert dev.debug_counters()[6] == 2          # the quad walk ran
         for k in range(len(g["queries"])):
             n = off[k + 1] - off[k]
             assert counts[k] == n
             assert _hit_sets_equal(idx[k], dist[k], n, g["hit_idx"][off[k]:off[k + 1]], g["hit_dist"][off[k]:off[k + 1]]), k
+    dev.params.walk_blocks_per_cu = 0
+    for name in ("walk_share", "walk_grab", "walk_grab_upto"):
+        dev.set_knob(name, -1 if name == "walk_share" else 0)
     assert int(counts.sum()) == int(off[-1]) and int(off[-1]) > 150 and int(counts.max()) >= 3
     # a cap below a query's hit count: the count is still the total, the stored hits are a subset of the set
     counts2, idx2, dist2, _, _ = dev.seed_lookup(g["queries"], cap=4)
@@ -760,10 +768,18 @@ def test_repeat_injected_cloud_second_search_at_the_default_cap(small_world):
     tree.close()
     assert sum(1 for _, st in want if st.hits >= 100 * copies) >= 3     # reads of the + strand: ~100 seeds x 5600 hits
     same = None
-    for mode, fast, second, walked in ((_abi.SEARCH_AUTO, 512, 0, 2), (_abi.SEARCH_AUTO, 0, 0, 2), (_abi.SEARCH_SET, 512, 1, 2),
-                                       (_abi.SEARCH_SET, 0, 1, 2), (_abi.SEARCH_EXACT, 512, 0, 0), (_abi.SEARCH_AUTO, 0, 1, 0)):
+    # (share: the set walk's lanes help each other -- the default --, do not (0), or two queries per wave at a time with 62
+    # helpers (2): the overflow segments of one query then fill from many lanes' leaves at once)
+    for mode, fast, second, walked, share in ((_abi.SEARCH_AUTO, 512, 0, 2, -1), (_abi.SEARCH_AUTO, 0, 0, 2, -1),
+                                              (_abi.SEARCH_SET, 512, 1, 2, -1), (_abi.SEARCH_SET, 0, 1, 2, -1),
+                                              (_abi.SEARCH_EXACT, 512, 0, 0, -1), (_abi.SEARCH_AUTO, 0, 1, 0, -1),
+                                              (_abi.SEARCH_AUTO, 512, 0, 2, 0), (_abi.SEARCH_AUTO, 512, 0, 2, 2),
+                                              (_abi.SEARCH_SET, 0, 1, 2, 2)):
         dev = pipeline.DeviceMapper(0)       # fresh: nothing learnt from earlier batches
         dev.upload_index(ix)
+        dev.set_knob("walk_share", -1 if share == 2 else share)
+        dev.set_knob("walk_grab", 2 if share == 2 else 0)
+        dev.set_knob("walk_grab_upto", 2040 if share == 2 else 0)
         if mode == _abi.SEARCH_AUTO:
             census = dev.index_census()
             assert len(census) == 4096 and census[len(census) // 100] >= copies   # (nearly) every sampled point: 5600+ hits

@@ -59,6 +59,11 @@ def main(rounds, first):
         dev.set_knob("classify_dense", int(rng.choice([-1, -1, 0])))   # dense pairs or lockstep scans in the chain classifier
         dev.set_knob("classify_resolve", int(rng.choice([-1, -1, 0])))  # ... chaining what it can itself, or nothing
         dev.set_knob("second_search", int(rng.choice([0, 0, 1])))  # over-cap queries: ranked, or searched a second time
+        # the set walk: lanes of a wave share a query's walk (default), do not, or few queries per wave and many helpers
+        share = int(rng.choice([-1, -1, 0, 3]))
+        dev.set_knob("walk_share", -1 if share == 3 else share)
+        dev.set_knob("walk_grab", int(rng.choice([1, 2, 4, 8])) if share == 3 else 0)
+        dev.set_knob("walk_grab_upto", 2040 if share == 3 else 0)
         # the hit cap: lowered caps put (nearly) every query beyond it -- the set walk's second search in the
         # reference's order, or, once the context has seen such a batch, the exact walk for everything
         nnp = int(rng.choice([5000, 5000, 40, 7]))
