@@ -382,6 +382,8 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       // iteration + its rank among the leaf's hits (ballot), i.e. exactly the order in which
       // searchLevel reports them.
       const uint32_t c = fifo_cnt;
+      // (shared walks: only a scan with entries of helpers can see a query in several runs of a window)
+      const bool multi = kShare && __ballot(mlane != lane && c > 0) != 0;
       const uint64_t lt = (1ull << lane) - 1ull;
       const uint64_t cb0 = __ballot(c & 1u), cb1 = __ballot(c & 2u), cb2 = __ballot(c & 4u);
       const uint32_t my_first = (uint32_t)__popcll(cb0 & lt) + 2u * (uint32_t)__popcll(cb1 & lt) +
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         // (shared walks: the entries of a query come from several lanes' FIFOs, so its points may form SEVERAL runs of a
         // window; som = all lanes of the window with a point of this lane's query, one ballot per distinct query)
         uint64_t som = 0;
-        if (kShare) {
+        if (multi) {
           for (uint64_t todo = rb; todo;) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)owner, __builtin_ctzll(todo));
             const uint64_t m = __ballot(pt && owner == o);
@@ -517,14 +519,14 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           }
         }
         const uint32_t in_run_below =
-            kShare ? (uint32_t)__popcll(hb & som & below) : (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
+            multi ? (uint32_t)__popcll(hb & som & below) : (uint32_t)__popcll(hb & below & ~((1ull << run_first) - 1ull));
         const uint32_t ord = hbase + in_run_below;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();  // every lane has read its owner's count
         // the last lane of a run adds the run's hits to the owner's count
         const uint64_t next_is_first_or_idle = (rb | ~pb) >> 1;  // bit L: lane L + 1 starts a run or has no point
-        if (kShare ? (pt && lane == 63u - (uint32_t)__clzll((long long)som))
-                   : (pt && (lane == 63u || ((next_is_first_or_idle >> lane) & 1ull) != 0))) {
+        if (multi ? (pt && lane == 63u - (uint32_t)__clzll((long long)som))
+                  : (pt && (lane == 63u || ((next_is_first_or_idle >> lane) & 1ull) != 0))) {
           const uint32_t cnt = in_run_below + (hit ? 1u : 0u);
           if (cnt) *(reinterpret_cast<uint32_t *>(&own_b[owner]) + hits_word) = hbase + cnt;
         }
