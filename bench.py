@@ -77,6 +77,7 @@ def parse():
                          "region; value / ms_per_step are the MEDIAN region, min / max / all are printed beside it")
     ap.add_argument("--stagger", type=float, default=1.0,
                     help="the contexts of a region start this fraction of (serial step / depth) apart (0: all at once)")
+    ap.add_argument("--ab-knob", default=None, help="development: NAME=V1,V2,... -- the serial pass repeated under each value of a knob")
     ap.add_argument("--depth", type=int, default=4,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
                          "that share the resident index (1 = strictly serial steps)")
@@ -297,6 +298,23 @@ def main():
     fence()
     serial = {"ms_per_step": (time.perf_counter() - t0) / args.steps * 1e3, "kernels": kernel_times([dev])}
     pool.for_each(lambda dv: dv.timing_reset())
+    if args.ab_knob:
+        # development A/B on the resident index (an index of 250 Mb takes minutes to build): the serial pass again under
+        # each value of one development knob, per-stage kernel times on stderr.  Needs SMHIP_DEV=1.
+        name, vals = args.ab_knob.split("=")
+        for v in [int(x) for x in vals.split(",")] * 2:
+            dev.set_knob(name, v)
+            for i in range(2):
+                step(dev, i)
+            fence()
+            dev.timing_reset()
+            for i in range(args.steps):
+                step(dev, i)
+            fence()
+            print("ab_knob %s=%d: %s  walker %s" % (name, v, {k: x["mean_ms"] for k, x in kernel_times([dev]).items()},
+                                                    walker_stats(dev)), file=sys.stderr, flush=True)
+            dev.timing_reset()
+        dev.set_knob(name, int(vals.split(",")[0]))
 
     # ---- timed regions.  Three kinds, every one EXACTLY K steps between two fences (barrier + synchronize on both sides),
     # the time taken as the max over ranks:

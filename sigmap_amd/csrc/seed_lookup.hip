@@ -979,14 +979,16 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     atomicAdd(&g_walk_prof[5], 1ull);
     atomicAdd(&g_walk_prof[6], pt_scan_setup);
     atomicAdd(&g_walk_prof[7], pt_scan_load);
-    atomicMax(&g_walk_prof[8], pt_all);
-    atomicMax(&g_walk_prof[9], pt_scan);
-    atomicMax(&g_walk_prof[10], pt_fetchq);
-    atomicMax(&g_walk_prof[11], pt_wait);
-    atomicMax(&g_walk_prof[12], (unsigned long long)st_walk);
-    atomicMax(&g_walk_prof[13], (unsigned long long)st_scan);
-    atomicMin(&g_walk_prof[14], pt_wall_begin);
-    atomicMax(&g_walk_prof[15], (unsigned long long)wall_clock64());
+    if (kShare) {  // (the maxima: of the shared walks only -- the census launch of a fresh index would hide a small batch's)
+      atomicMax(&g_walk_prof[8], pt_all);
+      atomicMax(&g_walk_prof[9], pt_scan);
+      atomicMax(&g_walk_prof[10], pt_fetchq);
+      atomicMax(&g_walk_prof[11], pt_wait);
+      atomicMax(&g_walk_prof[12], (unsigned long long)st_walk);
+      atomicMax(&g_walk_prof[13], (unsigned long long)st_scan);
+      atomicMin(&g_walk_prof[14], pt_wall_begin);
+      atomicMax(&g_walk_prof[15], (unsigned long long)wall_clock64());
+    }
   }
 #endif
   (void)pt_visit;
