@@ -59,7 +59,9 @@ void Sigmap::PinnedFree(void *p) { smhip_host_free(p); }
 void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
                   bool sdtw_cigar, bool share_device) {
   num_gpus = std::max(1, num_gpus);
-  num_streams = std::max(1, num_streams);
+  // (num_streams < 0: up to that many contexts per GPU, as many as the reads need -- the command line's default)
+  const bool auto_lanes = num_streams < 0;
+  num_streams = std::max(1, auto_lanes ? -num_streams : num_streams);
   if (device < 0 || device + (share_device ? 1 : num_gpus) > smhip_device_count())
     ExitWithMessage("No usable MI355X GPU for --device " + std::to_string(device) + " --gpus " +
                     std::to_string(num_gpus) + " (" + std::to_string(smhip_device_count()) +
@@ -214,13 +216,23 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   // ... and no more than a context's share of its GPU's block of reads: reads are admitted in input order by whichever
   // context has free slots, and a context with room for the whole block would take all of it and leave the GPU's other
   // contexts -- whose kernels fill the gaps between its chunk rounds -- without work
+  // Contexts in use per GPU: all of them when the GPU's reads outnumber one context's slots -- the other context's
+  // kernels then fill the gaps between a context's chunk rounds, and its uploads overlap them --, ONE when they fit a
+  // single context (default only; an explicit --streams is taken at its word): the rounds of multi-chunk reads are a
+  // chain whose length the longest read sets, two half-sized batches cost more than one whole (a batch of 5 000
+  // chunks is 20 % dearer per chunk than one of 10 000), and two chains side by side lengthen each other.  Measured,
+  // 10 000 reads of 8 / 30 chunks: 35.8 / 73.7 ms on one context, 39.7 - 45.8 / 94.1 on two; 50 000 reads of 8
+  // (more than a context's slots either way): 121.3 / 119.7 ms.
+  size_t lanes_used = (size_t)num_streams;
   {
     const size_t block_reads = (num_reads + (size_t)num_gpus - 1) / (size_t)num_gpus;
-    lane_budget = std::max<size_t>(1, std::min(lane_budget, (block_reads + (size_t)num_streams - 1) / (size_t)num_streams));
+    if (auto_lanes) lanes_used = std::min<size_t>(lanes_used, std::max<size_t>(1, (block_reads + lane_budget - 1) / lane_budget));
+    lane_budget = std::max<size_t>(1, std::min(lane_budget, (block_reads + lanes_used - 1) / lanes_used));
   }
+  // (the other contexts stay idle: created and holding the index, never given read slots or work)
   // read slots of every context: set-up like the index, before the mapping span
   for (auto &gpu : ctxs)
-    for (smhip_ctx *c : gpu)
+    for (smhip_ctx *c : std::vector<smhip_ctx *>(gpu.begin(), gpu.begin() + (long)lanes_used))
       if (smhip_reads_configure(c, (uint32_t)lane_budget, keep) != SMHIP_OK ||
           smhip_batch_reserve_for(c, &dp, (uint32_t)lane_budget, 288) != SMHIP_OK)  // ~225 seeds per 4000-sample chunk
         ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
@@ -236,7 +248,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     std::vector<std::thread> warm;
     std::vector<std::string> failed(ctxs.size() * (size_t)num_streams);
     for (int g = 0; g < num_gpus; ++g)
-      for (size_t k = 0; k < ctxs[g].size(); ++k)
+      for (size_t k = 0; k < lanes_used; ++k)
         warm.emplace_back([&, g, k] {
           smhip_ctx *ctx = ctxs[g][k];
           size_t lo = 0, hi = 0;
@@ -284,6 +296,23 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     for (const auto &f : failed)
       if (!f.empty()) ExitWithMessage("GPU warm-up batch failed: " + f);
   }
+  // A lane's large host buffers -- result records, the anchors downloaded after a round, the carry-over of the next --
+  // sized and TOUCHED here: a vector that grows inside the span pays for its fresh pages there (measured: 0.5 ms in the
+  // first round's anchor download, 0.6 ms where the carry-over first reached 150 000 anchors).
+  struct LaneScratch {
+    std::vector<smhip_carried_anchor> carried, next_carried, out_anchors;
+    std::vector<smhip_chunk_result> results;
+  };
+  std::vector<LaneScratch> lane_scratch((size_t)num_gpus * (size_t)num_streams);
+  for (int g = 0; g < num_gpus; ++g)
+    for (size_t k = 0; k < lanes_used; ++k) {
+      LaneScratch &sc = lane_scratch[(size_t)g * (size_t)num_streams + k];
+      const size_t anchors_room = std::min<size_t>((size_t)1 << 20, std::max<size_t>(lane_budget * 64, 4096));
+      sc.out_anchors.resize((size_t)1 << 20);  // (the download's first capacity)
+      sc.carried.resize(anchors_room); sc.carried.clear();
+      sc.next_carried.resize(anchors_room); sc.next_carried.clear();
+      sc.results.resize(lane_budget); sc.results.clear();
+    }
   phase("Warmed up the device contexts (one discarded round of first chunks each)");
   const double t_map = GetRealTime();
   // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
@@ -317,8 +346,11 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     std::vector<uint32_t> slots, chunk_idx, qstart, carried_off, plen, expect, want, want_at;
     std::vector<const int16_t *> pieces;
     std::vector<float> dig, rng, ofs;
-    std::vector<smhip_carried_anchor> carried, out_anchors;
-    std::vector<smhip_chunk_result> results;
+    // (the large ones come from the set-up: grown inside the span, their first pages cost a millisecond per round)
+    LaneScratch &scratch = lane_scratch[(size_t)g * (size_t)num_streams +
+                                        (size_t)(std::find(ctxs[g].begin(), ctxs[g].end(), ctx) - ctxs[g].begin())];
+    std::vector<smhip_carried_anchor> &carried = scratch.carried, &out_anchors = scratch.out_anchors;
+    std::vector<smhip_chunk_result> &results = scratch.results;
     std::vector<uint64_t> out_off;
     std::vector<float> dts, pdist;
     std::vector<int64_t> dte, pend, pstart;
@@ -328,7 +360,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
     // the carry-over of the reads in flight (the anchors of their chains, spatial_index.cc:303-322), in in_flight order:
     // next_off[i] .. next_off[i + 1] of next_carried belongs to in_flight[i].  Built while a round's results are looked
     // at, handed to the next round as it is: an anchor is copied once on its way from one download to the next upload.
-    std::vector<smhip_carried_anchor> next_carried;
+    std::vector<smhip_carried_anchor> &next_carried = scratch.next_carried;
     std::vector<uint32_t> next_off(1, 0u);
     auto finish = [&](size_t r) {
       ReadState &s = st[r];
@@ -507,7 +539,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   {
     std::vector<std::thread> workers;
     for (int g = 0; g < num_gpus; ++g)
-      for (size_t k = 0; k < ctxs[g].size(); ++k)
+      for (size_t k = 0; k < lanes_used; ++k)
         if (g || k) workers.emplace_back(lane, g, ctxs[g][k]);
     lane(0, ctxs[0][0]);
     for (auto &w : workers) w.join();
@@ -516,7 +548,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   std::cerr << "Finished mapping in " << map_span << ", # reads: " << num_reads << "\n";
   if (want_stats) {
     const LaneStats &t = total_stats;
-    const double lanes = (double)num_gpus * num_streams;
+    const double lanes = (double)num_gpus * (double)lanes_used;
     char buf[1024];
     snprintf(buf, sizeof buf,
              "STREAM_STATS {\"reads\": %zu, \"span_s\": %.6f, \"lanes\": %d, \"chunks_in_flight_per_lane\": %zu, \"rounds\": %llu, "
@@ -645,7 +677,8 @@ const char *kHelp =
     "      --gpus INT                  GPUs to map on: the index is broadcast over xGMI (RCCL), reads shard [1]\n"
     "      --gpus-share-device         (development) the --gpus are all GPU --device and share one index\n"
     "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
-    "      --streams INT               device contexts / HIP streams that share the index and the chunk budget [2]\n"
+    "      --streams INT               device contexts / HIP streams that share the index and the chunk budget\n"
+    "                                  [up to 2: one when a GPU's reads fit one context's share of --batch-chunks]\n"
     "      --features events|cwt       (development) with -s DIR -o FILE: dump every chunk's feature signal as text\n"
     "  -h, --help  Print help\n";
 }  // namespace
@@ -729,7 +762,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int device = a.Has("device") ? std::stoi(a.Str("device")) : 0;
     const size_t batch = a.Has("batch-chunks") ? (size_t)std::stoul(a.Str("batch-chunks")) : 32768;
     const int sdtw_band = a.Has("sdtw-band") ? std::stoi(a.Str("sdtw-band")) : 0;
-    const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : 2;
+    const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : -2;  // (default: up to two, as the reads need)
     const int gpus = a.Has("gpus") ? std::stoi(a.Str("gpus")) : 1;
     Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams, a.Has("sdtw-cigar"),
                                                                a.Has("gpus-share-device"));

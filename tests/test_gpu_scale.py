@@ -237,6 +237,16 @@ def test_cli_streaming_600_multichunk_reads(tmp_path, small_world):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert [strip(l) for l in open(tmp_path / "out3.paf").read().splitlines()] == got
+    # the default number of contexts: up to two, as the reads need -- two here (600 reads for 250 read slots each), one
+    # when they all fit one context's share of --batch-chunks (the CLI says how many lanes mapped); the same PAF
+    for k, (budget, lanes) in enumerate((("500", 2), ("4000", 1))):
+        env = dict(os.environ, SIGMAP_STREAM_STATS="1")
+        r = subprocess.run([exe, "-m", "-r", str(tmp_path / "ref.fa"), "-p", str(tmp_path / "model.txt"),
+                            "-x", str(tmp_path / "idx"), "-s", str(tmp_path / "reads"), "-o", str(tmp_path / ("outd%d.paf" % k)),
+                            "--batch-chunks", budget], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert '"lanes": %d,' % lanes in r.stderr, r.stderr[-600:]
+        assert [strip(l) for l in open(tmp_path / ("outd%d.paf" % k)).read().splitlines()] == got
     ix = small_world["ix"]
     tree = po.OracleTree.from_host_index(ix)
     ref_lens = small_world["ref_lens"]

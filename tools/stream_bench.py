@@ -3,7 +3,7 @@
 (sigmap.cc:647-696 of the reference: chunk after chunk until a stop rule fires; spatial_index.cc:303-322: the chains'
 anchors are carried into the next chunk), SURVEY.md 8(f) N2.
 
-    tools/stream_bench.py --reads 10000 --chunks-per-read 8 [--streams 2] [--batch-chunks 32768] [--check 96]
+    tools/stream_bench.py --reads 10000 --chunks-per-read 8 [--streams N] [--batch-chunks 32768] [--check 96]
 
 Reads (seeded): C chunks of 4000 samples each; a third start with junk (uniform random ADC counts inside the pA filter's
 range, 1 .. C / 3 chunks of it) so that the read only maps from a later chunk on and earlier chains are carried over;
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--chunks-per-read", type=int, default=8)
     ap.add_argument("--contigs", type=int, default=16)
     ap.add_argument("--contig-len", type=int, default=750000)
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=0, help="device contexts (0: the CLI's default -- up to two, as the reads need)")
     ap.add_argument("--batch-chunks", type=int, default=32768)
     ap.add_argument("--max-num-chunks", type=int, default=30)
     ap.add_argument("--sdtw-band", type=int, default=0)
@@ -110,7 +110,8 @@ def main():
         r = subprocess.run([exe, "-i", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-o", d + "/idx"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
     cmd = [exe, "-m", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-x", d + "/idx", "-s", rd, "-o", d + "/out.paf",
-           "--streams", str(a.streams), "--batch-chunks", str(a.batch_chunks), "--max-num-chunks", str(a.max_num_chunks)]
+           "--batch-chunks", str(a.batch_chunks), "--max-num-chunks", str(a.max_num_chunks)] + \
+          (["--streams", str(a.streams)] if a.streams > 0 else [])
     if a.sdtw_band:
         cmd += ["--sdtw-band", str(a.sdtw_band)]
     env = dict(os.environ, SIGMAP_STREAM_STATS="1")
