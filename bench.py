@@ -423,7 +423,8 @@ def main():
         # walker kernel (search mode) and the same walker sources (a hash of seed_lookup.hip + common.h recorded with
         # the profile) -- bytes counted for another kernel version are never paired with this run's duration
         import glob
-        walker_kernel = "SeedWalkKernel<2, 128>" if quad_walk else "SeedWalkKernel<0, 256>"
+        # (the set walk of a batch of up to 4 096 chunks shares a query's visits between lanes: ", true>")
+        walker_kernel = ("SeedWalkKernel<2, 128, %s>" % ("true" if R <= 4096 else "false")) if quad_walk else "SeedWalkKernel<0, 256, false>"
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 j = json.load(open(pmc))
@@ -555,6 +556,9 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(ix, raw[:4096], n_refs, ref_lens, args.cpu_seconds)
         if world == 1 and not args.no_streaming and not args.no_cpu:
+            # (this process's contexts go first: the CLI in the child sizes its read slots -- and with them its number of
+            # contexts -- by the memory the GPU has left)
+            pool.close()
             out["streaming"] = streaming_block(args)
         print(json.dumps(out), flush=True)
         phase_prof()

@@ -33,7 +33,10 @@ def parse_shape(text):
     return shape
 
 
-WALKERS = ("SeedWalkKernel<2, 128>", "SeedWalkKernel<2>", "SeedWalkKernel<0, 256>", "SeedWalkKernel<0>", "SeedWalkKernel<false>")
+# (the production search kernel under its names over the rounds; "<2, 128, false>": the set walk of a large batch, round 5
+# -- ", true>" is the same walk with a query's visits shared between the lanes of a wave, batches of up to 4 096 chunks)
+WALKERS = ("SeedWalkKernel<2, 128, false>", "SeedWalkKernel<2, 128, true>", "SeedWalkKernel<2, 128>", "SeedWalkKernel<2>",
+           "SeedWalkKernel<0, 256, false>", "SeedWalkKernel<0, 256>", "SeedWalkKernel<0>", "SeedWalkKernel<false>")
 
 
 def traffic_json(tag, red, per, shape_txt):
