@@ -158,23 +158,20 @@ __global__ void OrStatusKernel(smhip_chunk_result *results, uint32_t n, const ui
 int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *query_start_offsets,
                           const smhip_carried_anchor *carried, const uint32_t *carried_offsets) {
   const uint64_t n_carried = carried_offsets && n_chunks ? carried_offsets[n_chunks] : 0;
-  HIPCHK(ctx->qstart.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
-  HIPCHK(ctx->carried_off.Reserve(((uint64_t)n_chunks + 1) * sizeof(uint32_t)));
+  // [query start offsets (n)][carried offsets (n + 1)]: one device block, filled by ONE copy (absent arrays: zeros)
+  HIPCHK(ctx->qstart.Reserve((2 * (uint64_t)n_chunks + 2) * sizeof(uint32_t)));
+  ctx->d_carried_off = ctx->qstart.as<uint32_t>() + n_chunks;
   HIPCHK(ctx->carried.Reserve(std::max<uint64_t>(n_carried, 1) * sizeof(smhip_carried_anchor)));
   // small arrays through the pinned staging (words [2 n, 4 n + 2) of it: smhip_batch_select keeps its own two
   // arrays in front); the anchors themselves -- large, and only present in later chunk rounds -- directly
   HIPCHK(StageReserve(ctx, (4 * (size_t)n_chunks + 8) * sizeof(uint32_t)));
   uint32_t *st = static_cast<uint32_t *>(ctx->h_stage) + 2 * (size_t)n_chunks;
-  if (query_start_offsets) {
-    memcpy(st, query_start_offsets, (size_t)n_chunks * sizeof(uint32_t));
-    HIPCHK(hipMemcpyAsync(ctx->qstart.p, st, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  } else {
-    HIPCHK(hipMemsetAsync(ctx->qstart.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
-  }
+  if (query_start_offsets) memcpy(st, query_start_offsets, (size_t)n_chunks * sizeof(uint32_t));
+  else memset(st, 0, (size_t)n_chunks * sizeof(uint32_t));
+  if (carried) memcpy(st + n_chunks, carried_offsets, ((size_t)n_chunks + 1) * sizeof(uint32_t));
+  else memset(st + n_chunks, 0, ((size_t)n_chunks + 1) * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(ctx->qstart.p, st, (2 * (uint64_t)n_chunks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   if (carried) {
-    memcpy(st + n_chunks, carried_offsets, ((size_t)n_chunks + 1) * sizeof(uint32_t));
-    HIPCHK(hipMemcpyAsync(ctx->carried_off.p, st + n_chunks, ((uint64_t)n_chunks + 1) * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
     // the anchors through pinned memory of the context: one DMA, and the caller's array is free on return without
     // anybody waiting for the stream.  (The staging is reused by the next batch's call: by then this batch has been
     // collected -- every route to its results synchronises the stream.)
@@ -192,8 +189,6 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
       memcpy(ctx->h_carried, carried, bytes);
       HIPCHK(hipMemcpyAsync(ctx->carried.p, ctx->h_carried, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-  } else {
-    HIPCHK(hipMemsetAsync(ctx->carried_off.p, 0, ((uint64_t)n_chunks + 1) * sizeof(uint32_t), ctx->stream));
   }
   return SMHIP_OK;
 }
@@ -991,29 +986,32 @@ int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, cons
   }
   // (the staged samples are also what smhip_reads_upload_raw copies into: its DMA waits for convert_done, recorded below)
   HIPCHK(ctx->reads_raw.Reserve(std::max<uint64_t>(units, 1) * 16));
-  HIPCHK(ctx->reads_meta.Reserve(meta_bytes));
-  HIPCHK(ctx->reads_segstart.Reserve(seg_bytes));
+  // the four descriptor arrays lie in the staging one behind the other and travel as ONE copy into one device block
+  // with the same layout (a small copy is a blit kernel of its own, ~5 us in a round's dependent chain; a streaming
+  // round of a hundred reads is made of such)
+  const size_t block_bytes = meta_bytes + src_bytes + seg_bytes + exp_bytes;
+  HIPCHK(ctx->pieces_src.Reserve(block_bytes));
   HIPCHK(ctx->reads_seg.Reserve(n_segs * 2 * sizeof(uint32_t)));
   HIPCHK(ctx->reads_len.Reserve(n * sizeof(uint32_t)));
-  HIPCHK(ctx->pieces_src.Reserve(src_bytes));
-  HIPCHK(ctx->pieces_expect.Reserve(std::max<size_t>(exp_bytes, 4)));
+  char *dblock = static_cast<char *>(ctx->pieces_src.p);
+  const RawReadMeta *d_meta = reinterpret_cast<const RawReadMeta *>(dblock);
+  const PieceSrc *d_src = reinterpret_cast<const PieceSrc *>(dblock + meta_bytes);
+  const uint32_t *d_segstart = reinterpret_cast<const uint32_t *>(dblock + meta_bytes + src_bytes);
+  const uint32_t *d_expect = reinterpret_cast<const uint32_t *>(dblock + meta_bytes + src_bytes + seg_bytes);
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->convert_done, 0));  // (ordered anyway on this stream; cheap)
-  HIPCHK(hipMemcpyAsync(ctx->reads_meta.p, meta, meta_bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->pieces_src.p, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->reads_segstart.p, seg_start, seg_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (expect_len) HIPCHK(hipMemcpyAsync(ctx->pieces_expect.p, expect, exp_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dblock, hp, block_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->pieces_staged, ctx->stream));
   ctx->pieces_pending = true;
   {
     ScopedTimer t(ctx, T_CONVERT);
-    HIPCHK(LaunchGatherPieces(ctx, ctx->pieces_src.as<PieceSrc>(), n_pieces, ctx->reads_raw.p));
-    HIPCHK(LaunchRawConvert(ctx, ctx->reads_raw.as<int16_t>(), ctx->reads_meta.as<RawReadMeta>(),
-                            ctx->reads_segstart.as<uint32_t>(), n_pieces, (uint32_t)n_segs, ctx->reads_seg.as<uint32_t>(),
+    HIPCHK(LaunchGatherPieces(ctx, d_src, n_pieces, ctx->reads_raw.p));
+    HIPCHK(LaunchRawConvert(ctx, ctx->reads_raw.as<int16_t>(), d_meta,
+                            d_segstart, n_pieces, (uint32_t)n_segs, ctx->reads_seg.as<uint32_t>(),
                             ctx->reads_seg.as<uint32_t>() + n_segs,
                             SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
                             ctx->slot_len.as<uint32_t>(), ctx->reads_len.as<uint32_t>()));
     if (expect_len)
-      HIPCHK(LaunchCheckPieceLen(ctx, ctx->reads_len.as<uint32_t>(), ctx->pieces_expect.as<uint32_t>(), n_pieces, ctx->h_piece_flag));
+      HIPCHK(LaunchCheckPieceLen(ctx, ctx->reads_len.as<uint32_t>(), d_expect, n_pieces, ctx->h_piece_flag));
   }
   HIPCHK(hipEventRecord(ctx->convert_done, ctx->stream));
   return SMHIP_OK;
@@ -1039,8 +1037,7 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
     if (rc0) return rc0;
   }
   const uint64_t nb = std::max<uint64_t>(n_chunks, 1);
-  HIPCHK(ctx->sel_slots.Reserve(nb * sizeof(uint32_t)));
-  HIPCHK(ctx->sel_chunk.Reserve(nb * sizeof(uint32_t)));
+  HIPCHK(ctx->sel_slots.Reserve(2 * nb * sizeof(uint32_t)));  // [slots][chunk index]: one copy
   HIPCHK(ctx->chunk_begin.Reserve((nb + 1) * sizeof(uint64_t)));
   HIPCHK(ctx->chunk_len.Reserve((nb + 1) * sizeof(uint32_t)));
   // (through the pinned staging: [slots][chunk_index], and in UploadBatchSideInputs [qstart][carried_off] behind them)
@@ -1049,11 +1046,10 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
     uint32_t *st = static_cast<uint32_t *>(ctx->h_stage);
     memcpy(st, slots, (size_t)n_chunks * sizeof(uint32_t));
     memcpy(st + n_chunks, chunk_index, (size_t)n_chunks * sizeof(uint32_t));
-    HIPCHK(hipMemcpyAsync(ctx->sel_slots.p, st, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->sel_chunk.p, st + n_chunks, (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice,
-                          ctx->stream));
+    if (n_chunks)
+      HIPCHK(hipMemcpyAsync(ctx->sel_slots.p, st, 2 * (uint64_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   }
-  HIPCHK(LaunchSelectChunks(ctx, ctx->sel_slots.as<uint32_t>(), ctx->sel_chunk.as<uint32_t>(), n_chunks, chunk_size,
+  HIPCHK(LaunchSelectChunks(ctx, ctx->sel_slots.as<uint32_t>(), ctx->sel_slots.as<uint32_t>() + n_chunks, n_chunks, chunk_size,
                             SlotView{ctx->pa_tab.as<float *>(), ctx->pa_sshift, ctx->reads_keep},
                             ctx->slot_len.as<uint32_t>(), ctx->chunk_begin.as<uint64_t>(), ctx->chunk_len.as<uint32_t>()));
   ctx->chunk_src = nullptr;  // chunk_begin holds addresses (in floats)
@@ -1230,7 +1226,7 @@ int EnqueueSearch(smhip_ctx *ctx, const smhip_params *p, uint32_t R, uint64_t nq
                           ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(), ctx->q_points.as<uint32_t>(),
                           ctx->counters.as<uint32_t>(), ctx->ovf_pool.as<Hit>(), ctx->q_ovf_off.as<uint32_t>(), pool_cap));
   HIPCHK(LaunchAnchorCount(ctx, *p, ctx->q_off.as<uint32_t>(), ctx->q_count.as<uint32_t>(), ctx->q_nodes.as<uint32_t>(),
-                           ctx->q_points.as<uint32_t>(), ctx->carried_off.as<uint32_t>(), R,
+                           ctx->q_points.as<uint32_t>(), ctx->d_carried_off, R,
                            ctx->chunk_anchor_cnt.as<uint32_t>(), results));
   HIPCHK(LaunchScanU32ToU64(ctx, ctx->chunk_anchor_cnt.as<uint32_t>(), R, ctx->anchor_off.as<uint64_t>()));
   return SMHIP_OK;
@@ -1261,7 +1257,7 @@ int EnqueueBack(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs, uint32_t
   sa.q_count = ctx->q_count.as<uint32_t>();
   sa.ovf_tab = ctx->q_ovf_off.as<uint32_t>();
   sa.qstart = ctx->qstart.as<uint32_t>();
-  sa.carried_off = ctx->carried_off.as<uint32_t>();
+  sa.carried_off = ctx->d_carried_off;
   sa.carried = ctx->carried.as<smhip_carried_anchor>();
   sa.region = hit_slots;
   sa.ovf_pool = ctx->ovf_pool.as<Hit>();

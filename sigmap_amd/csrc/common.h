@@ -239,6 +239,7 @@ struct smhip_ctx {
   hipEvent_t pieces_staged = nullptr;
   bool pieces_pending = false;
   smhip::DevBuf pieces_src, pieces_expect;
+  uint32_t *d_carried_off = nullptr;  // the carried offsets of the batch: behind the query start offsets in `qstart`'s block
   uint32_t *h_piece_flag = nullptr;
   // carried anchors of smhip_batch_select staged in pinned memory (the call then returns without waiting)
   void *h_carried = nullptr;
