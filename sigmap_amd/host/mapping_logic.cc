@@ -4,8 +4,10 @@ namespace sigmap {
 size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
                             size_t contexts) {
   const double per_chunk = (double)keep_samples * sizeof(float) + 288.0 * (16.0 * fast_slots + 1400.0) +
-                           288.0 * std::min(std::max(hits_per_query, 0.0), 5000.0) * 60.0 + 120000.0;
-  const double fit = (double)free_bytes * 0.5 / per_chunk / (double)std::max<size_t>(contexts, 1);
+                           288.0 * std::min(std::max(hits_per_query, 0.0), 5000.0) * 110.0 + 120000.0;
+  const double fixed = 1.5e9;  // per context, whatever its budget: the walker's 1 GB of stack room, the capacities a batch never goes below
+  const double share = (double)free_bytes * 0.6 / (double)std::max<size_t>(contexts, 1) - fixed;
+  const double fit = share / per_chunk;
   return fit < 1.0 ? 1 : (size_t)fit;
 }
 

@@ -29,10 +29,13 @@ void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi);
 
 // Chunks one device context may have in flight so that `contexts` of them fit the GPU's free memory: per chunk a context
 // needs its slot of `keep_samples` floats, ~288 queries x (16 bytes x fast hit slots + ~1.4 KB of per-query records and
-// overflow pool) and ~60 bytes per anchor (288 x hits_per_query, capped at the reference's 5000 per query) + 120 KB of
-// per-chunk rows; half of the free memory is left to growth and to the other users of the device.  At least 1.
-// (12 Mb reference, 41 hits per query, 512 slots: 3.6 MB per chunk; 250 Mb, 850 hits, 1024 slots: 20 MB per chunk --
-// 8 000 chunks in flight are 160 GB.)
+// overflow pool) and ~110 bytes per anchor (288 x hits_per_query, capped at the reference's 5000 per query: what the
+// sort's and the chain stage's buffers are reserved at) + 120 KB of per-chunk rows, and 1.5 GB whatever its budget (the
+// walker's stack room, the capacities no batch goes below); four tenths of the free memory are left to growth and to
+// the other users of the device.  At least 1.
+// (12 Mb reference, 41 hits per query, 512 slots: 4.2 MB per chunk; 250 Mb, 850 hits, 1024 slots: 32 MB per chunk.
+// Round 5, eight "GPUs" folded onto one device at 250 Mb -- sixteen contexts: the earlier form, 60 bytes per anchor and
+// no fixed part, let each have 321 chunks and the warm-up ran out of memory.)
 size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
                             size_t contexts);
 

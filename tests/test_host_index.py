@@ -207,7 +207,8 @@ def test_chunk_bounds_cut_the_filtered_array_like_the_reference():
 def test_chunk_budget_for_the_baseline_reference_sizes():
     """What `sigmap -m` lets a context have in flight (host/mapping_logic.h ChunkBudgetForMemory): the default request
     of 32768 chunks over two contexts stands on a 12 Mb reference and is cut to a few thousand on a 250 Mb one
-    (4.98e8 points: ~850 hits per query, 1024 fast slots: 20 MB per chunk) instead of failing in hipMalloc; never 0."""
+    (4.98e8 points: ~850 hits per query, 1024 fast slots: 32 MB per chunk reserved) instead of failing in hipMalloc; sixteen
+    contexts on one device (eight GPUs' lanes folded onto one) get a couple of hundred each, not thousands; never 0."""
     L = _abi.host_lib()
     free = 250 << 30
     small = L.smhost_chunk_budget(free, 4000, 512, 41.0, 2)
@@ -215,6 +216,8 @@ def test_chunk_budget_for_the_baseline_reference_sizes():
     assert small >= 16384                      # 32768 / 2 contexts fits
     assert 2000 <= big <= 4000                 # (the 250 Mb shard test maps 8 000-chunk batches in ~170 GB with ONE context)
     assert big * 2 * 20.5e6 < free * 0.55
+    many = L.smhost_chunk_budget(free, 4000, 1024, 1100.0, 16)
+    assert 100 <= many <= 260 and 16 * (1.5e9 + many * 40e6) < free * 0.65
     assert L.smhost_chunk_budget(1 << 20, 4000, 2048, 5000.0, 8) == 1
     assert L.smhost_chunk_budget(free, 4000, 1024, 1e9, 2) == L.smhost_chunk_budget(free, 4000, 1024, 5000.0, 2)
 
