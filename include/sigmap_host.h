@@ -65,6 +65,10 @@ uint32_t smhost_raw_to_pa(const int16_t *raw, uint32_t n_raw, float digitisation
 uint64_t smhost_chunk_budget(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
                              uint32_t contexts);
 
+/* Device contexts of a GPU that `sigmap -m` gives work by default (host/mapping_logic.h ContextsForReads; the loop it
+   feeds replaces sigmap.cc:618-632): one when the GPU's reads fit one context's read slots, else as many as they fill. */
+uint64_t smhost_contexts_for_reads(uint64_t block_reads, uint64_t lane_budget, uint64_t max_contexts);
+
 /* Raw mode of the same function (the CLI's load phase): the read stays as ADC counts; what the reference's AddSignal
  * yields as signal_values.size() -- the FILTERED length (sigmap.cc:643: num_chunks = length / chunk_size) -- is counted,
  * and bounds[c] = the raw position at which the filtered array has c * chunk_size samples, c = 0 .. min(length /

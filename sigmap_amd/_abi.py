@@ -35,7 +35,7 @@ HOST_SYMBOLS = [
     "smhost_signals_get", "smhost_write_fast5", "smhost_write_blow5", "smhost_have_zstd", "smhost_shard_range", "smhost_print_alignment",
     "smhost_format_paf_record", "smhost_sequences_load", "smhost_sequences_free", "smhost_sequences_count",
     "smhost_sequences_num_bases", "smhost_sequences_get", "smhost_index_bind_device", "smhost_generate_chains",
-    "smhost_generate_events", "smhost_chunk_bounds", "smhost_chunk_budget",
+    "smhost_generate_events", "smhost_chunk_bounds", "smhost_chunk_budget", "smhost_contexts_for_reads",
 ]
 
 
@@ -150,6 +150,8 @@ def host_lib():
         L.smhost_raw_to_pa.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.smhost_chunk_budget.restype = C.c_uint64
         L.smhost_chunk_budget.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32]
+        L.smhost_contexts_for_reads.restype = C.c_uint64
+        L.smhost_contexts_for_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.smhost_chunk_bounds.restype = C.c_uint32
         L.smhost_chunk_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_uint32, C.c_void_p]

@@ -263,6 +263,10 @@ uint64_t smhost_chunk_budget(uint64_t free_bytes, uint32_t keep_samples, uint32_
   return (uint64_t)sigmap::ChunkBudgetForMemory(free_bytes, keep_samples, fast_slots, hits_per_query, contexts);
 }
 
+uint64_t smhost_contexts_for_reads(uint64_t block_reads, uint64_t lane_budget, uint64_t max_contexts) {
+  return (uint64_t)sigmap::ContextsForReads((size_t)block_reads, (size_t)lane_budget, (size_t)max_contexts);
+}
+
 int smhost_should_stop(const smhip_chunk_result *r, const smhost_map_params *p) {
   return ShouldStopMapping(*r, ToParams(p)) ? 1 : 0;
 }

@@ -11,6 +11,12 @@ size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t
   return fit < 1.0 ? 1 : (size_t)fit;
 }
 
+size_t ContextsForReads(size_t block_reads, size_t lane_budget, size_t max_contexts) {
+  const size_t budget = std::max<size_t>(lane_budget, 1);
+  const size_t need = std::max<size_t>(1, (block_reads + budget - 1) / budget);
+  return std::max<size_t>(1, std::min(need, std::max<size_t>(max_contexts, 1)));
+}
+
 void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi) {
   if (world < 1) world = 1;
   // item i belongs to part floor(i * world / n): part r starts at ceil(r * n / world)

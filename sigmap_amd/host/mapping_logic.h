@@ -39,6 +39,12 @@ void ShardRange(size_t n_items, int rank, int world, size_t *lo, size_t *hi);
 size_t ChunkBudgetForMemory(uint64_t free_bytes, uint32_t keep_samples, uint32_t fast_slots, double hits_per_query,
                             size_t contexts);
 
+// Device contexts of a GPU that `sigmap -m` gives work when the number is its to choose (no --streams on the command
+// line): one when the GPU's block of reads fits a single context's read slots (`lane_budget`: the rounds of multi-chunk
+// reads are a dependent chain -- two half-sized chains side by side are slower than one), otherwise as
+// many as the reads fill, up to `max_contexts`.  At least 1.
+size_t ContextsForReads(size_t block_reads, size_t lane_budget, size_t max_contexts);
+
 // Per-base CIGAR of a DTW path (print_alignment, fast_dtw.cc:160-209): codes 0 one-to-one, 1 one base
 // to several signals, 2 skip one signal, 3 skip one base; "(2M)(1M3I)(1D)...".  The format, including
 // that the run still open when the path ends is not written, is the reference's.

@@ -226,7 +226,7 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   size_t lanes_used = (size_t)num_streams;
   {
     const size_t block_reads = (num_reads + (size_t)num_gpus - 1) / (size_t)num_gpus;
-    if (auto_lanes) lanes_used = std::min<size_t>(lanes_used, std::max<size_t>(1, (block_reads + lane_budget - 1) / lane_budget));
+    if (auto_lanes) lanes_used = ContextsForReads(block_reads, lane_budget, (size_t)num_streams);
     lane_budget = std::max<size_t>(1, std::min(lane_budget, (block_reads + lanes_used - 1) / lanes_used));
   }
   // (the other contexts stay idle: created and holding the index, never given read slots or work)

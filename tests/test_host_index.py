@@ -222,6 +222,17 @@ def test_chunk_budget_for_the_baseline_reference_sizes():
     assert L.smhost_chunk_budget(free, 4000, 1024, 1e9, 2) == L.smhost_chunk_budget(free, 4000, 1024, 5000.0, 2)
 
 
+def test_contexts_for_reads_one_when_they_fit_one_context():
+    """The default number of device contexts per GPU of `sigmap -m` (host/mapping_logic.h ContextsForReads): one when
+    the GPU's block of reads fits a context's read slots, as many as the reads fill otherwise, never more than
+    --streams allows, never 0."""
+    f = _abi.host_lib().smhost_contexts_for_reads
+    assert f(10000, 16384, 2) == 1 and f(16384, 16384, 2) == 1 and f(16385, 16384, 2) == 2
+    assert f(50000, 16384, 2) == 2 and f(50000, 16384, 4) == 4 and f(40000, 16384, 4) == 3
+    assert f(0, 16384, 2) == 1 and f(5, 0, 2) == 2 and f(5, 1, 0) == 1
+    assert f(12500, 216, 2) == 2          # a GPU's block of configs[4] with sixteen contexts on one device
+
+
 def test_paf_logic_matches_oracle(small_world, oracle_tree):
     """smhost_format_paf on records assembled from the ORACLE's chains reproduces the oracle's
     own PAF text: pins the host-side decision/format code independently of the GPU."""
