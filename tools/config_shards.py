@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=8)
     ap.add_argument("--check", type=int, default=200, help="reads also mapped by the oracle (0: none)")
     ap.add_argument("--threads", type=int, default=32, help="host threads of the index build (sigmap -i -t)")
+    ap.add_argument("--unshared-check", action="store_true",
+                    help="a third run with the set walk's lane sharing switched off (development knob): the same PAF")
     a = ap.parse_args()
     exe = os.path.join(ROOT, "sigmap_amd", "bin", "sigmap")
     lm = synth.make_pore_model()
@@ -58,12 +60,15 @@ def main():
         assert r.returncode == 0, r.stderr[-2000:]
         out["index_s"] = round(time.perf_counter() - t0, 1)
         pafs = {}
-        for tag, extra in (("gpus_1", ["--gpus", "1"]), ("gpus_%d_on_one_device" % a.gpus, ["--gpus", str(a.gpus), "--gpus-share-device"])):
+        runs = [("gpus_1", ["--gpus", "1"], {}), ("gpus_%d_on_one_device" % a.gpus, ["--gpus", str(a.gpus), "--gpus-share-device"], {})]
+        if a.unshared_check:  # the batches of these runs are small enough for the set walk to share a query's walk between lanes
+            runs.append(("gpus_1_walks_not_shared", ["--gpus", "1"], {"SMHIP_DEV": "1", "SMHIP_WALK_SHARE": "0"}))
+        for tag, extra, more_env in runs:
             time.sleep(float(os.environ.get("CLI_E2E_PAUSE", "8")))   # (the driver scrubs a finished process's memory)
             t1 = time.perf_counter()
             r = subprocess.run([exe, "-m", "-r", d + "/ref.fa", "-p", d + "/model.txt", "-x", d + "/idx", "-s", d + "/reads",
                                 "-o", d + "/out_%s.paf" % tag] + extra, capture_output=True, text=True,
-                               env=dict(os.environ, SIGMAP_STREAM_STATS="1"))
+                               env=dict(os.environ, SIGMAP_STREAM_STATS="1", **more_env))
             assert r.returncode == 0, r.stderr[-2000:]
             wall = time.perf_counter() - t1
             span = [l for l in r.stderr.splitlines() if l.startswith("Finished mapping in")]
@@ -75,7 +80,7 @@ def main():
                         "process_wall_s": round(wall, 2), "cli": span[-1] if span else None,
                         "rows": len(pafs[tag]), "mapped": sum(1 for l in pafs[tag] if l.split("\t")[4] != "*")}
         tags = list(pafs)
-        out["paf_identical"] = pafs[tags[0]] == pafs[tags[1]]
+        out["paf_identical"] = all(pafs[t] == pafs[tags[0]] for t in tags[1:])
         if a.check > 0:
             from oracle import pyoracle as po
             from sigmap_amd import pipeline
