@@ -583,7 +583,7 @@ def streaming_block(args):
         if r.returncode != 0 or not lines:
             return {"error": (r.stderr or "no output")[-400:]}
         j = json.loads(lines[-1])
-        keep = ("metric", "reads_per_s", "chunks_per_s", "span_s", "all_span_s", "reads", "chunks_per_read", "read_kinds",
+        keep = ("metric", "reads_per_s", "chunks_per_s", "span_s", "all_span_s", "warmup_s", "no_warmup", "reads", "chunks_per_read", "read_kinds",
                 "mean_chunks_used", "mapped_fraction", "rounds", "lanes", "mean_batch", "host_share_of_lane_time",
                 "host_ms_per_round", "device_ms_per_round", "lane_seconds", "batches_mapped_twice", "oracle_check", "cli")
         return {k: j.get(k) for k in keep}

@@ -276,13 +276,23 @@ int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *r
  * of slot slots[r] (slots == NULL: slot r).  expect_len (optional): the filtered length of every piece as the caller
  * counted it (SignalBatch's load phase: pa = ((float)raw + offset) * (range / digitisation), 30 < pa < 200, the same
  * f32 operations); a piece of which the device keeps another number of samples makes the next call that collects
- * results fail with SMHIP_ECAP -- a chunk cut by the host's count would not be the reference's chunk.  Asynchronous:
- * the arrays passed are free on return, the pieces must stay untouched until the batch that maps them is collected. */
+ * results fail with SMHIP_ECAP -- a chunk cut by the host's count would not be the reference's chunk -- and the error
+ * is STICKY: every later smhip_map_sync / smhip_map_download* / smhip_batch_select of the context fails the same way
+ * until smhip_reads_upload_pieces is called again (nothing computed from the wrong chunks is ever handed out).
+ * Every piece is range-checked on the host against the blocks of smhip_host_alloc (memory pinned by someone else:
+ * one driver lookup per piece); a piece outside pinned memory is SMHIP_EINVAL, never an address given to the device.
+ * Asynchronous: the arrays passed are free on return, the pieces must stay untouched until the batch that maps them
+ * is collected. */
 int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, const uint32_t *piece_len,
                               const float *digitisation, const float *range, const float *offset,
                               const uint32_t *slots, const uint32_t *expect_len, uint32_t n_pieces);
 /* The next batch: chunk c = filtered samples [chunk_index[c] * chunk_size, + chunk_size) of slot
- * slots[c], clipped to the slot's length (sigmap.cc:647-652).  Other arguments as smhip_batch_upload. */
+ * slots[c], clipped to the slot's length (sigmap.cc:647-652).  Other arguments as smhip_batch_upload.
+ * Does not wait for the device: the caller's arrays go through pinned staging owned by the context and are free on
+ * return.  The intended order is select -> run -> collect -> next select; a caller that selects again BEFORE the
+ * previous batch was collected is still safe -- the call then waits (an event behind the copies that read the staging)
+ * until those copies have finished before it overwrites or regrows the staging.  After a piece-length mismatch
+ * (smhip_reads_upload_pieces, expect_len) it fails with SMHIP_ECAP until the pieces have been uploaded again. */
 int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *chunk_index, uint32_t chunk_size,
                        uint32_t n_chunks, const uint32_t *query_start_offsets,
                        const smhip_carried_anchor *carried, const uint32_t *carried_offsets);

@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <map>
 #include <mutex>
 
 #include <chrono>
@@ -82,8 +83,22 @@ int HipFail(smhip_ctx *ctx, hipError_t e, const char *what) {
 // Pinned host staging of the context (grow-only): small transfers to and from caller-owned pageable memory go
 // through it as ONE DMA each -- a hipMemcpyAsync on pageable memory is cut into many staged pieces, ~19 us of
 // blit kernel apiece on the stream (a 1.8 MB result download: a dozen of them).
+// The host is about to write h_stage / h_carried (or to free one): the copies that read them have finished.
+hipError_t StageWait(smhip_ctx *ctx) {
+  if (!ctx->stage_read_pending) return hipSuccess;
+  ctx->stage_read_pending = false;
+  return hipEventSynchronize(ctx->stage_read);
+}
+hipError_t StageMarkRead(smhip_ctx *ctx) {
+  hipError_t e = hipEventRecord(ctx->stage_read, ctx->stream);
+  if (e == hipSuccess) ctx->stage_read_pending = true;
+  return e;
+}
+
 hipError_t StageReserve(smhip_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_cap) return hipSuccess;
+  hipError_t w = StageWait(ctx);  // (nothing may still be reading the block that is freed)
+  if (w != hipSuccess) return w;
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   ctx->h_stage = nullptr;
   ctx->h_stage_cap = 0;
@@ -166,6 +181,7 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
   // arrays in front); the anchors themselves -- large, and only present in later chunk rounds -- directly
   HIPCHK(StageReserve(ctx, (4 * (size_t)n_chunks + 8) * sizeof(uint32_t)));
   uint32_t *st = static_cast<uint32_t *>(ctx->h_stage) + 2 * (size_t)n_chunks;
+  HIPCHK(StageWait(ctx));  // (a no-op behind smhip_batch_select, which waited before it wrote the words in front)
   if (query_start_offsets) memcpy(st, query_start_offsets, (size_t)n_chunks * sizeof(uint32_t));
   else memset(st, 0, (size_t)n_chunks * sizeof(uint32_t));
   if (carried) memcpy(st + n_chunks, carried_offsets, ((size_t)n_chunks + 1) * sizeof(uint32_t));
@@ -176,8 +192,7 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
     // anybody waiting for the stream.  (The staging is reused by the next batch's call: by then this batch has been
     // collected -- every route to its results synchronises the stream.)
     const size_t bytes = (size_t)n_carried * sizeof(smhip_carried_anchor);
-    if (bytes > ctx->h_carried_cap) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));  // (nothing may still be reading the old staging)
+    if (bytes > ctx->h_carried_cap) {  // (nothing reads the old block any more: StageWait above)
       if (ctx->h_carried) (void)hipHostFree(ctx->h_carried);
       ctx->h_carried = nullptr;
       ctx->h_carried_cap = 0;
@@ -190,6 +205,7 @@ int UploadBatchSideInputs(smhip_ctx *ctx, uint32_t n_chunks, const uint32_t *que
       HIPCHK(hipMemcpyAsync(ctx->carried.p, ctx->h_carried, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
   }
+  HIPCHK(StageMarkRead(ctx));
   return SMHIP_OK;
 }
 
@@ -278,6 +294,7 @@ int smhip_init(int device_ordinal, smhip_ctx **out) {
   {  // smhip_reads_upload_pieces: the event behind its staging copies, the mismatch word the device writes
     void *flag = nullptr;
     if (hipEventCreateWithFlags(&ctx->pieces_staged, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->stage_read, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&flag, 64, hipHostMallocDefault) != hipSuccess) {
       smhip_destroy(ctx);
       return SMHIP_EHIP;
@@ -312,6 +329,7 @@ void smhip_destroy(smhip_ctx *ctx) {
   if (ctx->h_piece_flag) (void)hipHostFree(ctx->h_piece_flag);
   if (ctx->h_carried) (void)hipHostFree(ctx->h_carried);
   if (ctx->pieces_staged) (void)hipEventDestroy(ctx->pieces_staged);
+  if (ctx->stage_read) (void)hipEventDestroy(ctx->stage_read);
   ctx->pieces_src.Free();
   ctx->pieces_expect.Free();
   if (ctx->h_run_info) (void)hipHostFree(ctx->h_run_info);
@@ -818,6 +836,23 @@ int UploadChunks(smhip_ctx *ctx, bool features, const float *samples_pa, const u
   ctx->refine_path_done = false;
   return SMHIP_OK;
 }
+// The blocks smhip_host_alloc handed out (start -> bytes): smhip_reads_upload_pieces checks EVERY piece against them on
+// the host -- the device dereferences the pieces' addresses, and one it cannot reach is a GPU fault that kills the
+// process, not an error code.  A lookup is a map search; a driver call per piece would cost more than the upload.
+std::mutex g_pinned_mu;
+std::map<uintptr_t, size_t> g_pinned;
+
+// [addr, addr + bytes) inside one block of the registry?  `hint` caches the block of the previous piece (the pieces of
+// a round mostly lie in a few arena blocks).
+bool InPinnedRegistry(uintptr_t addr, size_t bytes, std::pair<uintptr_t, size_t> *hint) {
+  if (addr >= hint->first && addr + bytes <= hint->first + hint->second) return true;
+  auto it = g_pinned.upper_bound(addr);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  if (addr + bytes > it->first + it->second) return false;
+  *hint = *it;
+  return true;
+}
 }  // namespace
 extern "C" {
 
@@ -825,13 +860,23 @@ int smhip_host_alloc(void **out, size_t bytes) {
   if (!out) return SMHIP_EINVAL;
   *out = nullptr;
   void *p = nullptr;
-  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) return SMHIP_ENOMEM;
+  const size_t n = std::max<size_t>(bytes, 1);
+  if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return SMHIP_ENOMEM;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned[(uintptr_t)p] = n;
+  }
   *out = p;
   return SMHIP_OK;
 }
 
 void smhip_host_free(void *p) {
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned.erase((uintptr_t)p);
+  }
+  (void)hipHostFree(p);
 }
 
 int smhip_reads_configure(smhip_ctx *ctx, uint32_t n_slots, uint32_t keep_samples) {
@@ -935,6 +980,7 @@ int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, cons
   if (ctx->n_slots == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_reads_upload_pieces before smhip_reads_configure");
   if (n_pieces == 0) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
+  ctx->pieces_bad = false;  // new pieces: the slots' contents are replaced
   if (ctx->pieces_pending) {  // the previous call's staging has been read
     HIPCHK(hipEventSynchronize(ctx->pieces_staged));
     ctx->pieces_pending = false;
@@ -973,15 +1019,24 @@ int smhip_reads_upload_pieces(smhip_ctx *ctx, const int16_t *const *pieces, cons
   }
   seg_start[n_pieces] = (uint32_t)n_segs;
   if (expect_len) memcpy(expect, expect_len, exp_bytes);
-  // The device dereferences the pieces' addresses: memory it cannot reach would be a GPU fault, not an error code.  The
-  // first and the last piece are looked up (a lookup per piece would cost more than the upload); the contract -- every
-  // piece in memory from smhip_host_alloc -- is the caller's to keep for the rest.
-  for (uint32_t r : {0u, n_pieces - 1u}) {
-    if (piece_len[r] == 0) continue;
-    void *dev_view = nullptr;
-    if (hipHostGetDevicePointer(&dev_view, const_cast<int16_t *>(pieces[r]), 0) != hipSuccess || dev_view == nullptr) {
-      (void)hipGetLastError();
-      return Fail(ctx, SMHIP_EINVAL, "smhip_reads_upload_pieces: the pieces must lie in pinned host memory (smhip_host_alloc)");
+  // The device dereferences the pieces' addresses: memory it cannot reach would be a GPU fault, not an error code.
+  // EVERY piece is checked: against the blocks of smhip_host_alloc (a map search), and a piece that lies in none of them
+  // -- pinned by somebody else -- with a driver lookup of its first and last sample.
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    std::pair<uintptr_t, size_t> hint{0, 0};
+    for (uint32_t r = 0; r < n_pieces; ++r) {
+      if (piece_len[r] == 0) continue;
+      const uintptr_t a = (uintptr_t)pieces[r];
+      const size_t bytes = (size_t)piece_len[r] * sizeof(int16_t);
+      if (InPinnedRegistry(a, bytes, &hint)) continue;
+      for (const int16_t *probe : {pieces[r], pieces[r] + (piece_len[r] - 1)}) {
+        void *dev_view = nullptr;
+        if (hipHostGetDevicePointer(&dev_view, const_cast<int16_t *>(probe), 0) != hipSuccess || dev_view == nullptr) {
+          (void)hipGetLastError();
+          return Fail(ctx, SMHIP_EINVAL, "smhip_reads_upload_pieces: every piece must lie in pinned host memory (smhip_host_alloc)");
+        }
+      }
     }
   }
   // (the staged samples are also what smhip_reads_upload_raw copies into: its DMA waits for convert_done, recorded below)
@@ -1026,6 +1081,9 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
     return Fail(ctx, SMHIP_EINVAL, "carried and carried_offsets must be given together");
   if (chunk_size == 0 || chunk_size > (uint32_t)kMaxSamples)
     return Fail(ctx, SMHIP_EINVAL, "chunk_size must be 1..4096 (reference chunk size is 4000, sigmap.cc:639)");
+  if (ctx->pieces_bad)
+    return Fail(ctx, SMHIP_ECAP, "smhip_batch_select: the slots hold pieces whose filtered lengths the host and the device do not "
+                                 "agree on (smhip_reads_upload_pieces, expect_len): upload the pieces again");
   for (uint32_t c = 0; c < n_chunks; ++c) {
     if (slots[c] >= ctx->n_slots) return Fail(ctx, SMHIP_EINVAL, "slot outside the configured range");
     if (((uint64_t)chunk_index[c] + 1) * chunk_size > ctx->reads_keep)
@@ -1042,6 +1100,7 @@ int smhip_batch_select(smhip_ctx *ctx, const uint32_t *slots, const uint32_t *ch
   HIPCHK(ctx->chunk_len.Reserve((nb + 1) * sizeof(uint32_t)));
   // (through the pinned staging: [slots][chunk_index], and in UploadBatchSideInputs [qstart][carried_off] behind them)
   HIPCHK(StageReserve(ctx, (4 * (size_t)n_chunks + 8) * sizeof(uint32_t)));
+  HIPCHK(StageWait(ctx));  // the previous batch's copies out of the staging have finished (they have, once it was collected)
   {
     uint32_t *st = static_cast<uint32_t *>(ctx->h_stage);
     memcpy(st, slots, (size_t)n_chunks * sizeof(uint32_t));
@@ -1463,11 +1522,21 @@ int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) 
 int FinishRun(smhip_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->h_piece_flag && *ctx->h_piece_flag) {
+    // Sticky for the batch: its chunks are not the reference's chunks, so nothing computed from them may be handed out --
+    // not by this call and not by a later one of a caller that ignored the error.  (A speculative batch's overflow record
+    // is dropped with it: the batch has to be rebuilt from pieces anyway.)
     *ctx->h_piece_flag = 0;
+    ctx->pieces_bad = true;
     ctx->spec_pending = false;
-    return Fail(ctx, SMHIP_ECAP, "smhip_reads_upload_pieces: the device's (30, 200) pA filter kept another number of samples of a piece "
-                                 "than expect_len says -- the chunk would not be the reference's chunk");
+    ctx->run_done = false;
+    ctx->batch_ready = false;
+    ctx->refine_done = false;
+    ctx->refine_path_done = false;
   }
+  if (ctx->pieces_bad)
+    return Fail(ctx, SMHIP_ECAP, "smhip_reads_upload_pieces: the device's (30, 200) pA filter kept another number of samples of a piece "
+                                 "than expect_len says -- the chunk would not be the reference's chunk (upload the pieces and "
+                                 "select the batch again)");
   if (!ctx->spec_pending) return SMHIP_OK;
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);

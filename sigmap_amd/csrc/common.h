@@ -288,6 +288,14 @@ struct smhip_ctx {
   void *h_run_info = nullptr;
   void *h_stage = nullptr;   // pinned staging of small transfers to / from pageable caller memory (api.hip StageReserve)
   size_t h_stage_cap = 0;
+  // recorded behind the last host-to-device copy that READS h_stage / h_carried: the host waits for it before it writes
+  // either again or frees one of them (api.hip StageWait) -- a caller that selects its next batch without having
+  // collected the previous one gets a wait, not a torn copy
+  hipEvent_t stage_read = nullptr;
+  bool stage_read_pending = false;
+  // smhip_reads_upload_pieces found a piece whose filtered length the host and the device do not agree on: every call
+  // that collects results fails until the next smhip_reads_upload_pieces / smhip_batch_select / smhip_batch_upload
+  bool pieces_bad = false;
   smhip_params spec_params{};
   smhip_params last_params{};  // the parameters of the last smhip_map_run with every automatic choice resolved
   uint32_t spec_n_refs = 0, spec_reruns = 0, spec_runs = 0;

@@ -109,11 +109,12 @@ __global__ __launch_bounds__(256) void GatherPiecesKernel(const PieceSrc *__rest
 
 // filtered length of every piece against what the host counted (SignalBatch's load phase): a difference means the two
 // do not agree on the (30, 200) pA filter -- the chunk would not be the reference's chunk.  The flag is a word of
-// pinned host memory.
+// pinned host memory, only ever raised to 1: a plain system-scope STORE (a read-modify-write atomic on host memory needs
+// PCIe atomics end to end; where a slot lacks them it is dropped or undefined, and the check would never fire).
 __global__ void CheckPieceLenKernel(const uint32_t *__restrict__ read_len, const uint32_t *__restrict__ expect, uint32_t n,
-                                    uint32_t *__restrict__ host_flag) {
+                                    uint32_t *host_flag) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n && read_len[r] != expect[r]) atomicOr(host_flag, 1u);
+  if (r < n && read_len[r] != expect[r]) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Batch descriptors from (slot, chunk index): chunk c = the slot's filtered samples

@@ -57,7 +57,7 @@ void Sigmap::PinnedFree(void *p) { smhip_host_free(p); }
 // one resident index, so that the read sharding, the per-GPU lanes and the merge of `--gpus N` can be
 // exercised on a one-GPU machine (RCCL itself refuses two ranks on one device).
 void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams,
-                  bool sdtw_cigar, bool share_device) {
+                  bool sdtw_cigar, bool share_device, bool warm_up) {
   num_gpus = std::max(1, num_gpus);
   // (num_streams < 0: up to that many contexts per GPU, as many as the reads need -- the command line's default)
   const bool auto_lanes = num_streams < 0;
@@ -238,13 +238,17 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
         ExitWithMessage(std::string("Read slots / batch buffers for ") + std::to_string(lane_budget) +
                         " chunks in flight per context (--batch-chunks / --streams): " + smhip_last_error(c));
   phase("Reserved read slots and batch buffers");
-  {
+  const double t_warm = GetRealTime();
+  if (warm_up) {
     // Warm-up, part of the set-up like the index load: every context maps one round of first chunks -- as many as it
     // will have in flight, taken from its GPU's first reads (again and again when those are fewer) -- and throws the
     // results away.  What a context's FIRST batch otherwise pays inside the mapping span, measured at 40 ms of a 60 ms
     // job of 10 000 reads (profiles/EXPERIMENTS.md, round 5): the scratch memory the runtime attaches to a hardware
     // queue at the first kernel that needs it, buffers that grow (a hipFree waits for the whole device), the route with
     // two host read-backs that sizes the later, speculative batches.  Results never depend on it.
+    // The reference's own span (sigmap.cc:617, 869 "Finished mapping in") starts right after loading and has no such
+    // step: the seconds spent here are printed next to the span and in STREAM_STATS (warmup_s), and --no-warmup maps
+    // without it -- the span then holds the first-batch costs, the comparison the reference's figure is.
     std::vector<std::thread> warm;
     std::vector<std::string> failed(ctxs.size() * (size_t)num_streams);
     for (int g = 0; g < num_gpus; ++g)
@@ -313,7 +317,9 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
       sc.next_carried.resize(anchors_room); sc.next_carried.clear();
       sc.results.resize(lane_budget); sc.results.clear();
     }
-  phase("Warmed up the device contexts (one discarded round of first chunks each)");
+  const double warm_span = warm_up ? GetRealTime() - t_warm : 0.0;
+  phase(warm_up ? "Warmed up the device contexts (one discarded round of first chunks each)"
+                : "Host buffers of the lanes touched (no warm-up round: --no-warmup)");
   const double t_map = GetRealTime();
   // GPU g maps reads [block[g], block[g + 1]) (contiguous blocks); reads are admitted
   // in order and stay with the context that admitted them (chain carry-over is per read)
@@ -546,17 +552,20 @@ void Sigmap::StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int
   }
   const double map_span = GetRealTime() - t_map;
   std::cerr << "Finished mapping in " << map_span << ", # reads: " << num_reads << "\n";
+  if (warm_up)
+    std::cerr << "(set-up before that span: " << warm_span << " s of warm-up on the job's own first chunks, results discarded; "
+              << "--no-warmup maps without it)\n";
   if (want_stats) {
     const LaneStats &t = total_stats;
     const double lanes = (double)num_gpus * (double)lanes_used;
     char buf[1024];
     snprintf(buf, sizeof buf,
-             "STREAM_STATS {\"reads\": %zu, \"span_s\": %.6f, \"lanes\": %d, \"chunks_in_flight_per_lane\": %zu, \"rounds\": %llu, "
+             "STREAM_STATS {\"reads\": %zu, \"span_s\": %.6f, \"warmup_s\": %.6f, \"lanes\": %d, \"chunks_in_flight_per_lane\": %zu, \"rounds\": %llu, "
              "\"chunks\": %llu, \"max_batch\": %llu, \"carried_anchors_uploaded\": %llu, \"anchors_downloaded\": %llu, "
              "\"speculative_batches\": %llu, \"batches_mapped_twice\": %llu, "
              "\"lane_seconds\": {\"admit_upload\": %.6f, \"build_batch\": %.6f, \"device\": %.6f, \"download_results\": %.6f, "
              "\"download_anchors\": %.6f, \"decide\": %.6f}}",
-             num_reads, map_span, (int)lanes, lane_budget, (unsigned long long)t.rounds, (unsigned long long)t.chunks,
+             num_reads, map_span, warm_span, (int)lanes, lane_budget, (unsigned long long)t.rounds, (unsigned long long)t.chunks,
              (unsigned long long)t.max_batch, (unsigned long long)t.carried_up, (unsigned long long)t.anchors_down,
              (unsigned long long)t.spec_runs, (unsigned long long)t.spec_reruns, t.admit, t.build,
              t.device, t.download, t.anchors, t.decide);
@@ -679,6 +688,8 @@ const char *kHelp =
     "      --batch-chunks INT          chunks in flight per GPU [32768]\n"
     "      --streams INT               device contexts / HIP streams that share the index and the chunk budget\n"
     "                                  [up to 2: one when a GPU's reads fit one context's share of --batch-chunks]\n"
+    "      --no-warmup                 no discarded round of first chunks before the mapping span (the span then holds the\n"
+    "                                  contexts' first-batch costs, like the reference's own)\n"
     "      --features events|cwt       (development) with -s DIR -o FILE: dump every chunk's feature signal as text\n"
     "  -h, --help  Print help\n";
 }  // namespace
@@ -687,7 +698,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
   static const std::map<std::string, std::string> shorts = {
       {"i", "build-index"}, {"d", "dimension"}, {"l", "max-leaf"}, {"m", "map"}, {"t", "num-threads"},
       {"r", "ref"}, {"p", "pore-model"}, {"x", "ref-index"}, {"s", "sig-dir"}, {"o", "output"}, {"h", "help"}};
-  static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar", "gpus-share-device"};
+  static const std::vector<std::string> flags = {"build-index", "map", "help", "sdtw-cigar", "gpus-share-device", "no-warmup"};
   // every option this program knows: anything else is an error, like the reference's cxxopts parser
   // (sigmap.cc:1378 `options.parse` throws on an unknown option)
   static const std::vector<std::string> valued = {
@@ -765,7 +776,7 @@ void ParseArgsAndRun(int argc, char *argv[]) {
     const int streams = a.Has("streams") ? std::stoi(a.Str("streams")) : -2;  // (default: up to two, as the reads need)
     const int gpus = a.Has("gpus") ? std::stoi(a.Str("gpus")) : 1;
     Sigmap(p, num_threads, ref, pm, dir, idx, out).StreamingMap(device, gpus, batch, sdtw_band, streams, a.Has("sdtw-cigar"),
-                                                               a.Has("gpus-share-device"));
+                                                               a.Has("gpus-share-device"), !a.Has("no-warmup"));
   } else {
     std::cerr << kHelp;
   }

@@ -35,7 +35,7 @@ class Sigmap {
   static void *PinnedAlloc(size_t bytes);
   static void PinnedFree(void *p);
   void StreamingMap(int device, int num_gpus, size_t max_batch_chunks, int sdtw_band, int num_streams, bool sdtw_cigar,
-                    bool share_device);
+                    bool share_device, bool warm_up = true);
   static void DumpFeatures(const std::string &kind, int device, const std::string &signal_directory,
                            const std::string &output_file_path);
 

@@ -38,5 +38,5 @@ def test_help_lists_the_reference_flags():
     assert r.returncode == 0
     for flag in ("--build-index", "--map", "--step-size", "--search-radius", "--max-num-chunks", "--min-num-anchors",
                  "--min-num-anchors-output", "--stop-mapping", "--stop-mapping-output", "--stop-mapping-mean",
-                 "--stop-mapping-mean-output", "--ref", "--pore-model", "--ref-index", "--sig-dir", "--output"):
+                 "--stop-mapping-mean-output", "--ref", "--pore-model", "--ref-index", "--sig-dir", "--output", "--no-warmup"):
         assert flag in r.stderr + r.stdout, flag

@@ -206,8 +206,23 @@ def test_pieces_pulled_from_pinned_memory_match_addsignal(device):
     device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=bad)
     with pytest.raises(RuntimeError):
         device.sync()
+    # ... sticky: a caller that ignores the error gets it again from every call that would hand out results or build a
+    # batch from these slots, until the pieces are uploaded again
+    with pytest.raises(RuntimeError):
+        device.sync()
+    with pytest.raises(RuntimeError, match="upload the pieces again"):
+        device.select(np.arange(3), np.zeros(3))
     device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=[len(w) for w in want])
     device.sync()                                 # ... and the context goes on
+    device.select(np.arange(3), np.zeros(3))
+    # EVERY piece is range-checked on the host, not only the ends of the list: one piece in the middle that runs past
+    # the end of its pinned block (or starts in front of it) is an error code, never an address handed to the device
+    mid = len(begins) // 2
+    for bad_begin, bad_len in ((total - 100, 4000), (-50000, 4000)):
+        bb, bl = list(begins), list(ln)
+        bb[mid], bl[mid] = bad_begin, bad_len
+        with pytest.raises(RuntimeError, match="pinned"):
+            device.upload_pieces(pin, bb, bl, dg, rg, of, slots=slots)
 
     class Pageable:                               # ordinary host memory: refused with an error code, not a GPU fault
         array = np.zeros(20000, np.int16)

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--sdtw-band", type=int, default=0)
     ap.add_argument("--check", type=int, default=96, help="reads compared with the oracle's streaming map")
     ap.add_argument("--runs", type=int, default=3, help="CLI mapping runs (the median span is reported)")
+    ap.add_argument("--skip-cold", action="store_true", help="no extra run with the CLI's --no-warmup")
     ap.add_argument("--workdir", default=None, help="keep / reuse the generated files here")
     ap.add_argument("--rocprof-dir", default=None, help="also one run under rocprofv3 --kernel-trace into this directory")
     a = ap.parse_args()
@@ -126,8 +127,21 @@ def main():
         j = json.loads(st[-1][len("STREAM_STATS "):])
         j["process_wall_s"] = round(wall, 3)
         runs.append(j)
+    # ... and ONE run without the CLI's warm-up round (--no-warmup): its span holds the contexts' first-batch costs, like
+    # the reference's own "Finished mapping in" span, which starts right after loading (sigmap.cc:617)
+    cold = None
+    if not a.skip_cold:
+        time.sleep(float(os.environ.get("CLI_E2E_PAUSE", "4")))
+        r = subprocess.run(cmd + ["--no-warmup"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        st = [l for l in r.stderr.splitlines() if l.startswith("STREAM_STATS ")]
+        cold = json.loads(st[-1][len("STREAM_STATS "):])
+        cold_paf = {}
+        for line in open(d + "/out.paf"):
+            cold_paf[line.split("\t", 1)[0]] = strip_mt(line)
     if os.environ.get("STREAM_ROUNDS_OUT"):    # one more run that logs every chunk round of every lane
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, SIGMAP_STREAM_STATS="2"))
+        assert r.returncode == 0, r.stderr[-3000:]
         with open(os.environ["STREAM_ROUNDS_OUT"], "w") as fh:
             fh.write("\n".join(l for l in r.stderr.splitlines() if l.startswith("STREAM_")) + "\n")
     if a.rocprof_dir:
@@ -140,6 +154,8 @@ def main():
     for line in open(d + "/out.paf"):
         paf[line.split("\t", 1)[0]] = strip_mt(line)
     assert len(paf) == a.reads
+    if cold is not None:
+        assert cold_paf == paf, "the PAF of the run without warm-up differs"
     mapped = sum(1 for l in paf.values() if l.split("\t")[4] != "*")
     ls = j["lane_seconds"]
     lane_total = sum(ls.values())
@@ -149,6 +165,12 @@ def main():
         "reads_per_s": round(a.reads / j["span_s"], 1),
         "chunks_per_s": round(j["chunks"] / j["span_s"], 1),
         "span_s": j["span_s"], "all_span_s": [r_["span_s"] for r_ in runs],
+        # set-up the span does NOT hold: the CLI's discarded round of the job's own first chunks on every context
+        "warmup_s": j.get("warmup_s"),
+        "no_warmup": None if cold is None else {
+            "span_s": cold["span_s"], "reads_per_s": round(a.reads / cold["span_s"], 1),
+            "what": "one run with --no-warmup: the span starts right after loading like the reference's (sigmap.cc:617) and "
+                    "holds every context's first-batch costs; same PAF"},
         "reads": a.reads, "chunks_per_read": a.chunks_per_read, "max_num_chunks": a.max_num_chunks,
         "read_kinds": {"clean": int((kinds == 0).sum()), "junk_prefixed": int((kinds == 1).sum()), "junk_only": int((kinds == 2).sum())},
         "mean_chunks_used": round(j["chunks"] / a.reads, 3),
