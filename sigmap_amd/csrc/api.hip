@@ -33,7 +33,7 @@ const KnobName kKnobNames[] = {{"lane_blocks_per_cu", &DevKnobs::lane_blocks_per
                                {"sort_lines", &DevKnobs::sort_lines}, {"second_search", &DevKnobs::second_search},
                                {"classify_dense", &DevKnobs::classify_dense}, {"classify_resolve", &DevKnobs::classify_resolve},
                                {"walk_share", &DevKnobs::walk_share}, {"walk_grab", &DevKnobs::walk_grab},
-                               {"walk_grab_upto", &DevKnobs::walk_grab_upto}};
+                               {"walk_grab_upto", &DevKnobs::walk_grab_upto}, {"set_groups_per_cu", &DevKnobs::set_groups_per_cu}};
 // the environment's knobs, honoured only behind SMHIP_DEV=1 (read once per context, in smhip_init)
 DevKnobs ReadDevKnobs() {
   DevKnobs k;

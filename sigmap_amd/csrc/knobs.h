@@ -8,6 +8,7 @@
 struct DevKnobs {
   bool enabled = false;        // SMHIP_DEV=1 at smhip_init
   int lane_blocks_per_cu = 0;  // SMHIP_LANE_BLOCKS_PER_CU: walker workgroups of 256 threads per CU
+  int set_groups_per_cu = 0;   // SMHIP_SET_GROUPS_PER_CU: the set walk's 128-thread workgroups per CU, 1 .. 8 (0: twice the above)
   int xcd_ranges = 1;          // SMHIP_XCD_RANGES=0: one visiting-order range instead of eight
   int scan_threshold = 0;      // SMHIP_SCAN_THRESHOLD: blocked lanes that trigger a scan phase
   int classes = 0;             // SMHIP_CLASSES: cost classes of the visiting order

@@ -238,9 +238,12 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
   uint32_t qc01 = 0, qc23 = 0, qc45 = 0;
   // top-of-stack cache: two 32-byte entries per lane in LDS, [slot][half][thread]
   __shared__ float4 tos[kSet ? 1 : 2][2][kSet ? 1 : kThreads];
-  __shared__ uint32_t lstk[kSet ? kSetStack : 1][kSet ? kThreads : 1];  // set walk: the newest pending references
-  // pending leaves of this lane's query, in the order they were reached (leaf ordinals)
-  __shared__ uint32_t fifo[kFifo][kThreads];
+  // pending leaves of this lane's query, in the order they were reached (leaf ordinals: rows 0 .. kFifo - 1), and -- set
+  // walk -- the newest pending references of its stack behind them: rows of one array, so that the visit's store of a
+  // passing slot is one instruction whichever of the two it goes to
+  __shared__ uint32_t lane_rows[kFifo + (kSet ? kSetStack : 0)][kThreads];
+  uint32_t(*const fifo)[kThreads] = lane_rows;
+  uint32_t(*const lstk)[kThreads] = lane_rows + (kSet ? kFifo : 0);
   __shared__ uint32_t ovf_lds[kSet ? 1 : kThreads];  // scan phase: overflow segment base of each lane's query
   // address of the first hit slot of each lane's query (HitSlots::At(qi, 0): a pointer-table load), taken when the
   // query is handed out: at emit time it is an LDS read -- a global load there made every scan iteration wait for
@@ -295,6 +298,19 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     if (!kShare) scan_threshold = max(1u, scan_threshold * grab / 64u);  // (shared: the helpers fill the wave)
     hand_thr = max(1u, hand_thr * grab / 64u);
   }
+  // the quad fetch's lane constants (set walk): where a lane's eight ds_bpermutes read from, its part of a record as a
+  // byte offset, the wave's staging area as an LDS byte address in a scalar register; quads_narrow: the quad array lies
+  // below 4 GiB, a record is base + a 32-bit offset (wave-uniform)
+  uint32_t bp_addr[8];
+  {
+    const uint32_t grp_ = lane / 7u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bp_addr[r] = (((uint32_t)r * 9u + grp_) & 63u) * 4u;
+  }
+  const uint32_t part16 = (lane - 7u * (lane / 7u)) * 16u;
+  const uint32_t stage_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)stage_w);
+  const bool quads_narrow = kSet && ix.n_quads < (1ull << 25);
   unsigned long long pt_scan = 0, pt_wait = 0, pt_fetchq = 0, pt_visit = 0, pt_scan_setup = 0, pt_scan_load = 0;
   const unsigned long long pt_begin = WALK_T();
 #ifdef SMHIP_PHASE_PROF
@@ -444,14 +460,18 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       };
       auto lookup = [&](uint32_t eb_, uint32_t p0_) {
         const uint32_t p = p0_ + lane;
-        uint32_t e_rel = 0, limit = n_points;
+        // (an entry's word is flat position << 13 | ...: position <= p iff word < (p + 1) << 13 -- compared as it
+        // comes from LDS, no shift per entry; positions stay below 2^19)
+        const uint32_t pl = (p + 1u) << 13;
+        uint32_t e_rel = 0;
+        bool pt = p < n_points;
 #pragma unroll
         for (int i = 1; i <= kWin; ++i) {
-          const uint32_t st_i = ents[eb_ + (uint32_t)i].y >> 13;  // (uniform address; past the end: a sentinel)
-          if (i < kWin) e_rel += st_i <= p ? 1u : 0u;
-          else limit = min(limit, st_i);
+          const uint32_t y_i = ents[eb_ + (uint32_t)i].y;  // (uniform address; past the end: a sentinel, 0xFFFFFFFF)
+          if (i < kWin) e_rel += y_i < pl ? 1u : 0u;
+          else pt = pt && !(y_i < pl);  // (a window reaches at most the start of entry eb + kWin)
         }
-        return Win{ents[min(eb_ + e_rel, 255u)], e_rel, p < limit};  // (pt: then t < n, the next entry starts above p)
+        return Win{ents[min(eb_ + e_rel, 255u)], e_rel, pt};  // (pt: then t < n, the next entry starts above p)
       };
       uint32_t eb = 0, p0 = 0;
       // the window's point loads (the 32-byte point: v0..v3, then v4, v5, position), from a valid address
@@ -459,7 +479,9 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a 128-bit register tuple: SM_PIN's operand type)
       auto load_points = [&](const Win &w_, uint32_t p0_, u32x4 &rv_, u32x4 &sv_) {
         const uint32_t t_ = p0_ + lane - (w_.mine.y >> 13);
-        const u32x4 *fh = reinterpret_cast<const u32x4 *>(pts4 + (w_.pt ? 2 * ((size_t)w_.mine.x + t_) : (size_t)0));
+        // (the slot number in 32 bits -- 27 bits of block offset << 3, + t < 32 --, one 64-bit shift-and-add for the address)
+        const uint32_t slot_ = w_.pt ? w_.mine.x + t_ : 0u;
+        const u32x4 *fh = reinterpret_cast<const u32x4 *>(pts4 + 2 * (size_t)slot_);
         rv_ = fh[0];
         sv_ = fh[1];
       };
@@ -497,6 +519,28 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
           const float f5 = __uint_as_float(ob.y) - __uint_as_float(sv.y);
           res += f5 * f5;
           hit = res < radius; /* RadiusResultSet::addPoint */
+        }
+        if (kSet && __ballot(pt && hbase + 64u > sink.fast_cap) == 0) {
+          // (round 6) The order-free walk does not care WHICH of its slots a hit of a query takes, only that no two hits
+          // take the same: when no query of the window can leave its fast slots in it (64 points at most), a hit's
+          // ordinal is simply what an LDS atomic on its query's count returns -- one DS instruction for the ~35 vector
+          // instructions of the run logic below (previous owner, run starts, rank inside the run, the run's last lane
+          // writing the count back), which stays for the windows that may reach the overflow pool, where a segment's
+          // first hit must be found, and for the walks that number hits in the reference's order.  (Hits of a query in
+          // several runs of a window -- shared walks -- need nothing special here.)
+          uint32_t ord_a = 0;
+          if (hit) ord_a = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&own_b[owner]) + hits_word, 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (hit && (ord_a < sink.nnp || sink.store_all)) {
+            typedef __attribute__((address_space(1))) u32x4 GlobalU4;
+            GlobalU4 *dst = (GlobalU4 *)(uintptr_t)(sbase_w[owner] + ord_a);
+            const u32x4 bits = {sv.z, sv.w, __float_as_uint(res), mine.x + t};
+            *dst = bits;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+          return;
         }
         const uint64_t hb = __ballot(hit);
         // runs of lanes with the same owner (the entries of an owner are consecutive); ordinal = the owner's
@@ -702,10 +746,54 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
     pt_fetchq += pt1 - pt0;
     if (kSet) {
       // quad records: SEVEN lanes fetch the seven used 16-byte parts of one 128-byte record (one line: one request),
-      // nine records per instruction (lane 63 idles), the 64th record with an eighth instruction; instruction r
-      // writes 63 x 16 bytes from unit 63 r on, so record s = 9 r + lane / 7 lands as the 112-byte row 7 s .. 7 s + 6
+      // nine records per instruction, the 64th record with an eighth instruction; instruction r
+      // writes 64 x 16 bytes from unit 63 r on, so record s = 9 r + lane / 7 lands as the 112-byte row 7 s .. 7 s + 6
       // (a stride of 28 words: sixteen lanes reading the same part of their rows touch all 64 banks once)
       const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
+      if (quads_narrow) {
+        // The whole fetch as one block of assembly (round 6): as C++ every one of the eight loads came out as select +
+        // compare + saveexec + BRANCH + a wave-uniform LDS address computed on the vector ALU and read back with
+        // v_readfirstlane + a two-instruction 64-bit address: 91 vector and ~60 scalar instructions and eight branches per
+        // visit.  Here: v_cmpx writes the exec mask straight from the distributed reference (-1: nothing to fetch), the
+        // address is a 32-bit offset from the array's base in scalar registers (the array is below 4 GiB: quads_narrow),
+        // M0 advances by a scalar add: 8 + 16 vector instructions, no branch.  Lane 63 (lane / 7 = 9, part 0) is not
+        // masked in instructions 0 .. 6: it fetches part 0 of record 9 r + 9 into unit 63 r + 63 -- the very unit lane 0
+        // of instruction r + 1 writes the same sixteen bytes to.  Instruction 7 fetches record 63 alone (lanes 0 .. 6).
+        uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+        unsigned long long save;
+        asm volatile(
+            "ds_bpermute_b32 %0, %9, %17\n\t"
+            "ds_bpermute_b32 %1, %10, %17\n\t"
+            "ds_bpermute_b32 %2, %11, %17\n\t"
+            "ds_bpermute_b32 %3, %12, %17\n\t"
+            "ds_bpermute_b32 %4, %13, %17\n\t"
+            "ds_bpermute_b32 %5, %14, %17\n\t"
+            "ds_bpermute_b32 %6, %15, %17\n\t"
+            "ds_bpermute_b32 %7, %16, %17\n\t"
+            "s_mov_b64 %8, exec\n\t"
+            "s_mov_b32 m0, %20\n\t"
+#define SM_QFETCH(k, T)                                   \
+            "s_waitcnt lgkmcnt(" #k ")\n\t"                 \
+            "v_cmpx_ne_u32_e32 vcc, -1, " T "\n\t"          \
+            "v_lshl_add_u32 " T ", " T ", 7, %18\n\t"       \
+            "global_load_lds_dwordx4 " T ", %19\n\t"        \
+            "s_mov_b64 exec, %8\n\t"                        \
+            "s_add_u32 m0, m0, 0x3f0\n\t"
+            SM_QFETCH(7, "%0") SM_QFETCH(6, "%1") SM_QFETCH(5, "%2") SM_QFETCH(4, "%3") SM_QFETCH(3, "%4")
+            SM_QFETCH(2, "%5") SM_QFETCH(1, "%6")
+#undef SM_QFETCH
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_and_b64 exec, %8, 0x7f\n\t"
+            "v_cmpx_ne_u32_e32 vcc, -1, %7\n\t"
+            "v_lshl_add_u32 %7, %7, 7, %18\n\t"
+            "global_load_lds_dwordx4 %7, %19\n\t"
+            "s_mov_b64 exec, %8\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&s"(save)
+            : "v"(bp_addr[0]), "v"(bp_addr[1]), "v"(bp_addr[2]), "v"(bp_addr[3]), "v"(bp_addr[4]), "v"(bp_addr[5]),
+              "v"(bp_addr[6]), "v"(bp_addr[7]), "v"(want), "v"(part16), "s"(ix.quads), "s"(stage_lds)
+            : "memory", "vcc", "scc");  // (and M0: a reserved register the compiler sets anew before every use of its own)
+      } else {
       const uint32_t grp = lane / 7u, part = lane - 7u * grp;
       uint32_t nsrc[8];
 #pragma unroll
@@ -723,6 +811,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA loads have landed
+      }
     } else {
       const uint32_t want = (active && mode == M_NODE && !(node & kLeafTag)) ? (node & kIdxMask) : 0xFFFFFFFFu;
       uint32_t nsrc[4];
@@ -780,27 +869,47 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
 #undef SM_QBOX
 #undef SM_GAP
           // a passing slot: a leaf goes to the FIFO at once while there is room, the first inner reference is the
-          // record to go on with, everything else waits on the stack
-          auto take = [&](uint32_t sum, uint32_t ref) {
-            if (sum > box_limit) return;
-            if ((ref & kLeafTag) && fifo_cnt < (uint32_t)kFifo) {
-              fifo[fifo_cnt++][threadIdx.x] = ref & kIdxMask;
-            } else if (!(ref & kLeafTag) && cur == 0xFFFFFFFFu) {
-              cur = ref;
-            } else if (sp < (uint32_t)kSetStack) {
-              lstk[sp][threadIdx.x] = ref;
-              ++sp;
-            } else if (sp < (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u) {
-              stk32[sp - (uint32_t)kSetStack] = ref;
-              ++sp;
-            } else {
-              atomicOr(&sink.counters[0], 1u);
-            }
+          // record to go on with, everything else waits on the stack.  Without branches (round 6: as an if / else chain
+          // every slot cost ~20 vector + ~35 scalar instructions and five to eight branches, all of them taken by some
+          // lane of a wave): the FIFO and the LDS part of the stack are rows of ONE array, so a slot is three
+          // predicates, one row number and one predicated LDS store; only a lane whose LDS stack is full leaves the
+          // straight line (its spill area in memory).
+          const uint32_t sp0 = sp;
+          uint32_t stk_bits = 0;  // slots that went to the stack (bit i: slot i)
+          auto take = [&](uint32_t sum, uint32_t ref, uint32_t bit) {
+            const bool pass = sum <= box_limit;
+            const bool leaf = (ref & kLeafTag) != 0;
+            const bool to_fifo = pass && leaf && fifo_cnt < (uint32_t)kFifo;
+            const bool to_cur = pass && !leaf && cur == 0xFFFFFFFFu;
+            const bool to_stk = pass && !to_fifo && !to_cur;
+            const uint32_t row = to_fifo ? fifo_cnt : (uint32_t)kFifo + sp;
+            if (to_fifo || (to_stk && sp < (uint32_t)kSetStack)) lane_rows[row][threadIdx.x] = to_fifo ? (ref & kIdxMask) : ref;
+            cur = to_cur ? ref : cur;
+            fifo_cnt += to_fifo ? 1u : 0u;
+            sp += to_stk ? 1u : 0u;
+            stk_bits |= to_stk ? bit : 0u;
           };
-          take(s0, rf.x);
-          take(s1, rf.y);
-          take(s2, rf.z);
-          take(s3, rf.w);
+          take(s0, rf.x, 1u);
+          take(s1, rf.y, 2u);
+          take(s2, rf.z, 4u);
+          take(s3, rf.w, 8u);
+          if (sp > (uint32_t)kSetStack) {
+            // (rare: the LDS rows of this lane's stack are full) entries number kSetStack and beyond go to the lane's
+            // spill area in memory -- the visit's stacked slots again, in order, from the depth the visit started at
+            constexpr uint32_t kCap = (uint32_t)kSetStack + (uint32_t)kStackDepth * 8u;
+            uint32_t k = sp0;
+            const uint32_t refs[4] = {rf.x, rf.y, rf.z, rf.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (stk_bits & (1u << i)) {
+                if (k >= (uint32_t)kSetStack && k < kCap) stk32[k - (uint32_t)kSetStack] = refs[i];
+                ++k;
+              }
+            if (sp > kCap) {  // deeper than the spill area: flagged (SMHIP_ST_STACK_FULL), the entry is lost
+              atomicOr(&sink.counters[0], 1u);
+              sp = kCap;
+            }
+          }
         } else {
           cur = node & (kLeafTag | kIdxMask);  // a leaf left over from the previous visit (the FIFO was full)
         }
@@ -1541,7 +1650,8 @@ hipError_t LaunchWalk(smhip_ctx *ctx, const smhip_params &p, int mode, const Que
   if (blocks_per_cu < 1 || blocks_per_cu > 8) blocks_per_cu = kLaneBlocksPerCU;
   int thr = env_thr > 0 ? env_thr : kScanThreshold;
   // (the set walk's workgroups are half the size: the same knob counts them in pairs)
-  const uint32_t set_blocks_per_cu = 2u * (uint32_t)blocks_per_cu;
+  uint32_t set_blocks_per_cu = 2u * (uint32_t)blocks_per_cu;
+  if (ctx->knobs.set_groups_per_cu >= 1 && ctx->knobs.set_groups_per_cu <= 8) set_blocks_per_cu = (uint32_t)ctx->knobs.set_groups_per_cu;
   if (mode == kWalkSet && env_thr <= 0) thr = kSetScanThreshold;
   if (thr < 1) thr = 1;
   if (thr > 64) thr = 64;
