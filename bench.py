@@ -572,12 +572,12 @@ def main():
 def streaming_block(args):
     """The product's real mode beside the headline (never part of `value`): 10 000 reads of 8 chunks -- a
     third junk-prefixed, 2 % junk throughout -- through the `sigmap -m` CLI in a child process (tools/stream_bench.py: its
-    own contexts, the reference's own "Finished mapping in" span, median of three runs, 32 sampled reads against the
+    own contexts, the reference's own "Finished mapping in" span, median of five runs + one without the CLI's warm-up round, 32 sampled reads against the
     oracle's streaming map).  A failure here never costs the bench line."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_bench.py"), "--reads", "10000", "--chunks-per-read", "8",
-                            "--contigs", str(args.contigs), "--contig-len", str(args.contig_len), "--check", "32"],
+                            "--contigs", str(args.contigs), "--contig-len", str(args.contig_len), "--check", "32", "--runs", "5"],
                            capture_output=True, text=True, timeout=420, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:

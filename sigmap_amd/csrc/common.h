@@ -96,6 +96,17 @@ __device__ __forceinline__ int WaveScanAdd(int v) {
 }
 #endif
 
+#ifdef __HIPCC__
+// Overflow segment of hit number fast_cap + k of a query (segments of fast_cap, 2 fast_cap, 4 fast_cap, ... hits:
+// seed_lookup.hip AllocOverflowSegment): floor(log2(k / fast_cap + 1)).  fast_cap is wave-uniform and, whenever the
+// library chose it, a power of two: a shift then -- the general 32-bit division is ~20 vector instructions, in the
+// walker's store path and the partition's hit loads of a large reference, where most hits live in the pool.
+__device__ __forceinline__ uint32_t OvfLevel(uint32_t k, uint32_t fast_cap) {
+  const uint32_t ratio = (fast_cap & (fast_cap - 1u)) == 0u ? k >> (uint32_t)__builtin_ctz(fast_cap | 0x80000000u) : k / fast_cap;
+  return 31u - (uint32_t)__clz((int)(ratio + 1u));
+}
+#endif
+
 // Device view of the index (all pointers device memory; layouts: seed_lookup.hip header).
 constexpr uint32_t kLeafTag = 0x80000000u;  // a node ref with this bit names a leaf (ordinal in the low 27 bits)
 

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kThreads, 4) void SeedWalkKernel(IndexView ix, cons
         const bool ov = emit && ord >= sink.fast_cap;
         if (__ballot(ov)) {  // (wave-uniform: a window without such a hit skips all of it)
           const uint32_t k = ord - sink.fast_cap;
-          const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
+          const uint32_t level = OvfLevel(k, sink.fast_cap);
           const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
           for (uint64_t ovm = __ballot(ov); ovm;) {
             const int leader = __builtin_ctzll(ovm);
@@ -1451,7 +1451,7 @@ __global__ void SlotLeafKernel(const uint32_t *__restrict__ leaf_tab, uint64_t n
 __device__ __forceinline__ Hit *HitAt(const Sink &sink, uint32_t qi, uint32_t i) {
   if (i < sink.fast_cap) return sink.region.At(qi, i);
   const uint32_t k = i - sink.fast_cap;
-  const uint32_t level = 31u - (uint32_t)__clz((int)(k / sink.fast_cap + 1));
+  const uint32_t level = OvfLevel(k, sink.fast_cap);
   const uint32_t first = sink.fast_cap * ((1u << level) - 1u);
   return sink.pool + (size_t)sink.ovf_tab[(size_t)qi * kOvfLevels + level] + (k - first);
 }
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(kSelThreads) void OverCapSelectKernel(IndexView ix,
     // a hit the pool had no room for (the batch is flagged and searched again with a larger pool): nothing to do here
     bool missing = false;
     if (H > sink.fast_cap && tid < (uint32_t)kOvfLevels) {
-      const uint32_t last_level = 31u - (uint32_t)__clz((int)((H - 1u - sink.fast_cap) / sink.fast_cap + 1));
+      const uint32_t last_level = OvfLevel(H - 1u - sink.fast_cap, sink.fast_cap);
       missing = last_level >= (uint32_t)kOvfLevels ||
                 (tid <= last_level && sink.ovf_tab[(size_t)qi * kOvfLevels + tid] == 0xFFFFFFFFu);
     }

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBigThreads, RPT == 2 ? 8 : 4) void SortPartitionKe
     auto load_hit = [&](uint32_t qi, const Hit *slots, uint32_t h) {
       if (h < a.fast_cap) return *reinterpret_cast<const uint4 *>(slots + h);
       const uint32_t kk = h - a.fast_cap;
-      const uint32_t level = 31u - (uint32_t)__clz((int)(kk / a.fast_cap + 1));
+      const uint32_t level = OvfLevel(kk, a.fast_cap);
       const uint32_t first = a.fast_cap * ((1u << level) - 1u);
       const uint32_t seg = level < (uint32_t)kOvfLevels ? a.ovf_tab[(size_t)qi * kOvfLevels + level] : 0xFFFFFFFFu;
       return seg != 0xFFFFFFFFu ? *reinterpret_cast<const uint4 *>(a.ovf_pool + (size_t)seg + (kk - first)) : make_uint4(0, 0, 0, 0);
