@@ -1354,50 +1354,31 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
                                uint32_t shift, uint32_t per_range, uint32_t classes,
                                uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
   const uint32_t total = n_queries_dev ? *n_queries_dev : n_queries_host;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  // The descent stops as soon as the bucket is decided: the leaves below a node are the ordinals [lo, hi) --
-  // leaves are numbered in tree order and inner records in pre-order, so the first child's subtree holds
-  // (second child's inner index - this index) leaves, or (second child's leaf ordinal - lo) -- and once lo and
-  // hi - 1 share a bucket the remaining ~6 of ~25 dependent record reads are not needed (same keys as a full
-  // descent).  A descent is a chain of dependent 16-byte loads and nothing else: a thread runs TWO of them side by
-  // side (round 6: its queries q and q + stride), so that two loads are in flight where one was.
-  struct Descent {
-    float q0, q1, q2, q3, q4, q5;
-    uint32_t node, lo, hi;
-    bool live;
-  };
-  auto start = [&](Descent &d, uint32_t q) {
-    d.live = q < total;
-    d.node = ix.root_ref;
-    d.lo = 0;
-    d.hi = (uint32_t)ix.n_leaves;
-    d.q0 = d.q1 = d.q2 = d.q3 = d.q4 = d.q5 = 0.0f;
-    if (d.live) {
-      const float4 a4 = *reinterpret_cast<const float4 *>(&qrec[q]);
-      const float2 b2 = *(reinterpret_cast<const float2 *>(&qrec[q]) + 2);
-      d.q0 = a4.x; d.q1 = a4.y; d.q2 = a4.z; d.q3 = a4.w; d.q4 = b2.x; d.q5 = b2.y;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    const QueryRec r = qrec[q];
+    // The descent stops as soon as the bucket is decided: the leaves below a node are the ordinals [lo, hi) --
+    // leaves are numbered in tree order and inner records in pre-order, so the first child's subtree holds
+    // (second child's inner index - this index) leaves, or (second child's leaf ordinal - lo) -- and once lo and
+    // hi - 1 share a bucket the remaining ~6 of ~25 dependent record reads are not needed (same keys as a full
+    // descent).
+    uint32_t node = ix.root_ref, lo = 0, hi = (uint32_t)ix.n_leaves;
+    while (!(node & kLeafTag) && (lo >> shift) != ((hi - 1u) >> shift)) {
+      const uint4 rec = ix.inner[(size_t)node * 4];
+      const float val = r.q[(rec.z >> 28) & 7u];
+      const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
+      const uint32_t ref2 = rec.w & (kLeafTag | kIdxMask);
+      const uint32_t n1 = (ref2 & kLeafTag) ? (ref2 & kIdxMask) - lo : ref2 - node;  // leaves below the first child
+      if ((diff1 + diff2) < 0) {
+        hi = lo + n1;
+        node = rec.z & (kLeafTag | kIdxMask);
+      } else {
+        lo += n1;
+        node = ref2;
+      }
     }
-  };
-  auto going = [&](const Descent &d) { return d.live && !(d.node & kLeafTag) && (d.lo >> shift) != ((d.hi - 1u) >> shift); };
-  auto step = [&](Descent &d, const uint4 &rec) {
-    const uint32_t idx = (rec.z >> 28) & 7u;  // (a select tree: an indexed local array would live in scratch memory)
-    const bool i0 = (idx & 1u) != 0, i1 = (idx & 2u) != 0, i2 = (idx & 4u) != 0;
-    const float val = i2 ? (i0 ? d.q5 : d.q4) : (i1 ? (i0 ? d.q3 : d.q2) : (i0 ? d.q1 : d.q0));
-    const float diff1 = val - __uint_as_float(rec.x), diff2 = val - __uint_as_float(rec.y);
-    const uint32_t ref2 = rec.w & (kLeafTag | kIdxMask);
-    const uint32_t n1 = (ref2 & kLeafTag) ? (ref2 & kIdxMask) - d.lo : ref2 - d.node;  // leaves below the first child
-    if ((diff1 + diff2) < 0) {
-      d.hi = d.lo + n1;
-      d.node = rec.z & (kLeafTag | kIdxMask);
-    } else {
-      d.lo += n1;
-      d.node = ref2;
-    }
-  };
-  auto finish = [&](const Descent &d, uint32_t q) {
-    if (!d.live) return;
-    const uint32_t lb = ((d.node & kLeafTag) ? (d.node & kIdxMask) : d.lo) >> shift, range = lb / per_range;
-    const float r2 = d.q0 * d.q0 + d.q1 * d.q1 + d.q2 * d.q2 + d.q3 * d.q3 + d.q4 * d.q4 + d.q5 * d.q5;
+    const uint32_t lb = ((node & kLeafTag) ? (node & kIdxMask) : lo) >> shift, range = lb / per_range;
+    const float r2 = r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3] + r.q[4] * r.q[4] +
+                     r.q[5] * r.q[5];
     uint32_t cls = 0;  // number of thresholds <= r2 (binary search over 15 sorted values)
 #pragma unroll
     for (uint32_t stepw = 8; stepw > 0; stepw >>= 1)
@@ -1406,23 +1387,6 @@ __global__ void QueryKeyKernel(IndexView ix, const QueryRec *__restrict__ qrec,
     const uint32_t key = (range * classes + cls) * per_range + (lb - range * per_range);
     keys[q] = key;
     atomicAdd(&hist[key], 1u);
-  };
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += 2u * stride) {
-    const uint32_t q2 = q + stride < q ? 0xFFFFFFFFu : q + stride;  // (no wrap-around)
-    Descent a, b;
-    start(a, q);
-    start(b, q2);
-    for (;;) {
-      const bool ga = going(a), gb = going(b);
-      if (!ga && !gb) break;
-      uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
-      if (ga) ra = ix.inner[(size_t)a.node * 4];
-      if (gb) rb = ix.inner[(size_t)b.node * 4];
-      if (ga) step(a, ra);
-      if (gb) step(b, rb);
-    }
-    finish(a, q);
-    finish(b, q2);
   }
 }
 
