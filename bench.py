@@ -78,9 +78,9 @@ def parse():
     ap.add_argument("--stagger", type=float, default=1.0,
                     help="the contexts of a region start this fraction of (serial step / depth) apart (0: all at once)")
     ap.add_argument("--ab-knob", default=None, help="development: NAME=V1,V2,... -- the serial pass repeated under each value of a knob")
-    ap.add_argument("--depth", type=int, default=4,
+    ap.add_argument("--depth", type=int, default=6,
                     help="batches in flight per GPU: steps are spread over this many contexts / HIP streams "
-                         "that share the resident index (1 = strictly serial steps)")
+                         "that share the resident index (1 = strictly serial steps; 4 -> 6: -1 %, ~25 GB of buffers each)")
     return ap.parse_args()
 
 

@@ -1519,6 +1519,10 @@ int RunBatchSpeculative(smhip_ctx *ctx, const smhip_params *p, uint32_t n_refs) 
 // Called by everything that hands results to the host: waits for the stream and, when a speculative batch
 // outgrew a capacity (or the hit pool), maps the batch again the synchronous way -- and repeats the sDTW
 // refinement that was enqueued behind it.
+// the sticky piece-length error (FinishRun below): what every call that hands out results of the batch answers first
+#define PIECES_BAD_MSG                                                                                                   \
+  "smhip_reads_upload_pieces: the device's (30, 200) pA filter kept another number of samples of a piece than expect_len " \
+  "says -- the chunk would not be the reference's chunk (upload the pieces and select the batch again)"
 int FinishRun(smhip_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->h_piece_flag && *ctx->h_piece_flag) {
@@ -1533,10 +1537,7 @@ int FinishRun(smhip_ctx *ctx) {
     ctx->refine_done = false;
     ctx->refine_path_done = false;
   }
-  if (ctx->pieces_bad)
-    return Fail(ctx, SMHIP_ECAP, "smhip_reads_upload_pieces: the device's (30, 200) pA filter kept another number of samples of a piece "
-                                 "than expect_len says -- the chunk would not be the reference's chunk (upload the pieces and "
-                                 "select the batch again)");
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->spec_pending) return SMHIP_OK;
   ctx->spec_pending = false;
   const RunInfo *info = static_cast<const RunInfo *>(ctx->h_run_info);
@@ -1698,6 +1699,7 @@ int smhip_map_sync(smhip_ctx *ctx) {
 int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carried_anchor *chain_anchors,
                        uint64_t chain_anchor_cap, uint64_t *chain_anchor_offsets) {
   if (!ctx || !results) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download before smhip_map_run");
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t R = ctx->n_chunks;
@@ -1743,6 +1745,7 @@ int smhip_map_download(smhip_ctx *ctx, smhip_chunk_result *results, smhip_carrie
 int smhip_map_download_anchors_of(smhip_ctx *ctx, const uint32_t *chunks, uint32_t n_listed, smhip_carried_anchor *chain_anchors,
                                   uint64_t chain_anchor_cap, uint64_t *chain_anchor_offsets) {
   if (!ctx || !chain_anchor_offsets || (n_listed && (!chunks || !chain_anchors))) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download_anchors_of before smhip_map_run");
   HIPCHK(hipSetDevice(ctx->device));
   chain_anchor_offsets[0] = 0;
@@ -1787,6 +1790,7 @@ int smhip_map_download_anchors_of(smhip_ctx *ctx, const uint32_t *chunks, uint32
 
 int smhip_map_download_chains(smhip_ctx *ctx, smhip_chain *chains, uint64_t chain_cap, uint64_t *chain_offsets) {
   if (!ctx || !chain_offsets) return Fail(ctx, SMHIP_EINVAL, "null argument");
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_map_download_chains before smhip_map_run");
   HIPCHK(hipSetDevice(ctx->device));
   const uint32_t R = ctx->n_chunks;
@@ -1869,6 +1873,7 @@ int smhip_mem_info(smhip_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) 
 
 int smhip_refine_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   if (!ctx) return SMHIP_EINVAL;
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_run before smhip_map_run");
   if (ctx->ref_n == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_run before smhip_reference_upload");
   if (band == 0) return Fail(ctx, SMHIP_EINVAL, "band must be positive");
@@ -1917,6 +1922,7 @@ int smhip_refine_download(smhip_ctx *ctx, float *dist, int64_t *end_pos) {
 
 int smhip_refine_path_run(smhip_ctx *ctx, uint32_t band, uint32_t pad) {
   if (!ctx) return SMHIP_EINVAL;
+  if (ctx->pieces_bad) return Fail(ctx, SMHIP_ECAP, PIECES_BAD_MSG);
   if (!ctx->run_done) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_path_run before smhip_map_run");
   if (ctx->ref_n == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_refine_path_run before smhip_reference_upload");
   if (band == 0) return Fail(ctx, SMHIP_EINVAL, "band must be positive");

@@ -212,6 +212,8 @@ def test_pieces_pulled_from_pinned_memory_match_addsignal(device):
         device.sync()
     with pytest.raises(RuntimeError, match="upload the pieces again"):
         device.select(np.arange(3), np.zeros(3))
+    with pytest.raises(RuntimeError, match="expect_len"):
+        device.download()
     device.upload_pieces(pin, begins, ln, dg, rg, of, slots=slots, expect=[len(w) for w in want])
     device.sync()                                 # ... and the context goes on
     device.select(np.arange(3), np.zeros(3))
@@ -261,6 +263,51 @@ def test_resident_reads_give_the_same_records_as_uploaded_pa(device, small_world
     assert device.download().tobytes() == base[:2 * m].tobytes()
     with pytest.raises(RuntimeError):   # a chunk beyond what a slot keeps is refused, not clipped silently
         device.select([0], [2])
+
+
+def test_select_before_the_previous_batch_was_collected(device, small_world):
+    """`smhip_batch_select` copies its arguments through pinned staging of the context without waiting for the stream;
+    a caller that selects the NEXT batch before it has collected the previous one must get a wait (an event behind the
+    copies that read the staging), never a torn copy: batches selected back to back -- other slots, other sizes, with
+    and without carried anchors, so that the staging is rewritten and regrown while the previous copies may still be
+    queued -- give the records of the same batches mapped one at a time."""
+    raw = small_world["raw"]
+    n = len(raw)
+    flat = np.ascontiguousarray(np.concatenate(raw).astype(np.int16))
+    ro = (np.arange(n + 1) * raw.shape[1]).astype(np.uint64)
+    device.configure_reads(n, 8000)
+    device.upload_raw(flat, ro, synth.DIGITISATION, synth.RANGE, synth.OFFSET)
+    rng = np.random.default_rng(77)
+    picks = [rng.permutation(n)[:k] for k in (n, 3, n - 1, 1, n // 2)]
+
+    def carried_for(k):   # a few synthetic carried anchors per chunk: the large staging block is used and regrown
+        if k % 2 == 0:
+            return None, None
+        per = 5 + 40 * k
+        ca = np.zeros(len(picks[k]) * per, _abi.CARRIED_DTYPE)
+        ca["ref_strand"] = rng.integers(0, 6, len(ca)); ca["target_position"] = rng.integers(0, 90000, len(ca))
+        ca["query_position"] = rng.integers(0, 400, len(ca)); ca["distance"] = rng.random(len(ca)).astype(np.float32) * 0.05
+        return ca, (np.arange(len(picks[k]) + 1) * per).astype(np.uint32)
+
+    carried = [carried_for(k) for k in range(len(picks))]
+    want = []
+    for sl, (ca, co) in zip(picks, carried):   # one at a time: select, run, collect
+        device.select(sl, np.zeros(len(sl)), carried=ca, carried_offsets=co)
+        device.run(3); device.sync()
+        want.append(device.download().tobytes())
+    got = []
+    for rep in range(3):                        # back to back: the next select right behind the run, nothing collected
+        for k, (sl, (ca, co)) in enumerate(zip(picks, carried)):
+            device.select(sl, np.zeros(len(sl)), carried=ca, carried_offsets=co)
+            device.run(3)
+            if k + 1 < len(picks):
+                nsl, (nca, nco) = picks[k + 1], carried[k + 1]
+                device.select(nsl, np.zeros(len(nsl)), carried=nca, carried_offsets=nco)   # replaces the batch: never run
+                device.select(sl, np.zeros(len(sl)), carried=ca, carried_offsets=co)       # ... and back again
+                device.run(3)
+            device.sync()
+            got.append(device.download().tobytes())
+    assert got == want * 3
 
 
 # ------------------------------------------------------------------ seed lookup (A10)
