@@ -278,7 +278,8 @@ int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *r
  * f32 operations); a piece of which the device keeps another number of samples makes the next call that collects
  * results fail with SMHIP_ECAP -- a chunk cut by the host's count would not be the reference's chunk -- and the error
  * is STICKY: every later smhip_map_sync / smhip_map_download* / smhip_batch_select of the context fails the same way
- * until smhip_reads_upload_pieces is called again (nothing computed from the wrong chunks is ever handed out).
+ * until smhip_reads_upload_pieces is called again or the slots are refilled by smhip_reads_upload_raw (nothing computed
+ * from the wrong chunks is ever handed out; a batch of smhip_batch_upload, which brings its own samples, is unaffected).
  * Every piece is range-checked on the host against the blocks of smhip_host_alloc (memory pinned by someone else:
  * one driver lookup per piece); a piece outside pinned memory is SMHIP_EINVAL, never an address given to the device.
  * Asynchronous: the arrays passed are free on return, the pieces must stay untouched until the batch that maps them

@@ -797,8 +797,9 @@ int UploadChunks(smhip_ctx *ctx, bool features, const float *samples_pa, const u
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->spec_pending) {  // a batch nobody collected: settle it before its inputs are replaced
     int rc0 = FinishRun(ctx);
-    if (rc0) return rc0;
+    if (rc0 && !ctx->pieces_bad) return rc0;
   }
+  ctx->pieces_bad = false;  // (this batch brings its own samples: a sticky piece-length error concerns the slots only)
   for (uint32_t c = 0; c < n_chunks; ++c) {
     if (sample_offsets[c + 1] < sample_offsets[c]) return Fail(ctx, SMHIP_EINVAL, "sample offsets must be non-decreasing");
     if (!features && sample_offsets[c + 1] - sample_offsets[c] > (uint32_t)kMaxSamples)
@@ -914,6 +915,7 @@ int smhip_reads_upload_raw(smhip_ctx *ctx, const int16_t *raw, const uint64_t *r
   if (ctx->n_slots == 0) return Fail(ctx, SMHIP_ESTATE, "smhip_reads_upload_raw before smhip_reads_configure");
   if (n_reads == 0) return SMHIP_OK;
   HIPCHK(hipSetDevice(ctx->device));
+  ctx->pieces_bad = false;  // (slots are refilled: a sticky piece-length error of smhip_reads_upload_pieces ends here)
   // per-read records + segment starts, staged in pinned host memory owned by the context
   const size_t meta_bytes = (size_t)n_reads * sizeof(RawReadMeta), seg_bytes = ((size_t)n_reads + 1) * sizeof(uint32_t);
   HIPCHK(hipStreamSynchronize(ctx->copy_stream));  // the previous upload's staging is free again
